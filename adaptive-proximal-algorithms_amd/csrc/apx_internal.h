@@ -1,0 +1,135 @@
+// apx_internal.h — private structs shared by the translation units of libadaprox_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/adaprox_hip.h"
+
+namespace apx {
+
+// ---- error plumbing: nothing throws across the C boundary ------------------------
+void set_error(const std::string& msg);
+int32_t fail(int32_t code, const std::string& msg);
+
+#define APX_HIP(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return ::apx::fail(APX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+  } while (0)
+
+#define APX_TRY(expr)                  \
+  do {                                 \
+    int32_t _s = (expr);               \
+    if (_s != APX_OK) return _s;       \
+  } while (0)
+
+#define APX_REQUIRE(cond, msg)                                   \
+  do {                                                           \
+    if (!(cond)) return ::apx::fail(APX_ERR_INVALID, (msg));     \
+  } while (0)
+
+inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+inline size_t dtype_size(int32_t dtype) { return dtype == APX_F32 ? 4 : 8; }
+
+constexpr int64_t kPad = 32;          // every vector / leading dimension is padded to 32 elements (>=128 B)
+constexpr int kMaxRedBlocks = 1024;   // grid cap of the fused vector kernels (= partials per quantity)
+constexpr int kRedQ = 8;              // quantities per partial buffer
+
+// ---- device control block: every scalar of the loop lives here --------------------
+struct Ctrl {
+  double gamma, sigma, rho, gamma_prev;
+  double st0, st1;                 // rule state: Ours/OursPlus (gamma1, gamma0); MM (gamma_prev, rho)
+  double f_x, bias_grad;           // smooth term value; logistic: mean(probs - y)
+  double g_x, h_Ax, objective;
+  double npr2, ndr2, norm_res;     // norm(primal_res)^2, norm(dual_res)^2, residual
+  double h_pre;                    // ||w/sigma + shift|| for the l2 conjugate prox
+  double tol;
+  double bt[4];                    // backtracking scalars: dot(grad, z-x), sum (z-x)^2, g(z), spare
+  double n_mean;                   // logistic: N of the mean
+  int64_t it;
+  int32_t done;
+  int32_t flags;
+  // rule
+  int32_t rule_kind, _pad;
+  double r_gamma, r_t, r_normA, r_delta, r_Theta, r_xi, r_nu, r_r;
+};
+
+// prox descriptor as the kernels see it (device pointers)
+struct ProxDev {
+  int32_t kind;
+  int32_t has_shift;
+  double lambda, lb, ub;
+  const void* lb_vec;
+  const void* ub_vec;
+  const void* shift;
+};
+
+struct GemvConfig {
+  int n_variant;       // index into the compiled gemv_n variants
+  int t_variant;
+  int64_t n_target_blocks;   // column splits are chosen so that grid ~ this
+  int64_t t_target_blocks;
+};
+
+}  // namespace apx
+
+struct apx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cu = 256;
+  // scratch
+  double* part = nullptr;        // GEMV partial sums
+  size_t part_bytes = 0;
+  double* red = nullptr;         // [kRedQ][kMaxRedBlocks] block partials of the fused vector kernels
+  double* scal = nullptr;        // small device scalar scratch (16 doubles)
+  double* h_scal = nullptr;      // pinned host mirror
+  void* h_stage = nullptr;       // pinned staging for small host<->device vectors
+  size_t h_stage_bytes = 0;
+  // profiling
+  bool profile = false;
+  struct Ev { hipEvent_t a, b; int kind; double bytes; };
+  std::vector<Ev> ev_pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+  apx_kernel_stat stats[APX_KSTAT_COUNT] = {};
+  apx::GemvConfig cfg;
+};
+
+struct apx_matrix {
+  apx_ctx* ctx = nullptr;
+  int64_t m = 0, n = 0, ld = 0, n_pad = 0;
+  int32_t dtype = APX_F64;
+  void* d = nullptr;
+};
+
+namespace apx {
+
+// ---- launchers implemented in gemv.hip -------------------------------------------
+int32_t ensure_part(apx_ctx* ctx, size_t bytes);
+// part_out[(split) * ld + row] ; returns number of splits used
+int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done);
+// out (T, length n_pad)
+int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done);
+// sums the gemv_n partials into y (T, length ld): `A*x` with no epilogue
+int32_t launch_sum_partials_rows(apx_ctx* ctx, int32_t dtype, int splits, int64_t m, int64_t ld, void* y,
+                                 const int* done);
+int gemv_n_variant_count();
+int gemv_t_variant_count();
+const char* gemv_n_variant_name(int i);
+const char* gemv_t_variant_name(int i);
+
+// ---- device buffers --------------------------------------------------------------
+struct DBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DBuf() { if (p) (void)hipFree(p); }
+  DBuf() = default;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  int32_t alloc_zero(size_t nbytes, hipStream_t s);
+};
+
+}  // namespace apx

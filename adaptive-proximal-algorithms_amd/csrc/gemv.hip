@@ -1,0 +1,167 @@
+// gemv.hip — launch geometry, compiled variants and HIP-event timing of the two GEMV kernels.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "apx_internal.h"
+#include "gemv_kernels.h"
+
+namespace apx {
+
+using NLaunch = void (*)(dim3, hipStream_t, const void*, int64_t, const void*, double*, int64_t, int64_t,
+                         int64_t, const int*);
+using TLaunch = void (*)(dim3, hipStream_t, const void*, int64_t, const void*, void*, double*, int64_t, int64_t,
+                         int64_t, const int*);
+
+template <typename T, int RPT, int UNR, bool NT, int XM, bool PIPE>
+static void n_launch(dim3 grid, hipStream_t s, const void* A, int64_t ld, const void* x, double* part,
+                     int64_t m_pad, int64_t n, int64_t cps, const int* done) {
+  hipLaunchKernelGGL((gemv_n_kernel<T, RPT, UNR, NT, XM, PIPE>), grid, dim3(kBlock), 0, s, (const T*)A, ld,
+                     (const T*)x, part, m_pad, n, cps, done);
+}
+
+template <typename T, int CPB, int UNR, bool NT, bool PIPE>
+static void t_launch(dim3 grid, hipStream_t s, const void* A, int64_t ld, const void* r, void* out, double* part,
+                     int64_t rps, int64_t m_pad, int64_t n_pad, const int* done) {
+  hipLaunchKernelGGL((gemv_t_kernel<T, CPB, UNR, NT, PIPE>), grid, dim3(kBlock), 0, s, (const T*)A, ld,
+                     (const T*)r, (T*)out, part, rps, m_pad, n_pad, done);
+}
+
+struct NVar { const char* name; int rpt, unr; NLaunch f64, f32; };
+struct TVar { const char* name; int cpb, unr; TLaunch f64, f32; };
+
+#define NV(RPT, UNR, NT, XM, PIPE)                                                        \
+  { "n_rpt" #RPT "_unr" #UNR "_nt" #NT "_x" #XM "_p" #PIPE, RPT, UNR,                    \
+    n_launch<double, RPT, UNR, NT, XM, PIPE>, n_launch<float, RPT, UNR, NT, XM, PIPE> }
+#define TV(CPB, UNR, NT, PIPE)                                                            \
+  { "t_cpb" #CPB "_unr" #UNR "_nt" #NT "_p" #PIPE, CPB, UNR,                              \
+    t_launch<double, CPB, UNR, NT, PIPE>, t_launch<float, CPB, UNR, NT, PIPE> }
+
+// Variant 0 is the default; the others exist so that one gpurun call can sweep them
+// (apx_ctx_set_gemv_config / tools/gemv_sweep.py) — the choice is by measurement on MI355X.
+static const NVar kNVars[] = {
+    NV(2, 8, false, 0, true),  NV(2, 8, false, 0, false), NV(1, 8, false, 0, true),  NV(4, 4, false, 0, true),
+    NV(2, 8, true, 0, true),   NV(2, 8, false, 1, true),  NV(1, 16, false, 0, true), NV(4, 8, false, 0, true),
+    NV(2, 4, false, 0, true),  NV(1, 8, true, 0, true),   NV(4, 4, true, 0, true),   NV(2, 8, true, 1, true),
+    NV(1, 4, false, 0, false), NV(2, 16, false, 0, true),
+};
+static const TVar kTVars[] = {
+    TV(8, 2, false, true),  TV(8, 2, false, false), TV(4, 4, false, true),  TV(16, 1, false, true),
+    TV(8, 2, true, true),   TV(4, 2, false, true),  TV(8, 1, false, true),  TV(16, 2, false, true),
+    TV(4, 4, true, true),   TV(16, 1, true, true),  TV(8, 4, false, true),  TV(4, 8, false, true),
+};
+
+int gemv_n_variant_count() { return (int)(sizeof(kNVars) / sizeof(kNVars[0])); }
+int gemv_t_variant_count() { return (int)(sizeof(kTVars) / sizeof(kTVars[0])); }
+const char* gemv_n_variant_name(int i) { return kNVars[i].name; }
+const char* gemv_t_variant_name(int i) { return kTVars[i].name; }
+
+int32_t ensure_part(apx_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->part_bytes) return APX_OK;
+  // growing the scratch must not race with kernels still using the old buffer
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->part) (void)hipFree(ctx->part);
+  ctx->part = nullptr;
+  ctx->part_bytes = 0;
+  const size_t want = bytes + bytes / 4;
+  APX_HIP(hipMalloc((void**)&ctx->part, want));
+  ctx->part_bytes = want;
+  return APX_OK;
+}
+
+// ---- HIP-event timing of single launches (bench.py roofline; off by default) ---------
+static int32_t prof_begin(apx_ctx* ctx, int kind, double bytes) {
+  if (!ctx->profile) return APX_OK;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!ctx->ev_free.empty()) {
+    ev = ctx->ev_free.back();
+    ctx->ev_free.pop_back();
+  } else {
+    APX_HIP(hipEventCreate(&ev.first));
+    APX_HIP(hipEventCreate(&ev.second));
+  }
+  APX_HIP(hipEventRecord(ev.first, ctx->stream));
+  ctx->ev_pending.push_back({ev.first, ev.second, kind, bytes});
+  return APX_OK;
+}
+static int32_t prof_end(apx_ctx* ctx) {
+  if (!ctx->profile) return APX_OK;
+  APX_HIP(hipEventRecord(ctx->ev_pending.back().b, ctx->stream));
+  return APX_OK;
+}
+
+int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
+  const NVar& v = kNVars[ctx->cfg.n_variant];
+  const int V = A->dtype == APX_F32 ? 4 : 2;
+  const int64_t rows_per_block = (int64_t)kBlock * V * v.rpt;
+  const int64_t row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
+  int64_t S = std::max<int64_t>(1, (ctx->cfg.n_target_blocks + row_tiles - 1) / row_tiles);
+  int64_t cps = round_up((A->n + S - 1) / S, v.unr);
+  if (cps < v.unr) cps = v.unr;
+  S = (A->n + cps - 1) / cps;
+  if (S < 1) S = 1;
+  APX_REQUIRE(S <= 65535 && row_tiles <= 2147483647LL, "gemv_n grid too large");
+  APX_TRY(ensure_part(ctx, (size_t)S * A->ld * sizeof(double)));
+  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)A->m * (double)A->n * dtype_size(A->dtype)));
+  dim3 grid((unsigned)row_tiles, (unsigned)S);
+  (A->dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, A->d, A->ld, x, ctx->part, A->ld, A->n, cps, done);
+  APX_TRY(prof_end(ctx));
+  APX_HIP(hipGetLastError());
+  *splits_out = (int)S;
+  return APX_OK;
+}
+
+int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
+  const TVar& v = kTVars[ctx->cfg.t_variant];
+  const int V = A->dtype == APX_F32 ? 4 : 2;
+  const int64_t col_blocks = A->n_pad / v.cpb;
+  const int64_t step = (int64_t)kBlock * V * v.unr;
+  int64_t SR = std::max<int64_t>(1, ctx->cfg.t_target_blocks / std::max<int64_t>(1, col_blocks));
+  int64_t rps = round_up((A->ld + SR - 1) / SR, step);
+  SR = (A->ld + rps - 1) / rps;
+  APX_REQUIRE(SR <= 65535 && col_blocks <= 2147483647LL, "gemv_t grid too large");
+  if (SR > 1) APX_TRY(ensure_part(ctx, (size_t)SR * A->n_pad * sizeof(double)));
+  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, (double)A->m * (double)A->n * dtype_size(A->dtype)));
+  dim3 grid((unsigned)col_blocks, (unsigned)SR);
+  (A->dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, A->d, A->ld, r, out, ctx->part, rps, A->ld, A->n_pad,
+                                         done);
+  APX_TRY(prof_end(ctx));
+  if (SR > 1) {
+    const unsigned g = (unsigned)((A->n_pad + kBlock - 1) / kBlock);
+    if (A->dtype == APX_F32)
+      hipLaunchKernelGGL(gemv_t_finish<float>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, (int)SR, A->n_pad,
+                         (float*)out, done);
+    else
+      hipLaunchKernelGGL(gemv_t_finish<double>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, (int)SR,
+                         A->n_pad, (double*)out, done);
+  }
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_partials_rows(const double* __restrict__ part, int splits, int64_t ld,
+                                                            int64_t m, T* __restrict__ y,
+                                                            const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * ld + i];
+    y[i] = (T)s;
+  }
+}
+
+int32_t launch_sum_partials_rows(apx_ctx* ctx, int32_t dtype, int splits, int64_t m, int64_t ld, void* y,
+                                 const int* done) {
+  const unsigned g = (unsigned)std::min<int64_t>(kMaxRedBlocks, (m + kBlock - 1) / kBlock);
+  if (dtype == APX_F32)
+    hipLaunchKernelGGL(sum_partials_rows<float>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, splits, ld, m,
+                       (float*)y, done);
+  else
+    hipLaunchKernelGGL(sum_partials_rows<double>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, splits, ld, m,
+                       (double*)y, done);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+}  // namespace apx

@@ -1,0 +1,427 @@
+// matrix.hip — context, dense column-major matrices resident in HBM, and the `A*x` / `A'*y`
+// operator entry points of the C-ABI.
+//
+// HBM layout: one allocation of ld * n_pad elements, ld = round_up(m, 32), n_pad =
+// round_up(n, 32), every pad entry zero.  Column j starts at a 128-B boundary (fp32) /
+// 256-B boundary (fp64), so every 16-B lane access of the GEMV kernels is aligned and
+// whole-wave loads are 1 KiB contiguous.  A 50 000 x 100 000 fp64 matrix is 40.0 GB of the
+// 288 GB; nothing is tiled or duplicated.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "apx_internal.h"
+#include "gemv_kernels.h"
+
+namespace apx {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int32_t fail(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int32_t DBuf::alloc_zero(size_t nbytes, hipStream_t s) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+  if (nbytes == 0) nbytes = 256;
+  APX_HIP(hipMalloc(&p, nbytes));
+  bytes = nbytes;
+  APX_HIP(hipMemsetAsync(p, 0, nbytes, s));
+  return APX_OK;
+}
+
+// splitmix64 finaliser — same function as oracle/problems.py::hash_uniform
+__device__ __forceinline__ double hash_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed * 0x9E3779B97F4A7C15ULL + idx;
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fill_uniform(T* __restrict__ A, int64_t ld, int64_t m, int64_t n,
+                                                         uint64_t seed, double lo, double hi, int64_t row_offset,
+                                                         int64_t m_total) {
+  const int64_t j = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const uint64_t idx = (uint64_t)j * (uint64_t)m_total + (uint64_t)(row_offset + i);
+    A[j * ld + i] = (T)(lo + (hi - lo) * hash_uniform(seed, idx));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scale_columns(T* __restrict__ A, int64_t ld, int64_t m, int64_t n,
+                                                          const double* __restrict__ alpha) {
+  const int64_t j = blockIdx.y;
+  const double a = alpha[j];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock)
+    A[j * ld + i] = (T)((double)A[j * ld + i] * a);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fill_column(T* __restrict__ col, int64_t m, double value) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock)
+    col[i] = (T)value;
+}
+
+// sum of squares over the whole padded buffer (pads are zero); block partials in a fixed order
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ A, int64_t total, double* __restrict__ red) {
+  constexpr int V = V16<T>::N;
+  double s = 0.0;
+  const int64_t nvec = total / V;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kBlock) {
+    const auto v = ld16<T, false>(A + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) s = fma((double)v[e], (double)v[e], s);
+  }
+  __shared__ double sh[kBlock / 64];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sh[0];
+    for (int w = 1; w < kBlock / 64; ++w) t += sh[w];
+    red[blockIdx.x] = t;
+  }
+}
+
+}  // namespace apx
+
+using namespace apx;
+
+extern "C" {
+
+int32_t apx_abi_version(void) { return APX_ABI_VERSION; }
+const char* apx_last_error(void) { return g_last_error.c_str(); }
+
+int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
+  APX_REQUIRE(out != nullptr, "apx_ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  APX_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(APX_ERR_HIP, "apx_ctx_create: no HIP device visible (the HIP path has no CPU fallback)");
+  APX_REQUIRE(device >= 0 && device < ndev, "apx_ctx_create: bad device index");
+  APX_HIP(hipSetDevice(device));
+  apx_ctx* ctx = new apx_ctx();
+  ctx->device = device;
+  if (stream != nullptr) {
+    ctx->stream = (hipStream_t)stream;
+    ctx->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(APX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    ctx->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  auto bail = [&](hipError_t e, const char* what) {
+    apx_ctx_destroy(ctx);
+    return fail(APX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&ctx->red, sizeof(double) * kRedQ * kMaxRedBlocks)) != hipSuccess) return bail(e, "hipMalloc red");
+  if ((e = hipMalloc((void**)&ctx->scal, sizeof(double) * 16)) != hipSuccess) return bail(e, "hipMalloc scal");
+  if ((e = hipHostMalloc((void**)&ctx->h_scal, sizeof(double) * 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+  // defaults: measured best on MI355X; overridable for sweeps
+  ctx->cfg.n_variant = 0;
+  ctx->cfg.t_variant = 0;
+  ctx->cfg.n_target_blocks = 16 * (int64_t)ctx->num_cu;
+  ctx->cfg.t_target_blocks = 8 * (int64_t)ctx->num_cu;
+  if (const char* s = getenv("APX_GEMV_N_VARIANT")) ctx->cfg.n_variant = atoi(s);
+  if (const char* s = getenv("APX_GEMV_T_VARIANT")) ctx->cfg.t_variant = atoi(s);
+  if (const char* s = getenv("APX_GEMV_N_BLOCKS")) ctx->cfg.n_target_blocks = atoll(s);
+  if (const char* s = getenv("APX_GEMV_T_BLOCKS")) ctx->cfg.t_target_blocks = atoll(s);
+  if (ctx->cfg.n_variant < 0 || ctx->cfg.n_variant >= gemv_n_variant_count()) ctx->cfg.n_variant = 0;
+  if (ctx->cfg.t_variant < 0 || ctx->cfg.t_variant >= gemv_t_variant_count()) ctx->cfg.t_variant = 0;
+  *out = ctx;
+  return APX_OK;
+}
+
+int32_t apx_ctx_destroy(apx_ctx* ctx) {
+  if (ctx == nullptr) return APX_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& ev : ctx->ev_pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (auto& ev : ctx->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (ctx->part) (void)hipFree(ctx->part);
+  if (ctx->red) (void)hipFree(ctx->red);
+  if (ctx->scal) (void)hipFree(ctx->scal);
+  if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return APX_OK;
+}
+
+int32_t apx_ctx_sync(apx_ctx* ctx) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_sync: ctx is NULL");
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  return APX_OK;
+}
+
+int32_t apx_ctx_stream(apx_ctx* ctx, void** stream_out) {
+  APX_REQUIRE(ctx != nullptr && stream_out != nullptr, "apx_ctx_stream: NULL argument");
+  *stream_out = (void*)ctx->stream;
+  return APX_OK;
+}
+
+int32_t apx_ctx_profile(apx_ctx* ctx, int32_t enable) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_profile: ctx is NULL");
+  ctx->profile = enable != 0;
+  return APX_OK;
+}
+
+int32_t apx_ctx_kernel_stats(apx_ctx* ctx, apx_kernel_stat* stats, int32_t reset) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_kernel_stats: ctx is NULL");
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& ev : ctx->ev_pending) {
+    float ms = 0.f;
+    APX_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+    ctx->stats[ev.kind].launches += 1;
+    ctx->stats[ev.kind].total_ms += (double)ms;
+    ctx->stats[ev.kind].bytes += ev.bytes;
+    ctx->ev_free.push_back({ev.a, ev.b});
+  }
+  ctx->ev_pending.clear();
+  if (stats != nullptr) memcpy(stats, ctx->stats, sizeof(ctx->stats));
+  if (reset) memset(ctx->stats, 0, sizeof(ctx->stats));
+  return APX_OK;
+}
+
+int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_variant, int64_t n_blocks,
+                                int64_t t_blocks) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_set_gemv_config: ctx is NULL");
+  if (n_variant >= 0) {
+    APX_REQUIRE(n_variant < gemv_n_variant_count(), "gemv_n variant out of range");
+    ctx->cfg.n_variant = n_variant;
+  }
+  if (t_variant >= 0) {
+    APX_REQUIRE(t_variant < gemv_t_variant_count(), "gemv_t variant out of range");
+    ctx->cfg.t_variant = t_variant;
+  }
+  if (n_blocks > 0) ctx->cfg.n_target_blocks = n_blocks;
+  if (t_blocks > 0) ctx->cfg.t_target_blocks = t_blocks;
+  return APX_OK;
+}
+
+int32_t apx_gemv_variant_count(int32_t transposed) {
+  return transposed ? gemv_t_variant_count() : gemv_n_variant_count();
+}
+
+const char* apx_gemv_variant_name(int32_t transposed, int32_t i) {
+  if (i < 0 || i >= apx_gemv_variant_count(transposed)) return "";
+  return transposed ? gemv_t_variant_name(i) : gemv_n_variant_name(i);
+}
+
+// ---- matrices ----------------------------------------------------------------------
+int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx_matrix** out) {
+  APX_REQUIRE(ctx != nullptr && out != nullptr, "apx_matrix_create: NULL argument");
+  APX_REQUIRE(m >= 0 && n >= 0, "apx_matrix_create: negative dimension");
+  APX_REQUIRE(dtype == APX_F64 || dtype == APX_F32, "apx_matrix_create: bad dtype");
+  *out = nullptr;
+  APX_HIP(hipSetDevice(ctx->device));
+  apx_matrix* A = new apx_matrix();
+  A->ctx = ctx;
+  A->m = m;
+  A->n = n;
+  A->dtype = dtype;
+  A->ld = round_up(std::max<int64_t>(m, 1), kPad);
+  A->n_pad = round_up(std::max<int64_t>(n, 1), kPad);
+  const size_t bytes = (size_t)A->ld * (size_t)A->n_pad * dtype_size(dtype);
+  hipError_t e = hipMalloc(&A->d, bytes);
+  if (e != hipSuccess) {
+    delete A;
+    return fail(APX_ERR_HIP, std::string("apx_matrix_create: hipMalloc of ") + std::to_string(bytes) + " B: " +
+                                 hipGetErrorString(e));
+  }
+  e = hipMemsetAsync(A->d, 0, bytes, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(A->d);
+    delete A;
+    return fail(APX_ERR_HIP, std::string("apx_matrix_create: memset: ") + hipGetErrorString(e));
+  }
+  *out = A;
+  return APX_OK;
+}
+
+int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, int64_t lda, int32_t dtype,
+                          apx_matrix** out) {
+  APX_REQUIRE(host != nullptr || m * n == 0, "apx_matrix_upload: host is NULL");
+  APX_REQUIRE(lda >= m, "apx_matrix_upload: lda < m");
+  APX_TRY(apx_matrix_create(ctx, m, n, dtype, out));
+  apx_matrix* A = *out;
+  if (m > 0 && n > 0) {
+    const size_t es = dtype_size(dtype);
+    hipError_t e = hipMemcpy2DAsync(A->d, (size_t)A->ld * es, host, (size_t)lda * es, (size_t)m * es, (size_t)n,
+                                    hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      apx_matrix_free(A);
+      *out = nullptr;
+      return fail(APX_ERR_HIP, std::string("apx_matrix_upload: ") + hipGetErrorString(e));
+    }
+  }
+  return APX_OK;
+}
+
+int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda) {
+  APX_REQUIRE(A != nullptr && host != nullptr, "apx_matrix_download: NULL argument");
+  APX_REQUIRE(lda >= A->m, "apx_matrix_download: lda < m");
+  APX_HIP(hipSetDevice(A->ctx->device));
+  const size_t es = dtype_size(A->dtype);
+  if (A->m > 0 && A->n > 0) {
+    APX_HIP(hipMemcpy2DAsync(host, (size_t)lda * es, A->d, (size_t)A->ld * es, (size_t)A->m * es, (size_t)A->n,
+                             hipMemcpyDeviceToHost, A->ctx->stream));
+  }
+  APX_HIP(hipStreamSynchronize(A->ctx->stream));
+  return APX_OK;
+}
+
+int32_t apx_matrix_free(apx_matrix* A) {
+  if (A == nullptr) return APX_OK;
+  (void)hipSetDevice(A->ctx->device);
+  (void)hipStreamSynchronize(A->ctx->stream);
+  if (A->d) (void)hipFree(A->d);
+  delete A;
+  return APX_OK;
+}
+
+int32_t apx_matrix_shape(const apx_matrix* A, int64_t* m, int64_t* n, int32_t* dtype) {
+  APX_REQUIRE(A != nullptr, "apx_matrix_shape: A is NULL");
+  if (m) *m = A->m;
+  if (n) *n = A->n;
+  if (dtype) *dtype = A->dtype;
+  return APX_OK;
+}
+
+static inline dim3 grid_mn(int64_t m, int64_t n) {
+  return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (m + kBlock - 1) / kBlock)), (unsigned)n);
+}
+
+int32_t apx_matrix_fill_uniform(apx_matrix* A, uint64_t seed, double lo, double hi, int64_t row_offset,
+                                int64_t m_total) {
+  APX_REQUIRE(A != nullptr, "apx_matrix_fill_uniform: A is NULL");
+  if (m_total <= 0) m_total = A->m;
+  APX_REQUIRE(row_offset >= 0 && row_offset + A->m <= m_total, "apx_matrix_fill_uniform: shard outside the global matrix");
+  if (A->m == 0 || A->n == 0) return APX_OK;
+  APX_HIP(hipSetDevice(A->ctx->device));
+  // gridDim.y is limited to 65535: walk the columns in slabs
+  for (int64_t j0 = 0; j0 < A->n; j0 += 65535) {
+    const int64_t nj = std::min<int64_t>(65535, A->n - j0);
+    const size_t es = dtype_size(A->dtype);
+    char* base = (char*)A->d + (size_t)j0 * A->ld * es;
+    const uint64_t seed_eff = seed;
+    // the column index enters the hash through idx = j*m_total + i, so slab launches pass j0 via row offset trick:
+    // idx = (j0 + jj)*m_total + row_offset + i  ==  jj*m_total + (j0*m_total + row_offset + i)
+    const int64_t off = j0 * m_total + row_offset;
+    if (A->dtype == APX_F32)
+      hipLaunchKernelGGL(k_fill_uniform<float>, grid_mn(A->m, nj), dim3(kBlock), 0, A->ctx->stream, (float*)base,
+                         A->ld, A->m, nj, seed_eff, lo, hi, off, m_total);
+    else
+      hipLaunchKernelGGL(k_fill_uniform<double>, grid_mn(A->m, nj), dim3(kBlock), 0, A->ctx->stream, (double*)base,
+                         A->ld, A->m, nj, seed_eff, lo, hi, off, m_total);
+  }
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t apx_matrix_scale_columns(apx_matrix* A, const double* alpha) {
+  APX_REQUIRE(A != nullptr && alpha != nullptr, "apx_matrix_scale_columns: NULL argument");
+  if (A->m == 0 || A->n == 0) return APX_OK;
+  APX_HIP(hipSetDevice(A->ctx->device));
+  DBuf d_alpha;
+  APX_TRY(d_alpha.alloc_zero((size_t)A->n * sizeof(double), A->ctx->stream));
+  APX_HIP(hipMemcpyAsync(d_alpha.p, alpha, (size_t)A->n * sizeof(double), hipMemcpyHostToDevice, A->ctx->stream));
+  for (int64_t j0 = 0; j0 < A->n; j0 += 65535) {
+    const int64_t nj = std::min<int64_t>(65535, A->n - j0);
+    const size_t es = dtype_size(A->dtype);
+    char* base = (char*)A->d + (size_t)j0 * A->ld * es;
+    if (A->dtype == APX_F32)
+      hipLaunchKernelGGL(k_scale_columns<float>, grid_mn(A->m, nj), dim3(kBlock), 0, A->ctx->stream, (float*)base,
+                         A->ld, A->m, nj, (const double*)d_alpha.p + j0);
+    else
+      hipLaunchKernelGGL(k_scale_columns<double>, grid_mn(A->m, nj), dim3(kBlock), 0, A->ctx->stream, (double*)base,
+                         A->ld, A->m, nj, (const double*)d_alpha.p + j0);
+  }
+  APX_HIP(hipGetLastError());
+  APX_HIP(hipStreamSynchronize(A->ctx->stream));
+  return APX_OK;
+}
+
+int32_t apx_matrix_fill_column(apx_matrix* A, int64_t j, double value) {
+  APX_REQUIRE(A != nullptr, "apx_matrix_fill_column: A is NULL");
+  APX_REQUIRE(j >= 0 && j < A->n, "apx_matrix_fill_column: column out of range");
+  if (A->m == 0) return APX_OK;
+  APX_HIP(hipSetDevice(A->ctx->device));
+  const size_t es = dtype_size(A->dtype);
+  char* col = (char*)A->d + (size_t)j * A->ld * es;
+  const unsigned g = (unsigned)std::min<int64_t>(1024, (A->m + kBlock - 1) / kBlock);
+  if (A->dtype == APX_F32)
+    hipLaunchKernelGGL(k_fill_column<float>, dim3(g), dim3(kBlock), 0, A->ctx->stream, (float*)col, A->m, value);
+  else
+    hipLaunchKernelGGL(k_fill_column<double>, dim3(g), dim3(kBlock), 0, A->ctx->stream, (double*)col, A->m, value);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t apx_matrix_sumsq(const apx_matrix* A, double* out) {
+  APX_REQUIRE(A != nullptr && out != nullptr, "apx_matrix_sumsq: NULL argument");
+  apx_ctx* ctx = A->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  const int64_t total = A->ld * A->n_pad;
+  const int nblk = kMaxRedBlocks;
+  if (A->dtype == APX_F32)
+    hipLaunchKernelGGL(k_sumsq<float>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const float*)A->d, total, ctx->red);
+  else
+    hipLaunchKernelGGL(k_sumsq<double>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const double*)A->d, total, ctx->red);
+  APX_HIP(hipGetLastError());
+  std::vector<double> h(nblk);
+  APX_HIP(hipMemcpyAsync(h.data(), ctx->red, sizeof(double) * nblk, hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += h[i];
+  *out = s;
+  return APX_OK;
+}
+
+// `A*x` (src/counting.jl:68-74): x host (n), y host (m)
+int32_t apx_gemv_n(const apx_matrix* A, const void* x, void* y) {
+  APX_REQUIRE(A != nullptr && x != nullptr && y != nullptr, "apx_gemv_n: NULL argument");
+  apx_ctx* ctx = A->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  const size_t es = dtype_size(A->dtype);
+  DBuf dx, dy;
+  APX_TRY(dx.alloc_zero((size_t)A->n_pad * es, ctx->stream));
+  APX_TRY(dy.alloc_zero((size_t)A->ld * es, ctx->stream));
+  APX_HIP(hipMemcpyAsync(dx.p, x, (size_t)A->n * es, hipMemcpyHostToDevice, ctx->stream));
+  int splits = 0;
+  APX_TRY(launch_gemv_n(ctx, A, dx.p, &splits, nullptr));
+  APX_TRY(launch_sum_partials_rows(ctx, A->dtype, splits, A->m, A->ld, dy.p, nullptr));
+  APX_HIP(hipMemcpyAsync(y, dy.p, (size_t)A->m * es, hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  return APX_OK;
+}
+
+// `A'*y` (src/counting.jl:76-82): r host (m), g host (n)
+int32_t apx_gemv_t(const apx_matrix* A, const void* r, void* g) {
+  APX_REQUIRE(A != nullptr && r != nullptr && g != nullptr, "apx_gemv_t: NULL argument");
+  apx_ctx* ctx = A->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  const size_t es = dtype_size(A->dtype);
+  DBuf dr, dg;
+  APX_TRY(dr.alloc_zero((size_t)A->ld * es, ctx->stream));
+  APX_TRY(dg.alloc_zero((size_t)A->n_pad * es, ctx->stream));
+  APX_HIP(hipMemcpyAsync(dr.p, r, (size_t)A->m * es, hipMemcpyHostToDevice, ctx->stream));
+  APX_TRY(launch_gemv_t(ctx, A, dr.p, dg.p, nullptr));
+  APX_HIP(hipMemcpyAsync(g, dg.p, (size_t)A->n * es, hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  return APX_OK;
+}
+
+}  // extern "C"

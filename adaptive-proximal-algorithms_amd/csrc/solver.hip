@@ -1,0 +1,725 @@
+// solver.hip — problems (f, g, h, A) and the solver loops of the reference, driven from the
+// host as stream-ordered launches with every loop scalar resident on the device.
+//
+//   adaptive_primal_dual   src/AdaProx.jl:312-364   (the generic loop; everything else wraps it)
+//   adaptive_proxgrad      src/AdaProx.jl:418-421   (h = Zero, A = 0)
+//   fixed_proxgrad         src/AdaProx.jl:457-459
+//   condat_vu              src/AdaProx.jl:367-416   (default-parameter branch)
+//   backtracking_proxgrad  src/AdaProx.jl:34-64     (host reads f_z / ub_z per trial: data-dependent branch)
+//
+// Termination: the reference tests `norm_res <= tol` every iteration.  Here the test runs
+// on the device (k_rule / k_final set Ctrl.done) and every later kernel starts with
+// `if (done) return`, so the state FREEZES at the converged iterate while the host is
+// still enqueueing; the host only reads the flag back every `poll_every` iterations.
+// The returned (x, y, it) are exactly those of the iteration whose test passed.
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+#include "apx_internal.h"
+#include "vecops.h"
+
+using namespace apx;
+
+struct apx_problem {
+  apx_ctx* ctx = nullptr;
+  int32_t f_kind = APX_F_ZERO, dtype = APX_F64;
+  int64_t n = 0, m = 0, n_pad = 0, m_pad = 0;
+  const apx_matrix* A_f = nullptr;
+  const apx_matrix* A_lin = nullptr;
+  apx_eval_fn eval_cb = nullptr;
+  apx_pullback_fn pb_cb = nullptr;
+  void* cb_user = nullptr;
+  apx_allreduce_fn allreduce = nullptr;
+  void* ar_user = nullptr;
+  double n_mean = 0.0;
+  DBuf b, res, grad, fsc_buf, xtmp, ctrl_buf;
+  DBuf g_lb, g_ub, g_shift, h_lb, h_ub, h_shift;
+  ProxDev gd{}, hd{};
+  std::vector<char> hbuf;
+  bool have_eval = false;
+  bool fsc_reduced = false;
+  apx_solver* active = nullptr;
+
+  Ctrl* ctrl() const { return (Ctrl*)ctrl_buf.p; }
+  const int* done_ptr() const { return (const int*)((const char*)ctrl_buf.p + offsetof(Ctrl, done)); }
+  double* fsc() const { return (double*)fsc_buf.p; }
+  size_t es() const { return dtype_size(dtype); }
+};
+
+struct apx_solver {
+  apx_problem* p = nullptr;
+  apx_rule rule{};
+  double tol = 0.0;
+  int32_t poll_every = 16;
+  DBuf x, xprev, gprev, v, aty, y, ax, axprev, recs;
+  int64_t rec_cap = 0;
+  apx_record* host_recs = nullptr;
+  int64_t iters = 0;        // iterations enqueued so far
+  bool stopped = false;     // the host has seen done == 1
+};
+
+namespace {
+
+int32_t h2d(apx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return APX_OK;
+  APX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));   // src is pageable caller memory: do not outlive the call
+  return APX_OK;
+}
+int32_t d2h(apx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return APX_OK;
+  APX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  return APX_OK;
+}
+
+int32_t make_prox_dev(apx_ctx* ctx, const apx_prox_desc& d, int32_t dtype, int64_t len, DBuf& lb, DBuf& ub,
+                      DBuf& shift, ProxDev* out) {
+  APX_REQUIRE(d.kind >= APX_G_ZERO && d.kind <= APX_G_L2, "unknown prox kind");
+  const size_t es = dtype_size(dtype);
+  ProxDev p{};
+  p.kind = d.kind;
+  p.lambda = d.lambda;
+  p.lb = d.lb;
+  p.ub = d.ub;
+  if (d.kind == APX_G_BOXV) {
+    APX_REQUIRE(d.lb_vec != nullptr && d.ub_vec != nullptr, "IndBox with vector bounds needs lb_vec and ub_vec");
+    APX_TRY(lb.alloc_zero((size_t)round_up(len, kPad) * es, ctx->stream));
+    APX_TRY(ub.alloc_zero((size_t)round_up(len, kPad) * es, ctx->stream));
+    APX_TRY(h2d(ctx, lb.p, d.lb_vec, (size_t)len * es));
+    APX_TRY(h2d(ctx, ub.p, d.ub_vec, (size_t)len * es));
+    p.lb_vec = lb.p;
+    p.ub_vec = ub.p;
+  }
+  if (d.shift != nullptr) {
+    APX_TRY(shift.alloc_zero((size_t)round_up(len, kPad) * es, ctx->stream));
+    APX_TRY(h2d(ctx, shift.p, d.shift, (size_t)len * es));
+    p.shift = shift.p;
+    p.has_shift = 1;
+  }
+  *out = p;
+  return APX_OK;
+}
+
+int32_t do_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dtype) {
+  const int32_t rc = p->allreduce(p->ar_user, buf, count, dtype, (void*)p->ctx->stream);
+  if (rc != 0) return fail(APX_ERR_CALLBACK, "all-reduce callback failed");
+  return APX_OK;
+}
+
+// `f_x, pb = eval_with_pullback(f, x)` on a device x.  need_f: f_x must be final in Ctrl
+// when this returns to the stream (backtracking); otherwise a row-sharded f may defer the
+// scalar all-reduce to the pullback, where it rides along with the gradient.
+int32_t eval_f(apx_problem* p, const void* x_dev, bool need_f) {
+  apx_ctx* ctx = p->ctx;
+  p->fsc_reduced = false;
+  switch (p->f_kind) {
+    case APX_F_ZERO:
+      break;
+    case APX_F_LEAST_SQUARES:
+    case APX_F_LOGISTIC: {
+      int splits = 0;
+      APX_TRY(launch_gemv_n(ctx, p->A_f, x_dev, &splits, p->done_ptr()));
+      const bool local_final = p->allreduce == nullptr;
+      APX_TRY(vo_finish_rows(ctx, p->dtype, p->f_kind, splits, p->A_f->ld, p->A_f->m, p->b.p, x_dev, p->n, p->res.p,
+                             p->ctrl(), p->fsc(), local_final));
+      if (!local_final && need_f) {
+        APX_TRY(do_allreduce(p, p->fsc(), 2, APX_F64));
+        APX_TRY(vo_f_final(ctx, p->f_kind, p->fsc(), p->ctrl()));
+        p->fsc_reduced = true;
+      }
+      break;
+    }
+    case APX_F_CALLBACK: {
+      const size_t bytes = (size_t)p->n * p->es();
+      p->hbuf.resize(bytes);
+      APX_TRY(d2h(ctx, p->hbuf.data(), x_dev, bytes));
+      double fx = 0.0;
+      if (p->eval_cb(p->cb_user, p->hbuf.data(), p->n, &fx) != 0) return fail(APX_ERR_CALLBACK, "eval callback failed");
+      ctx->h_scal[32] = fx;
+      APX_HIP(hipMemcpyAsync((char*)p->ctrl_buf.p + offsetof(Ctrl, f_x), &ctx->h_scal[32], sizeof(double),
+                             hipMemcpyHostToDevice, ctx->stream));
+      APX_HIP(hipStreamSynchronize(ctx->stream));
+      break;
+    }
+    default:
+      return fail(APX_ERR_INVALID, "unknown f kind");
+  }
+  p->have_eval = true;
+  return APX_OK;
+}
+
+// `pb()`: gradient at the x of the latest eval, written to p->grad
+int32_t pullback_f(apx_problem* p) {
+  apx_ctx* ctx = p->ctx;
+  APX_REQUIRE(p->have_eval, "pullback before eval_with_pullback");
+  switch (p->f_kind) {
+    case APX_F_ZERO:
+      APX_HIP(hipMemsetAsync(p->grad.p, 0, (size_t)p->n_pad * p->es(), ctx->stream));
+      break;
+    case APX_F_LEAST_SQUARES:
+    case APX_F_LOGISTIC: {
+      APX_TRY(launch_gemv_t(ctx, p->A_f, p->res.p, p->grad.p, p->done_ptr()));
+      if (p->allreduce != nullptr) {
+        // [A_k' r_k] summed over the row shards; the partial f scalars ride along (K12)
+        APX_TRY(do_allreduce(p, p->grad.p, p->A_f->n_pad, p->dtype));
+        if (!p->fsc_reduced) {
+          APX_TRY(do_allreduce(p, p->fsc(), 2, APX_F64));
+          APX_TRY(vo_f_final(ctx, p->f_kind, p->fsc(), p->ctrl()));
+          p->fsc_reduced = true;
+        }
+      }
+      if (p->f_kind == APX_F_LOGISTIC) APX_TRY(vo_logistic_grad(ctx, p->dtype, p->grad.p, p->n, p->ctrl()));
+      break;
+    }
+    case APX_F_CALLBACK: {
+      const size_t bytes = (size_t)p->n * p->es();
+      p->hbuf.resize(bytes);
+      if (p->pb_cb(p->cb_user, p->hbuf.data(), p->n) != 0) return fail(APX_ERR_CALLBACK, "pullback callback failed");
+      APX_TRY(h2d(ctx, p->grad.p, p->hbuf.data(), bytes));
+      break;
+    }
+  }
+  return APX_OK;
+}
+
+int32_t init_ctrl(apx_problem* p, const apx_rule* rule, double tol) {
+  Ctrl c{};
+  c.tol = tol;
+  c.n_mean = p->n_mean;
+  c.rule_kind = rule->kind;
+  c.r_gamma = rule->gamma;
+  c.r_t = rule->t;
+  c.r_normA = rule->norm_A;
+  c.r_delta = rule->delta;
+  c.r_Theta = rule->Theta;
+  c.r_xi = rule->xi;
+  c.r_nu = rule->nu;
+  c.r_r = rule->r;
+  switch (rule->kind) {
+    case APX_RULE_FIXED:       // :213-215
+      APX_REQUIRE(rule->gamma > 0, "FixedStepsize: gamma must be positive");
+      c.gamma = rule->gamma;
+      c.sigma = rule->gamma * (rule->t * rule->t);
+      break;
+    case APX_RULE_MM:          // :222-224
+      APX_REQUIRE(rule->gamma > 0, "MalitskyMishchenkoRule: gamma must be positive");
+      c.gamma = rule->gamma;
+      c.sigma = rule->gamma * (rule->t * rule->t);
+      c.st0 = rule->gamma;
+      c.st1 = std::numeric_limits<double>::infinity();
+      break;
+    case APX_RULE_OURS: {      // :240-256
+      double g = 0.0;
+      if (rule->gamma > 0) g = rule->gamma;
+      else if (rule->norm_A > 0) g = 1.0 / (2.0 * rule->Theta * rule->t * rule->norm_A);
+      else return fail(APX_ERR_INVALID, "you must provide gamma > 0 if norm_A = 0");   // :246
+      c.r_gamma = g;
+      c.gamma = g;
+      c.sigma = g * (rule->t * rule->t);
+      c.st0 = g;
+      c.st1 = g;
+      break;
+    }
+    case APX_RULE_OURS_PLUS:   // :284-297
+      if (!(rule->gamma > 0)) return fail(APX_ERR_INVALID, "you must provide gamma > 0");   // :288
+      c.gamma = rule->gamma;
+      c.sigma = rule->gamma;
+      c.st0 = rule->gamma;
+      c.st1 = rule->gamma;
+      break;
+    default:
+      return fail(APX_ERR_INVALID, "unknown step-size rule");
+  }
+  c.gamma_prev = c.gamma;
+  c.rho = 1.0;
+  APX_TRY(h2d(p->ctx, p->ctrl_buf.p, &c, sizeof(Ctrl)));
+  return APX_OK;
+}
+
+int32_t read_ctrl(apx_problem* p, Ctrl* out) { return d2h(p->ctx, out, p->ctrl_buf.p, sizeof(Ctrl)); }
+
+}  // namespace
+
+extern "C" {
+
+int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem** out) {
+  APX_REQUIRE(ctx != nullptr && d != nullptr && out != nullptr, "apx_problem_create: NULL argument");
+  *out = nullptr;
+  APX_REQUIRE(d->dtype == APX_F64 || d->dtype == APX_F32, "apx_problem_create: bad dtype");
+  APX_REQUIRE(d->n > 0, "apx_problem_create: n must be positive");
+  APX_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<apx_problem> p(new apx_problem());
+  p->ctx = ctx;
+  p->f_kind = d->f_kind;
+  p->dtype = d->dtype;
+  p->n = d->n;
+  p->n_pad = round_up(d->n, kPad) + kPad;   // room for a logistic X with n-1 == k*32 columns
+  p->A_f = d->A_f;
+  p->A_lin = d->A_lin;
+  p->allreduce = d->allreduce;
+  p->ar_user = d->allreduce_user;
+  const size_t es = dtype_size(d->dtype);
+
+  switch (d->f_kind) {
+    case APX_F_ZERO:
+      break;
+    case APX_F_LEAST_SQUARES:
+    case APX_F_LOGISTIC: {
+      APX_REQUIRE(d->A_f != nullptr && d->b != nullptr, "f needs its matrix A_f and the vector b / labels y");
+      APX_REQUIRE(d->A_f->ctx == ctx && d->A_f->dtype == d->dtype, "A_f: wrong context or dtype");
+      const int64_t ncol = d->f_kind == APX_F_LOGISTIC ? d->n - 1 : d->n;
+      APX_REQUIRE(d->A_f->n == ncol, d->f_kind == APX_F_LOGISTIC
+                                         ? "LogisticLoss: n must be columns(X) + 1 (bias is the last coordinate)"
+                                         : "LinearLeastSquares: n must equal columns(A)");
+      APX_REQUIRE(d->A_f->n_pad <= p->n_pad, "internal: gradient buffer too small");
+      APX_TRY(p->b.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
+      APX_TRY(p->res.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
+      APX_TRY(h2d(ctx, p->b.p, d->b, (size_t)d->A_f->m * es));
+      p->n_mean = (double)(d->n_total_rows > 0 ? d->n_total_rows : d->A_f->m);
+      break;
+    }
+    case APX_F_CALLBACK:
+      APX_REQUIRE(d->eval_cb != nullptr && d->pullback_cb != nullptr, "callback f needs eval_cb and pullback_cb");
+      APX_REQUIRE(d->allreduce == nullptr, "callback f cannot be row-sharded by the library");
+      p->eval_cb = d->eval_cb;
+      p->pb_cb = d->pullback_cb;
+      p->cb_user = d->cb_user;
+      break;
+    default:
+      return fail(APX_ERR_INVALID, "apx_problem_create: unknown f kind");
+  }
+
+  if (d->A_lin != nullptr) {
+    APX_REQUIRE(d->A_lin->ctx == ctx && d->A_lin->dtype == d->dtype, "A_lin: wrong context or dtype");
+    APX_REQUIRE(d->A_lin->n == d->n, "A_lin: columns must equal n");
+    APX_REQUIRE(d->m == 0 || d->m == d->A_lin->m, "m must equal rows(A_lin)");
+    p->m = d->A_lin->m;
+    p->m_pad = d->A_lin->ld;
+  } else {
+    // `A = 0`, `h = Zero()` — adaptive_proxgrad (src/AdaProx.jl:419)
+    APX_REQUIRE(d->h.kind == APX_G_ZERO && d->h.shift == nullptr, "h must be Zero when there is no linear operator");
+    p->m = 0;
+    p->m_pad = 0;
+  }
+  if (d->g.kind == APX_G_L2)
+    return fail(APX_ERR_UNSUPPORTED, "g = NormL2 is not built into the fused step kernel (h = NormL2 is)");
+
+  APX_TRY(make_prox_dev(ctx, d->g, d->dtype, d->n, p->g_lb, p->g_ub, p->g_shift, &p->gd));
+  APX_TRY(make_prox_dev(ctx, d->h, d->dtype, std::max<int64_t>(p->m, 1), p->h_lb, p->h_ub, p->h_shift, &p->hd));
+
+  APX_TRY(p->grad.alloc_zero((size_t)p->n_pad * es, ctx->stream));
+  APX_TRY(p->xtmp.alloc_zero((size_t)p->n_pad * es, ctx->stream));
+  APX_TRY(p->fsc_buf.alloc_zero(sizeof(double) * 8, ctx->stream));
+  APX_TRY(p->ctrl_buf.alloc_zero(sizeof(Ctrl), ctx->stream));
+  apx_rule r{};
+  r.kind = APX_RULE_FIXED;
+  r.gamma = 1.0;
+  r.t = 1.0;
+  APX_TRY(init_ctrl(p.get(), &r, 0.0));
+  *out = p.release();
+  return APX_OK;
+}
+
+int32_t apx_problem_destroy(apx_problem* p) {
+  if (p == nullptr) return APX_OK;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  delete p;
+  return APX_OK;
+}
+
+int32_t apx_eval(apx_problem* p, const void* x, double* f_x) {
+  APX_REQUIRE(p != nullptr && x != nullptr && f_x != nullptr, "apx_eval: NULL argument");
+  APX_REQUIRE(p->active == nullptr, "apx_eval: a solver is active on this problem");
+  APX_HIP(hipSetDevice(p->ctx->device));
+  APX_TRY(h2d(p->ctx, p->xtmp.p, x, (size_t)p->n * p->es()));
+  APX_TRY(eval_f(p, p->xtmp.p, true));
+  Ctrl c;
+  APX_TRY(read_ctrl(p, &c));
+  *f_x = c.f_x;
+  return APX_OK;
+}
+
+int32_t apx_pullback(apx_problem* p, void* grad) {
+  APX_REQUIRE(p != nullptr && grad != nullptr, "apx_pullback: NULL argument");
+  APX_REQUIRE(p->active == nullptr, "apx_pullback: a solver is active on this problem");
+  APX_HIP(hipSetDevice(p->ctx->device));
+  APX_TRY(pullback_f(p));
+  APX_TRY(d2h(p->ctx, grad, p->grad.p, (size_t)p->n * p->es()));
+  return APX_OK;
+}
+
+int32_t apx_prox(apx_ctx* ctx, const apx_prox_desc* desc, int32_t conj, int32_t dtype, const void* v, int64_t n,
+                 double gamma, void* y, double* g_y) {
+  APX_REQUIRE(ctx != nullptr && desc != nullptr && v != nullptr && y != nullptr, "apx_prox: NULL argument");
+  APX_REQUIRE(n > 0, "apx_prox: n must be positive");
+  APX_REQUIRE(dtype == APX_F64 || dtype == APX_F32, "apx_prox: bad dtype");
+  APX_HIP(hipSetDevice(ctx->device));
+  const size_t es = dtype_size(dtype);
+  DBuf lb, ub, shift, dv, dy;
+  ProxDev pd{};
+  APX_TRY(make_prox_dev(ctx, *desc, dtype, n, lb, ub, shift, &pd));
+  APX_TRY(dv.alloc_zero((size_t)round_up(n, kPad) * es, ctx->stream));
+  APX_TRY(dy.alloc_zero((size_t)round_up(n, kPad) * es, ctx->stream));
+  APX_TRY(h2d(ctx, dv.p, v, (size_t)n * es));
+  APX_TRY(vo_prox(ctx, dtype, dv.p, dy.p, n, pd, gamma, conj != 0, ctx->scal));
+  APX_TRY(d2h(ctx, y, dy.p, (size_t)n * es));
+  if (g_y != nullptr) {
+    double s = 0.0;
+    APX_TRY(d2h(ctx, &s, ctx->scal, sizeof(double)));
+    *g_y = conj ? std::numeric_limits<double>::quiet_NaN() : vo_gval_final_host(pd, s);
+  }
+  return APX_OK;
+}
+
+int32_t apx_prox_value(apx_ctx* ctx, const apx_prox_desc* desc, int32_t dtype, const void* x, int64_t n,
+                       double* value) {
+  APX_REQUIRE(ctx != nullptr && desc != nullptr && x != nullptr && value != nullptr, "apx_prox_value: NULL argument");
+  APX_REQUIRE(n > 0, "apx_prox_value: n must be positive");
+  APX_REQUIRE(dtype == APX_F64 || dtype == APX_F32, "apx_prox_value: bad dtype");
+  APX_HIP(hipSetDevice(ctx->device));
+  const size_t es = dtype_size(dtype);
+  DBuf lb, ub, shift, dx;
+  ProxDev pd{};
+  APX_TRY(make_prox_dev(ctx, *desc, dtype, n, lb, ub, shift, &pd));
+  APX_TRY(dx.alloc_zero((size_t)round_up(n, kPad) * es, ctx->stream));
+  APX_TRY(h2d(ctx, dx.p, x, (size_t)n * es));
+  APX_TRY(vo_gval(ctx, dtype, dx.p, n, pd, ctx->scal));
+  double s = 0.0;
+  APX_TRY(d2h(ctx, &s, ctx->scal, sizeof(double)));
+  *value = vo_gval_final_host(pd, s);
+  return APX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// stepping interface = the generic primal-dual loop
+// ---------------------------------------------------------------------------------------
+int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, const void* y0, double tol,
+                          const apx_solve_opts* opts, apx_solver** out) {
+  APX_REQUIRE(p != nullptr && rule != nullptr && x0 != nullptr && out != nullptr, "apx_solver_create: NULL argument");
+  APX_REQUIRE(p->active == nullptr, "apx_solver_create: another solver is active on this problem");
+  *out = nullptr;
+  apx_ctx* ctx = p->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  if (opts != nullptr && opts->use_graph)
+    return fail(APX_ERR_UNSUPPORTED, "hipGraph replay of the iteration is not built in this version");
+  const bool lin = p->A_lin != nullptr;
+  APX_REQUIRE(!lin || y0 != nullptr, "adaptive_primal_dual needs y0");
+  std::unique_ptr<apx_solver> s(new apx_solver());
+  s->p = p;
+  s->rule = *rule;
+  s->tol = tol;
+  s->poll_every = (opts != nullptr && opts->poll_every > 0) ? opts->poll_every : 16;
+  const size_t es = p->es();
+  const size_t nb = (size_t)p->n_pad * es;
+  APX_TRY(s->x.alloc_zero(nb, ctx->stream));
+  APX_TRY(s->xprev.alloc_zero(nb, ctx->stream));
+  APX_TRY(s->gprev.alloc_zero(nb, ctx->stream));
+  APX_TRY(s->v.alloc_zero(nb, ctx->stream));
+  if (lin) {
+    const size_t mb = (size_t)p->m_pad * es;
+    APX_TRY(s->aty.alloc_zero(nb, ctx->stream));
+    APX_TRY(s->y.alloc_zero(mb, ctx->stream));
+    APX_TRY(s->ax.alloc_zero(mb, ctx->stream));
+    APX_TRY(s->axprev.alloc_zero(mb, ctx->stream));
+  }
+  if (opts != nullptr && opts->records != nullptr && opts->record_cap > 0) {
+    s->rec_cap = opts->record_cap;
+    s->host_recs = opts->records;
+    APX_TRY(s->recs.alloc_zero((size_t)s->rec_cap * sizeof(apx_record), ctx->stream));
+  }
+  APX_TRY(init_ctrl(p, rule, tol));                                            // :324
+  APX_TRY(h2d(ctx, s->x.p, x0, (size_t)p->n * es));
+  if (lin) APX_TRY(h2d(ctx, s->y.p, y0, (size_t)p->m * es));
+
+  if (lin) {                                                                   // :327  A_x = A * x
+    int splits = 0;
+    APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, nullptr));
+    APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, nullptr));
+  }
+  APX_TRY(eval_f(p, s->x.p, false));                                           // :328
+  APX_TRY(pullback_f(p));
+  if (lin) APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, nullptr));   // :329
+  APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
+                  p->gd, p->ctrl()));                                          // :330-332
+  if (lin)                                                                     // :331  A_x_prev = A_x
+    APX_HIP(hipMemcpyAsync(s->axprev.p, s->ax.p, (size_t)p->m_pad * es, hipMemcpyDeviceToDevice, ctx->stream));
+  p->active = s.get();
+  *out = s.release();
+  return APX_OK;
+}
+
+static int32_t enqueue_iteration(apx_solver* s) {
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  const bool lin = p->A_lin != nullptr;
+  if (lin) {                                                                   // :335
+    int splits = 0;
+    APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, p->done_ptr()));
+    APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, p->done_ptr()));
+  }
+  APX_TRY(eval_f(p, s->x.p, false));                                           // :336
+  APX_TRY(pullback_f(p));
+  APX_TRY(vo_reduce_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p,
+                         lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
+                         s->rec_cap));                                         // :338-342
+  if (lin) {
+    APX_TRY(vo_dual(ctx, p->dtype, s->y.p, s->ax.p, s->axprev.p, p->m, p->hd, p->ctrl(), (apx_record*)s->recs.p,
+                    s->rec_cap));                                              // :344-354
+    APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, p->done_ptr()));    // :358
+  }
+  APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
+                  p->gd, p->ctrl()));                                          // :359-361
+  return APX_OK;
+}
+
+static int32_t poll_done(apx_solver* s, bool* done) {
+  apx_ctx* ctx = s->p->ctx;
+  int32_t* h = (int32_t*)&ctx->h_scal[40];
+  APX_HIP(hipMemcpyAsync(h, s->p->done_ptr(), sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  *done = *h != 0;
+  return APX_OK;
+}
+
+int32_t apx_solver_step(apx_solver* s, int64_t iters, int32_t sync) {
+  APX_REQUIRE(s != nullptr && iters >= 0, "apx_solver_step: bad argument");
+  APX_HIP(hipSetDevice(s->p->ctx->device));
+  const bool cb = s->p->f_kind == APX_F_CALLBACK;
+  for (int64_t k = 0; k < iters && !s->stopped; ++k) {
+    APX_TRY(enqueue_iteration(s));
+    s->iters += 1;
+    if (cb || (s->iters % s->poll_every) == 0) {
+      bool done = false;
+      APX_TRY(poll_done(s, &done));
+      if (done) s->stopped = true;
+    }
+  }
+  if (sync) APX_HIP(hipStreamSynchronize(s->p->ctx->stream));
+  return APX_OK;
+}
+
+int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* res) {
+  APX_REQUIRE(s != nullptr, "apx_solver_result: solver is NULL");
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  Ctrl c;
+  APX_TRY(read_ctrl(p, &c));
+  const bool lin = p->A_lin != nullptr;
+  if (x_out != nullptr) APX_TRY(d2h(ctx, x_out, s->x.p, (size_t)p->n * p->es()));
+  if (y_out != nullptr && lin) APX_TRY(d2h(ctx, y_out, s->y.p, (size_t)p->m * p->es()));
+  int64_t nrec = 0;
+  if (s->host_recs != nullptr) {
+    nrec = std::min<int64_t>(c.it, s->rec_cap);
+    APX_TRY(d2h(ctx, s->host_recs, s->recs.p, (size_t)nrec * sizeof(apx_record)));
+  }
+  if (res != nullptr) {
+    memset(res, 0, sizeof(*res));
+    const bool conv = c.done != 0;
+    const int64_t k = conv ? c.it : s->iters;
+    res->numit = k;
+    res->converged = conv ? 1 : 0;
+    res->flags = c.flags;
+    res->gamma = c.gamma;
+    res->sigma = c.sigma;
+    res->norm_res = c.norm_res;
+    res->objective = c.objective;
+    // SURVEY §3.4 identities (src/AdaProx.jl:324-363)
+    res->f_evals = k + 1;
+    res->grad_f_evals = k + 1;
+    res->prox_g_evals = conv ? k : k + 1;
+    res->prox_h_evals = k;
+    res->A_evals = lin ? k + 1 : -1;           // mul_count(0) === nothing (Appendix A.7)
+    res->At_evals = lin ? (conv ? k : k + 1) : -1;
+    res->n_records = nrec;
+    if (c.flags & APX_FLAG_DOMAIN) {
+      set_error("a step-size rule took sqrt of a negative number (Julia would throw DomainError)");
+      return APX_ERR_DOMAIN;
+    }
+  }
+  return APX_OK;
+}
+
+int32_t apx_solver_destroy(apx_solver* s) {
+  if (s == nullptr) return APX_OK;
+  (void)hipSetDevice(s->p->ctx->device);
+  (void)hipStreamSynchronize(s->p->ctx->stream);
+  if (s->p->active == s) s->p->active = nullptr;
+  delete s;
+  return APX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// one-shot entry points
+// ---------------------------------------------------------------------------------------
+int32_t apx_adaptive_primal_dual(apx_problem* p, const apx_rule* rule, const void* x0, const void* y0, double tol,
+                                 int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out,
+                                 apx_result* res) {
+  APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
+  apx_solver* s = nullptr;
+  APX_TRY(apx_solver_create(p, rule, x0, y0, tol, opts, &s));
+  int32_t rc = apx_solver_step(s, maxit, 1);
+  if (rc == APX_OK) rc = apx_solver_result(s, x_out, y_out, res);
+  apx_solver_destroy(s);
+  return rc;
+}
+
+int32_t apx_adaptive_proxgrad(apx_problem* p, const apx_rule* rule, const void* x0, double tol, int64_t maxit,
+                              const apx_solve_opts* opts, void* x_out, apx_result* res) {
+  APX_REQUIRE(p != nullptr, "apx_adaptive_proxgrad: problem is NULL");
+  APX_REQUIRE(p->A_lin == nullptr, "adaptive_proxgrad: the problem must have no linear operator (A = 0, h = Zero)");
+  return apx_adaptive_primal_dual(p, rule, x0, nullptr, tol, maxit, opts, x_out, nullptr, res);
+}
+
+int32_t apx_fixed_proxgrad(apx_problem* p, double gamma, const void* x0, double tol, int64_t maxit,
+                           const apx_solve_opts* opts, void* x_out, apx_result* res) {
+  apx_rule r{};                      // FixedStepsize(gamma, one(gamma))  :458
+  r.kind = APX_RULE_FIXED;
+  r.gamma = gamma;
+  r.t = 1.0;
+  return apx_adaptive_proxgrad(p, &r, x0, tol, maxit, opts, x_out, res);
+}
+
+int32_t apx_condat_vu(apx_problem* p, double Lf, double norm_A, const void* x0, const void* y0, double tol,
+                      int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res) {
+  APX_REQUIRE(p != nullptr && p->A_lin != nullptr, "condat_vu needs a linear operator");
+  if (norm_A < 0) {                  // :402-404  norm_A = norm(A)  (Frobenius)
+    double ss = 0.0;
+    APX_TRY(apx_matrix_sumsq(p->A_lin, &ss));
+    norm_A = std::sqrt(ss);
+  }
+  const double par = 5.0, par2 = 100.0;                                  // :400-401
+  const double alpha = (norm_A > par * Lf) ? 1.0 : par2 * norm_A / Lf;   // :405-409
+  const double gamma = 1.0 / (Lf / 2 + norm_A / alpha);                  // :410
+  const double sigma = 0.99 / (norm_A * alpha);                          // :411
+  apx_rule r{};
+  r.kind = APX_RULE_FIXED;           // FixedStepsize(gamma, sqrt(sigma / gamma))  :414
+  r.gamma = gamma;
+  r.t = std::sqrt(sigma / gamma);
+  return apx_adaptive_primal_dual(p, &r, x0, y0, tol, maxit, opts, x_out, y_out, res);
+}
+
+// backtracking_proxgrad — src/AdaProx.jl:34-64
+int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol,
+                                  int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
+  APX_REQUIRE(p != nullptr && x0 != nullptr && x_out != nullptr, "apx_backtracking_proxgrad: NULL argument");
+  APX_REQUIRE(p->A_lin == nullptr, "backtracking_proxgrad: the problem must have no linear operator");
+  APX_REQUIRE(p->active == nullptr, "a solver is active on this problem");
+  APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
+  apx_ctx* ctx = p->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  const size_t es = p->es();
+  const size_t nb = (size_t)p->n_pad * es;
+  DBuf bx, bz;
+  APX_TRY(bx.alloc_zero(nb, ctx->stream));
+  APX_TRY(bz.alloc_zero(nb, ctx->stream));
+  void* x = bx.p;
+  void* z = bz.p;
+  apx_rule r{};
+  r.kind = APX_RULE_FIXED;
+  r.gamma = 1.0;
+  r.t = 1.0;
+  APX_TRY(init_ctrl(p, &r, 0.0));
+  APX_TRY(h2d(ctx, x, x0, (size_t)p->n * es));
+  apx_record* recs = opts ? opts->records : nullptr;
+  const int64_t rec_cap = (opts && opts->records) ? opts->record_cap : 0;
+
+  auto read_scalars = [&](double* out4) -> int32_t {   // {dot, ss, graw, f_x}
+    APX_HIP(hipMemcpyAsync(ctx->h_scal, ctx->scal, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    APX_HIP(hipMemcpyAsync(ctx->h_scal + 3, (char*)p->ctrl_buf.p + offsetof(Ctrl, f_x), sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    APX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) out4[i] = ctx->h_scal[i];
+    return APX_OK;
+  };
+
+  int64_t f_evals = 0, grad_evals = 0, prox_evals = 0;
+  int32_t flags = 0;
+  double gamma = gamma0;                                                  // :51
+  APX_TRY(eval_f(p, x, true));                                            // :52
+  f_evals++;
+  double sc[4];
+  APX_TRY(read_scalars(sc));
+  double f_x = sc[3];
+  APX_TRY(pullback_f(p));
+  grad_evals++;
+
+  void* last_z = x;
+  int64_t it_done = maxit;
+  bool converged = false;
+  double norm_res = std::numeric_limits<double>::quiet_NaN(), objective = norm_res;
+  for (int64_t it = 1; it <= maxit; ++it) {                               // :53
+    gamma = xi * gamma;                                                   // :54  backtrack_stepsize(xi * gamma, ...)
+    double f_z = 0, ub_z = 0, nrm = 0, g_z = 0;
+    auto trial = [&]() -> int32_t {
+      APX_TRY(vo_bt_trial(ctx, p->dtype, x, p->grad.p, z, p->n, p->gd, gamma, ctx->scal));   // :35 / :43
+      prox_evals++;
+      APX_TRY(eval_f(p, z, true));                                        // :37 / :45
+      f_evals++;
+      APX_TRY(read_scalars(sc));
+      nrm = std::sqrt(sc[1]);
+      ub_z = f_x + sc[0] + 1.0 / (2.0 * gamma) * (nrm * nrm);             // :26
+      g_z = vo_gval_final_host(p->gd, sc[2]);
+      f_z = sc[3];
+      return APX_OK;
+    };
+    APX_TRY(trial());
+    while (f_z > ub_z) {                                                  // :38
+      gamma *= shrink;                                                    // :39
+      if (gamma < 1e-12) flags |= APX_FLAG_TINY_GAMMA;                    // :40-42 (logs, continues)
+      APX_TRY(trial());
+      if (gamma == 0.0 || !std::isfinite(gamma)) break;                   // the reference would spin forever here
+    }
+    norm_res = nrm / gamma;                                               // :55
+    objective = f_z + g_z;
+    if (recs != nullptr && it <= rec_cap) {                               // :56
+      apx_record& rr = recs[it - 1];
+      rr.it = it;
+      rr.gamma = gamma;
+      rr.sigma = std::numeric_limits<double>::quiet_NaN();
+      rr.norm_res = norm_res;
+      rr.objective = objective;
+      rr.f_x = f_z;
+      rr.f_evals = f_evals;
+      rr.grad_evals = grad_evals;
+    }
+    last_z = z;
+    if (norm_res <= tol) {                                                // :57-59
+      it_done = it;
+      converged = true;
+      break;
+    }
+    std::swap(x, z);                                                      // :60  x, f_x = z, f_z
+    f_x = f_z;
+    APX_TRY(pullback_f(p));                                               // :61  grad_x = pb()
+    grad_evals++;
+    last_z = x;
+  }
+  APX_TRY(d2h(ctx, x_out, last_z, (size_t)p->n * es));
+  if (res != nullptr) {
+    memset(res, 0, sizeof(*res));
+    res->numit = it_done;
+    res->converged = converged ? 1 : 0;
+    res->flags = flags;
+    res->gamma = gamma;
+    res->sigma = std::numeric_limits<double>::quiet_NaN();
+    res->norm_res = norm_res;
+    res->objective = objective;
+    res->f_evals = f_evals;
+    res->grad_f_evals = grad_evals;
+    res->prox_g_evals = prox_evals;
+    res->prox_h_evals = -1;
+    res->A_evals = -1;
+    res->At_evals = -1;
+    res->n_records = std::min<int64_t>(it_done, rec_cap);
+  }
+  return APX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,32 @@
+// vecops.h — launchers of the fused vector kernels (vecops.hip).
+#pragma once
+#include "apx_internal.h"
+
+namespace apx {
+
+// second stage of gemv_n + f epilogue; partial f sums land in fsc[0..1]; finalize => Ctrl.f_x
+int32_t vo_finish_rows(apx_ctx* ctx, int32_t dtype, int fk, int splits, int64_t ld, int64_t m, const void* b,
+                       const void* x, int64_t n, void* res, Ctrl* c, double* fsc, bool finalize);
+int32_t vo_f_final(apx_ctx* ctx, int fk, const double* fsc, Ctrl* c);
+int32_t vo_logistic_grad(apx_ctx* ctx, int32_t dtype, void* grad, int64_t n, const Ctrl* c);
+// K7+K8 then the rule (and, without a linear operator, the end of the iteration)
+int32_t vo_reduce_rule(apx_ctx* ctx, int32_t dtype, const void* x, const void* xprev, const void* grad,
+                       const void* gprev, const void* v, const void* aty, int64_t n, const ProxDev& g, Ctrl* c,
+                       bool has_lin, apx_record* recs, int64_t rec_cap);
+// K9 then the end of the iteration
+int32_t vo_dual(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axprev, int64_t m, const ProxDev& h,
+                Ctrl* c, apx_record* recs, int64_t rec_cap);
+// K5+K6
+int32_t vo_step(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v,
+                const void* aty, int64_t n, const ProxDev& g, const Ctrl* c);
+// K10: out3 (device) = { <grad, z-x>, sum (z-x)^2, raw g(z) accumulator }
+int32_t vo_bt_trial(apx_ctx* ctx, int32_t dtype, const void* x, const void* grad, void* z, int64_t n,
+                    const ProxDev& g, double gamma, double* out3);
+// op-level prox; out_val_sum (device) = raw accumulator of g(y)
+int32_t vo_prox(apx_ctx* ctx, int32_t dtype, const void* v, void* y, int64_t n, const ProxDev& g, double gamma,
+                bool conj, double* out_val_sum);
+// g(x) raw accumulator -> out_val_sum (device)
+int32_t vo_gval(apx_ctx* ctx, int32_t dtype, const void* x, int64_t n, const ProxDev& g, double* out_val_sum);
+double vo_gval_final_host(const ProxDev& g, double s);
+
+}  // namespace apx

@@ -1,0 +1,677 @@
+// vecops.hip — the O(m) / O(n) part of the iteration as a handful of fused kernels
+// (K2, K4-K11 of SURVEY §2.1).  Every reduction is two-stage (block partials in a fixed
+// order -> one single-block kernel), no atomics, so iterates are bit-reproducible.
+// All loop scalars (gamma, sigma, rho, rule state, residual, done flag) live in the
+// device `Ctrl` block: the host never has to read anything back inside the loop.
+//
+// Element arithmetic follows the order of the Julia source and is compiled with
+// -ffp-contract=off (Julia does not contract `x - gamma*g` into an fma); explicit
+// fma() is only used inside dot-product accumulations.
+#include <algorithm>
+#include <cmath>
+
+#include "apx_internal.h"
+#include "gemv_kernels.h"
+#include "vecops.h"
+
+namespace apx {
+
+// ---------------------------------------------------------------------------------
+// block-level helpers
+// ---------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ void block_partials_store(double (&v)[Q], double* __restrict__ red) {
+  __shared__ double sh[kBlock / 64][Q];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const double s = wave_sum(v[q]);
+    if (lane == 0) sh[wv][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < Q) {
+    double s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
+    red[(int64_t)threadIdx.x * kMaxRedBlocks + blockIdx.x] = s;
+  }
+}
+
+// single-block: sum `nblk` partials of quantity q (fixed order), result valid on every thread
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ red, int q, int nblk) {
+  __shared__ double sh[kBlock / 64];
+  __shared__ double total;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += kBlock) s += red[(int64_t)q * kMaxRedBlocks + i];
+  s = wave_sum(s);
+  __syncthreads();   // protects sh/total across successive calls
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sh[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) t += sh[w];
+    total = t;
+  }
+  __syncthreads();
+  return total;
+}
+
+// ---------------------------------------------------------------------------------
+// prox operators, element form (ProximalOperators.jl / ProximalCore.jl restated,
+// SURVEY §8a P1-P4; same forms as oracle/adaprox_oracle.py)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ double shift_at(const ProxDev& g, int64_t i) {
+  return g.has_shift ? (double)reinterpret_cast<const T*>(g.shift)[i] : 0.0;
+}
+
+// prox_{gamma g}(z) for the un-translated term; `aux` = ||z||_2 for NormL2
+template <typename T>
+__device__ __forceinline__ double prox_core(const ProxDev& g, double z, double gamma, int64_t i, double aux) {
+  switch (g.kind) {
+    case APX_G_L1: {   // y = z + (z <= -gl ? gl : (z >= gl ? -gl : -z))
+      const double gl = gamma * g.lambda;
+      return z + (z <= -gl ? gl : (z >= gl ? -gl : -z));
+    }
+    case APX_G_BOX:
+      return z < g.lb ? g.lb : (z > g.ub ? g.ub : z);
+    case APX_G_BOXV: {
+      const double lb = (double)reinterpret_cast<const T*>(g.lb_vec)[i];
+      const double ub = (double)reinterpret_cast<const T*>(g.ub_vec)[i];
+      return z < lb ? lb : (z > ub ? ub : z);
+    }
+    case APX_G_INDZERO:
+      return 0.0;
+    case APX_G_L2: {   // scale = max(0, 1 - lambda*gamma/||z||)
+      const double sc = fmax(0.0, 1.0 - g.lambda * gamma / aux);
+      return sc * z;
+    }
+    default:
+      return z;   // Zero
+  }
+}
+
+// Translate(g, b): z = v + b ; y = prox_g(z) ; y -= b
+template <typename T>
+__device__ __forceinline__ double prox_elem(const ProxDev& g, double v, double gamma, int64_t i, double aux) {
+  if (g.has_shift) {
+    const double b = shift_at<T>(g, i);
+    return prox_core<T>(g, v + b, gamma, i, aux) - b;
+  }
+  return prox_core<T>(g, v, gamma, i, aux);
+}
+
+// prox of convex_conjugate(h) at w with step sigma (src/AdaProx.jl:325,345):
+//   Zero -> IndZero (0) ; IndZero -> Zero (w) ; otherwise Moreau:
+//   u = w/sigma ; p = prox_{h,1/sigma}(u) ; y = w - sigma*p      (ProximalCore prox_conjugate!)
+template <typename T>
+__device__ __forceinline__ double prox_conj_elem(const ProxDev& h, double w, double sigma, int64_t i, double aux) {
+  if (h.kind == APX_G_ZERO && !h.has_shift) return 0.0;
+  if (h.kind == APX_G_INDZERO && !h.has_shift) return w;
+  const double u = w / sigma;
+  const double p = prox_elem<T>(h, u, 1.0 / sigma, i, aux);
+  return w - sigma * p;
+}
+
+// value g(x): accumulate `gval_elem`, finish with `gval_final`
+template <typename T>
+__device__ __forceinline__ double gval_elem(const ProxDev& g, double x, int64_t i) {
+  const double z = x + shift_at<T>(g, i);
+  switch (g.kind) {
+    case APX_G_L1: return fabs(z);
+    case APX_G_L2: return z * z;
+    case APX_G_BOX: return (z < g.lb || z > g.ub) ? 1.0 : 0.0;
+    case APX_G_BOXV: {
+      const double lb = (double)reinterpret_cast<const T*>(g.lb_vec)[i];
+      const double ub = (double)reinterpret_cast<const T*>(g.ub_vec)[i];
+      return (z < lb || z > ub) ? 1.0 : 0.0;
+    }
+    case APX_G_INDZERO: return z != 0.0 ? 1.0 : 0.0;
+    default: return 0.0;
+  }
+}
+__device__ __forceinline__ double gval_final(const ProxDev& g, double s) {
+  switch (g.kind) {
+    case APX_G_L1: return g.lambda * s;
+    case APX_G_L2: return g.lambda * sqrt(s);
+    case APX_G_BOX:
+    case APX_G_BOXV:
+    case APX_G_INDZERO: return s > 0.0 ? INFINITY : 0.0;
+    default: return 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// K2 / K4: second stage of gemv_n fused with the f-specific epilogue
+//   least squares: res = A*w - b ; sum res^2                     (experiments/lasso/runme.jl:22,24)
+//   logistic     : logits = X*w[1:end-1] .+ w[end] ; u = 1 + exp(-logits)
+//                  loss terms (y-1)*logits - log(u) ; res = 1/u - y   (sparse_logreg/runme.jl:24-36)
+// ---------------------------------------------------------------------------------
+template <typename T, int FK>
+__global__ __launch_bounds__(kBlock) void k_finish_rows(const double* __restrict__ part, int splits, int64_t ld,
+                                                        int64_t m, const T* __restrict__ b,
+                                                        const T* __restrict__ x, int64_t n,
+                                                        T* __restrict__ res, double* __restrict__ red,
+                                                        const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  double q[2] = {0.0, 0.0};
+  double bias = 0.0;
+  if constexpr (FK == APX_F_LOGISTIC) bias = (double)x[n - 1];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * ld + i];
+    if constexpr (FK == APX_F_LEAST_SQUARES) {
+      const T r = (T)(s - (double)b[i]);
+      res[i] = r;
+      q[0] = fma((double)r, (double)r, q[0]);
+    } else {
+      const double logit = s + bias;
+      const double u = 1.0 + exp(-logit);
+      const double yi = (double)b[i];
+      q[0] += (yi - 1.0) * logit - log(u);
+      const T d = (T)(1.0 / u - yi);
+      res[i] = d;
+      q[1] += (double)d;
+    }
+  }
+  block_partials_store<2>(q, red);
+}
+
+// single block: reduce the f partials into fsc[0..1]; FINAL also publishes f_x / bias_grad
+__device__ __forceinline__ void f_finalize(Ctrl* c, int fk, const double* fsc) {
+  if (fk == APX_F_LEAST_SQUARES) {
+    const double nr = sqrt(fsc[0]);          // 0.5 * norm(res)^2 : nrm2 THEN square (Appendix A.2)
+    c->f_x = 0.5 * (nr * nr);
+  } else {
+    c->f_x = -(fsc[0] / c->n_mean);          // -mean(...)
+    c->bias_grad = fsc[1] / c->n_mean;       // mean(probs - y)
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_f_reduce(const double* __restrict__ red, int nblk, int fk,
+                                                     double* __restrict__ fsc, Ctrl* c, int finalize) {
+  if (c->done != 0) return;
+  const double s0 = reduce_partials(red, 0, nblk);
+  const double s1 = reduce_partials(red, 1, nblk);
+  if (threadIdx.x == 0) {
+    fsc[0] = s0;
+    fsc[1] = s1;
+    if (finalize) f_finalize(c, fk, fsc);
+  }
+}
+
+__global__ void k_f_final(int fk, const double* __restrict__ fsc, Ctrl* c) {
+  if (c->done != 0) return;
+  if (threadIdx.x == 0 && blockIdx.x == 0) f_finalize(c, fk, fsc);
+}
+
+// logistic pullback tail: grad[1:end-1] = X'*(probs - y) ./ N ; grad[end] = mean(probs - y)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_logistic_grad(T* __restrict__ grad, int64_t n, const Ctrl* c) {
+  if (c->done != 0) return;
+  const double N = c->n_mean;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock)
+    grad[j] = (j == n - 1) ? (T)c->bias_grad : (T)((double)grad[j] / N);
+}
+
+// ---------------------------------------------------------------------------------
+// K7 + K8 (+ K11): primal residual and the step-size reductions in one pass over n
+//   primal_res = (v - x)/gamma + grad_x + At_y                     (src/AdaProx.jl:338)
+//   ||dg||^2, <dg,dx>, ||dx||^2, dg = grad_x - grad_x_prev, dx = x - x_prev   (:260-261, :227)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reduce_n(const T* __restrict__ x, const T* __restrict__ xprev,
+                                                     const T* __restrict__ grad, const T* __restrict__ gprev,
+                                                     const T* __restrict__ v, const T* __restrict__ aty,
+                                                     int64_t n, ProxDev g, const Ctrl* c,
+                                                     double* __restrict__ red) {
+  if (c->done != 0) return;
+  const double gamma = c->gamma;
+  double q[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xi = (double)x[i], gi = (double)grad[i];
+    double pr = ((double)v[i] - xi) / gamma + gi;
+    if (aty != nullptr) pr = pr + (double)aty[i];
+    const double dg = gi - (double)gprev[i];
+    const double dx = xi - (double)xprev[i];
+    q[0] = fma(pr, pr, q[0]);
+    q[1] = fma(dg, dg, q[1]);
+    q[2] = fma(dg, dx, q[2]);
+    q[3] = fma(dx, dx, q[3]);
+    q[4] += gval_elem<T>(g, xi, i);
+  }
+  block_partials_store<5>(q, red);
+}
+
+// ---------------------------------------------------------------------------------
+// step-size rules (src/AdaProx.jl:208-308), scalar, one thread
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double jl_min2(double a, double b) {   // Julia min: NaN-propagating
+  if (isnan(a) || isnan(b)) return NAN;
+  return a < b ? a : b;
+}
+__device__ __forceinline__ double jl_sqrt(double v, int32_t* flags) {   // Julia: DomainError for v < 0
+  if (v < 0.0) { *flags |= APX_FLAG_DOMAIN; return NAN; }
+  return sqrt(v);
+}
+__device__ __forceinline__ double nan_to_zero(double v) { return isnan(v) ? 0.0 : v; }   // :24
+
+__device__ void rule_update(Ctrl* c, double s_dg2, double s_dgdx, double s_dx2) {
+  int32_t fl = 0;
+  const double gamma_prev = c->gamma;
+  double gamma = c->gamma, sigma = c->sigma;
+  switch (c->rule_kind) {
+    case APX_RULE_FIXED:   // :213-215
+      gamma = c->r_gamma;
+      sigma = c->r_gamma * (c->r_t * c->r_t);
+      break;
+    case APX_RULE_MM: {    // :226-230
+      const double g_prev = c->st0, rho = c->st1;
+      const double L = sqrt(s_dg2) / sqrt(s_dx2);
+      gamma = jl_min2(jl_sqrt(1.0 + rho, &fl) * g_prev, 1.0 / (2.0 * L));
+      sigma = gamma * (c->r_t * c->r_t);
+      c->st0 = gamma;
+      c->st1 = gamma / g_prev;
+      break;
+    }
+    case APX_RULE_OURS: {  // :258-273
+      const double g1 = c->st0, g0 = c->st1;
+      const double ndg = sqrt(s_dg2), ndx = sqrt(s_dx2);
+      const double xi = (c->r_t * c->r_t) * (g1 * g1) * (c->r_normA * c->r_normA);
+      const double C = nan_to_zero((ndg * ndg) / s_dgdx);
+      const double L = nan_to_zero(s_dgdx / (ndx * ndx));
+      const double D = g1 * L * (g1 * C - 1.0);
+      const double d1 = 1.0 + c->r_delta;
+      const double inner = 1.0 - 4.0 * xi * (d1 * d1);
+      const double t1 = g1 * jl_sqrt(1.0 + g1 / g0, &fl);
+      const double t2 = 1.0 / (2.0 * c->r_Theta * c->r_t * c->r_normA);
+      const double t3 = g1 * jl_sqrt(inner, &fl) /
+                        jl_sqrt(2.0 * d1 * (D + jl_sqrt(D * D + xi * inner, &fl)), &fl);
+      gamma = jl_min2(jl_min2(t1, t2), t3);
+      sigma = gamma * (c->r_t * c->r_t);
+      c->st0 = gamma;
+      c->st1 = g1;
+      break;
+    }
+    case APX_RULE_OURS_PLUS: {   // :299-308
+      const double g1 = c->st0, g0 = c->st1;
+      const double ndg = sqrt(s_dg2), ndx = sqrt(s_dx2);
+      const double C = nan_to_zero((ndg * ndg) / s_dgdx);
+      const double L = nan_to_zero(s_dgdx / (ndx * ndx));
+      const double D = nan_to_zero(1.0 - 2.0 * c->r_r + g1 * L * (g1 * C + 2.0 * (c->r_r - 1.0)));
+      const double a = jl_sqrt(1.0 / (c->r_r * (c->r_nu + c->r_xi)) + g1 / g0, &fl);
+      const double b = jl_sqrt((c->r_nu * (1.0 + c->r_xi) - 1.0) / (c->r_nu * (c->r_nu + c->r_xi)), &fl) /
+                       jl_sqrt(fmax(D, 0.0), &fl);
+      gamma = g1 * jl_min2(a, b);
+      sigma = gamma;
+      c->st0 = gamma;
+      c->st1 = g1;
+      break;
+    }
+  }
+  if (isnan(gamma)) fl |= APX_FLAG_NAN_GAMMA;
+  c->gamma_prev = gamma_prev;
+  c->gamma = gamma;
+  c->sigma = sigma;
+  c->rho = gamma / gamma_prev;     // :342
+  c->flags |= fl;
+}
+
+__device__ __forceinline__ void finish_iteration(Ctrl* c, apx_record* recs, int64_t rec_cap) {
+  // norm_res = sqrt(norm(primal_res)^2 + norm(dual_res)^2)           (:348)
+  c->norm_res = sqrt(c->npr2 + c->ndr2);
+  c->objective = c->f_x + c->g_x + c->h_Ax;                          // (:351)
+  if (recs != nullptr && c->it <= rec_cap) {
+    apx_record r;
+    r.it = c->it;
+    r.gamma = c->gamma;
+    r.sigma = c->sigma;
+    r.norm_res = c->norm_res;
+    r.objective = c->objective;
+    r.f_x = c->f_x;
+    r.f_evals = c->it + 1;
+    r.grad_evals = c->it + 1;
+    recs[c->it - 1] = r;
+  }
+  if (c->norm_res <= c->tol) c->done = 1;                            // (:354)
+}
+
+// single block: finish K7/K8, update the rule (:340-342); without a linear operator also
+// close the iteration (dual_res == 0 for adaptive_proxgrad: h = Zero, A = 0)
+__global__ __launch_bounds__(kBlock) void k_rule(const double* __restrict__ red, int nblk, ProxDev g, Ctrl* c,
+                                                 int has_lin, apx_record* recs, int64_t rec_cap) {
+  if (c->done != 0) return;
+  const double s_pr = reduce_partials(red, 0, nblk);
+  const double s_dg2 = reduce_partials(red, 1, nblk);
+  const double s_dgdx = reduce_partials(red, 2, nblk);
+  const double s_dx2 = reduce_partials(red, 3, nblk);
+  const double s_g = reduce_partials(red, 4, nblk);
+  if (threadIdx.x != 0) return;
+  c->it += 1;
+  const double npr = sqrt(s_pr);
+  c->npr2 = npr * npr;
+  c->g_x = gval_final(g, s_g);
+  rule_update(c, s_dg2, s_dgdx, s_dx2);
+  if (!has_lin) {
+    c->ndr2 = 0.0;
+    c->h_Ax = 0.0;
+    finish_iteration(c, recs, rec_cap);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// K9: dual extrapolation, conjugate prox, dual residual (src/AdaProx.jl:344-347)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dual_pre(const T* __restrict__ y, const T* __restrict__ ax,
+                                                     const T* __restrict__ axprev, int64_t m, ProxDev h,
+                                                     const Ctrl* c, double* __restrict__ red) {
+  if (c->done != 0) return;
+  const double sigma = c->sigma, rho = c->rho;
+  double q[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double a = (double)ax[i];
+    const double w = (double)y[i] + sigma * ((1.0 + rho) * a - rho * (double)axprev[i]);
+    const double z = w / sigma + shift_at<T>(h, i);
+    q[0] = fma(z, z, q[0]);
+  }
+  block_partials_store<1>(q, red);
+}
+
+__global__ __launch_bounds__(kBlock) void k_dual_pre_final(const double* __restrict__ red, int nblk, Ctrl* c) {
+  if (c->done != 0) return;
+  const double s = reduce_partials(red, 0, nblk);
+  if (threadIdx.x == 0) c->h_pre = sqrt(s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dual(T* __restrict__ y, const T* __restrict__ ax,
+                                                 T* __restrict__ axprev, int64_t m, ProxDev h, const Ctrl* c,
+                                                 double* __restrict__ red) {
+  if (c->done != 0) return;
+  const double sigma = c->sigma, rho = c->rho, aux = c->h_pre;
+  double q[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double a = (double)ax[i];
+    const double w = (double)y[i] + sigma * ((1.0 + rho) * a - rho * (double)axprev[i]);   // :344
+    const T yn = (T)prox_conj_elem<T>(h, w, sigma, i, aux);                                // :345
+    const double dr = (w - (double)yn) / sigma - a;                                        // :347
+    q[0] = fma(dr, dr, q[0]);
+    q[1] += gval_elem<T>(h, a, i);
+    y[i] = yn;
+    axprev[i] = (T)a;                                                                      // :360 (A_x_prev)
+  }
+  block_partials_store<2>(q, red);
+}
+
+__global__ __launch_bounds__(kBlock) void k_final(const double* __restrict__ red, int nblk, ProxDev h, Ctrl* c,
+                                                  apx_record* recs, int64_t rec_cap) {
+  if (c->done != 0) return;
+  const double s_dr = reduce_partials(red, 0, nblk);
+  const double s_h = reduce_partials(red, 1, nblk);
+  if (threadIdx.x != 0) return;
+  const double ndr = sqrt(s_dr);
+  c->ndr2 = ndr * ndr;
+  c->h_Ax = gval_final(h, s_h);
+  finish_iteration(c, recs, rec_cap);
+}
+
+// ---------------------------------------------------------------------------------
+// K5 + K6: v = x - gamma*(grad_x + At_y) ; rotate prev buffers ; x = prox_{gamma g}(v)
+// (src/AdaProx.jl:330-332, :359-361)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_step(T* __restrict__ x, T* __restrict__ xprev,
+                                                 const T* __restrict__ grad, T* __restrict__ gprev,
+                                                 T* __restrict__ v, const T* __restrict__ aty, int64_t n,
+                                                 ProxDev g, const Ctrl* c) {
+  if (c->done != 0) return;
+  const double gamma = c->gamma;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xi = (double)x[i], gi = (double)grad[i];
+    double gs = gi;
+    if (aty != nullptr) gs = gi + (double)aty[i];
+    const T vi = (T)(xi - gamma * gs);
+    v[i] = vi;
+    xprev[i] = (T)xi;
+    gprev[i] = (T)gi;
+    x[i] = (T)prox_elem<T>(g, (double)vi, gamma, i, 0.0);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// K10: backtracking trial  z = prox_{gamma g}(x - gamma*grad) ; <grad, z-x> ; ||z-x||^2 ; g(z)
+// (src/AdaProx.jl:35-36, :26)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bt_trial(const T* __restrict__ x, const T* __restrict__ grad,
+                                                     T* __restrict__ z, int64_t n, ProxDev g, double gamma,
+                                                     double* __restrict__ red) {
+  double q[3] = {0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xi = (double)x[i], gi = (double)grad[i];
+    const T vi = (T)(xi - gamma * gi);
+    const T zi = (T)prox_elem<T>(g, (double)vi, gamma, i, 0.0);
+    const double d = (double)zi - xi;
+    q[0] = fma(gi, d, q[0]);
+    q[1] = fma(d, d, q[1]);
+    q[2] += gval_elem<T>(g, (double)zi, i);
+    z[i] = zi;
+  }
+  block_partials_store<3>(q, red);
+}
+
+// single block: raw sums of the first nq quantities -> out[0..nq)
+__global__ __launch_bounds__(kBlock) void k_sum_q(const double* __restrict__ red, int nblk, int nq,
+                                                  double* __restrict__ out) {
+  for (int q = 0; q < nq; ++q) {
+    const double s = reduce_partials(red, q, nblk);
+    if (threadIdx.x == 0) out[q] = s;
+  }
+}
+
+// generic prox for the op-level entry point (apx_prox): optional conjugate, optional l2 pre-pass
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sumsq_shift(const T* __restrict__ v, int64_t n, ProxDev g,
+                                                        double scale, double* __restrict__ red) {
+  double q[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double z = (double)v[i] * scale + shift_at<T>(g, i);
+    q[0] = fma(z, z, q[0]);
+  }
+  block_partials_store<1>(q, red);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_prox(const T* __restrict__ v, T* __restrict__ y, int64_t n, ProxDev g,
+                                                 double gamma, int conj, const double* __restrict__ aux_sumsq,
+                                                 double* __restrict__ red) {
+  const double aux = aux_sumsq != nullptr ? sqrt(aux_sumsq[0]) : 0.0;
+  double q[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double vi = (double)v[i];
+    const T yi = conj ? (T)prox_conj_elem<T>(g, vi, gamma, i, aux) : (T)prox_elem<T>(g, vi, gamma, i, aux);
+    y[i] = yi;
+    q[0] += gval_elem<T>(g, (double)yi, i);
+  }
+  block_partials_store<1>(q, red);
+}
+
+// g(x): raw accumulator of the value of a proximable term (finished by gval_final / vo_gval_final_host)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gval(const T* __restrict__ x, int64_t n, ProxDev g,
+                                                 double* __restrict__ red) {
+  double q[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    q[0] += gval_elem<T>(g, (double)x[i], i);
+  block_partials_store<1>(q, red);
+}
+
+// ---------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------
+static inline unsigned vgrid(int64_t n) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(kMaxRedBlocks, (n + kBlock - 1) / kBlock));
+}
+
+#define DISPATCH_T(dtype, CALL_F64, CALL_F32) \
+  do {                                        \
+    if ((dtype) == APX_F32) { CALL_F32; }     \
+    else { CALL_F64; }                        \
+  } while (0)
+
+int32_t vo_finish_rows(apx_ctx* ctx, int32_t dtype, int fk, int splits, int64_t ld, int64_t m, const void* b,
+                       const void* x, int64_t n, void* res, Ctrl* c, double* fsc, bool finalize) {
+  const unsigned g = vgrid(m);
+  const int* done = &c->done;
+  if (fk == APX_F_LEAST_SQUARES) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((k_finish_rows<double, APX_F_LEAST_SQUARES>), dim3(g), dim3(kBlock), 0, ctx->stream,
+                                  ctx->part, splits, ld, m, (const double*)b, (const double*)x, n, (double*)res,
+                                  ctx->red, done),
+               hipLaunchKernelGGL((k_finish_rows<float, APX_F_LEAST_SQUARES>), dim3(g), dim3(kBlock), 0, ctx->stream,
+                                  ctx->part, splits, ld, m, (const float*)b, (const float*)x, n, (float*)res,
+                                  ctx->red, done));
+  } else {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((k_finish_rows<double, APX_F_LOGISTIC>), dim3(g), dim3(kBlock), 0, ctx->stream,
+                                  ctx->part, splits, ld, m, (const double*)b, (const double*)x, n, (double*)res,
+                                  ctx->red, done),
+               hipLaunchKernelGGL((k_finish_rows<float, APX_F_LOGISTIC>), dim3(g), dim3(kBlock), 0, ctx->stream,
+                                  ctx->part, splits, ld, m, (const float*)b, (const float*)x, n, (float*)res,
+                                  ctx->red, done));
+  }
+  hipLaunchKernelGGL(k_f_reduce, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)g, fk, fsc, c,
+                     finalize ? 1 : 0);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_f_final(apx_ctx* ctx, int fk, const double* fsc, Ctrl* c) {
+  hipLaunchKernelGGL(k_f_final, dim3(1), dim3(64), 0, ctx->stream, fk, fsc, c);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_logistic_grad(apx_ctx* ctx, int32_t dtype, void* grad, int64_t n, const Ctrl* c) {
+  const unsigned g = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_logistic_grad<double>, dim3(g), dim3(kBlock), 0, ctx->stream, (double*)grad, n, c),
+             hipLaunchKernelGGL(k_logistic_grad<float>, dim3(g), dim3(kBlock), 0, ctx->stream, (float*)grad, n, c));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_reduce_rule(apx_ctx* ctx, int32_t dtype, const void* x, const void* xprev, const void* grad,
+                       const void* gprev, const void* v, const void* aty, int64_t n, const ProxDev& g, Ctrl* c,
+                       bool has_lin, apx_record* recs, int64_t rec_cap) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_reduce_n<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)x,
+                                (const double*)xprev, (const double*)grad, (const double*)gprev, (const double*)v,
+                                (const double*)aty, n, g, c, ctx->red),
+             hipLaunchKernelGGL(k_reduce_n<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)x,
+                                (const float*)xprev, (const float*)grad, (const float*)gprev, (const float*)v,
+                                (const float*)aty, n, g, c, ctx->red));
+  hipLaunchKernelGGL(k_rule, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, g, c, has_lin ? 1 : 0, recs,
+                     rec_cap);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_dual(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axprev, int64_t m, const ProxDev& h,
+                Ctrl* c, apx_record* recs, int64_t rec_cap) {
+  const unsigned gr = vgrid(m);
+  if (h.kind == APX_G_L2) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_dual_pre<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)y,
+                                  (const double*)ax, (const double*)axprev, m, h, c, ctx->red),
+               hipLaunchKernelGGL(k_dual_pre<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)y,
+                                  (const float*)ax, (const float*)axprev, m, h, c, ctx->red));
+    hipLaunchKernelGGL(k_dual_pre_final, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, c);
+  }
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_dual<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)y, (const double*)ax,
+                                (double*)axprev, m, h, c, ctx->red),
+             hipLaunchKernelGGL(k_dual<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)y, (const float*)ax,
+                                (float*)axprev, m, h, c, ctx->red));
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, h, c, recs, rec_cap);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_step(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v,
+                const void* aty, int64_t n, const ProxDev& g, const Ctrl* c) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_step<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)x, (double*)xprev,
+                                (const double*)grad, (double*)gprev, (double*)v, (const double*)aty, n, g, c),
+             hipLaunchKernelGGL(k_step<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)x, (float*)xprev,
+                                (const float*)grad, (float*)gprev, (float*)v, (const float*)aty, n, g, c));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_bt_trial(apx_ctx* ctx, int32_t dtype, const void* x, const void* grad, void* z, int64_t n,
+                    const ProxDev& g, double gamma, double* out3) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_bt_trial<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)x,
+                                (const double*)grad, (double*)z, n, g, gamma, ctx->red),
+             hipLaunchKernelGGL(k_bt_trial<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)x,
+                                (const float*)grad, (float*)z, n, g, gamma, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 3, out3);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_prox(apx_ctx* ctx, int32_t dtype, const void* v, void* y, int64_t n, const ProxDev& g, double gamma,
+                bool conj, double* out_val_sum) {
+  const unsigned gr = vgrid(n);
+  double* aux = nullptr;
+  if (g.kind == APX_G_L2) {
+    // ||z||, z = v (+shift) for the plain prox, z = v/gamma (+shift) for the conjugate
+    const double scale = conj ? 1.0 / gamma : 1.0;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_sumsq_shift<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)v, n,
+                                  g, scale, ctx->red),
+               hipLaunchKernelGGL(k_sumsq_shift<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)v, n,
+                                  g, scale, ctx->red));
+    hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, ctx->scal + 8);
+    aux = ctx->scal + 8;
+  }
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_prox<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)v, (double*)y,
+                                n, g, gamma, conj ? 1 : 0, aux, ctx->red),
+             hipLaunchKernelGGL(k_prox<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)v, (float*)y, n,
+                                g, gamma, conj ? 1 : 0, aux, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, out_val_sum);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_gval(apx_ctx* ctx, int32_t dtype, const void* x, int64_t n, const ProxDev& g, double* out_val_sum) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_gval<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)x, n, g,
+                                ctx->red),
+             hipLaunchKernelGGL(k_gval<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)x, n, g,
+                                ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, out_val_sum);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+double vo_gval_final_host(const ProxDev& g, double s) {
+  switch (g.kind) {
+    case APX_G_L1: return g.lambda * s;
+    case APX_G_L2: return g.lambda * std::sqrt(s);
+    case APX_G_BOX:
+    case APX_G_BOXV:
+    case APX_G_INDZERO: return s > 0.0 ? INFINITY : 0.0;
+    default: return 0.0;
+  }
+}
+
+}  // namespace apx

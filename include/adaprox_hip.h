@@ -1,0 +1,273 @@
+/*
+ * adaprox_hip.h — C-ABI of the MI355X-native adaptive proximal-gradient hot path.
+ *
+ * Drop-in boundary for AdaProx.jl (pylat/adaptive-proximal-algorithms).  The
+ * reference has no FFI of its own: its boundary is Julia multiple dispatch on
+ * `eval_with_pullback(f, x)` / `prox(g, v, gamma)` / `A*x` / `A'*y`
+ * (src/AdaProx.jl:11-16, src/counting.jl:36-82) and the keyword-argument solver
+ * entry points (src/AdaProx.jl:50, :312-322, :367-381, :418, :457).  Each entry
+ * point below names the reference interface it replaces.  Julia reaches these
+ * with `ccall` (see INTEGRATION.md and julia/AdaProxHIP.jl); tests and bench.py
+ * reach them with Python `ctypes`.
+ *
+ * Conventions
+ *  - every function returns an int32 status (APX_OK = 0); apx_last_error() gives
+ *    the message of the last failure on the calling thread.  Nothing throws
+ *    across the boundary.
+ *  - host pointers are plain caller-owned buffers, valid for the duration of the
+ *    call only.  Device memory lives behind the opaque handles.
+ *  - matrices are column-major (Julia layout).  dtype selects fp64 / fp32 storage.
+ *  - a context is bound to one device and one HIP stream and is NOT thread-safe
+ *    (the reference is single-threaded too: src/counting.jl:4-14).
+ */
+#ifndef ADAPROX_HIP_H
+#define ADAPROX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APX_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+  APX_OK = 0,
+  APX_ERR_INVALID = 1,      /* bad argument (Julia: `error(...)` / `@assert`)         */
+  APX_ERR_HIP = 2,          /* HIP runtime failure (no device, OOM, launch failure)   */
+  APX_ERR_UNSUPPORTED = 3,  /* combination not built (e.g. callback f + hipGraph)     */
+  APX_ERR_DOMAIN = 4,       /* Julia would have thrown DomainError (sqrt of negative) */
+  APX_ERR_CALLBACK = 5      /* a user callback returned non-zero                      */
+};
+
+/* warning bits reported in apx_result.flags (the loop keeps going, like the reference) */
+enum {
+  APX_FLAG_TINY_GAMMA = 1,  /* backtracking gamma < 1e-12: `@error` logged, src/AdaProx.jl:40-42 */
+  APX_FLAG_NAN_GAMMA = 2,   /* the rule produced a NaN step (Julia `min` propagates NaN)         */
+  APX_FLAG_DOMAIN = 4       /* sqrt of a negative number inside a rule (Julia: DomainError)      */
+};
+
+enum { APX_F64 = 0, APX_F32 = 1 };
+
+/* smooth term f — `eval_with_pullback(f, x)` implementations of the experiments */
+enum {
+  APX_F_ZERO = 0,           /* experiments/least_absolute_deviation/runme.jl:18-21 */
+  APX_F_LEAST_SQUARES = 1,  /* LinearLeastSquares, experiments/lasso/runme.jl:16-27 */
+  APX_F_LOGISTIC = 2,       /* LogisticLoss, experiments/sparse_logreg/runme.jl:18-39 (bias = last coord) */
+  APX_F_CALLBACK = 3        /* any user f: host callbacks (the f callable convention)  */
+};
+
+/* nonsmooth terms g / h — ProximalOperators.jl / ProximalCore.jl objects */
+enum {
+  APX_G_ZERO = 0,           /* ProximalCore.Zero      : prox = identity                */
+  APX_G_L1 = 1,             /* NormL1(lambda)         : soft-threshold                 */
+  APX_G_BOX = 2,            /* IndBox(lb, ub) scalars : clamp                          */
+  APX_G_BOXV = 3,           /* IndBox(lb[], ub[])     : per-coordinate clamp           */
+  APX_G_INDZERO = 4,        /* ProximalCore.IndZero   : prox = 0                       */
+  APX_G_L2 = 5              /* NormL2(lambda)         : block soft-threshold           */
+};
+
+/* step-size rules — src/AdaProx.jl:208-308 */
+enum {
+  APX_RULE_FIXED = 0,       /* FixedStepsize(gamma, t)            :208-215 */
+  APX_RULE_MM = 1,          /* MalitskyMishchenkoRule(gamma, t)   :217-230 */
+  APX_RULE_OURS = 2,        /* OurRule(gamma,t,norm_A,delta,Theta):232-273 */
+  APX_RULE_OURS_PLUS = 3    /* OurRulePlus(gamma,xi,nu,r)         :277-308 */
+};
+
+typedef struct apx_ctx apx_ctx;
+typedef struct apx_matrix apx_matrix;
+typedef struct apx_problem apx_problem;
+typedef struct apx_solver apx_solver;
+
+/* A proximable term: kind + parameters.  `shift` (length = vector length, host,
+ * may be NULL) wraps the term in Translate(., shift): x -> g(x + shift)
+ * (ProximalOperators.Translate; LAD uses Translate(NormL1(), -y),
+ * experiments/least_absolute_deviation/runme.jl:41). */
+typedef struct {
+  int32_t kind;          /* APX_G_*                                   */
+  int32_t _pad;
+  double lambda;         /* NormL1 / NormL2 weight                    */
+  double lb, ub;         /* IndBox scalar bounds                      */
+  const void* lb_vec;    /* IndBox vector bounds (host, dtype of problem), APX_G_BOXV */
+  const void* ub_vec;
+  const void* shift;     /* Translate shift b (host, dtype of problem) or NULL */
+} apx_prox_desc;
+
+/* host callbacks for a user-defined smooth term (APX_F_CALLBACK):
+ *   eval(user, x, n, &f_x)   — `f_x, pb = eval_with_pullback(f, x)`; must retain what pb needs
+ *   pullback(user, grad, n)  — `pb()`: gradient at the x of the latest eval
+ * x / grad are host buffers of the problem's dtype.  Return 0 on success. */
+typedef int32_t (*apx_eval_fn)(void* user, const void* x, int64_t n, double* f_x);
+typedef int32_t (*apx_pullback_fn)(void* user, void* grad, int64_t n);
+
+/* all-reduce hook for the row-sharded multi-GPU path: sums `count` elements of
+ * dtype `dtype` at DEVICE pointer `buf` across ranks, enqueued on `stream`
+ * (hipStream_t).  bench.py / the Python host wire this to torch.distributed
+ * (backend "nccl" = RCCL over xGMI).  NULL = single device. */
+typedef int32_t (*apx_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, void* stream);
+
+typedef struct {
+  int32_t f_kind;          /* APX_F_*                                                        */
+  int32_t dtype;           /* APX_F64 / APX_F32 — storage of all vectors of this problem     */
+  int64_t n;               /* primal dimension (logistic: columns of X + 1 for the bias)     */
+  int64_t m;               /* dual dimension = rows of A_lin (0 when there is no A_lin)      */
+  const apx_matrix* A_f;   /* matrix of the smooth term (A of least squares, X of logistic)  */
+  const void* b;           /* host: b (least squares) or labels y in {0,1} (logistic); length rows(A_f) */
+  int64_t n_total_rows;    /* logistic: N of the mean (global rows when row-sharded); 0 => rows(A_f)    */
+  apx_eval_fn eval_cb;     /* APX_F_CALLBACK                                                 */
+  apx_pullback_fn pullback_cb;
+  void* cb_user;
+  apx_prox_desc g;         /* g : prox_{gamma g}                                              */
+  apx_prox_desc h;         /* h : the loop uses prox of convex_conjugate(h), src/AdaProx.jl:325 */
+  const apx_matrix* A_lin; /* linear operator A of h(Ax); NULL <=> `A = 0` (adaptive_proxgrad, :419) */
+  apx_allreduce_fn allreduce;  /* row-sharded A_f: all-reduce of [A_k' r_k ; partial f]        */
+  void* allreduce_user;
+} apx_problem_desc;
+
+typedef struct {
+  int32_t kind;            /* APX_RULE_*                      */
+  int32_t _pad;
+  double gamma;            /* all rules                        */
+  double t;                /* Fixed / MM / Ours                */
+  double norm_A;           /* Ours                             */
+  double delta;            /* Ours                             */
+  double Theta;            /* Ours                             */
+  double xi, nu, r;        /* OursPlus                         */
+} apx_rule;
+
+/* One `@logmsg Record` row (src/AdaProx.jl:56, :351).  The *_evals fields of the
+ * reference record are functions of `it` and are rebuilt host-side. */
+typedef struct {
+  int64_t it;
+  double gamma;
+  double sigma;            /* NaN for backtracking_proxgrad (no sigma field at :56) */
+  double norm_res;
+  double objective;        /* f_x + g(x) + h(A_x)  (:351)   or  f_z + g_z (:56)     */
+  double f_x;
+  int64_t f_evals;         /* cumulative eval_with_pullback calls at this record     */
+  int64_t grad_evals;      /* cumulative pullback calls at this record               */
+} apx_record;
+
+typedef struct {
+  int64_t numit;           /* the `it` / `numit` the reference returns                */
+  int32_t converged;       /* 1: returned through `norm_res <= tol`, 0: maxit         */
+  int32_t flags;           /* APX_FLAG_* warning bits                                 */
+  double gamma, sigma, norm_res, objective;   /* last iteration                       */
+  /* Counting semantics (src/counting.jl:16-23) */
+  int64_t f_evals, grad_f_evals, prox_g_evals, prox_h_evals, A_evals, At_evals;
+  int64_t n_records;       /* rows written to the caller's record buffer              */
+} apx_result;
+
+typedef struct {
+  apx_record* records;     /* caller buffer for per-iteration records, or NULL        */
+  int64_t record_cap;      /* rows available; the first record_cap iterations are kept */
+  int32_t use_graph;       /* 1: replay the iteration as a captured hipGraph          */
+  int32_t poll_every;      /* convergence flag is read back every this many iterations (0 = default 16) */
+} apx_solve_opts;
+
+/* kernel timing collected with HIP events on the context's stream (bench.py roofline) */
+typedef struct {
+  int64_t launches;
+  double total_ms;
+  double bytes;            /* algorithmic bytes moved by those launches (m*n*sizeof(T) each) */
+} apx_kernel_stat;
+
+enum { APX_KSTAT_GEMV_N = 0, APX_KSTAT_GEMV_T = 1, APX_KSTAT_COUNT = 2 };
+
+/* ---- library / context ----------------------------------------------------- */
+int32_t apx_abi_version(void);
+const char* apx_last_error(void);
+/* stream: an existing hipStream_t to adopt (e.g. torch's current stream) or NULL to create one */
+int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out);
+int32_t apx_ctx_destroy(apx_ctx* ctx);
+int32_t apx_ctx_sync(apx_ctx* ctx);
+int32_t apx_ctx_stream(apx_ctx* ctx, void** stream_out);
+/* enable/disable per-launch HIP-event timing of the GEMV kernels; read / reset the totals */
+int32_t apx_ctx_profile(apx_ctx* ctx, int32_t enable);
+int32_t apx_ctx_kernel_stats(apx_ctx* ctx, apx_kernel_stat* stats /* [APX_KSTAT_COUNT] */, int32_t reset);
+
+/* tuning hooks (no reference counterpart): pick one of the compiled GEMV variants and the
+ * target grid size; negative / zero arguments leave a field unchanged.  Defaults are the
+ * measured-best configuration on MI355X. */
+int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_variant, int64_t n_blocks,
+                                int64_t t_blocks);
+int32_t apx_gemv_variant_count(int32_t transposed);
+const char* apx_gemv_variant_name(int32_t transposed, int32_t i);
+
+/* ---- dense matrices (the `A` / `X` the experiments build) ------------------ */
+int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx_matrix** out); /* zero-filled */
+/* column-major host matrix with leading dimension lda (elements) -> device */
+int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, int64_t lda,
+                          int32_t dtype, apx_matrix** out);
+int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda);
+int32_t apx_matrix_free(apx_matrix* A);
+int32_t apx_matrix_shape(const apx_matrix* A, int64_t* m, int64_t* n, int32_t* dtype);
+/* element (i,j) = lo + (hi-lo)*u(seed, j*m_total + row_offset + i); counter-based, so a
+ * row shard of a global m_total x n matrix is generated independently on each GPU
+ * (stands in for `rand(m, n) .* 2 .- 1`, experiments/lasso/runme.jl:49) */
+int32_t apx_matrix_fill_uniform(apx_matrix* A, uint64_t seed, double lo, double hi,
+                                int64_t row_offset, int64_t m_total);
+/* A[:, j] *= alpha[j]   (`C * diagm(0 => alpha)`, experiments/lasso/runme.jl:68) */
+int32_t apx_matrix_scale_columns(apx_matrix* A, const double* alpha);
+/* A[:, j] = value       (`hcat(X, ones(m,1))`, experiments/least_absolute_deviation/runme.jl:42) */
+int32_t apx_matrix_fill_column(apx_matrix* A, int64_t j, double value);
+/* sum of squares of all entries: norm(A)^2, Frobenius (runme.jl:46; Appendix A.1) */
+int32_t apx_matrix_sumsq(const apx_matrix* A, double* out);
+/* `A*x` and `A'*y` (src/counting.jl:68-82): host vectors in, host vectors out */
+int32_t apx_gemv_n(const apx_matrix* A, const void* x, void* y);
+int32_t apx_gemv_t(const apx_matrix* A, const void* r, void* g);
+
+/* ---- problem = (f, g, h, A) ------------------------------------------------ */
+int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* desc, apx_problem** out);
+int32_t apx_problem_destroy(apx_problem* p);
+/* `f_x, pb = eval_with_pullback(f, x)` (src/AdaProx.jl:11): keeps the residual on device */
+int32_t apx_eval(apx_problem* p, const void* x, double* f_x);
+/* `pb()`: gradient at the x of the latest apx_eval (one GEMV-T on the saved residual) */
+int32_t apx_pullback(apx_problem* p, void* grad);
+/* `y, g_y = prox(g, v, gamma)` (ProximalCore.prox); conj != 0 applies convex_conjugate(desc) */
+int32_t apx_prox(apx_ctx* ctx, const apx_prox_desc* desc, int32_t conj, int32_t dtype,
+                 const void* v, int64_t n, double gamma, void* y, double* g_y);
+
+/* `g(x)` — the callable value of a proximable term, used by the logged objective
+ * `f_x + g(x) + h(A_x)` (src/AdaProx.jl:351) */
+int32_t apx_prox_value(apx_ctx* ctx, const apx_prox_desc* desc, int32_t dtype, const void* x, int64_t n,
+                       double* value);
+
+/* ---- solvers --------------------------------------------------------------- */
+/* adaptive_primal_dual(x, y; f, g, h, A, rule, tol, maxit)  — src/AdaProx.jl:312-364 */
+int32_t apx_adaptive_primal_dual(apx_problem* p, const apx_rule* rule, const void* x0, const void* y0,
+                                 double tol, int64_t maxit, const apx_solve_opts* opts,
+                                 void* x_out, void* y_out, apx_result* res);
+/* adaptive_proxgrad(x; f, g, rule, tol, maxit)              — src/AdaProx.jl:418-421 */
+int32_t apx_adaptive_proxgrad(apx_problem* p, const apx_rule* rule, const void* x0,
+                              double tol, int64_t maxit, const apx_solve_opts* opts,
+                              void* x_out, apx_result* res);
+/* fixed_proxgrad(x; f, g, gamma, tol, maxit)                — src/AdaProx.jl:457-459 */
+int32_t apx_fixed_proxgrad(apx_problem* p, double gamma, const void* x0,
+                           double tol, int64_t maxit, const apx_solve_opts* opts,
+                           void* x_out, apx_result* res);
+/* condat_vu(x, y; f, g, h, A, Lf, norm_A, tol, maxit), default-parameter branch — src/AdaProx.jl:367-416.
+ * norm_A < 0 => computed as the Frobenius norm of A_lin (`norm(A)`, :403). */
+int32_t apx_condat_vu(apx_problem* p, double Lf, double norm_A, const void* x0, const void* y0,
+                      double tol, int64_t maxit, const apx_solve_opts* opts,
+                      void* x_out, void* y_out, apx_result* res);
+/* backtracking_proxgrad(x0; f, g, gamma0, xi, shrink, tol, maxit) — src/AdaProx.jl:34-64 */
+int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0, double xi, double shrink,
+                                  double tol, int64_t maxit, const apx_solve_opts* opts,
+                                  void* x_out, apx_result* res);
+
+/* ---- stepping interface (bench.py times exactly K iterations with data resident) ---- */
+/* runs the pre-loop of adaptive_primal_dual (src/AdaProx.jl:324-332) and leaves the state on device */
+int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, const void* y0,
+                          double tol, const apx_solve_opts* opts, apx_solver** out);
+/* enqueues `iters` iterations of :334-362 on the stream; does not wait unless sync != 0 */
+int32_t apx_solver_step(apx_solver* s, int64_t iters, int32_t sync);
+int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* res);
+int32_t apx_solver_destroy(apx_solver* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAPROX_HIP_H */
