@@ -557,7 +557,7 @@ def _builtin_eval(f, w):
     """`eval_with_pullback` of a built-in f at op level: GEMV-N now, GEMV-T when pb() is called."""
     w = np.ascontiguousarray(w, dtype=f.A.dtype)
     if f._op is None:
-        f._op = _Problem(f, Zero(), Zero(), None, f.A.dtype, f.A.ctx)
+        f._op = _Problem(f, Zero(), Zero(), None, f.A.dtype, f.A.ctx).finalize(f.n)
     op = f._op
     fx = C.c_double()
     L.check(op.lib.apx_eval(op.h, _ptr(w), C.byref(fx)))

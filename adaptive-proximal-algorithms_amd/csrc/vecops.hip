@@ -114,10 +114,10 @@ __device__ __forceinline__ double prox_conj_elem(const ProxDev& h, double w, dou
   return w - sigma * p;
 }
 
-// value g(x): accumulate `gval_elem`, finish with `gval_final`
+// value g(x): accumulate `gval_elem`, finish with `gval_final`.  gval_core is the
+// un-translated term; Translate(g, b)(x) = g(x + b).
 template <typename T>
-__device__ __forceinline__ double gval_elem(const ProxDev& g, double x, int64_t i) {
-  const double z = x + shift_at<T>(g, i);
+__device__ __forceinline__ double gval_core(const ProxDev& g, double z, int64_t i) {
   switch (g.kind) {
     case APX_G_L1: return fabs(z);
     case APX_G_L2: return z * z;
@@ -130,6 +130,21 @@ __device__ __forceinline__ double gval_elem(const ProxDev& g, double x, int64_t 
     case APX_G_INDZERO: return z != 0.0 ? 1.0 : 0.0;
     default: return 0.0;
   }
+}
+template <typename T>
+__device__ __forceinline__ double gval_elem(const ProxDev& g, double x, int64_t i) {
+  return gval_core<T>(g, x + shift_at<T>(g, i), i);
+}
+// prox that also accumulates the value the prox call returns: for Translate that is the
+// value of the INNER prox at the inner point (`v = prox!(y, f.f, z, gamma)`), not g(y + b)
+template <typename T>
+__device__ __forceinline__ double prox_elem_val(const ProxDev& g, double v, double gamma, int64_t i, double aux,
+                                                double* val) {
+  const double b = shift_at<T>(g, i);
+  const double z = g.has_shift ? v + b : v;
+  const T p = (T)prox_core<T>(g, z, gamma, i, aux);
+  *val += gval_core<T>(g, (double)p, i);
+  return g.has_shift ? (double)p - b : (double)p;
 }
 __device__ __forceinline__ double gval_final(const ProxDev& g, double s) {
   switch (g.kind) {
@@ -452,11 +467,10 @@ __global__ __launch_bounds__(kBlock) void k_bt_trial(const T* __restrict__ x, co
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const double xi = (double)x[i], gi = (double)grad[i];
     const T vi = (T)(xi - gamma * gi);
-    const T zi = (T)prox_elem<T>(g, (double)vi, gamma, i, 0.0);
+    const T zi = (T)prox_elem_val<T>(g, (double)vi, gamma, i, 0.0, &q[2]);
     const double d = (double)zi - xi;
     q[0] = fma(gi, d, q[0]);
     q[1] = fma(d, d, q[1]);
-    q[2] += gval_elem<T>(g, (double)zi, i);
     z[i] = zi;
   }
   block_partials_store<3>(q, red);
@@ -491,9 +505,9 @@ __global__ __launch_bounds__(kBlock) void k_prox(const T* __restrict__ v, T* __r
   double q[1] = {0.0};
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const double vi = (double)v[i];
-    const T yi = conj ? (T)prox_conj_elem<T>(g, vi, gamma, i, aux) : (T)prox_elem<T>(g, vi, gamma, i, aux);
+    const T yi = conj ? (T)prox_conj_elem<T>(g, vi, gamma, i, aux)
+                      : (T)prox_elem_val<T>(g, vi, gamma, i, aux, &q[0]);
     y[i] = yi;
-    q[0] += gval_elem<T>(g, (double)yi, i);
   }
   block_partials_store<1>(q, red);
 }

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the adaptive proximal-gradient hot path on MI355X.
+
+Metric (BASELINE.json): prox-grad iterations/sec of `adaptive_proxgrad` (OurRule) on the
+dense lasso of experiments/lasso/runme.jl with A 50 000 x 100 000 fp64 (40.0 GB resident in
+HBM), plus the fraction of the HBM roofline of the dominant GEMV kernel.
+
+A "step" = ONE iteration of src/AdaProx.jl:334-362 = GEMV-N (A x - b, ||r||^2) + GEMV-T
+(A' r) + the fused residual / step-size / soft-threshold kernels, on data already resident
+in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every
+rank holds a 50 000-row shard of the (50 000 N) x 100 000 matrix (BASELINE config C4 at
+N = 8) and the partial gradient A_k' r_k is all-reduced with RCCL over xGMI each iteration.
+`value` = shard-iterations per second summed over the ranks (= iterations/sec at N = 1).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--m", type=int, default=50_000, help="rows per GPU")
+    ap.add_argument("--n", type=int, default=100_000)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=12)
+    return ap.parse_args()
+
+
+def cpu_baseline(n: int, m_full: int, rows: int, iters: int, seed: int) -> dict:
+    """The oracle (numpy -> OpenBLAS dgemv, the BLAS family Julia's `A*x` reaches) timed on the
+    host cores on a bounded row-sample of the same workload, scaled per byte to the full
+    matrix.  A reported baseline, not the target."""
+    from oracle import adaprox_oracle as O
+    from oracle import problems as P
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    prob = P.random_lasso(rows, n, pfactor=10, seed=seed)
+    gam = 1.0 / P.opnorm_sq_power(prob.A, iters=5)
+    f, g = O.LinearLeastSquares(prob.A, prob.b), O.NormL1(prob.lam)
+    O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=2)       # warm-up
+    t0 = time.perf_counter()
+    O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=iters)
+    dt = time.perf_counter() - t0
+    its_sample = (iters + 1) / dt                       # iters loop passes + the pre-loop gradient
+    return {
+        "value": its_sample * rows / m_full, "unit": "iters/sec", "cores": threads, "kind": "port",
+        "sample": f"oracle (numpy/OpenBLAS dgemv, {threads} threads) on a {rows}x{n} fp64 lasso of the same "
+                  f"generator, {iters} iterations in {dt:.2f} s = {its_sample:.2f} it/s on the sample, scaled by "
+                  f"bytes ({rows}/{m_full}) to the {m_full}x{n} matrix; Julia runtime absent on this image",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import adaprox_amd as apx
+    from importlib import import_module
+    problems = import_module("adaptive-proximal-algorithms_amd.problems")
+    sharded = import_module("adaptive-proximal-algorithms_amd.sharded")
+
+    stream = torch.cuda.Stream(device=local_rank)
+    with torch.cuda.stream(stream):
+        ctx = apx.Context(device=local_rank, stream=stream.cuda_stream)
+        apx.set_default_context(ctx)
+        ar_host = sharded.host_allreduce(dist, local_rank) if world > 1 else None
+        ar_dev = sharded.device_allreduce(dist, local_rank) if world > 1 else None
+
+        t_setup = time.perf_counter()
+        prob = problems.device_lasso(args.m, args.n, pfactor=10, seed=args.seed, rank=rank, world=world,
+                                     power_iters=30, ctx=ctx, allreduce_host=ar_host)
+        t_setup = time.perf_counter() - t_setup
+
+        f = apx.LinearLeastSquares(prob.A, prob.b, allreduce=ar_dev)
+        g = apx.NormL1(prob.lam)
+        solver = apx.Solver(np.zeros(args.n), f=f, g=g, rule=apx.OurRule(gamma=1.0 / prob.Lf), tol=0.0,
+                            ctx=ctx, poll_every=1 << 30)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        solver.step(args.warmup, sync=True)
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)                       # HIP events around every GEMV launch, on the launch stream
+        barrier()
+        t0 = time.perf_counter()
+        solver.step(args.steps, sync=False)
+        barrier()
+        dt = time.perf_counter() - t0
+        ctx.profile(False)
+        stats = ctx.kernel_stats(reset=True)
+
+        x, _, res = solver.result()
+        if not np.all(np.isfinite(x)):
+            sys.exit("bench.py: non-finite iterate")
+        solver.close()
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        es = 8
+        per_kernel = {}
+        for k, st in stats.items():
+            if st["launches"]:
+                avg_ms = st["total_ms"] / st["launches"]
+                per_kernel[k] = {"launches": st["launches"], "avg_ms": avg_ms,
+                                 "GBps": st["bytes"] / st["launches"] / (avg_ms * 1e-3) / 1e9}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
+        algo_bytes = float(args.m) * args.n * es                 # one streaming read of A per launch
+        achieved = per_kernel[dom]["GBps"]
+        iters_per_s = args.steps / dt
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "prox-grad iters/sec on dense lasso A 50k x 100k (adaptive_proxgrad, OurRule)",
+            "value": world * iters_per_s, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"lasso, dense A {args.m}x{args.n} fp64 per GPU, adaptive_proxgrad on "
+                                   f"{world} MI355X (GEMV + soft-threshold + stepsize reductions)"
+                                   + ("" if world == 1 else f"; row-sharded {args.m * world}x{args.n}, RCCL all-reduce of A'r"),
+                       "rows_per_gpu": args.m, "cols": args.n, "rule": "OurRule(gamma=1/Lf)",
+                       "parallelism": "single" if world == 1 else f"row-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "per_kernel": per_kernel,
+                         "iteration_frac": 2 * algo_bytes * iters_per_s / 1e9 / HBM_PEAK_GBS},
+            "setup_s": t_setup, "final_objective": res.objective, "lasso_optimum": prob.optimum,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.n, args.m, args.cpu_rows, args.cpu_iters, args.seed)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
