@@ -24,6 +24,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 from typing import Any, Callable, Optional
 
 import numpy as np
@@ -99,6 +100,8 @@ class Context:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+            return
         try:
             self.close()
         except Exception:
@@ -233,6 +236,8 @@ class DeviceMatrix:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+            return
         try:
             self.free()
         except Exception:
@@ -756,6 +761,8 @@ class _Problem:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+            return
         try:
             self.close()
         except Exception:
@@ -961,6 +968,8 @@ class Solver:
         self.prob.close()
 
     def __del__(self):
+        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+            return
         try:
             self.close()
         except Exception:

@@ -81,6 +81,10 @@ struct apx_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cu = 256;
+  // matrices / problems created on this context keep it alive: apx_ctx_destroy on a context
+  // that still has children only marks it, and the last child to go frees it
+  int64_t children = 0;
+  bool zombie = false;
   // scratch
   double* part = nullptr;        // GEMV partial sums
   size_t part_bytes = 0;
@@ -106,6 +110,9 @@ struct apx_matrix {
 };
 
 namespace apx {
+
+void ctx_retain(apx_ctx* ctx);
+void ctx_release(apx_ctx* ctx);
 
 // ---- launchers implemented in gemv.hip -------------------------------------------
 int32_t ensure_part(apx_ctx* ctx, size_t bytes);

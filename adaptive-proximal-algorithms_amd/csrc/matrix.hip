@@ -22,6 +22,12 @@ int32_t fail(int32_t code, const std::string& msg) {
   return code;
 }
 
+void ctx_retain(apx_ctx* ctx) { ctx->children += 1; }
+void ctx_release(apx_ctx* ctx) {
+  ctx->children -= 1;
+  if (ctx->children <= 0 && ctx->zombie) apx_ctx_destroy(ctx);
+}
+
 int32_t DBuf::alloc_zero(size_t nbytes, hipStream_t s) {
   if (p) (void)hipFree(p);
   p = nullptr;
@@ -131,7 +137,7 @@ int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
   // defaults: measured best on MI355X; overridable for sweeps
   ctx->cfg.n_variant = 0;
   ctx->cfg.t_variant = 0;
-  ctx->cfg.n_target_blocks = 16 * (int64_t)ctx->num_cu;
+  ctx->cfg.n_target_blocks = 32 * (int64_t)ctx->num_cu;
   ctx->cfg.t_target_blocks = 8 * (int64_t)ctx->num_cu;
   if (const char* s = getenv("APX_GEMV_N_VARIANT")) ctx->cfg.n_variant = atoi(s);
   if (const char* s = getenv("APX_GEMV_T_VARIANT")) ctx->cfg.t_variant = atoi(s);
@@ -143,8 +149,19 @@ int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
   return APX_OK;
 }
 
+static void ctx_free(apx_ctx* ctx);
+
 int32_t apx_ctx_destroy(apx_ctx* ctx) {
   if (ctx == nullptr) return APX_OK;
+  if (ctx->children > 0) {   // matrices / problems still alive: defer
+    ctx->zombie = true;
+    return APX_OK;
+  }
+  ctx_free(ctx);
+  return APX_OK;
+}
+
+static void ctx_free(apx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& ev : ctx->ev_pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -156,7 +173,6 @@ int32_t apx_ctx_destroy(apx_ctx* ctx) {
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
-  return APX_OK;
 }
 
 int32_t apx_ctx_sync(apx_ctx* ctx) {
@@ -246,6 +262,7 @@ int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx
     delete A;
     return fail(APX_ERR_HIP, std::string("apx_matrix_create: memset: ") + hipGetErrorString(e));
   }
+  ctx_retain(ctx);
   *out = A;
   return APX_OK;
 }
@@ -288,7 +305,9 @@ int32_t apx_matrix_free(apx_matrix* A) {
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->stream);
   if (A->d) (void)hipFree(A->d);
+  apx_ctx* ctx = A->ctx;
   delete A;
+  ctx_release(ctx);
   return APX_OK;
 }
 

@@ -321,6 +321,7 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   r.gamma = 1.0;
   r.t = 1.0;
   APX_TRY(init_ctrl(p.get(), &r, 0.0));
+  ctx_retain(ctx);
   *out = p.release();
   return APX_OK;
 }
@@ -329,7 +330,9 @@ int32_t apx_problem_destroy(apx_problem* p) {
   if (p == nullptr) return APX_OK;
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
+  apx_ctx* ctx = p->ctx;
   delete p;
+  ctx_release(ctx);
   return APX_OK;
 }
 

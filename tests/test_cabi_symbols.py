@@ -1,0 +1,119 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports
+exactly the symbols include/adaprox_hip.h declares, the ctypes mirror of the structs has the
+C layout, and the product refuses to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "adaprox_hip.h")
+
+
+@pytest.fixture(scope="module")
+def apx():
+    import __graft_entry__ as g
+    lib_path = os.path.join(ROOT, "adaptive-proximal-algorithms_amd", "csrc", "libadaprox_hip.so")
+    if not os.path.exists(lib_path):
+        g.build()
+    import adaprox_amd as apx
+    return apx
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(apx_[a-z0-9_]+)\s*\(", src)) - {"apx_eval_fn", "apx_pullback_fn", "apx_allreduce_fn"})
+
+
+def test_library_exports_every_declared_symbol(apx):
+    lib = apx.load()
+    decl = _declared()
+    assert len(decl) >= 35
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/adaprox_hip.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", apx.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\sT\s+(apx_[a-z0-9_]+)", out)))
+    assert exported == decl, "exported apx_* symbols and the header disagree"
+
+
+def test_ctypes_prototypes_cover_the_header(apx):
+    L = __import__("importlib").import_module("adaptive-proximal-algorithms_amd._lib")
+    assert sorted(L.PROTOTYPES) == _declared()
+
+
+def test_struct_layouts_match_the_header(apx, tmp_path):
+    """sizeof/offsetof of every struct crossing the boundary, from a C compile of the header."""
+    L = __import__("importlib").import_module("adaptive-proximal-algorithms_amd._lib")
+    prog = tmp_path / "layout.c"
+    prog.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "adaprox_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(apx_prox_desc), sizeof(apx_problem_desc), sizeof(apx_rule),
+         sizeof(apx_record), sizeof(apx_result), sizeof(apx_solve_opts), sizeof(apx_kernel_stat));
+  printf("%zu %zu %zu %zu\n", offsetof(apx_problem_desc, g), offsetof(apx_problem_desc, h),
+         offsetof(apx_problem_desc, A_lin), offsetof(apx_problem_desc, allreduce));
+  printf("%zu %zu %zu\n", offsetof(apx_result, f_evals), offsetof(apx_result, n_records), offsetof(apx_rule, xi));
+  return 0;
+}''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    sizes = list(map(int, lines[0].split()))
+    assert sizes == [C.sizeof(L.ProxDesc), C.sizeof(L.ProblemDesc), C.sizeof(L.Rule), C.sizeof(L.Record),
+                     C.sizeof(L.Result), C.sizeof(L.SolveOpts), C.sizeof(L.KernelStat)]
+    offs = list(map(int, lines[1].split()))
+    assert offs == [L.ProblemDesc.g.offset, L.ProblemDesc.h.offset, L.ProblemDesc.A_lin.offset,
+                    L.ProblemDesc.allreduce.offset]
+    offs = list(map(int, lines[2].split()))
+    assert offs == [L.Result.f_evals.offset, L.Result.n_records.offset, L.Rule.xi.offset]
+
+
+def test_header_is_plain_c_and_cites_the_reference():
+    src = open(HEADER).read()
+    subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", HEADER], check=True)
+    for cite in ("src/AdaProx.jl:312-364", "src/AdaProx.jl:418-421", "src/AdaProx.jl:34-64", "src/AdaProx.jl:367-416",
+                 "src/AdaProx.jl:457-459", "src/counting.jl", "experiments/lasso/runme.jl:16-27"):
+        assert cite in src, f"header does not cite {cite}"
+    # no torch / C++ types in the signatures: plain pointers and sizes only
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for banned in ("torch", "at::", "c10::", "std::", "#include <hip"):
+        assert banned not in code, f"{banned} leaks into the C-ABI header"
+
+
+def test_no_device_means_loud_failure_not_fallback(apx):
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is visible")
+    except ImportError:
+        pass
+    with pytest.raises(apx.ApxError) as ei:
+        apx.Context(device=0)
+    assert "no" in str(ei.value).lower()
+    with pytest.raises(apx.ApxError):
+        apx.DeviceMatrix.from_numpy(np.eye(2))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "adaptive-proximal-algorithms_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{fn} imports oracle/"
+
+
+def test_rule_constructors_mirror_reference_errors(apx):
+    with pytest.raises(ValueError, match="you must provide gamma > 0 if norm_A = 0"):
+        apx.OurRule()                                  # src/AdaProx.jl:246
+    with pytest.raises(ValueError, match="you must provide gamma > 0"):
+        apx.OurRulePlus()                              # src/AdaProx.jl:288
+    r = apx.OurRule(norm_A=2.0, t=0.5)                 # :244  1 / (2 * Theta * t * norm_A)
+    assert r.gamma == pytest.approx(1 / (2 * 1.2 * 0.5 * 2.0))
+    assert (r.t, r.delta, r.Theta) == (0.5, 0.0, 1.2)

@@ -60,7 +60,7 @@ def test_every_gemv_n_variant(apx, variant):
             ctx.set_gemv_config(n_variant=variant, n_blocks=blocks)
             assert _rel(dA @ x, A @ x) < 1e-12
     finally:
-        ctx.set_gemv_config(n_variant=0, n_blocks=16 * 256)
+        ctx.set_gemv_config(n_variant=0, n_blocks=32 * 256)
 
 
 @pytest.mark.parametrize("variant", range(12))
