@@ -135,9 +135,11 @@ int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
   if ((e = hipMalloc((void**)&ctx->scal, sizeof(double) * 16)) != hipSuccess) return bail(e, "hipMalloc scal");
   if ((e = hipHostMalloc((void**)&ctx->h_scal, sizeof(double) * 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   // defaults: measured best on MI355X; overridable for sweeps
-  ctx->cfg.n_variant = 0;
-  ctx->cfg.t_variant = 0;
-  ctx->cfg.n_target_blocks = 32 * (int64_t)ctx->num_cu;
+  // sweep of round 1 (gpurun_out/sweep2.log, C2 matrix): every NT variant is within 1.5 %;
+  // n_rpt2_unr16_nt @ 4096 blocks 6.89 TB/s, t_cpb4_unr8_nt 7.17 TB/s were the fastest
+  ctx->cfg.n_variant = 4;
+  ctx->cfg.t_variant = 2;
+  ctx->cfg.n_target_blocks = 16 * (int64_t)ctx->num_cu;
   ctx->cfg.t_target_blocks = 8 * (int64_t)ctx->num_cu;
   if (const char* s = getenv("APX_GEMV_N_VARIANT")) ctx->cfg.n_variant = atoi(s);
   if (const char* s = getenv("APX_GEMV_T_VARIANT")) ctx->cfg.t_variant = atoi(s);

@@ -47,38 +47,32 @@ def test_gemv_pair_matches_numpy(apx, m, n, dtype):
 
 @pytest.mark.parametrize("variant", range(14))
 def test_every_gemv_n_variant(apx, variant):
-    ctx = apx.default_context()
+    ctx = apx.Context(0)          # private context: the default one keeps its tuned configuration
     if variant >= len(ctx.gemv_variants(False)):
         pytest.skip("no such variant")
     rng = np.random.default_rng(variant)
     m, n = 1537, 2111
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
     x = rng.standard_normal(n)
-    dA = apx.DeviceMatrix.from_numpy(A)
-    try:
-        for blocks in (64, 4096):
-            ctx.set_gemv_config(n_variant=variant, n_blocks=blocks)
-            assert _rel(dA @ x, A @ x) < 1e-12
-    finally:
-        ctx.set_gemv_config(n_variant=0, n_blocks=32 * 256)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    for blocks in (64, 4096):
+        ctx.set_gemv_config(n_variant=variant, n_blocks=blocks)
+        assert _rel(dA @ x, A @ x) < 1e-12
 
 
 @pytest.mark.parametrize("variant", range(12))
 def test_every_gemv_t_variant(apx, variant):
-    ctx = apx.default_context()
+    ctx = apx.Context(0)          # private context: the default one keeps its tuned configuration
     if variant >= len(ctx.gemv_variants(True)):
         pytest.skip("no such variant")
     rng = np.random.default_rng(100 + variant)
     m, n = 9001, 333
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
     r = rng.standard_normal(m)
-    dA = apx.DeviceMatrix.from_numpy(A)
-    try:
-        for blocks in (1, 8192):
-            ctx.set_gemv_config(t_variant=variant, t_blocks=blocks)
-            assert _rel(dA.T @ r, A.T @ r) < 1e-12
-    finally:
-        ctx.set_gemv_config(t_variant=0, t_blocks=8 * 256)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    for blocks in (1, 8192):
+        ctx.set_gemv_config(t_variant=variant, t_blocks=blocks)
+        assert _rel(dA.T @ r, A.T @ r) < 1e-12
 
 
 def test_device_generator_is_bit_exact(apx):
