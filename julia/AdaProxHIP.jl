@@ -1,0 +1,247 @@
+# AdaProxHIP.jl — Julia host shim over libadaprox_hip.so (include/adaprox_hip.h).
+#
+# UNVERIFIED IN THIS REPOSITORY'S PIPELINE: neither the build container nor the GPU test
+# boxes have a Julia runtime, so this file has never been executed.  It is the binding a
+# maintainer of pylat/adaptive-proximal-algorithms would add; the same C entry points are
+# exercised end-to-end by the Python ctypes mirror (adaptive-proximal-algorithms_amd/api.py)
+# and `tests/test_cabi_symbols.py` checks the struct layouts used below against the header.
+#
+# Usage (drop-in for the three hot-path solvers; everything else stays AdaProx):
+#
+#     using AdaProx, ProximalOperators
+#     include("AdaProxHIP.jl"); using .AdaProxHIP
+#     ctx = AdaProxHIP.Context(0)
+#     A_d = AdaProxHIP.HipMatrix(ctx, A)                       # one upload; A stays in HBM
+#     f   = AdaProxHIP.HipLeastSquares(A_d, b)                  # replaces LinearLeastSquares(A, b)
+#     sol, numit = AdaProxHIP.adaptive_proxgrad(zeros(n); f = f, g = NormL1(lam),
+#                                               rule = AdaProx.OurRule(gamma = gam_init), tol, maxit, name)
+#
+# Records are replayed as `@logmsg AdaProx.Record` with the schema of src/AdaProx.jl:351 / :56,
+# so experiments/logging.jl and the plotting code work unchanged.
+module AdaProxHIP
+
+using Logging
+using LinearAlgebra
+import AdaProx
+using ProximalCore: Zero, IndZero
+using ProximalOperators: NormL1, NormL2, IndBox, Translate
+
+const LIB = get(ENV, "ADAPROX_HIP_LIB", joinpath(@__DIR__, "..", "adaptive-proximal-algorithms_amd", "csrc", "libadaprox_hip.so"))
+
+# ---- enums (include/adaprox_hip.h) -------------------------------------------------------
+const APX_F64, APX_F32 = Int32(0), Int32(1)
+const F_ZERO, F_LS, F_LOGISTIC, F_CALLBACK = Int32(0), Int32(1), Int32(2), Int32(3)
+const G_ZERO, G_L1, G_BOX, G_BOXV, G_INDZERO, G_L2 = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4), Int32(5)
+const RULE_FIXED, RULE_MM, RULE_OURS, RULE_OURS_PLUS = Int32(0), Int32(1), Int32(2), Int32(3)
+
+struct ProxDesc            # apx_prox_desc
+    kind::Int32; _pad::Int32
+    lambda::Cdouble; lb::Cdouble; ub::Cdouble
+    lb_vec::Ptr{Cvoid}; ub_vec::Ptr{Cvoid}; shift::Ptr{Cvoid}
+end
+
+struct ProblemDesc         # apx_problem_desc
+    f_kind::Int32; dtype::Int32
+    n::Int64; m::Int64
+    A_f::Ptr{Cvoid}; b::Ptr{Cvoid}; n_total_rows::Int64
+    eval_cb::Ptr{Cvoid}; pullback_cb::Ptr{Cvoid}; cb_user::Ptr{Cvoid}
+    g::ProxDesc; h::ProxDesc
+    A_lin::Ptr{Cvoid}
+    allreduce::Ptr{Cvoid}; allreduce_user::Ptr{Cvoid}
+end
+
+struct Rule                # apx_rule
+    kind::Int32; _pad::Int32
+    gamma::Cdouble; t::Cdouble; norm_A::Cdouble; delta::Cdouble; Theta::Cdouble
+    xi::Cdouble; nu::Cdouble; r::Cdouble
+end
+
+struct Record              # apx_record
+    it::Int64; gamma::Cdouble; sigma::Cdouble; norm_res::Cdouble; objective::Cdouble; f_x::Cdouble
+    f_evals::Int64; grad_evals::Int64
+end
+
+mutable struct Result      # apx_result
+    numit::Int64; converged::Int32; flags::Int32
+    gamma::Cdouble; sigma::Cdouble; norm_res::Cdouble; objective::Cdouble
+    f_evals::Int64; grad_f_evals::Int64; prox_g_evals::Int64; prox_h_evals::Int64; A_evals::Int64; At_evals::Int64
+    n_records::Int64
+    Result() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0)
+end
+
+struct SolveOpts           # apx_solve_opts
+    records::Ptr{Record}; record_cap::Int64; use_graph::Int32; poll_every::Int32
+end
+
+function check(code::Integer)
+    code == 0 && return
+    msg = unsafe_string(ccall((:apx_last_error, LIB), Cstring, ()))
+    code == 4 && throw(DomainError(NaN, msg))      # APX_ERR_DOMAIN: sqrt of a negative inside a rule
+    error("adaprox_hip error $code: $msg")
+end
+
+# ---- handles -----------------------------------------------------------------------------
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer = 0)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:apx_ctx_create, LIB), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, out))
+        c = new(out[])
+        finalizer(c -> ccall((:apx_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), c.h), c)
+        return c
+    end
+end
+
+dtype_code(::Type{Float64}) = APX_F64
+dtype_code(::Type{Float32}) = APX_F32
+
+"Dense column-major matrix resident in HBM — plays the role of the Julia `Matrix` A."
+mutable struct HipMatrix{T}
+    ctx::Context
+    h::Ptr{Cvoid}
+    m::Int; n::Int
+    function HipMatrix(ctx::Context, A::StridedMatrix{T}) where {T<:Union{Float32,Float64}}
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        m, n = size(A)
+        GC.@preserve A check(ccall((:apx_matrix_upload, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Int32, Ref{Ptr{Cvoid}}),
+            ctx.h, pointer(A), m, n, stride(A, 2), dtype_code(T), out))
+        M = new{T}(ctx, out[], m, n)
+        finalizer(M -> ccall((:apx_matrix_free, LIB), Int32, (Ptr{Cvoid},), M.h), M)
+        return M
+    end
+end
+Base.size(A::HipMatrix) = (A.m, A.n)
+Base.eltype(::HipMatrix{T}) where {T} = T
+
+# `A*x`, `A'*y`, `norm(A)` (src/counting.jl:65-82)
+function Base.:*(A::HipMatrix{T}, x::Vector{T}) where {T}
+    y = Vector{T}(undef, A.m)
+    check(ccall((:apx_gemv_n, LIB), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), A.h, x, y)); y
+end
+struct HipAdjoint{T}; A::HipMatrix{T}; end
+LinearAlgebra.adjoint(A::HipMatrix) = HipAdjoint(A)
+function Base.:*(At::HipAdjoint{T}, r::Vector{T}) where {T}
+    g = Vector{T}(undef, At.A.n)
+    check(ccall((:apx_gemv_t, LIB), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), At.A.h, r, g)); g
+end
+function LinearAlgebra.norm(A::HipMatrix)          # Frobenius, like norm(::Matrix)
+    s = Ref{Cdouble}(0)
+    check(ccall((:apx_matrix_sumsq, LIB), Int32, (Ptr{Cvoid}, Ref{Cdouble}), A.h, s)); sqrt(s[])
+end
+
+# ---- smooth terms --------------------------------------------------------------------------
+"LinearLeastSquares of experiments/lasso/runme.jl:16-27 with A resident on the GPU."
+struct HipLeastSquares{T}; A::HipMatrix{T}; b::Vector{T}; end
+"LogisticLoss of experiments/sparse_logreg/runme.jl:18-39 (bias = last coordinate)."
+struct HipLogistic{T}; X::HipMatrix{T}; y::Vector{T}; end
+
+f_fields(f::HipLeastSquares) = (F_LS, f.A, f.b, f.A.n)
+f_fields(f::HipLogistic) = (F_LOGISTIC, f.X, f.y, f.X.n + 1)
+
+# ---- prox terms -> descriptors (keep the arrays alive in `keep`) -----------------------------
+proxdesc(::Zero, T, keep) = ProxDesc(G_ZERO, 0, 0.0, -Inf, Inf, C_NULL, C_NULL, C_NULL)
+proxdesc(::IndZero, T, keep) = ProxDesc(G_INDZERO, 0, 0.0, -Inf, Inf, C_NULL, C_NULL, C_NULL)
+proxdesc(g::NormL1{<:Real}, T, keep) = ProxDesc(G_L1, 0, Float64(g.lambda), -Inf, Inf, C_NULL, C_NULL, C_NULL)
+proxdesc(g::NormL2, T, keep) = ProxDesc(G_L2, 0, Float64(g.lambda), -Inf, Inf, C_NULL, C_NULL, C_NULL)
+function proxdesc(g::IndBox, T, keep)
+    if g.lb isa Real && g.ub isa Real
+        return ProxDesc(G_BOX, 0, 0.0, Float64(g.lb), Float64(g.ub), C_NULL, C_NULL, C_NULL)
+    end
+    lb, ub = collect(T, g.lb), collect(T, g.ub); push!(keep, lb, ub)
+    ProxDesc(G_BOXV, 0, 0.0, -Inf, Inf, pointer(lb), pointer(ub), C_NULL)
+end
+function proxdesc(g::Translate, T, keep)
+    d = proxdesc(g.f, T, keep)
+    b = collect(T, g.b); push!(keep, b)
+    ProxDesc(d.kind, 0, d.lambda, d.lb, d.ub, d.lb_vec, d.ub_vec, pointer(b))
+end
+
+# ---- rules ---------------------------------------------------------------------------------
+ruledesc(r::AdaProx.FixedStepsize) = Rule(RULE_FIXED, 0, r.gamma, r.t, 0, 0, 0, 0, 0, 0)
+ruledesc(r::AdaProx.MalitskyMishchenkoRule) = Rule(RULE_MM, 0, r.gamma, r.t, 0, 0, 0, 0, 0, 0)
+ruledesc(r::AdaProx.OurRule) = Rule(RULE_OURS, 0, r.gamma, r.t, r.norm_A, r.delta, r.Theta, 0, 0, 0)
+ruledesc(r::AdaProx.OurRulePlus) = Rule(RULE_OURS_PLUS, 0, r.gamma, 1, 0, 0, 0, r.xi, r.nu, r.r)
+
+unwrap(c::AdaProx.Counting) = c.f
+unwrap(x) = x
+cnt(c::AdaProx.Counting, f::Symbol, inc) = getfield(c, f) + inc
+cnt(_, ::Symbol, _) = nothing
+
+function with_problem(body, f, g, h, A, ::Type{T}) where {T}
+    fu, gu, hu, Au = unwrap(f), unwrap(g), unwrap(h), unwrap(A)
+    keep = Any[]
+    fk, Af, b, n = f_fields(fu)
+    A_lin = Au isa HipMatrix ? Au.h : C_NULL
+    m = Au isa HipMatrix ? Au.m : 0
+    desc = ProblemDesc(fk, dtype_code(T), n, m, Af.h, pointer(b), 0, C_NULL, C_NULL, C_NULL,
+                       proxdesc(gu, T, keep), proxdesc(hu, T, keep), A_lin, C_NULL, C_NULL)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve b keep begin
+        check(ccall((:apx_problem_create, LIB), Int32, (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), Af.ctx.h, Ref(desc), out))
+        try
+            return body(out[])
+        finally
+            ccall((:apx_problem_destroy, LIB), Int32, (Ptr{Cvoid},), out[])
+        end
+    end
+end
+
+function bump!(f, g, h, A, res::Result)
+    f isa AdaProx.Counting && (f.eval_count += res.f_evals; f.grad_count += res.grad_f_evals)
+    g isa AdaProx.Counting && (g.prox_count += res.prox_g_evals)
+    h isa AdaProx.Counting && res.prox_h_evals >= 0 && (h.prox_count += res.prox_h_evals)
+    A isa AdaProx.Counting && res.A_evals >= 0 && (A.mul_count += res.A_evals; A.amul_count += res.At_evals)
+end
+
+"adaptive_primal_dual — src/AdaProx.jl:312-364"
+function adaptive_primal_dual(x::Vector{T}, y::Vector{T}; f, g, h, A, rule, tol = 1e-5, maxit = 10_000, name = "AdaPDM") where {T}
+    maxit = floor(Int, maxit)
+    with_problem(f, g, h, A, T) do prob
+        recs = Vector{Record}(undef, max(maxit, 1))
+        opts = SolveOpts(pointer(recs), maxit, 0, 0)
+        res = Result(); x_out = similar(x); y_out = similar(y)
+        lin = unwrap(A) isa HipMatrix
+        GC.@preserve recs check(ccall((:apx_adaptive_primal_dual, LIB), Int32,
+            (Ptr{Cvoid}, Ref{Rule}, Ptr{T}, Ptr{T}, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ptr{T}, Ref{Result}),
+            prob, Ref(ruledesc(rule)), x, lin ? y : C_NULL, tol, maxit, Ref(opts), x_out, lin ? y_out : C_NULL, res))
+        for i in 1:res.n_records                      # replay `@logmsg Record` (:351)
+            r = recs[i]; k = r.it
+            @logmsg AdaProx.Record "" method=name it=k gamma=r.gamma sigma=r.sigma norm_res=r.norm_res objective=r.objective grad_f_evals=cnt(f, :grad_count, k + 1) prox_g_evals=cnt(g, :prox_count, k) prox_h_evals=cnt(h, :prox_count, k) A_evals=cnt(A, :mul_count, k + 1) At_evals=cnt(A, :amul_count, k) f_evals=cnt(f, :eval_count, k + 1)
+        end
+        bump!(f, g, h, A, res)
+        return x_out, (lin ? y_out : zero(x_out)), Int(res.numit)
+    end
+end
+
+"adaptive_proxgrad — src/AdaProx.jl:418-421"
+function adaptive_proxgrad(x; f, g, rule, tol = 1e-5, maxit = 100_000, name = "AdaPGM")
+    x, _, numit = adaptive_primal_dual(x, zero(x); f, g, h = Zero(), A = 0, rule, tol, maxit, name)
+    return x, numit
+end
+
+"fixed_proxgrad — src/AdaProx.jl:457-459"
+fixed_proxgrad(x; f, g, gamma, tol = 1e-5, maxit = 100_000, name = "Fixed stepsize PGM") =
+    adaptive_proxgrad(x; f, g, rule = AdaProx.FixedStepsize(gamma, one(gamma)), tol, maxit, name)
+
+"backtracking_proxgrad — src/AdaProx.jl:50-64"
+function backtracking_proxgrad(x0::Vector{T}; f, g, gamma0, xi = 1.0, shrink = 0.5, tol = 1e-5, maxit = 100_000, name = "Backtracking PG") where {T}
+    maxit = floor(Int, maxit)
+    with_problem(f, g, Zero(), 0, T) do prob
+        recs = Vector{Record}(undef, max(maxit, 1))
+        opts = SolveOpts(pointer(recs), maxit, 0, 0)
+        res = Result(); z = similar(x0)
+        GC.@preserve recs check(ccall((:apx_backtracking_proxgrad, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{T}, Cdouble, Cdouble, Cdouble, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ref{Result}),
+            prob, x0, gamma0, xi, shrink, tol, maxit, Ref(opts), z, res))
+        (res.flags & 1) != 0 && @error "step size became too small ($(res.gamma))"     # :40-42
+        for i in 1:res.n_records                      # replay `@logmsg Record` (:56)
+            r = recs[i]
+            @logmsg AdaProx.Record "" method=name it=r.it gamma=r.gamma norm_res=r.norm_res objective=r.objective grad_f_evals=cnt(f, :grad_count, r.grad_evals) prox_g_evals=cnt(g, :prox_count, r.f_evals - 1) f_evals=cnt(f, :eval_count, r.f_evals)
+        end
+        bump!(f, g, nothing, nothing, res)
+        return z, Int(res.numit)
+    end
+end
+
+end # module
