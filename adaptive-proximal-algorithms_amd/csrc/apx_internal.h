@@ -72,6 +72,8 @@ struct GemvConfig {
   int t_variant;
   int64_t n_target_blocks;   // column splits are chosen so that grid ~ this
   int64_t t_target_blocks;
+  bool n_auto;               // cap the column splits by the partial-sum traffic (off once a sweep pins a config)
+  int n_variant_narrow;      // RPT=1 variant used when the cap leaves too few blocks
 };
 
 }  // namespace apx

@@ -91,11 +91,26 @@ static int32_t prof_end(apx_ctx* ctx) {
 }
 
 int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
-  const NVar& v = kNVars[ctx->cfg.n_variant];
   const int V = A->dtype == APX_F32 ? 4 : 2;
-  const int64_t rows_per_block = (int64_t)kBlock * V * v.rpt;
-  const int64_t row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
+  int vi = ctx->cfg.n_variant;
+  int64_t rows_per_block = (int64_t)kBlock * V * kNVars[vi].rpt;
+  int64_t row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
   int64_t S = std::max<int64_t>(1, (ctx->cfg.n_target_blocks + row_tiles - 1) / row_tiles);
+  if (ctx->cfg.n_auto) {
+    // every column split writes and re-reads an m-vector of fp64 partials: keep that below ~1 %
+    // of the A stream (S*16 B per row against n*sizeof(T)); when that leaves too few blocks for a
+    // wide row tile, fall back to the narrow-tile variant (short-and-wide problems such as C3)
+    const int64_t s_cap = std::max<int64_t>(1, A->n * (int64_t)dtype_size(A->dtype) / 1600);
+    if (S > s_cap) {
+      S = s_cap;
+      if (row_tiles * S < 8 * (int64_t)ctx->num_cu && kNVars[vi].rpt > 1) {
+        vi = ctx->cfg.n_variant_narrow;
+        rows_per_block = (int64_t)kBlock * V * kNVars[vi].rpt;
+        row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
+      }
+    }
+  }
+  const NVar& v = kNVars[vi];
   int64_t cps = round_up((A->n + S - 1) / S, v.unr);
   if (cps < v.unr) cps = v.unr;
   S = (A->n + cps - 1) / cps;

@@ -140,8 +140,10 @@ int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
   ctx->cfg.n_variant = 4;
   ctx->cfg.t_variant = 2;
   ctx->cfg.n_target_blocks = 16 * (int64_t)ctx->num_cu;
+  ctx->cfg.n_auto = true;
+  ctx->cfg.n_variant_narrow = 3;   // n_rpt1_unr16_nt
   ctx->cfg.t_target_blocks = 8 * (int64_t)ctx->num_cu;
-  if (const char* s = getenv("APX_GEMV_N_VARIANT")) ctx->cfg.n_variant = atoi(s);
+  if (const char* s = getenv("APX_GEMV_N_VARIANT")) { ctx->cfg.n_variant = atoi(s); ctx->cfg.n_auto = false; }
   if (const char* s = getenv("APX_GEMV_T_VARIANT")) ctx->cfg.t_variant = atoi(s);
   if (const char* s = getenv("APX_GEMV_N_BLOCKS")) ctx->cfg.n_target_blocks = atoll(s);
   if (const char* s = getenv("APX_GEMV_T_BLOCKS")) ctx->cfg.t_target_blocks = atoll(s);
@@ -218,7 +220,9 @@ int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_varia
   if (n_variant >= 0) {
     APX_REQUIRE(n_variant < gemv_n_variant_count(), "gemv_n variant out of range");
     ctx->cfg.n_variant = n_variant;
+    ctx->cfg.n_auto = false;   // an explicit choice (sweeps) is taken literally
   }
+  if (n_blocks > 0) ctx->cfg.n_auto = false;
   if (t_variant >= 0) {
     APX_REQUIRE(t_variant < gemv_t_variant_count(), "gemv_t variant out of range");
     ctx->cfg.t_variant = t_variant;

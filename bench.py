@@ -87,7 +87,14 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # APX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (the 1-GPU box
+    # rehearsal of what the driver launches with N ranks)
+    use_dist = world > 1 or os.environ.get("APX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -100,8 +107,8 @@ def main():
     with torch.cuda.stream(stream):
         ctx = apx.Context(device=local_rank, stream=stream.cuda_stream)
         apx.set_default_context(ctx)
-        ar_host = sharded.host_allreduce(dist, local_rank) if world > 1 else None
-        ar_dev = sharded.device_allreduce(dist, local_rank) if world > 1 else None
+        ar_host = sharded.host_allreduce(dist, local_rank) if use_dist else None
+        ar_dev = sharded.device_allreduce(dist, local_rank) if use_dist else None
 
         t_setup = time.perf_counter()
         prob = problems.device_lasso(args.m, args.n, pfactor=10, seed=args.seed, rank=rank, world=world,
@@ -114,7 +121,7 @@ def main():
                             ctx=ctx, poll_every=1 << 30)
 
         def barrier():
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -134,7 +141,7 @@ def main():
             sys.exit("bench.py: non-finite iterate")
         solver.close()
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -178,7 +185,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.n, args.m, args.cpu_rows, args.cpu_iters, args.seed)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,67 @@
+"""Times the non-headline BASELINE configs at full size on one MI355X (C3 logreg fp32,
+C5 LAD via Condat-Vu, C2 backtracking, C1 small lasso).  Same protocol as bench.py: data
+resident, warm-up, K timed iterations, HIP-event kernel times from the library."""
+import sys, os, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import adaprox_amd as apx
+from importlib import import_module
+problems = import_module("adaptive-proximal-algorithms_amd.problems")
+
+ctx = apx.Context(0)
+apx.set_default_context(ctx)
+out = {}
+
+def timed(solver, steps, warm, bytes_per_iter):
+    solver.step(warm, sync=True)
+    ctx.kernel_stats(reset=True); ctx.profile(True); ctx.sync()
+    t0 = time.perf_counter()
+    solver.step(steps, sync=True)
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    st = ctx.kernel_stats(reset=True)
+    k = {n: dict(avg_ms=v["total_ms"] / v["launches"], GBps=v["bytes"] / v["total_ms"] / 1e6) for n, v in st.items() if v["launches"]}
+    x, y, res = solver.result()
+    assert np.all(np.isfinite(x))
+    return dict(iters_per_s=steps / dt, ms_per_iter=dt / steps * 1e3, frac_of_8TBs=bytes_per_iter * steps / dt / 8e12, kernels=k,
+                objective=res.objective, norm_res=res.norm_res)
+
+which = sys.argv[1:] or ["c3", "c5", "c2bt", "c1"]
+if "c3" in which:
+    m, n = 100_000, 10_000
+    p = problems.device_logreg(m, n, seed=0, lam=0.01, dtype=np.float32, ctx=ctx)
+    f = apx.LogisticLoss(p.X, p.y)
+    s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=f, g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    out["C3 sparse_logreg dense 100000x10000 fp32, adaptive_proxgrad"] = timed(s, 200, 20, 2 * m * n * 4)
+    s.close(); p.X.free()
+if "c5" in which:
+    m, n = 50_000, 20_000
+    p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx)
+    norm_A = p.norm_A
+    gamma = 1.0 / (0.0 / 2 + norm_A / 1.0); sigma = 0.99 / (norm_A * 1.0)       # condat_vu, Lf = 0 (src/AdaProx.jl:405-411)
+    rule = apx.FixedStepsize(gamma, np.sqrt(sigma / gamma))
+    s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=p.A, rule=rule, tol=0.0, ctx=ctx, poll_every=1 << 30)
+    out["C5 LAD 50000x20000 fp64, condat_vu via adaptive_primal_dual"] = timed(s, 100, 10, 2 * m * n * 8)
+    s.close(); p.A.free()
+if "c2bt" in which:
+    m, n = 50_000, 100_000
+    p = problems.device_lasso(m, n, seed=0, power_iters=20, ctx=ctx)
+    f = apx.Counting(apx.LinearLeastSquares(p.A, p.b)); g = apx.NormL1(p.lam)
+    apx.backtracking_proxgrad(np.zeros(n), f=f, g=g, gamma0=1 / p.Lf, xi=1.5, tol=0.0, maxit=2)
+    e0, g0 = f.eval_count, f.grad_count
+    t0 = time.perf_counter()
+    z, it = apx.backtracking_proxgrad(np.zeros(n), f=f, g=g, gamma0=1 / p.Lf, xi=1.5, tol=0.0, maxit=20)
+    dt = time.perf_counter() - t0
+    passes = (f.eval_count - e0) + (f.grad_count - g0)
+    out["C2 lasso 50000x100000 fp64, backtracking_proxgrad xi=1.5"] = dict(iters_per_s=20 / dt, ms_per_iter=dt / 20 * 1e3, passes_over_A=passes,
+        frac_of_8TBs=passes * m * n * 8 / dt / 8e12)
+    p.A.free()
+if "c1" in which:
+    m, n = 500, 1000
+    p = problems.device_lasso(m, n, seed=0, power_iters=50, ctx=ctx)
+    f = apx.LinearLeastSquares(p.A, p.b)
+    s = apx.Solver(np.zeros(n), f=f, g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=1 / p.Lf), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    out["C1 lasso 500x1000 fp64, adaptive_proxgrad (launch-bound)"] = timed(s, 500, 20, 2 * m * n * 8)
+    s.close()
+print(json.dumps(out, indent=1))
+json.dump(out, open("gpurun_out/bench_configs.json", "w"), indent=1)
