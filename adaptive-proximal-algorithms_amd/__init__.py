@@ -16,6 +16,7 @@ from .api import (  # noqa: F401
     LinearLeastSquares, LogisticLoss, eval_with_pullback, eval_with_gradient,
     FixedStepsize, MalitskyMishchenkoRule, OurRule, OurRulePlus,
     adaptive_primal_dual, adaptive_proxgrad, fixed_proxgrad, condat_vu, backtracking_proxgrad,
+    adaptive_linesearch_primal_dual,
     Solver,
 )
 

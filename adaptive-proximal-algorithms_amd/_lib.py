@@ -65,6 +65,11 @@ class SolveOpts(C.Structure):
                 ("poll_every", c_int32)]
 
 
+class LinesearchParams(C.Structure):
+    _fields_ = [("gamma", c_double), ("eta", c_double), ("t", c_double), ("delta", c_double), ("Theta", c_double),
+                ("r", c_double), ("R", c_double), ("max_linesearch", c_int64)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("launches", c_int64), ("total_ms", c_double), ("bytes", c_double)]
 
@@ -111,6 +116,8 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, _P(Result)]),
     "apx_backtracking_proxgrad": (c_int32, [c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_int64,
                                             _P(SolveOpts), c_void_p, _P(Result)]),
+    "apx_adaptive_linesearch_primal_dual": (c_int32, [c_void_p, _P(LinesearchParams), c_void_p, c_void_p, c_double,
+                                                      c_int64, _P(SolveOpts), c_void_p, c_void_p, _P(Result)]),
     "apx_solver_create": (c_int32, [c_void_p, _P(Rule), c_void_p, c_void_p, c_double, _P(SolveOpts), _P(c_void_p)]),
     "apx_solver_step": (c_int32, [c_void_p, c_int64, c_int32]),
     "apx_solver_result": (c_int32, [c_void_p, c_void_p, c_void_p, _P(Result)]),

@@ -899,6 +899,47 @@ def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=
                                 record=record, ctx=ctx)
 
 
+def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=1.0, delta=1e-8, Theta=1.2, r=2,
+                                    R=0.95, tol=1e-5, maxit=10_000, name="AdaPDM+", record: Record = None,
+                                    ctx: Optional[Context] = None, max_linesearch: int = 0):
+    """src/AdaProx.jl:463-550 ("AdaPDM+").  Returns (x, y, it)."""
+    maxit = int(math.floor(maxit))
+    # the @assert's of :481-488 (AssertionError in Julia)
+    assert eta > 0, "eta must be positive"
+    assert Theta > (delta + 1), "must be Theta > (delta + 1)"
+    if gamma is not None:
+        assert gamma <= 1 / (2 * Theta * t * eta), "gamma is too large"
+    dtype = _problem_dtype(x, f, A)
+    x = _as_vec(x, dtype)
+    prob = _Problem(f, g, h, A, dtype, ctx).finalize(x.size)
+    try:
+        yv = _as_vec(y, dtype)
+        if yv.size != prob._d.m:
+            raise ValueError(f"y has length {yv.size} but A has {prob._d.m} rows")
+        opts, recs = _opts(maxit, record is not None)
+        res = L.Result()
+        prm = L.LinesearchParams(float(gamma) if gamma is not None else 0.0, float(eta), float(t), float(delta),
+                                 float(Theta), float(r), float(R), int(max_linesearch))
+        x_out, y_out = np.empty_like(x), np.empty_like(yv)
+        base = _count_bases(f, g, h, A)
+        prob.check(prob.lib.apx_adaptive_linesearch_primal_dual(prob.h, C.byref(prm), _ptr(x), _ptr(yv), float(tol),
+                                                                maxit, C.byref(opts), _ptr(x_out), _ptr(y_out),
+                                                                C.byref(res)))
+        _advance_counts(f, g, h, A, res, prob.f_is_callback)
+        if record is not None:
+            for i in range(int(res.n_records)):
+                rr = recs[i]
+                k, at = int(rr.it), int(rr.grad_evals)        # at = A'*y products so far (1 + linesearch trials)
+                record(dict(method=name, it=k, gamma=rr.gamma, sigma=rr.sigma, norm_res=rr.norm_res,
+                            objective=rr.objective,
+                            grad_f_evals=_at(base, "grad", k + 1), prox_g_evals=_at(base, "prox_g", k),
+                            prox_h_evals=_at(base, "prox_h", at - 1), A_evals=_at(base, "mul", k + 1),
+                            At_evals=_at(base, "amul", at), f_evals=_at(base, "eval", k + 1)))
+        return x_out, y_out, int(res.numit)
+    finally:
+        prob.close()
+
+
 def backtracking_proxgrad(x0, *, f, g, gamma0, xi=1.0, shrink=0.5, tol=1e-5, maxit=100_000,
                           name="Backtracking PG", record: Record = None, ctx: Optional[Context] = None):
     """src/AdaProx.jl:50-64.  Returns (z, it)."""

@@ -608,6 +608,175 @@ int32_t apx_condat_vu(apx_problem* p, double Lf, double norm_A, const void* x0, 
   return apx_adaptive_primal_dual(p, &r, x0, y0, tol, maxit, opts, x_out, y_out, res);
 }
 
+// adaptive_linesearch_primal_dual ("AdaPDM+") — src/AdaProx.jl:463-550.
+// The linesearch test `eta >= ||A'y_next - A'y|| / ||y_next - y||` (:527) is a data-dependent
+// host branch per trial, like backtracking: every trial costs one GEMV-T (pass over A) plus a
+// 32-byte read-back; the step-size scalars (gamma, eta, Delta, ...) live on the host in fp64.
+int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch_params* prm, const void* x0,
+                                            const void* y0, double tol, int64_t maxit, const apx_solve_opts* opts,
+                                            void* x_out, void* y_out, apx_result* res) {
+  APX_REQUIRE(p != nullptr && prm != nullptr && x0 != nullptr && y0 != nullptr && x_out != nullptr,
+              "apx_adaptive_linesearch_primal_dual: NULL argument");
+  APX_REQUIRE(p->A_lin != nullptr, "adaptive_linesearch_primal_dual needs a linear operator");
+  APX_REQUIRE(p->active == nullptr, "a solver is active on this problem");
+  APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
+  double eta = prm->eta;
+  const double t = prm->t, delta = prm->delta, Theta = prm->Theta, r = prm->r, R = prm->R;
+  APX_REQUIRE(eta > 0, "eta must be positive");                                    // :481
+  APX_REQUIRE(Theta > (delta + 1), "must be Theta > (delta + 1)");                 // :482
+  double gamma = prm->gamma > 0 ? prm->gamma : 1.0 / (2.0 * Theta * t * eta);      // :484-486
+  APX_REQUIRE(gamma <= 1.0 / (2.0 * Theta * t * eta), "gamma is too large");       // :488
+  const int64_t max_ls = prm->max_linesearch > 0 ? prm->max_linesearch : 10000;
+
+  apx_ctx* ctx = p->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  const size_t es = p->es();
+  const size_t nb = (size_t)p->n_pad * es, mb = (size_t)p->m_pad * es;
+  DBuf bx, bxprev, bgprev, bv, baty, baty2, by, by2, bax, baxprev;
+  for (DBuf* b : {&bx, &bxprev, &bgprev, &bv, &baty, &baty2}) APX_TRY(b->alloc_zero(nb, ctx->stream));
+  for (DBuf* b : {&by, &by2, &bax, &baxprev}) APX_TRY(b->alloc_zero(mb, ctx->stream));
+  void *y = by.p, *ynext = by2.p, *aty = baty.p, *aty_next = baty2.p, *ax = bax.p, *axprev = baxprev.p;
+  apx_rule rr{};
+  rr.kind = APX_RULE_FIXED;
+  rr.gamma = gamma;
+  rr.t = 1.0;
+  APX_TRY(init_ctrl(p, &rr, 0.0));
+  APX_TRY(h2d(ctx, bx.p, x0, (size_t)p->n * es));
+  APX_TRY(h2d(ctx, y, y0, (size_t)p->m * es));
+  apx_record* recs = opts ? opts->records : nullptr;
+  const int64_t rec_cap = (opts && opts->records) ? opts->record_cap : 0;
+  double* d_gamma = (double*)((char*)p->ctrl_buf.p + offsetof(Ctrl, gamma));
+
+  auto set_gamma = [&](double g) -> int32_t {     // Ctrl.gamma feeds k_reduce_n / k_step
+    ctx->h_scal[48] = g;
+    APX_HIP(hipMemcpyAsync(d_gamma, &ctx->h_scal[48], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    APX_HIP(hipStreamSynchronize(ctx->stream));
+    return APX_OK;
+  };
+  auto mul_A = [&]() -> int32_t {                 // A_x = A * x
+    int splits = 0;
+    APX_TRY(launch_gemv_n(ctx, p->A_lin, bx.p, &splits, nullptr));
+    return launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, ax, nullptr);
+  };
+
+  double gamma_prev = gamma;                                                       // :491
+  const double delta1 = 1.0 + delta;                                               // :490
+  APX_TRY(mul_A());                                                                // :494
+  APX_TRY(eval_f(p, bx.p, false));                                                 // :495
+  APX_TRY(pullback_f(p));
+  APX_TRY(launch_gemv_t(ctx, p->A_lin, y, aty, nullptr));                          // :496
+  APX_TRY(vo_step(ctx, p->dtype, bx.p, bxprev.p, p->grad.p, bgprev.p, bv.p, aty, p->n, p->gd, p->ctrl()));   // :497-499
+  std::swap(ax, axprev);                                                           // :498  A_x_prev = A_x
+
+  int64_t it_done = maxit, trials_total = 0;
+  bool converged = false;
+  int32_t flags = 0;
+  double sigma = t * t * gamma, norm_res = std::numeric_limits<double>::quiet_NaN(), objective = norm_res;
+  for (int64_t it = 1; it <= maxit; ++it) {                                        // :501
+    APX_TRY(mul_A());                                                              // :502
+    APX_TRY(eval_f(p, bx.p, false));                                               // :503
+    APX_TRY(pullback_f(p));
+    APX_TRY(vo_reduce_sums(ctx, p->dtype, bx.p, bxprev.p, p->grad.p, bgprev.p, bv.p, aty, p->n, p->gd, p->ctrl(),
+                           ctx->scal + 4));                                        // :505, :507-508
+    APX_HIP(hipMemcpyAsync(ctx->h_scal + 4, ctx->scal + 4, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    APX_HIP(hipMemcpyAsync(ctx->h_scal + 9, (char*)p->ctrl_buf.p + offsetof(Ctrl, f_x), sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    APX_HIP(hipStreamSynchronize(ctx->stream));
+    const double npr = std::sqrt(ctx->h_scal[4]);
+    const double ndg = std::sqrt(ctx->h_scal[5]), dgdx = ctx->h_scal[6], ndx = std::sqrt(ctx->h_scal[7]);
+    const double g_x = vo_gval_final_host(p->gd, ctx->h_scal[8]);
+    const double f_x = ctx->h_scal[9];
+    double C = (ndg * ndg) / dgdx;                                                 // :507
+    if (std::isnan(C)) C = 0.0;
+    double L = dgdx / (ndx * ndx);                                                 // :508
+    if (std::isnan(L)) L = 0.0;
+    const double Delta = gamma * L * (gamma * C - 1.0);                            // :509
+    const double xi_bar = (t * t) * (gamma * gamma) * (eta * eta) * (delta1 * delta1);   // :510
+    const double m4xim1 = 1.0 - 4.0 * xi_bar;                                      // :511
+    eta = R * eta;                                                                 // :513
+    sigma = t * t * gamma;                                                         // :515
+    double ndr2 = 0.0, h_raw = 0.0;
+    int64_t trials = 0;
+    for (;;) {                                                                     // :516
+      auto jsqrt = [&](double v) { if (v < 0) { flags |= APX_FLAG_DOMAIN; return std::numeric_limits<double>::quiet_NaN(); } return std::sqrt(v); };
+      auto jmin = [](double a, double b) { return (std::isnan(a) || std::isnan(b)) ? std::numeric_limits<double>::quiet_NaN() : (a < b ? a : b); };
+      const double tg = t * eta * gamma;
+      const double g1 = gamma * jsqrt(1.0 + gamma / gamma_prev);
+      const double g2 = 1.0 / (2.0 * Theta * t * eta);
+      const double g3 = gamma * jsqrt(m4xim1 / (2.0 * delta1 * (Delta + jsqrt(Delta * Delta + m4xim1 * (tg * tg)))));
+      const double gamma_next = jmin(jmin(g1, g2), g3);                            // :517-521
+      const double rho = gamma_next / gamma;                                       // :522
+      sigma = t * t * gamma_next;                                                  // :523
+      APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, axprev, ynext, p->m, p->hd, sigma, rho, ctx->scal));   // :524-525
+      APX_TRY(launch_gemv_t(ctx, p->A_lin, ynext, aty_next, nullptr));             // :526
+      APX_TRY(vo_diff_sumsq(ctx, p->dtype, aty_next, aty, p->n, ctx->scal + 3));
+      APX_HIP(hipMemcpyAsync(ctx->h_scal, ctx->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      APX_HIP(hipStreamSynchronize(ctx->stream));
+      trials_total++;
+      const double ratio = std::sqrt(ctx->h_scal[3]) / std::sqrt(ctx->h_scal[0]);
+      if (eta >= ratio) {                                                          // :527
+        gamma_prev = gamma;                                                        // :528
+        gamma = gamma_next;
+        std::swap(y, ynext);                                                       // :529
+        std::swap(aty, aty_next);
+        ndr2 = ctx->h_scal[1];
+        h_raw = ctx->h_scal[2];
+        break;
+      }
+      eta *= r;                                                                    // :532
+      if (++trials >= max_ls)
+        return fail(APX_ERR_UNSUPPORTED, "AdaPDM+ linesearch did not terminate (the reference would spin forever)");
+    }
+    const double ndr = std::sqrt(ndr2);                                            // :535
+    norm_res = std::sqrt(npr * npr + ndr * ndr);                                   // :536
+    objective = f_x + g_x + vo_gval_final_host(p->hd, h_raw);
+    if (recs != nullptr && it <= rec_cap) {                                        // :538-540
+      apx_record& q = recs[it - 1];
+      q.it = it;
+      q.gamma = gamma;
+      q.sigma = sigma;
+      q.norm_res = norm_res;
+      q.objective = objective;
+      q.f_x = f_x;
+      q.f_evals = it + 1;
+      q.grad_evals = 1 + trials_total;      // A' * y_next products so far (+ the one at :496)
+    }
+    if (norm_res <= tol) {                                                         // :541-543
+      it_done = it;
+      converged = true;
+      break;
+    }
+    APX_TRY(set_gamma(gamma));
+    APX_TRY(vo_step(ctx, p->dtype, bx.p, bxprev.p, p->grad.p, bgprev.p, bv.p, aty, p->n, p->gd, p->ctrl()));   // :545-547
+    std::swap(ax, axprev);                                                         // :546  A_x_prev = A_x
+  }
+  APX_TRY(d2h(ctx, x_out, bx.p, (size_t)p->n * es));
+  if (y_out != nullptr) APX_TRY(d2h(ctx, y_out, y, (size_t)p->m * es));
+  if (res != nullptr) {
+    memset(res, 0, sizeof(*res));
+    const int64_t k = it_done;
+    res->numit = k;
+    res->converged = converged ? 1 : 0;
+    res->flags = flags;
+    res->gamma = gamma;
+    res->sigma = sigma;
+    res->norm_res = norm_res;
+    res->objective = objective;
+    res->f_evals = k + 1;
+    res->grad_f_evals = k + 1;
+    res->prox_g_evals = converged ? k : k + 1;
+    res->prox_h_evals = trials_total;
+    res->A_evals = k + 1;
+    res->At_evals = 1 + trials_total;
+    res->n_records = std::min<int64_t>(k, rec_cap);
+    if (flags & APX_FLAG_DOMAIN) {
+      set_error("sqrt of a negative number in the AdaPDM+ step-size formula (Julia would throw DomainError)");
+      return APX_ERR_DOMAIN;
+    }
+  }
+  return APX_OK;
+}
+
 // backtracking_proxgrad — src/AdaProx.jl:34-64
 int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol,
                                   int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {

@@ -25,6 +25,13 @@ int32_t vo_bt_trial(apx_ctx* ctx, int32_t dtype, const void* x, const void* grad
 // op-level prox; out_val_sum (device) = raw accumulator of g(y)
 int32_t vo_prox(apx_ctx* ctx, int32_t dtype, const void* v, void* y, int64_t n, const ProxDev& g, double gamma,
                 bool conj, double* out_val_sum);
+// host-driven loops (AdaPDM+): raw sums to device scalars, read back by the host
+int32_t vo_reduce_sums(apx_ctx* ctx, int32_t dtype, const void* x, const void* xprev, const void* grad,
+                       const void* gprev, const void* v, const void* aty, int64_t n, const ProxDev& g, const Ctrl* c,
+                       double* out5);
+int32_t vo_dual_trial(apx_ctx* ctx, int32_t dtype, const void* y, const void* ax, const void* axprev, void* ynext,
+                      int64_t m, const ProxDev& h, double sigma, double rho, double* out3);
+int32_t vo_diff_sumsq(apx_ctx* ctx, int32_t dtype, const void* a, const void* b, int64_t n, double* out1);
 // g(x) raw accumulator -> out_val_sum (device)
 int32_t vo_gval(apx_ctx* ctx, int32_t dtype, const void* x, int64_t n, const ProxDev& g, double* out_val_sum);
 double vo_gval_final_host(const ProxDev& g, double s);

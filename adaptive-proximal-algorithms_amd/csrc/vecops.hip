@@ -512,6 +512,60 @@ __global__ __launch_bounds__(kBlock) void k_prox(const T* __restrict__ v, T* __r
   block_partials_store<1>(q, red);
 }
 
+// ---------------------------------------------------------------------------------
+// AdaPDM+ linesearch trial (src/AdaProx.jl:522-527, :535): the dual update with HOST-side
+// sigma / rho, written to y_next (y, A_x_prev untouched until the trial is accepted)
+//   q0 = ||y_next - y||^2 ; q1 = ||(w - y_next)/sigma - A_x||^2 ; q2 = raw h(A_x)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dual_trial(const T* __restrict__ y, const T* __restrict__ ax,
+                                                       const T* __restrict__ axprev, T* __restrict__ ynext,
+                                                       int64_t m, ProxDev h, double sigma, double rho,
+                                                       const double* __restrict__ aux_sumsq,
+                                                       double* __restrict__ red) {
+  const double aux = aux_sumsq != nullptr ? sqrt(aux_sumsq[0]) : 0.0;
+  double q[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double a = (double)ax[i], yi = (double)y[i];
+    const double w = yi + sigma * ((1.0 + rho) * a - rho * (double)axprev[i]);     // :524
+    const T yn = (T)prox_conj_elem<T>(h, w, sigma, i, aux);                        // :525
+    const double dy = (double)yn - yi;
+    const double dr = (w - (double)yn) / sigma - a;                                // :535
+    q[0] = fma(dy, dy, q[0]);
+    q[1] = fma(dr, dr, q[1]);
+    q[2] += gval_elem<T>(h, a, i);
+    ynext[i] = yn;
+  }
+  block_partials_store<3>(q, red);
+}
+
+// sum (w/sigma + shift)^2 for the l2-ball conjugate prox of a trial (host sigma / rho)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dual_pre_v(const T* __restrict__ y, const T* __restrict__ ax,
+                                                       const T* __restrict__ axprev, int64_t m, ProxDev h,
+                                                       double sigma, double rho, double* __restrict__ red) {
+  double q[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double a = (double)ax[i];
+    const double w = (double)y[i] + sigma * ((1.0 + rho) * a - rho * (double)axprev[i]);
+    const double z = w / sigma + shift_at<T>(h, i);
+    q[0] = fma(z, z, q[0]);
+  }
+  block_partials_store<1>(q, red);
+}
+
+// ||a - b||^2   (`norm(At_y_next - At_y)`, :527)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_diff_sumsq(const T* __restrict__ a, const T* __restrict__ b, int64_t n,
+                                                       double* __restrict__ red) {
+  double q[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double d = (double)a[i] - (double)b[i];
+    q[0] = fma(d, d, q[0]);
+  }
+  block_partials_store<1>(q, red);
+}
+
 // g(x): raw accumulator of the value of a proximable term (finished by gval_final / vo_gval_final_host)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_gval(const T* __restrict__ x, int64_t n, ProxDev g,
@@ -661,6 +715,61 @@ int32_t vo_prox(apx_ctx* ctx, int32_t dtype, const void* v, void* y, int64_t n, 
              hipLaunchKernelGGL(k_prox<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)v, (float*)y, n,
                                 g, gamma, conj ? 1 : 0, aux, ctx->red));
   hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, out_val_sum);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+// K7/K8 sums for a HOST-driven loop: out5 (device) = raw { pr^2, dg^2, dg.dx, dx^2, g(x) }; gamma from Ctrl
+int32_t vo_reduce_sums(apx_ctx* ctx, int32_t dtype, const void* x, const void* xprev, const void* grad,
+                       const void* gprev, const void* v, const void* aty, int64_t n, const ProxDev& g, const Ctrl* c,
+                       double* out5) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_reduce_n<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)x,
+                                (const double*)xprev, (const double*)grad, (const double*)gprev, (const double*)v,
+                                (const double*)aty, n, g, c, ctx->red),
+             hipLaunchKernelGGL(k_reduce_n<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)x,
+                                (const float*)xprev, (const float*)grad, (const float*)gprev, (const float*)v,
+                                (const float*)aty, n, g, c, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 5, out5);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+// AdaPDM+ trial: out3 (device) = { ||y_next - y||^2, ||dual_res||^2, raw h(A_x) }
+int32_t vo_dual_trial(apx_ctx* ctx, int32_t dtype, const void* y, const void* ax, const void* axprev, void* ynext,
+                      int64_t m, const ProxDev& h, double sigma, double rho, double* out3) {
+  const unsigned gr = vgrid(m);
+  double* aux = nullptr;
+  if (h.kind == APX_G_L2) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_dual_pre_v<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)y,
+                                  (const double*)ax, (const double*)axprev, m, h, sigma, rho, ctx->red),
+               hipLaunchKernelGGL(k_dual_pre_v<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)y,
+                                  (const float*)ax, (const float*)axprev, m, h, sigma, rho, ctx->red));
+    hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, ctx->scal + 12);
+    aux = ctx->scal + 12;
+  }
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_dual_trial<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)y,
+                                (const double*)ax, (const double*)axprev, (double*)ynext, m, h, sigma, rho, aux,
+                                ctx->red),
+             hipLaunchKernelGGL(k_dual_trial<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)y,
+                                (const float*)ax, (const float*)axprev, (float*)ynext, m, h, sigma, rho, aux,
+                                ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 3, out3);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_diff_sumsq(apx_ctx* ctx, int32_t dtype, const void* a, const void* b, int64_t n, double* out1) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_diff_sumsq<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)a,
+                                (const double*)b, n, ctx->red),
+             hipLaunchKernelGGL(k_diff_sumsq<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)a,
+                                (const float*)b, n, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, out1);
   APX_HIP(hipGetLastError());
   return APX_OK;
 }

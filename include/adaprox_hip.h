@@ -258,6 +258,18 @@ int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0,
                                   double tol, int64_t maxit, const apx_solve_opts* opts,
                                   void* x_out, apx_result* res);
 
+/* adaptive_linesearch_primal_dual(x, y; f, g, h, A, gamma, eta, t, delta, Theta, r, R, tol, maxit)
+ * "AdaPDM+" — src/AdaProx.jl:463-550.  gamma <= 0 means `nothing` (=> 1/(2 Theta t eta), :484-486).
+ * max_linesearch bounds the reference's unbounded inner `while true` (:516); 0 => 10000.
+ * The `@assert`s of :481-488 come back as APX_ERR_INVALID. */
+typedef struct {
+  double gamma, eta, t, delta, Theta, r, R;
+  int64_t max_linesearch;
+} apx_linesearch_params;
+int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch_params* prm, const void* x0,
+                                            const void* y0, double tol, int64_t maxit, const apx_solve_opts* opts,
+                                            void* x_out, void* y_out, apx_result* res);
+
 /* ---- stepping interface (bench.py times exactly K iterations with data resident) ---- */
 /* runs the pre-loop of adaptive_primal_dual (src/AdaProx.jl:324-332) and leaves the state on device */
 int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, const void* y0,

@@ -370,8 +370,9 @@ class ConvexConjugate:
 
 def convex_conjugate(h):
     """ProximalCore.convex_conjugate (used at src/AdaProx.jl:325)."""
-    if isinstance(h, Counting):
-        return convex_conjugate(h.f)
+    # a Counting-wrapped h is not `::Zero` for Julia's dispatch: it takes the generic
+    # ConvexConjugate(Counting(h)) route, whose prox! calls the wrapped prox! and therefore
+    # advances h.prox_count (that is what counting.jl:25-27 `is_convex(::Counting)` is for)
     if isinstance(h, Zero):
         return IndZero()
     if isinstance(h, IndZero):
@@ -703,3 +704,95 @@ def fixed_proxgrad(x, *, f, g, gamma, tol=1e-5, maxit=100_000, name="Fixed steps
     """src/AdaProx.jl:457-459."""
     return adaptive_proxgrad(x, f=f, g=g, rule=FixedStepsize(gamma, 1.0), tol=tol, maxit=maxit,
                              name=name, record=record, trace=trace)
+
+
+# ----------------------------------------------------------------------------
+# Linesearch version of adaptive_primal_dual, "AdaPDM+"  (src/AdaProx.jl:463-550)
+# SURVEY §8f rank 1: what experiments/least_absolute_deviation actually showcases.
+# ----------------------------------------------------------------------------
+
+def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=1.0, delta=1e-8,
+                                    Theta=1.2, r=2, R=0.95, tol=1e-5, maxit=10_000, name="AdaPDM+",
+                                    record: Record = None, trace: Optional[list] = None,
+                                    max_linesearch: int = 10_000):
+    """src/AdaProx.jl:463-550.  Returns (x, y, it).  ``max_linesearch`` bounds the inner
+    ``while true`` (the reference has no bound and spins forever when ``y_next == y`` makes the
+    ratio NaN); hitting it raises."""
+    maxit = int(math.floor(maxit))
+    assert eta > 0, "eta must be positive"                            # :481
+    assert Theta > (delta + 1), "must be Theta > (delta + 1)"         # :482
+    if gamma is None:                                                 # :484-486
+        gamma = 1 / (2 * Theta * t * eta)
+    assert gamma <= 1 / (2 * Theta * t * eta), "gamma is too large"   # :488
+
+    delta1 = 1 + delta                                                # :490
+    gamma_prev = gamma                                                # :491
+    h_conj = convex_conjugate(h)                                      # :492
+
+    A_x = mul(A, x)                                                   # :494
+    _, grad_x = eval_with_gradient(f, x)                              # :495
+    At_y = amul(A, y)                                                 # :496
+    v = x - gamma * (grad_x + At_y)                                   # :497
+    x_prev, A_x_prev, grad_x_prev = x, A_x, grad_x                    # :498
+    x, _ = prox(g, v, gamma)                                          # :499
+
+    for it in range(1, maxit + 1):                                    # :501
+        A_x = mul(A, x)                                               # :502
+        f_x, grad_x = eval_with_gradient(f, x)                        # :503
+
+        primal_res = (v - x) / gamma + grad_x + At_y                  # :505
+
+        dg = grad_x - grad_x_prev
+        dx = x - x_prev
+        C = nan_to_zero(jl_div(jl_norm(dg) ** 2, jl_dot(dg, dx)))     # :507
+        L = nan_to_zero(jl_div(jl_dot(dg, dx), jl_norm(dx) ** 2))     # :508
+        Delta = gamma * L * (gamma * C - 1)                           # :509
+        xi_bar = t ** 2 * gamma ** 2 * eta ** 2 * delta1 ** 2         # :510
+        m4xim1 = 1 - 4 * xi_bar                                       # :511
+
+        eta = R * eta                                                 # :513
+        w = y                                                         # :514
+        sigma = t ** 2 * gamma                                        # :515
+        trials = 0
+        while True:                                                   # :516
+            gamma_next = jl_min(                                      # :517-521
+                gamma * jl_sqrt_nan(1 + jl_div(gamma, gamma_prev)),
+                jl_div(1.0, 2 * Theta * t * eta),
+                gamma * jl_sqrt_nan(jl_div(m4xim1, 2 * delta1 * (Delta + jl_sqrt_nan(
+                    Delta ** 2 + m4xim1 * (t * eta * gamma) ** 2)))),
+            )
+            rho = jl_div(gamma_next, gamma)                           # :522
+            sigma = t ** 2 * gamma_next                               # :523
+            w = y + sigma * ((1 + rho) * A_x - rho * A_x_prev)        # :524
+            y_next, _ = prox(h_conj, w, sigma)                        # :525
+            At_y_next = amul(A, y_next)                               # :526
+            if eta >= jl_div(jl_norm(At_y_next - At_y), jl_norm(y_next - y)):   # :527
+                gamma, gamma_prev = gamma_next, gamma                 # :528
+                y, At_y = y_next, At_y_next                           # :529
+                break
+            eta *= r                                                  # :532
+            trials += 1
+            if trials >= max_linesearch:
+                raise RuntimeError("AdaPDM+ linesearch did not terminate (the reference would spin forever)")
+
+        dual_res = (w - y) / sigma - A_x                              # :535
+        norm_res = math.sqrt(jl_norm(primal_res) ** 2 + jl_norm(dual_res) ** 2)   # :536
+
+        if record is not None:                                        # :538-540
+            def _emit():
+                record(dict(method=name, it=it, gamma=gamma, sigma=sigma, norm_res=norm_res,
+                            objective=(f_x + call_g(g, x) + call_g(h, A_x)),
+                            grad_f_evals=grad_count(f), prox_g_evals=prox_count(g),
+                            prox_h_evals=prox_count(h), A_evals=mul_count(A),
+                            At_evals=amul_count(A), f_evals=eval_count(f)))
+            without_counting(_emit)
+        if trace is not None:
+            trace.append(dict(it=it, gamma=gamma, sigma=sigma, eta=eta, norm_res=norm_res,
+                              x=np.array(x, copy=True), y=np.array(y, copy=True)))
+        if norm_res <= tol:                                           # :541-543
+            return x, y, it
+
+        v = x - gamma * (grad_x + At_y)                               # :545
+        x_prev, A_x_prev, grad_x_prev = x, A_x, grad_x                # :546
+        x, _ = prox(g, v, gamma)                                      # :547
+    return x, y, maxit                                                # :549
