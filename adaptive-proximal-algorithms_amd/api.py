@@ -790,8 +790,9 @@ def _problem_dtype(x, f, A):
     return x.dtype if x.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 
 
-def _opts(maxit: int, want_records: bool, poll_every: int = 0):
+def _opts(maxit: int, want_records: bool, poll_every: int = 0, use_graph: bool = False):
     o = L.SolveOpts()
+    o.use_graph = 1 if use_graph else 0
     recs = None
     if want_records and maxit > 0:
         recs = (L.Record * int(maxit))()
@@ -809,8 +810,10 @@ def _nan_none(v):
 # solvers
 # --------------------------------------------------------------------------------------
 def adaptive_primal_dual(x, y, *, f, g, h, A, rule, tol=1e-5, maxit=10_000, name="AdaPDM",
-                         record: Record = None, ctx: Optional[Context] = None, poll_every: int = 0):
-    """src/AdaProx.jl:312-364.  Returns (x, y, it)."""
+                         record: Record = None, ctx: Optional[Context] = None, poll_every: int = 0,
+                         use_graph: bool = False):
+    """src/AdaProx.jl:312-364.  Returns (x, y, it).  ``use_graph`` replays the iteration as a
+    captured hipGraph (same kernels, same results; pays off for launch-bound small problems)."""
     maxit = int(math.floor(maxit))                     # maxit may be a Float64 in the experiments
     dtype = _problem_dtype(x, f, A)
     x = _as_vec(x, dtype)
@@ -820,7 +823,7 @@ def adaptive_primal_dual(x, y, *, f, g, h, A, rule, tol=1e-5, maxit=10_000, name
         yv = None if no_lin else _as_vec(y, dtype)
         if not no_lin and yv.size != prob._d.m:
             raise ValueError(f"y has length {yv.size} but A has {prob._d.m} rows")
-        opts, recs = _opts(maxit, record is not None, poll_every)
+        opts, recs = _opts(maxit, record is not None, poll_every, use_graph)
         res = L.Result()
         x_out = np.empty_like(x)
         y_out = None if no_lin else np.empty_like(yv)
@@ -869,10 +872,11 @@ def _advance_counts(f, g, h, A, res, f_is_callback):
 
 
 def adaptive_proxgrad(x, *, f, g, rule, tol=1e-5, maxit=100_000, name="AdaPGM", record: Record = None,
-                      ctx: Optional[Context] = None, poll_every: int = 0):
+                      ctx: Optional[Context] = None, poll_every: int = 0, use_graph: bool = False):
     """src/AdaProx.jl:418-421.  Returns (x, numit)."""
     x, _, numit = adaptive_primal_dual(x, None, f=f, g=g, h=Zero(), A=0, rule=rule, tol=tol, maxit=maxit,
-                                       name=name, record=record, ctx=ctx, poll_every=poll_every)
+                                       name=name, record=record, ctx=ctx, poll_every=poll_every,
+                                       use_graph=use_graph)
     return x, numit
 
 
@@ -977,7 +981,7 @@ def backtracking_proxgrad(x0, *, f, g, gamma0, xi=1.0, shrink=0.5, tol=1e-5, max
 # --------------------------------------------------------------------------------------
 class Solver:
     def __init__(self, x, y=None, *, f, g, h=None, A=None, rule, tol=0.0, ctx: Optional[Context] = None,
-                 poll_every: int = 0):
+                 poll_every: int = 0, use_graph: bool = False):
         dtype = _problem_dtype(x, f, A)
         x = _as_vec(x, dtype)
         no_lin = A is None or (np.isscalar(_unwrap(A)) and _unwrap(A) == 0)
@@ -986,6 +990,7 @@ class Solver:
         yv = None if no_lin else _as_vec(y, dtype)
         opts = L.SolveOpts()
         opts.poll_every = poll_every
+        opts.use_graph = 1 if use_graph else 0
         h_ = C.c_void_p()
         r = rule._rule()
         self.prob.check(self.prob.lib.apx_solver_create(self.prob.h, C.byref(r), _ptr(x), _ptr(yv), float(tol),

@@ -98,6 +98,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if not os.path.exists(os.path.join(ROOT, "adaptive-proximal-algorithms_amd", "csrc", "libadaprox_hip.so")):
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()          # in-tree hipcc build (the .so is git-ignored)
+        if use_dist:
+            dist.barrier()
     import adaprox_amd as apx
     from importlib import import_module
     problems = import_module("adaptive-proximal-algorithms_amd.problems")

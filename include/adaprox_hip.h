@@ -163,7 +163,9 @@ typedef struct {
 typedef struct {
   apx_record* records;     /* caller buffer for per-iteration records, or NULL        */
   int64_t record_cap;      /* rows available; the first record_cap iterations are kept */
-  int32_t use_graph;       /* 1: replay the iteration as a captured hipGraph          */
+  int32_t use_graph;       /* 1: replay the iteration as a captured hipGraph (device-only
+                              iterations: no callback f, no all-reduce hook); bit-identical
+                              results, fewer launch gaps on launch-bound (small) problems */
   int32_t poll_every;      /* convergence flag is read back every this many iterations (0 = default 16) */
 } apx_solve_opts;
 
