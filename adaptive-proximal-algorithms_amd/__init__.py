@@ -20,4 +20,6 @@ from .api import (  # noqa: F401
     Solver,
 )
 
+from .baselines import backtracking_nesterov, fixed_nesterov, agraal, malitsky_pock  # noqa: F401,E402
+
 Record = -1  # `const Record = Logging.LogLevel(-1)` (src/AdaProx.jl:7): records go to the `record=` callable

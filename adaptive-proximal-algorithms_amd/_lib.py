@@ -118,6 +118,14 @@ PROTOTYPES = {
                                             _P(SolveOpts), c_void_p, _P(Result)]),
     "apx_adaptive_linesearch_primal_dual": (c_int32, [c_void_p, _P(LinesearchParams), c_void_p, c_void_p, c_double,
                                                       c_int64, _P(SolveOpts), c_void_p, c_void_p, _P(Result)]),
+    "apx_backtracking_nesterov": (c_int32, [c_void_p, c_void_p, c_double, c_double, c_double, c_int64, _P(SolveOpts),
+                                            c_void_p, _P(Result)]),
+    "apx_fixed_nesterov": (c_int32, [c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_int64,
+                                     _P(SolveOpts), c_void_p, _P(Result)]),
+    "apx_agraal": (c_int32, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_int64,
+                             _P(SolveOpts), c_void_p, _P(Result)]),
+    "apx_malitsky_pock": (c_int32, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_int64,
+                                    _P(SolveOpts), c_void_p, c_void_p, _P(Result)]),
     "apx_solver_create": (c_int32, [c_void_p, _P(Rule), c_void_p, c_void_p, c_double, _P(SolveOpts), _P(c_void_p)]),
     "apx_solver_step": (c_int32, [c_void_p, c_int64, c_int32]),
     "apx_solver_result": (c_int32, [c_void_p, c_void_p, c_void_p, _P(Result)]),

@@ -19,55 +19,11 @@
 #include <limits>
 #include <memory>
 
-#include "apx_internal.h"
-#include "vecops.h"
+#include "solver_internal.h"
 
 using namespace apx;
 
-struct apx_problem {
-  apx_ctx* ctx = nullptr;
-  int32_t f_kind = APX_F_ZERO, dtype = APX_F64;
-  int64_t n = 0, m = 0, n_pad = 0, m_pad = 0;
-  const apx_matrix* A_f = nullptr;
-  const apx_matrix* A_lin = nullptr;
-  apx_eval_fn eval_cb = nullptr;
-  apx_pullback_fn pb_cb = nullptr;
-  void* cb_user = nullptr;
-  apx_allreduce_fn allreduce = nullptr;
-  void* ar_user = nullptr;
-  double n_mean = 0.0;
-  DBuf b, res, grad, fsc_buf, xtmp, ctrl_buf;
-  DBuf g_lb, g_ub, g_shift, h_lb, h_ub, h_shift;
-  ProxDev gd{}, hd{};
-  std::vector<char> hbuf;
-  bool have_eval = false;
-  bool fsc_reduced = false;
-  apx_solver* active = nullptr;
-
-  Ctrl* ctrl() const { return (Ctrl*)ctrl_buf.p; }
-  const int* done_ptr() const { return (const int*)((const char*)ctrl_buf.p + offsetof(Ctrl, done)); }
-  bool fsc_packed = false;   // fp64 + all-reduce: the f scalars live at grad[fsc_off .. +1]
-  int64_t fsc_off() const { return round_up(n, kPad); }   // >= n and >= A_f->n_pad: never a gradient slot
-  double* fsc() const { return fsc_packed ? (double*)grad.p + fsc_off() : (double*)fsc_buf.p; }
-  size_t es() const { return dtype_size(dtype); }
-};
-
-struct apx_solver {
-  apx_problem* p = nullptr;
-  apx_rule rule{};
-  double tol = 0.0;
-  int32_t poll_every = 16;
-  DBuf x, xprev, gprev, v, aty, y, ax, axprev, recs;
-  int64_t rec_cap = 0;
-  apx_record* host_recs = nullptr;
-  int64_t iters = 0;        // iterations enqueued so far
-  bool stopped = false;     // the host has seen done == 1
-  bool use_graph = false;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-};
-
-namespace {
+namespace apx {
 
 int32_t h2d(apx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return APX_OK;
@@ -82,7 +38,7 @@ int32_t d2h(apx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return APX_OK;
 }
 
-int32_t make_prox_dev(apx_ctx* ctx, const apx_prox_desc& d, int32_t dtype, int64_t len, DBuf& lb, DBuf& ub,
+static int32_t make_prox_dev(apx_ctx* ctx, const apx_prox_desc& d, int32_t dtype, int64_t len, DBuf& lb, DBuf& ub,
                       DBuf& shift, ProxDev* out) {
   APX_REQUIRE(d.kind >= APX_G_ZERO && d.kind <= APX_G_L2, "unknown prox kind");
   const size_t es = dtype_size(dtype);
@@ -110,7 +66,7 @@ int32_t make_prox_dev(apx_ctx* ctx, const apx_prox_desc& d, int32_t dtype, int64
   return APX_OK;
 }
 
-int32_t do_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dtype) {
+static int32_t do_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dtype) {
   const int32_t rc = p->allreduce(p->ar_user, buf, count, dtype, (void*)p->ctx->stream);
   if (rc != 0) return fail(APX_ERR_CALLBACK, "all-reduce callback failed");
   return APX_OK;
@@ -256,7 +212,13 @@ int32_t init_ctrl(apx_problem* p, const apx_rule* rule, double tol) {
 
 int32_t read_ctrl(apx_problem* p, Ctrl* out) { return d2h(p->ctx, out, p->ctrl_buf.p, sizeof(Ctrl)); }
 
-}  // namespace
+int32_t mul_A_lin(apx_problem* p, const void* x_dev, void* ax) {
+  int splits = 0;
+  APX_TRY(launch_gemv_n(p->ctx, p->A_lin, x_dev, &splits, nullptr));
+  return launch_sum_partials_rows(p->ctx, p->dtype, splits, p->m, p->m_pad, ax, nullptr);
+}
+
+}  // namespace apx
 
 extern "C" {
 

@@ -1,0 +1,66 @@
+// solver_internal.h — problem / solver objects and the eval / pullback machinery shared by
+// solver.hip (the reference's generic loops) and baselines.hip (its comparison methods).
+#pragma once
+#include <cstddef>
+#include <vector>
+
+#include "apx_internal.h"
+#include "vecops.h"
+
+struct apx_problem {
+  apx_ctx* ctx = nullptr;
+  int32_t f_kind = APX_F_ZERO, dtype = APX_F64;
+  int64_t n = 0, m = 0, n_pad = 0, m_pad = 0;
+  const apx_matrix* A_f = nullptr;
+  const apx_matrix* A_lin = nullptr;
+  apx_eval_fn eval_cb = nullptr;
+  apx_pullback_fn pb_cb = nullptr;
+  void* cb_user = nullptr;
+  apx_allreduce_fn allreduce = nullptr;
+  void* ar_user = nullptr;
+  double n_mean = 0.0;
+  apx::DBuf b, res, grad, fsc_buf, xtmp, ctrl_buf;
+  apx::DBuf g_lb, g_ub, g_shift, h_lb, h_ub, h_shift;
+  apx::ProxDev gd{}, hd{};
+  std::vector<char> hbuf;
+  bool have_eval = false;
+  bool fsc_reduced = false;
+  apx_solver* active = nullptr;
+
+  apx::Ctrl* ctrl() const { return (apx::Ctrl*)ctrl_buf.p; }
+  const int* done_ptr() const { return (const int*)((const char*)ctrl_buf.p + offsetof(apx::Ctrl, done)); }
+  bool fsc_packed = false;   // fp64 + all-reduce: the f scalars live at grad[fsc_off .. +1]
+  int64_t fsc_off() const { return apx::round_up(n, apx::kPad); }   // >= n and >= A_f->n_pad: never a gradient slot
+  double* fsc() const { return fsc_packed ? (double*)grad.p + fsc_off() : (double*)fsc_buf.p; }
+  size_t es() const { return apx::dtype_size(dtype); }
+};
+
+struct apx_solver {
+  apx_problem* p = nullptr;
+  apx_rule rule{};
+  double tol = 0.0;
+  int32_t poll_every = 16;
+  apx::DBuf x, xprev, gprev, v, aty, y, ax, axprev, recs;
+  int64_t rec_cap = 0;
+  apx_record* host_recs = nullptr;
+  int64_t iters = 0;        // iterations enqueued so far
+  bool stopped = false;     // the host has seen done == 1
+  bool use_graph = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+};
+
+namespace apx {
+
+int32_t h2d(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
+int32_t d2h(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
+// `f_x, pb = eval_with_pullback(f, x)` on a device x (need_f: f_x final in Ctrl on return to the stream)
+int32_t eval_f(apx_problem* p, const void* x_dev, bool need_f);
+// `pb()`: gradient at the x of the latest eval, written to p->grad
+int32_t pullback_f(apx_problem* p);
+int32_t init_ctrl(apx_problem* p, const apx_rule* rule, double tol);
+int32_t read_ctrl(apx_problem* p, Ctrl* out);
+// A_x = A_lin * x  into ax (T, length m_pad)
+int32_t mul_A_lin(apx_problem* p, const void* x_dev, void* ax);
+
+}  // namespace apx

@@ -32,6 +32,16 @@ int32_t vo_reduce_sums(apx_ctx* ctx, int32_t dtype, const void* x, const void* x
 int32_t vo_dual_trial(apx_ctx* ctx, int32_t dtype, const void* y, const void* ax, const void* axprev, void* ynext,
                       int64_t m, const ProxDev& h, double sigma, double rho, double* out3);
 int32_t vo_diff_sumsq(apx_ctx* ctx, int32_t dtype, const void* a, const void* b, int64_t n, double* out1);
+// comparison baselines
+int32_t vo_extrap(apx_ctx* ctx, int32_t dtype, void* out, const void* a, const void* b, double c, int64_t n);
+int32_t vo_xbar(apx_ctx* ctx, int32_t dtype, void* xbar, const void* x, double phi, int64_t n);
+int32_t vo_mp_trial(apx_ctx* ctx, int32_t dtype, const void* xprev, const void* aty, const void* atyprev,
+                    const void* gradprev, void* v, void* x, int64_t n, const ProxDev& g, double theta, double gamma,
+                    double* out3);
+int32_t vo_mp_dualres(apx_ctx* ctx, int32_t dtype, const void* yold, const void* axold, const void* ynew,
+                      const void* axnew, int64_t m, double sigma_prev, const ProxDev& h, double* out2);
+int32_t vo_primal_res(apx_ctx* ctx, int32_t dtype, const void* v, const void* x, const void* grad, const void* aty,
+                      int64_t n, double gamma, const ProxDev& g, double* out2);
 // g(x) raw accumulator -> out_val_sum (device)
 int32_t vo_gval(apx_ctx* ctx, int32_t dtype, const void* x, int64_t n, const ProxDev& g, double* out_val_sum);
 double vo_gval_final_host(const ProxDev& g, double s);

@@ -566,6 +566,85 @@ __global__ __launch_bounds__(kBlock) void k_diff_sumsq(const T* __restrict__ a, 
   block_partials_store<1>(q, red);
 }
 
+// ---------------------------------------------------------------------------------
+// comparison baselines
+// ---------------------------------------------------------------------------------
+// out = a + c*(a - b)      Nesterov extrapolation, src/AdaProx.jl:80, :129
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_extrap(T* __restrict__ out, const T* __restrict__ a,
+                                                   const T* __restrict__ b, double c, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double ai = (double)a[i];
+    out[i] = (T)(ai + c * (ai - (double)b[i]));
+  }
+}
+
+// x_bar = ((phi - 1)*x + x_bar) / phi      aGRAAL, src/AdaProx.jl:179
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_xbar(T* __restrict__ xbar, const T* __restrict__ x, double phi,
+                                                 int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    xbar[i] = (T)(((phi - 1.0) * (double)x[i] + (double)xbar[i]) / phi);
+}
+
+// Malitsky-Pock trial, src/AdaProx.jl:558-560 / :571-573:
+//   At_ybar = (1+theta)*At_y - theta*At_y_prev ; v = x_prev - gamma*(At_ybar + grad_prev) ; x = prox_g(v)
+//   q0 = ||x - x_prev||^2 ; q1 = <grad_prev, x - x_prev> ; q2 = raw g(x)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mp_trial(const T* __restrict__ xprev, const T* __restrict__ aty,
+                                                     const T* __restrict__ atyprev, const T* __restrict__ gradprev,
+                                                     T* __restrict__ v, T* __restrict__ x, int64_t n, ProxDev g,
+                                                     double theta, double gamma, double* __restrict__ red) {
+  double q[3] = {0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xp = (double)xprev[i], gp = (double)gradprev[i];
+    const double ybar = (1.0 + theta) * (double)aty[i] - theta * (double)atyprev[i];
+    const T vi = (T)(xp - gamma * (ybar + gp));
+    const T xi = (T)prox_elem_val<T>(g, (double)vi, gamma, i, 0.0, &q[2]);
+    const double d = (double)xi - xp;
+    q[0] = fma(d, d, q[0]);
+    q[1] = fma(gp, d, q[1]);
+    v[i] = vi;
+    x[i] = xi;
+  }
+  block_partials_store<3>(q, red);
+}
+
+// Malitsky-Pock dual residual, src/AdaProx.jl:601, :617:  w = y_old + sigma_prev*A_x_old ;
+//   dual_res = (w - y_new)/sigma_prev - A_x_new ;  q0 = ||dual_res||^2 ; q1 = raw h(A_x_new)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mp_dualres(const T* __restrict__ yold, const T* __restrict__ axold,
+                                                       const T* __restrict__ ynew, const T* __restrict__ axnew,
+                                                       int64_t m, double sigma_prev, ProxDev h,
+                                                       double* __restrict__ red) {
+  double q[2] = {0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double w = (double)yold[i] + sigma_prev * (double)axold[i];
+    const double an = (double)axnew[i];
+    const double dr = (w - (double)ynew[i]) / sigma_prev - an;
+    q[0] = fma(dr, dr, q[0]);
+    q[1] += gval_elem<T>(h, an, i);
+  }
+  block_partials_store<2>(q, red);
+}
+
+// primal_res = (v - x)/gamma + grad + At_y with a HOST gamma:  q0 = ||primal_res||^2 ; q1 = raw g(x)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_primal_res(const T* __restrict__ v, const T* __restrict__ x,
+                                                       const T* __restrict__ grad, const T* __restrict__ aty,
+                                                       int64_t n, double gamma, ProxDev g,
+                                                       double* __restrict__ red) {
+  double q[2] = {0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xi = (double)x[i];
+    double pr = ((double)v[i] - xi) / gamma + (double)grad[i];
+    if (aty != nullptr) pr = pr + (double)aty[i];
+    q[0] = fma(pr, pr, q[0]);
+    q[1] += gval_elem<T>(g, xi, i);
+  }
+  block_partials_store<2>(q, red);
+}
+
 // g(x): raw accumulator of the value of a proximable term (finished by gval_final / vo_gval_final_host)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_gval(const T* __restrict__ x, int64_t n, ProxDev g,
@@ -770,6 +849,72 @@ int32_t vo_diff_sumsq(apx_ctx* ctx, int32_t dtype, const void* a, const void* b,
              hipLaunchKernelGGL(k_diff_sumsq<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)a,
                                 (const float*)b, n, ctx->red));
   hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, out1);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_extrap(apx_ctx* ctx, int32_t dtype, void* out, const void* a, const void* b, double c, int64_t n) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_extrap<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)out,
+                                (const double*)a, (const double*)b, c, n),
+             hipLaunchKernelGGL(k_extrap<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)out, (const float*)a,
+                                (const float*)b, c, n));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_xbar(apx_ctx* ctx, int32_t dtype, void* xbar, const void* x, double phi, int64_t n) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_xbar<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)xbar,
+                                (const double*)x, phi, n),
+             hipLaunchKernelGGL(k_xbar<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)xbar, (const float*)x,
+                                phi, n));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_mp_trial(apx_ctx* ctx, int32_t dtype, const void* xprev, const void* aty, const void* atyprev,
+                    const void* gradprev, void* v, void* x, int64_t n, const ProxDev& g, double theta, double gamma,
+                    double* out3) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_mp_trial<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)xprev,
+                                (const double*)aty, (const double*)atyprev, (const double*)gradprev, (double*)v,
+                                (double*)x, n, g, theta, gamma, ctx->red),
+             hipLaunchKernelGGL(k_mp_trial<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)xprev,
+                                (const float*)aty, (const float*)atyprev, (const float*)gradprev, (float*)v,
+                                (float*)x, n, g, theta, gamma, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 3, out3);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_mp_dualres(apx_ctx* ctx, int32_t dtype, const void* yold, const void* axold, const void* ynew,
+                      const void* axnew, int64_t m, double sigma_prev, const ProxDev& h, double* out2) {
+  const unsigned gr = vgrid(m);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_mp_dualres<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)yold,
+                                (const double*)axold, (const double*)ynew, (const double*)axnew, m, sigma_prev, h,
+                                ctx->red),
+             hipLaunchKernelGGL(k_mp_dualres<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)yold,
+                                (const float*)axold, (const float*)ynew, (const float*)axnew, m, sigma_prev, h,
+                                ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 2, out2);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_primal_res(apx_ctx* ctx, int32_t dtype, const void* v, const void* x, const void* grad, const void* aty,
+                      int64_t n, double gamma, const ProxDev& g, double* out2) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_primal_res<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)v,
+                                (const double*)x, (const double*)grad, (const double*)aty, n, gamma, g, ctx->red),
+             hipLaunchKernelGGL(k_primal_res<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)v,
+                                (const float*)x, (const float*)grad, (const float*)aty, n, gamma, g, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 2, out2);
   APX_HIP(hipGetLastError());
   return APX_OK;
 }

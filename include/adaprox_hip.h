@@ -272,6 +272,22 @@ int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch
                                             const void* y0, double tol, int64_t maxit, const apx_solve_opts* opts,
                                             void* x_out, void* y_out, apx_result* res);
 
+/* ---- comparison baselines of the experiments -------------------- */
+/* backtracking_nesterov(x0; f, g, gamma0, shrink, tol, maxit) — src/AdaProx.jl:66-84 */
+int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0, double shrink, double tol,
+                                  int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
+/* fixed_nesterov(x0; f, g, Lf | gamma, muf, mug, theta, tol, maxit) — src/AdaProx.jl:91-142.
+ * Pass gamma (= 1/Lf when the caller has Lf); theta < 0 means `nothing`. */
+int32_t apx_fixed_nesterov(apx_problem* p, const void* x0, double gamma, double muf, double mug, double theta,
+                           double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
+/* agraal(x1; f, g, x0, gamma0, gamma_max, phi, tol, maxit) — src/AdaProx.jl:150-192.
+ * x0 is required (the host draws x1 + randn for `nothing`); gamma0 <= 0 means `nothing`. */
+int32_t apx_agraal(apx_problem* p, const void* x1, const void* x0, double gamma0, double gamma_max, double phi,
+                   double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
+/* malitsky_pock(x, y; f, g, h, A, sigma, t, tol, maxit) — src/AdaProx.jl:555-629 */
+int32_t apx_malitsky_pock(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol,
+                          int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res);
+
 /* ---- stepping interface (bench.py times exactly K iterations with data resident) ---- */
 /* runs the pre-loop of adaptive_primal_dual (src/AdaProx.jl:324-332) and leaves the state on device */
 int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, const void* y0,

@@ -796,3 +796,171 @@ def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=
         x_prev, A_x_prev, grad_x_prev = x, A_x, grad_x                # :546
         x, _ = prox(g, v, gamma)                                      # :547
     return x, y, maxit                                                # :549
+
+
+# ----------------------------------------------------------------------------
+# Comparison baselines: Nesterov variants, aGRAAL, Malitsky-Pock
+# ----------------------------------------------------------------------------
+
+def backtracking_nesterov(x0, *, f, g, gamma0, shrink=0.5, tol=1e-5, maxit=100_000,
+                          name="Backtracking Nesterov", record: Record = None, trace=None):
+    """src/AdaProx.jl:66-84.  Returns (z, it)."""
+    maxit = int(math.floor(maxit))
+    x, z, gamma = x0, x0, gamma0                                     # :67
+    theta = 1.0                                                      # :68
+    f_x, grad_x = eval_with_gradient(f, x)                           # :69
+    for it in range(1, maxit + 1):                                   # :70
+        z_prev = z                                                   # :71
+        gamma, z, f_z, g_z, _ = backtrack_stepsize(gamma, f, g, x, f_x, grad_x, shrink)   # :72
+        norm_res = jl_norm(z - x) / gamma                            # :73
+        if record is not None:                                       # :74
+            record(dict(method=name, it=it, gamma=gamma, norm_res=norm_res, objective=(f_z + g_z),
+                        grad_f_evals=grad_count(f), prox_g_evals=prox_count(g), f_evals=eval_count(f)))
+        if trace is not None:
+            trace.append(dict(it=it, gamma=gamma, norm_res=norm_res, x=np.array(z, copy=True)))
+        if norm_res <= tol:                                          # :75-77
+            return z, it
+        theta_prev = theta                                           # :78
+        theta = (1 + math.sqrt(1 + 4 * theta_prev ** 2)) / 2         # :79
+        x = z + (theta_prev - 1) / theta * (z - z_prev)              # :80
+        f_x, grad_x = eval_with_gradient(f, x)                       # :81
+    return z, maxit                                                  # :83
+
+
+def fixed_nesterov(x0, *, f, g, Lf=None, muf=0, mug=0, gamma=None, theta=None, tol=1e-5, maxit=100_000,
+                   name="Fixed Nesterov", record: Record = None, trace=None):
+    """src/AdaProx.jl:91-142.  Returns (x, it)."""
+    maxit = int(math.floor(maxit))
+    assert (gamma is None) != (Lf is None)                           # :104
+    if gamma is None:                                                # :105-107
+        gamma = 1 / Lf
+    mu = muf + mug                                                   # :108
+    q = gamma * mu / (1 + gamma * mug)                               # :109
+    assert q < 1                                                     # :110
+    if theta is None:                                                # :111-117
+        theta = 1 / math.sqrt(q) if q > 0 else 0
+    assert 0 <= theta <= jl_div(1.0, math.sqrt(q))                   # :118
+    x, x_prev = x0, x0                                               # :119
+    for it in range(1, maxit + 1):                                   # :120
+        theta_prev = theta                                           # :121
+        if mu == 0:                                                  # :122-128
+            theta = (1 + math.sqrt(1 + 4 * theta_prev ** 2)) / 2
+            beta = (theta_prev - 1) / theta
+        else:
+            theta = (1 - q * theta_prev ** 2 + math.sqrt((1 - q * theta_prev ** 2) ** 2 + 4 * theta_prev ** 2)) / 2
+            beta = (theta_prev - 1) * (1 + gamma * mug - theta * gamma * mu) / theta / (1 - gamma * muf)
+        z = x + beta * (x - x_prev)                                  # :129
+        _, grad_z = eval_with_gradient(f, z)                         # :130
+        x_prev = x                                                   # :131
+        x, g_x = prox(g, z - gamma * grad_z, gamma)                  # :132
+        norm_res = jl_norm(x - z) / gamma                            # :133
+        if record is not None:                                       # :134-136 (lazy, inside without_counting)
+            def _emit():
+                record(dict(method=name, it=it, gamma=gamma, norm_res=norm_res, objective=(call_f(f, x) + g_x),
+                            grad_f_evals=grad_count(f), prox_g_evals=prox_count(g), f_evals=eval_count(f)))
+            without_counting(_emit)
+        if trace is not None:
+            trace.append(dict(it=it, gamma=gamma, norm_res=norm_res, x=np.array(x, copy=True)))
+        if norm_res <= tol:                                          # :137-139
+            return x, it
+    return x, maxit                                                  # :141
+
+
+def agraal(x1, *, f, g, x0=None, gamma0=None, gamma_max=1e6, phi=1.5, tol=1e-5, maxit=100_000, name="aGRAAL",
+           record: Record = None, trace=None):
+    """src/AdaProx.jl:150-192.  ``x0`` must be given to be reproducible (the reference draws
+    ``x1 + randn(size(x1))`` when it is ``nothing``, :162-164)."""
+    maxit = int(math.floor(maxit))
+    if x0 is None:                                                   # :162-164
+        x0 = x1 + np.random.default_rng(0).standard_normal(x1.shape)
+    x, x_prev, x_bar = x1, x0, x1                                    # :165
+    _, grad_x = eval_with_gradient(f, x)                             # :166
+    _, grad_x_prev = eval_with_gradient(f, x_prev)                   # :167
+    if gamma0 is None:                                               # :168-170
+        gamma0 = jl_div(jl_norm(x - x_prev), jl_norm(grad_x - grad_x_prev))
+    gamma = gamma0                                                   # :171
+    rho = 1 / phi + 1 / phi ** 2                                     # :172
+    theta = 1.0                                                      # :173
+    for it in range(1, maxit + 1):                                   # :174
+        C = jl_div(jl_norm(x - x_prev) ** 2, jl_norm(grad_x - grad_x_prev) ** 2)   # :175
+        gamma_prev = gamma                                           # :176
+        gamma = jl_min(rho * gamma_prev, jl_div(phi * theta * C, 4 * gamma_prev), gamma_max)   # :177
+        theta = phi * gamma / gamma_prev                             # :178
+        x_bar = ((phi - 1) * x + x_bar) / phi                        # :179
+        x_prev, grad_x_prev = x, grad_x                              # :180
+        x, g_x = prox(g, x_bar - gamma * grad_x_prev, gamma)         # :181
+        norm_res = jl_norm(x - x_prev) / gamma                       # :182
+        if record is not None:                                       # :183-185
+            def _emit():
+                record(dict(method=name, it=it, gamma=gamma, norm_res=norm_res, objective=(call_f(f, x) + g_x),
+                            grad_f_evals=grad_count(f), prox_g_evals=prox_count(g), f_evals=eval_count(f)))
+            without_counting(_emit)
+        if trace is not None:
+            trace.append(dict(it=it, gamma=gamma, norm_res=norm_res, x=np.array(x, copy=True)))
+        if norm_res <= tol:                                          # :186-188
+            return x, it
+        _, grad_x = eval_with_gradient(f, x)                         # :189
+    return x, maxit                                                  # :191
+
+
+def backtrack_stepsize_MP(sigma, sigma_prev, t, x_prev, y, y_prev, grad_x_prev, A_x_prev, At_y, At_y_prev, f, g, A,
+                          f_x_prev, warn=None):
+    """src/AdaProx.jl:555-579."""
+    def attempt(sigma):
+        theta = sigma / sigma_prev                                   # :556 / :569
+        gamma = t ** 2 * sigma                                       # :557 / :570
+        At_ybar = (1 + theta) * At_y - theta * At_y_prev             # :558 / :571
+        v = x_prev - gamma * (At_ybar + grad_x_prev)                 # :559 / :572
+        x, _ = prox(g, v, gamma)                                     # :560 / :573
+        A_x = mul(A, x)                                              # :561 / :574
+        f_x, pb = eval_with_pullback(f, x)                           # :562 / :575
+        lhs = gamma * sigma * jl_norm(A_x - A_x_prev) ** 2 + 2 * gamma * (
+            f_x - f_x_prev - jl_dot(grad_x_prev, x - x_prev))        # :563 / :576
+        return gamma, x, v, A_x, f_x, pb, lhs
+    gamma, x, v, A_x, f_x, pb, lhs = attempt(sigma)
+    while lhs > 0.95 * jl_norm(x - x_prev) ** 2:                     # :564
+        sigma /= 2                                                   # :565
+        if sigma < 1e-12 and warn is not None:                       # :566-568
+            warn(gamma)
+        gamma, x, v, A_x, f_x, pb, lhs = attempt(sigma)
+    return sigma, gamma, x, v, A_x, f_x, pb                          # :578
+
+
+def malitsky_pock(x, y, *, f, g, h, A, sigma, t=1.0, tol=1e-5, maxit=10_000, name="MP-ls", record: Record = None,
+                  trace=None):
+    """src/AdaProx.jl:581-629.  Returns (x, y, it)."""
+    maxit = int(math.floor(maxit))
+    h_conj = convex_conjugate(h)                                     # :594
+    theta = 1.0                                                      # :595
+    y_prev = y                                                       # :596
+    A_x = mul(A, x)                                                  # :597
+    At_y = amul(A, y)                                                # :598
+    for it in range(1, maxit + 1):                                   # :599
+        At_y_prev = At_y                                             # :600
+        w = y + sigma * A_x                                          # :601
+        y, _ = prox(h_conj, w, sigma)                                # :602
+        At_y = amul(A, y)                                            # :603
+        sigma_prev = sigma                                           # :605
+        sigma = sigma * math.sqrt(1 + theta)                         # :606
+        f_x_prev, grad_x_prev = eval_with_gradient(f, x)             # :608
+        x_prev, A_x_prev = x, A_x                                    # :609
+        sigma, gamma, x, v, A_x, f_x, pb = backtrack_stepsize_MP(    # :610-611
+            sigma, sigma_prev, t, x_prev, y, y_prev, grad_x_prev, A_x_prev, At_y, At_y_prev, f, g, A, f_x_prev)
+        grad_x = pb()                                                # :612
+        y_prev = y                                                   # :614
+        primal_res = (v - x) / gamma + grad_x + At_y                 # :616
+        dual_res = (w - y) / sigma_prev - A_x                        # :617
+        norm_res = math.sqrt(jl_norm(primal_res) ** 2 + jl_norm(dual_res) ** 2)   # :618
+        if record is not None:                                       # :620-622
+            def _emit():
+                record(dict(method=name, it=it, gamma=gamma, sigma=sigma, norm_res=norm_res,
+                            objective=(f_x + call_g(g, x) + call_g(h, A_x)),
+                            grad_f_evals=grad_count(f), prox_g_evals=prox_count(g), prox_h_evals=prox_count(h),
+                            A_evals=mul_count(A), At_evals=amul_count(A), f_evals=eval_count(f)))
+            without_counting(_emit)
+        if trace is not None:
+            trace.append(dict(it=it, gamma=gamma, sigma=sigma, norm_res=norm_res, x=np.array(x, copy=True),
+                              y=np.array(y, copy=True)))
+        if norm_res <= tol:                                          # :624-626
+            return x, y, it
+    return x, y, maxit                                               # :628
