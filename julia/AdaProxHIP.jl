@@ -171,14 +171,19 @@ cnt(_, ::Symbol, _) = nothing
 function with_problem(body, f, g, h, A, ::Type{T}) where {T}
     fu, gu, hu, Au = unwrap(f), unwrap(g), unwrap(h), unwrap(A)
     keep = Any[]
-    fk, Af, b, n = f_fields(fu)
     A_lin = Au isa HipMatrix ? Au.h : C_NULL
     m = Au isa HipMatrix ? Au.m : 0
-    desc = ProblemDesc(fk, dtype_code(T), n, m, Af.h, pointer(b), 0, C_NULL, C_NULL, C_NULL,
+    if fu isa Zero                       # experiments/least_absolute_deviation/runme.jl:18-21
+        fk, Af_h, b, n, ctx = F_ZERO, C_NULL, T[], Au.n, Au.ctx
+    else
+        fk, Af, b, n = f_fields(fu)
+        Af_h, ctx = Af.h, Af.ctx
+    end
+    desc = ProblemDesc(fk, dtype_code(T), n, m, Af_h, isempty(b) ? C_NULL : pointer(b), 0, C_NULL, C_NULL, C_NULL,
                        proxdesc(gu, T, keep), proxdesc(hu, T, keep), A_lin, C_NULL, C_NULL)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve b keep begin
-        check(ccall((:apx_problem_create, LIB), Int32, (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), Af.ctx.h, Ref(desc), out))
+        check(ccall((:apx_problem_create, LIB), Int32, (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), ctx.h, Ref(desc), out))
         try
             return body(out[])
         finally
@@ -241,6 +246,106 @@ function backtracking_proxgrad(x0::Vector{T}; f, g, gamma0, xi = 1.0, shrink = 0
         end
         bump!(f, g, nothing, nothing, res)
         return z, Int(res.numit)
+    end
+end
+
+struct LinesearchParams    # apx_linesearch_params
+    gamma::Cdouble; eta::Cdouble; t::Cdouble; delta::Cdouble; Theta::Cdouble; r::Cdouble; R::Cdouble
+    max_linesearch::Int64
+end
+
+# shared tail of the primal-dual style entry points: replay records with the :351 schema
+function replay_pd(name, recs, res, f, g, h, A, at_of, proxh_of)
+    for i in 1:res.n_records
+        r = recs[i]; k = r.it
+        @logmsg AdaProx.Record "" method=name it=k gamma=r.gamma sigma=r.sigma norm_res=r.norm_res objective=r.objective grad_f_evals=cnt(f, :grad_count, k + 1) prox_g_evals=cnt(g, :prox_count, k) prox_h_evals=cnt(h, :prox_count, proxh_of(r)) A_evals=cnt(A, :mul_count, k + 1) At_evals=cnt(A, :amul_count, at_of(r)) f_evals=cnt(f, :eval_count, k + 1)
+    end
+end
+
+"adaptive_linesearch_primal_dual (AdaPDM+) — src/AdaProx.jl:463-550"
+function adaptive_linesearch_primal_dual(x::Vector{T}, y::Vector{T}; f, g, h, A, gamma = nothing, eta = 1.0, t = 1.0,
+        delta = 1e-8, Theta = 1.2, r = 2, R = 0.95, tol = 1e-5, maxit = 10_000, name = "AdaPDM+") where {T}
+    @assert eta > 0 "eta must be positive"
+    @assert Theta > (delta + 1) "must be Theta > (delta + 1)"
+    maxit = floor(Int, maxit)
+    with_problem(f, g, h, A, T) do prob
+        recs = Vector{Record}(undef, max(maxit, 1))
+        opts = SolveOpts(pointer(recs), maxit, 0, 0)
+        prm = LinesearchParams(gamma === nothing ? 0.0 : gamma, eta, t, delta, Theta, r, R, 0)
+        res = Result(); x_out = similar(x); y_out = similar(y)
+        GC.@preserve recs check(ccall((:apx_adaptive_linesearch_primal_dual, LIB), Int32,
+            (Ptr{Cvoid}, Ref{LinesearchParams}, Ptr{T}, Ptr{T}, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ptr{T}, Ref{Result}),
+            prob, Ref(prm), x, y, tol, maxit, Ref(opts), x_out, y_out, res))
+        replay_pd(name, recs, res, f, g, h, A, r -> r.grad_evals, r -> r.grad_evals - 1)
+        bump!(f, g, h, A, res)
+        return x_out, y_out, Int(res.numit)
+    end
+end
+
+"malitsky_pock — src/AdaProx.jl:581-629"
+function malitsky_pock(x::Vector{T}, y::Vector{T}; f, g, h, A, sigma, t = 1.0, tol = 1e-5, maxit = 10_000, name = "MP-ls") where {T}
+    maxit = floor(Int, maxit)
+    with_problem(f, g, h, A, T) do prob
+        recs = Vector{Record}(undef, max(maxit, 1))
+        opts = SolveOpts(pointer(recs), maxit, 0, 0)
+        res = Result(); x_out = similar(x); y_out = similar(y)
+        GC.@preserve recs check(ccall((:apx_malitsky_pock, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Cdouble, Cdouble, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ptr{T}, Ref{Result}),
+            prob, x, y, sigma, t, tol, maxit, Ref(opts), x_out, y_out, res))
+        for i in 1:res.n_records                   # record schema :621; trials = f_evals - it
+            r = recs[i]; k = r.it; tr = r.f_evals - k
+            @logmsg AdaProx.Record "" method=name it=k gamma=r.gamma sigma=r.sigma norm_res=r.norm_res objective=r.objective grad_f_evals=cnt(f, :grad_count, 2k) prox_g_evals=cnt(g, :prox_count, tr) prox_h_evals=cnt(h, :prox_count, k) A_evals=cnt(A, :mul_count, 1 + tr) At_evals=cnt(A, :amul_count, 1 + k) f_evals=cnt(f, :eval_count, r.f_evals)
+        end
+        bump!(f, g, h, A, res)
+        return x_out, y_out, Int(res.numit)
+    end
+end
+
+# proximal-gradient style baselines share one driver: `call` performs the ccall
+function pg_baseline(call, name, x0::Vector{T}, f, g, maxit, counts) where {T}
+    maxit = floor(Int, maxit)
+    with_problem(f, g, Zero(), 0, T) do prob
+        recs = Vector{Record}(undef, max(maxit, 1))
+        opts = SolveOpts(pointer(recs), maxit, 0, 0)
+        res = Result(); x_out = similar(x0)
+        GC.@preserve recs check(call(prob, Ref(opts), x_out, res))
+        for i in 1:res.n_records                   # record schema :74 / :135 / :184
+            r = recs[i]; (ge, pe, fe) = counts(r)
+            @logmsg AdaProx.Record "" method=name it=r.it gamma=r.gamma norm_res=r.norm_res objective=r.objective grad_f_evals=cnt(f, :grad_count, ge) prox_g_evals=cnt(g, :prox_count, pe) f_evals=cnt(f, :eval_count, fe)
+        end
+        bump!(f, g, nothing, nothing, res)
+        return x_out, Int(res.numit)
+    end
+end
+
+"backtracking_nesterov — src/AdaProx.jl:66-84"
+backtracking_nesterov(x0::Vector{T}; f, g, gamma0, shrink = 0.5, tol = 1e-5, maxit = 100_000, name = "Backtracking Nesterov") where {T} =
+    pg_baseline(name, x0, f, g, maxit, r -> (r.grad_evals, r.f_evals - r.it, r.f_evals)) do prob, opts, x_out, res
+        ccall((:apx_backtracking_nesterov, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{T}, Cdouble, Cdouble, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ref{Result}),
+              prob, x0, gamma0, shrink, tol, floor(Int, maxit), opts, x_out, res)
+    end
+
+"fixed_nesterov — src/AdaProx.jl:91-142"
+function fixed_nesterov(x0::Vector{T}; f, g, Lf = nothing, muf = 0, mug = 0, gamma = nothing, theta = nothing, tol = 1e-5,
+                        maxit = 100_000, name = "Fixed Nesterov") where {T}
+    @assert (gamma === nothing) != (Lf === nothing)
+    gamma === nothing && (gamma = 1 / Lf)
+    pg_baseline(name, x0, f, g, maxit, r -> (r.it, r.it, r.it)) do prob, opts, x_out, res
+        ccall((:apx_fixed_nesterov, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{T}, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ref{Result}),
+              prob, x0, gamma, muf, mug, theta === nothing ? -1.0 : theta, tol, floor(Int, maxit), opts, x_out, res)
+    end
+end
+
+"agraal — src/AdaProx.jl:150-192"
+function agraal(x1::Vector{T}; f, g, x0 = nothing, gamma0 = nothing, gamma_max = 1e6, phi = 1.5, tol = 1e-5,
+                maxit = 100_000, name = "aGRAAL") where {T}
+    x0 === nothing && (x0 = x1 + randn(size(x1)))
+    pg_baseline(name, x1, f, g, maxit, r -> (r.it + 1, r.it, r.it + 1)) do prob, opts, x_out, res
+        ccall((:apx_agraal, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Cdouble, Cdouble, Cdouble, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ref{Result}),
+              prob, x1, x0, gamma0 === nothing ? 0.0 : gamma0, gamma_max, phi, tol, floor(Int, maxit), opts, x_out, res)
     end
 end
 
