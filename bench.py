@@ -36,8 +36,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--m", type=int, default=50_000, help="rows per GPU")
-    ap.add_argument("--n", type=int, default=100_000)
+    # (long names: torch.distributed.run's own parser treats a bare `--m` after the script as an
+    # ambiguous abbreviation of its options)
+    ap.add_argument("--rows", dest="m", type=int, default=50_000, help="rows per GPU")
+    ap.add_argument("--cols", dest="n", type=int, default=100_000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
@@ -86,7 +88,12 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # APX_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a ONE-GPU box — every rank uses
+    # device 0 and the collectives go through gloo (RCCL refuses two ranks on one device).  Checks
+    # the sharding / all-reduce logic with real ranks; its timings mean nothing.
+    share_gpu = os.environ.get("APX_BENCH_SHARE_GPU") == "1"
+    dev = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev)
     # APX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (the 1-GPU box
     # rehearsal of what the driver launches with N ranks)
     use_dist = world > 1 or os.environ.get("APX_BENCH_FORCE_DIST") == "1"
@@ -96,7 +103,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
 
     if not os.path.exists(os.path.join(ROOT, "adaptive-proximal-algorithms_amd", "csrc", "libadaprox_hip.so")):
         if local_rank == 0:
@@ -109,12 +119,12 @@ def main():
     problems = import_module("adaptive-proximal-algorithms_amd.problems")
     sharded = import_module("adaptive-proximal-algorithms_amd.sharded")
 
-    stream = torch.cuda.Stream(device=local_rank)
+    stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        ctx = apx.Context(device=local_rank, stream=stream.cuda_stream)
+        ctx = apx.Context(device=dev, stream=stream.cuda_stream)
         apx.set_default_context(ctx)
-        ar_host = sharded.host_allreduce(dist, local_rank) if use_dist else None
-        ar_dev = sharded.device_allreduce(dist, local_rank) if use_dist else None
+        ar_host = sharded.host_allreduce(dist, dev) if use_dist else None
+        ar_dev = sharded.device_allreduce(dist, dev) if use_dist else None
 
         t_setup = time.perf_counter()
         prob = problems.device_lasso(args.m, args.n, pfactor=10, seed=args.seed, rank=rank, world=world,
@@ -148,7 +158,7 @@ def main():
         solver.close()
 
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else f"cuda:{dev}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -166,7 +176,9 @@ def main():
         iters_per_s = args.steps / dt
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        # PMC traffic was collected (separate rocprofv3 --pmc passes, profiles/README.md) for the
+        # default per-GPU shape only
+        if os.path.exists(tpath) and (args.m, args.n) == (50_000, 100_000) and not share_gpu:
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
