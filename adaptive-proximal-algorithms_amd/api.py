@@ -100,7 +100,7 @@ class Context:
             self._h = None
 
     def __del__(self):
-        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+        if sys is None or sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
             return
         try:
             self.close()
@@ -236,7 +236,7 @@ class DeviceMatrix:
             self._h = None
 
     def __del__(self):
-        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+        if sys is None or sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
             return
         try:
             self.free()
@@ -761,7 +761,7 @@ class _Problem:
             self.h = None
 
     def __del__(self):
-        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+        if sys is None or sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
             return
         try:
             self.close()
@@ -1014,7 +1014,7 @@ class Solver:
         self.prob.close()
 
     def __del__(self):
-        if sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
+        if sys is None or sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone
             return
         try:
             self.close()

@@ -47,7 +47,6 @@ struct Ctrl {
   double npr2, ndr2, norm_res;     // norm(primal_res)^2, norm(dual_res)^2, residual
   double h_pre;                    // ||w/sigma + shift|| for the l2 conjugate prox
   double tol;
-  double bt[4];                    // backtracking scalars: dot(grad, z-x), sum (z-x)^2, g(z), spare
   double n_mean;                   // logistic: N of the mean
   int64_t it;
   int32_t done;
@@ -92,9 +91,7 @@ struct apx_ctx {
   size_t part_bytes = 0;
   double* red = nullptr;         // [kRedQ][kMaxRedBlocks] block partials of the fused vector kernels
   double* scal = nullptr;        // small device scalar scratch (16 doubles)
-  double* h_scal = nullptr;      // pinned host mirror
-  void* h_stage = nullptr;       // pinned staging for small host<->device vectors
-  size_t h_stage_bytes = 0;
+  double* h_scal = nullptr;      // pinned host scalars (64 doubles): read-backs of scal / Ctrl fields
   // profiling
   bool profile = false;
   struct Ev { hipEvent_t a, b; int kind; double bytes; };

@@ -20,6 +20,14 @@ static void n_launch(dim3 grid, hipStream_t s, const void* A, int64_t ld, const 
                      (const T*)x, part, m_pad, n, cps, done);
 }
 
+// interleaved-chunk variant: `n` carries n_pad, `cps` is unused
+template <typename T, int RPT, int UNR, bool NT>
+static void n_launch_il(dim3 grid, hipStream_t s, const void* A, int64_t ld, const void* x, double* part,
+                        int64_t m_pad, int64_t n_pad, int64_t, const int* done) {
+  hipLaunchKernelGGL((gemv_n_il_kernel<T, RPT, UNR, NT>), grid, dim3(kBlock), 0, s, (const T*)A, ld, (const T*)x,
+                     part, m_pad, n_pad, done);
+}
+
 template <typename T, int CPB, int UNR, bool NT, bool PIPE>
 static void t_launch(dim3 grid, hipStream_t s, const void* A, int64_t ld, const void* r, void* out, double* part,
                      int64_t rps, int64_t m_pad, int64_t n_pad, const int* done) {
@@ -27,12 +35,15 @@ static void t_launch(dim3 grid, hipStream_t s, const void* A, int64_t ld, const 
                      (const T*)r, (T*)out, part, rps, m_pad, n_pad, done);
 }
 
-struct NVar { const char* name; int rpt, unr; NLaunch f64, f32; };
+struct NVar { const char* name; int rpt, unr; NLaunch f64, f32; bool il; };
 struct TVar { const char* name; int cpb, unr; TLaunch f64, f32; };
 
 #define NV(RPT, UNR, NT, XM, PIPE)                                                        \
   { "n_rpt" #RPT "_unr" #UNR "_nt" #NT "_x" #XM "_p" #PIPE, RPT, UNR,                    \
-    n_launch<double, RPT, UNR, NT, XM, PIPE>, n_launch<float, RPT, UNR, NT, XM, PIPE> }
+    n_launch<double, RPT, UNR, NT, XM, PIPE>, n_launch<float, RPT, UNR, NT, XM, PIPE>, false }
+#define NVI(RPT, UNR, NT)                                                                 \
+  { "n_il_rpt" #RPT "_unr" #UNR "_nt" #NT, RPT, UNR,                                      \
+    n_launch_il<double, RPT, UNR, NT>, n_launch_il<float, RPT, UNR, NT>, true }
 #define TV(CPB, UNR, NT, PIPE)                                                            \
   { "t_cpb" #CPB "_unr" #UNR "_nt" #NT "_p" #PIPE, CPB, UNR,                              \
     t_launch<double, CPB, UNR, NT, PIPE>, t_launch<float, CPB, UNR, NT, PIPE> }
@@ -44,6 +55,8 @@ static const NVar kNVars[] = {
     NV(1, 8, true, 0, true),   NV(2, 8, true, 0, true),   NV(4, 4, true, 0, true),   NV(1, 16, true, 0, true),
     NV(2, 16, true, 0, true),  NV(1, 8, true, 1, true),   NV(2, 4, true, 0, true),   NV(1, 4, true, 0, true),
     NV(4, 8, true, 0, true),   NV(1, 8, true, 0, false),  NV(2, 8, false, 0, true),  NV(1, 8, false, 0, true),
+    NVI(2, 16, true),          NVI(1, 16, true),          NVI(2, 8, true),           NVI(4, 8, true),
+    NVI(1, 8, true),           NVI(4, 16, true),          NVI(2, 16, false),
 };
 static const TVar kTVars[] = {
     TV(4, 4, true, true),   TV(8, 2, true, true),   TV(4, 8, true, true),   TV(2, 8, true, true),
@@ -115,11 +128,16 @@ int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
   if (cps < v.unr) cps = v.unr;
   S = (A->n + cps - 1) / cps;
   if (S < 1) S = 1;
+  int64_t n_arg = A->n;
+  if (v.il) {   // chunks of v.unr columns dealt round-robin to the S splits; n_pad % unr == 0
+    n_arg = A->n_pad;
+    S = std::min<int64_t>(S, A->n_pad / v.unr);
+  }
   APX_REQUIRE(S <= 65535 && row_tiles <= 2147483647LL, "gemv_n grid too large");
   APX_TRY(ensure_part(ctx, (size_t)S * A->ld * sizeof(double)));
   APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)A->m * (double)A->n * dtype_size(A->dtype)));
   dim3 grid((unsigned)row_tiles, (unsigned)S);
-  (A->dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, A->d, A->ld, x, ctx->part, A->ld, A->n, cps, done);
+  (A->dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, A->d, A->ld, x, ctx->part, A->ld, n_arg, cps, done);
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
   *splits_out = (int)S;

@@ -232,4 +232,74 @@ __global__ __launch_bounds__(kBlock) void gemv_n_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------
+// gemv_n, interleaved column chunks ("il"): split s of S owns the UNR-column chunks
+// s, s+S, s+2S, ... instead of one contiguous band of n/S columns.  All resident blocks then
+// sweep the matrix together, so the addresses in flight chip-wide span S*UNR columns
+// (~0.5 GB at C2) instead of half the matrix — friendlier to the TLBs and DRAM pages, same
+// bytes, same partial layout.  x is read through the scalar cache (uniform index); the
+// x vector must be readable (zero-padded) up to n_pad, which is a multiple of UNR.
+// grid = (ceil(m_pad / (256*V*RPT)), S)
+// ----------------------------------------------------------------------------------
+template <typename T, int RPT, int UNR, bool NT>
+__global__ __launch_bounds__(kBlock) void gemv_n_il_kernel(
+    const T* __restrict__ A, int64_t ld, const T* __restrict__ x, double* __restrict__ part,
+    int64_t m_pad, int64_t n_pad, const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  constexpr int V = V16<T>::N;
+  constexpr int64_t STEP = (int64_t)kBlock * V;
+  const int tid = threadIdx.x;
+  const int64_t row_base = (int64_t)blockIdx.x * (STEP * RPT) + (int64_t)tid * V;
+  int64_t rowk[RPT];
+  bool live[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int64_t rr = row_base + k * STEP;
+    live[k] = rr < m_pad;
+    rowk[k] = live[k] ? rr : 0;
+  }
+  double acc[RPT][V];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[k][e] = 0.0;
+
+  const int64_t nchunks = n_pad / UNR;
+  const int64_t S = gridDim.y;
+  for (int64_t chunk = blockIdx.y; chunk < nchunks; chunk += S) {
+    const int64_t j0 = chunk * UNR;
+    const T* Ac = A + j0 * ld;
+    typename V16<T>::type av[UNR][RPT];
+    double xj[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) av[u][k] = ld16<T, NT>(Ac + u * ld + rowk[k]);
+      xj[u] = (double)x[j0 + u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int k = 0; k < RPT; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[k][e] = fma((double)av[u][k][e], xj[u], acc[k][e]);
+  }
+
+  double* po = part + (int64_t)blockIdx.y * m_pad;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    if (live[k]) {
+      dvec2* dst = reinterpret_cast<dvec2*>(po + row_base + k * STEP);
+#pragma unroll
+      for (int e = 0; e < V; e += 2) {
+        dvec2 o;
+        o[0] = acc[k][e];
+        o[1] = acc[k][e + 1];
+        dst[e / 2] = o;
+      }
+    }
+  }
+}
+
 }  // namespace apx

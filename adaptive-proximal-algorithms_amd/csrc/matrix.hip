@@ -174,7 +174,6 @@ static void ctx_free(apx_ctx* ctx) {
   if (ctx->red) (void)hipFree(ctx->red);
   if (ctx->scal) (void)hipFree(ctx->scal);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
-  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -45,7 +45,7 @@ def test_gemv_pair_matches_numpy(apx, m, n, dtype):
     assert np.array_equal(dA.to_numpy(), A)
 
 
-@pytest.mark.parametrize("variant", range(14))
+@pytest.mark.parametrize("variant", range(24))
 def test_every_gemv_n_variant(apx, variant):
     ctx = apx.Context(0)          # private context: the default one keeps its tuned configuration
     if variant >= len(ctx.gemv_variants(False)):
