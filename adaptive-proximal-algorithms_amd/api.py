@@ -145,6 +145,32 @@ class DeviceMatrix:
         return cls(ctx, h, m, n, _code(Af.dtype))
 
     @classmethod
+    def from_sparse(cls, A, ctx: Optional[Context] = None) -> "DeviceMatrix":
+        """A scipy.sparse matrix (any format) -> compressed storage on the device; plays the role of
+        the `SparseMatrixCSC` of experiments/libsvm.jl.  CSC input is passed through as such
+        (that is Julia's own layout), anything else as CSR."""
+        ctx = ctx or default_context()
+        fmt = getattr(A, "format", None)
+        if fmt not in ("csr", "csc"):
+            A = A.tocsr()
+            fmt = "csr"
+        A = A.copy()
+        A.sum_duplicates()
+        A.sort_indices()
+        if A.dtype not in (np.float32, np.float64):
+            A = A.astype(np.float64)
+        m, n = A.shape
+        ptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        idx = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data)
+        h = C.c_void_p()
+        L.check(ctx._lib.apx_matrix_upload_sparse(ctx._h, m, n, int(A.nnz), 0 if fmt == "csr" else 1, _ptr(ptr),
+                                                  _ptr(idx), _ptr(val), _code(val.dtype), C.byref(h)))
+        M = cls(ctx, h, m, n, _code(val.dtype))
+        M.nnz = int(A.nnz)
+        return M
+
+    @classmethod
     def zeros(cls, m: int, n: int, dtype=np.float64, ctx: Optional[Context] = None) -> "DeviceMatrix":
         ctx = ctx or default_context()
         h = C.c_void_p()
@@ -269,7 +295,9 @@ def as_device_matrix(A, ctx: Optional[Context] = None) -> DeviceMatrix:
         return A
     if isinstance(A, np.ndarray):
         return DeviceMatrix.from_numpy(A, ctx)
-    raise TypeError(f"cannot use {type(A)} as a dense matrix")
+    if hasattr(A, "tocsr") and hasattr(A, "nnz"):          # scipy.sparse
+        return DeviceMatrix.from_sparse(A, ctx)
+    raise TypeError(f"cannot use {type(A)} as a matrix")
 
 
 # --------------------------------------------------------------------------------------

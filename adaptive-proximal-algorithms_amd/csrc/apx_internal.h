@@ -105,7 +105,17 @@ struct apx_matrix {
   apx_ctx* ctx = nullptr;
   int64_t m = 0, n = 0, ld = 0, n_pad = 0;
   int32_t dtype = APX_F64;
-  void* d = nullptr;
+  void* d = nullptr;           // dense: column-major ld x n_pad
+  // sparse storage: BOTH orientations are kept, each as compressed rows, so
+  // `A*x` and `A'*y` are gather-style row products with a fixed summation order (no atomics)
+  bool sparse = false;
+  int64_t nnz = 0;
+  int64_t* rptr = nullptr;     // rows of A      : m + 1
+  int32_t* rind = nullptr;     //                  nnz column indices
+  void* rval = nullptr;
+  int64_t* tptr = nullptr;     // rows of A'     : n + 1
+  int32_t* tind = nullptr;     //                  nnz row indices
+  void* tval = nullptr;
 };
 
 namespace apx {
@@ -122,6 +132,9 @@ int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* ou
 // sums the gemv_n partials into y (T, length ld): `A*x` with no epilogue
 int32_t launch_sum_partials_rows(apx_ctx* ctx, int32_t dtype, int splits, int64_t m, int64_t ld, void* y,
                                  const int* done);
+// sparse.hip: the same two products for compressed storage (same output conventions)
+int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done);
+int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done);
 int gemv_n_variant_count();
 int gemv_t_variant_count();
 const char* gemv_n_variant_name(int i);

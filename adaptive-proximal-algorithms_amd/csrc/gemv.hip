@@ -104,6 +104,7 @@ static int32_t prof_end(apx_ctx* ctx) {
 }
 
 int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
+  if (A->sparse) return launch_spmv_n(ctx, A, x, splits_out, done);
   const int V = A->dtype == APX_F32 ? 4 : 2;
   int vi = ctx->cfg.n_variant;
   int64_t rows_per_block = (int64_t)kBlock * V * kNVars[vi].rpt;
@@ -145,6 +146,7 @@ int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
 }
 
 int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
+  if (A->sparse) return launch_spmv_t(ctx, A, r, out, done);
   const TVar& v = kTVars[ctx->cfg.t_variant];
   const int V = A->dtype == APX_F32 ? 4 : 2;
   const int64_t col_blocks = A->n_pad / v.cpb;

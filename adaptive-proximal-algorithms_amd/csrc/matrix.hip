@@ -97,6 +97,23 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ A, int64
   }
 }
 
+// the same over a plain array of `count` elements (sparse value arrays)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sumsq_elems(const T* __restrict__ v, int64_t count, double* __restrict__ red) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock)
+    s = fma((double)v[i], (double)v[i], s);
+  __shared__ double sh[kBlock / 64];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sh[0];
+    for (int w = 1; w < kBlock / 64; ++w) t += sh[w];
+    red[blockIdx.x] = t;
+  }
+}
+
 }  // namespace apx
 
 using namespace apx;
@@ -294,6 +311,7 @@ int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, 
 
 int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda) {
   APX_REQUIRE(A != nullptr && host != nullptr, "apx_matrix_download: NULL argument");
+  APX_REQUIRE(!A->sparse, "apx_matrix_download: dense matrices only");
   APX_REQUIRE(lda >= A->m, "apx_matrix_download: lda < m");
   APX_HIP(hipSetDevice(A->ctx->device));
   const size_t es = dtype_size(A->dtype);
@@ -310,6 +328,8 @@ int32_t apx_matrix_free(apx_matrix* A) {
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->stream);
   if (A->d) (void)hipFree(A->d);
+  for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval})
+    if (q) (void)hipFree(q);
   apx_ctx* ctx = A->ctx;
   delete A;
   ctx_release(ctx);
@@ -331,6 +351,7 @@ static inline dim3 grid_mn(int64_t m, int64_t n) {
 int32_t apx_matrix_fill_uniform(apx_matrix* A, uint64_t seed, double lo, double hi, int64_t row_offset,
                                 int64_t m_total) {
   APX_REQUIRE(A != nullptr, "apx_matrix_fill_uniform: A is NULL");
+  APX_REQUIRE(!A->sparse, "apx_matrix_fill_uniform: dense matrices only");
   if (m_total <= 0) m_total = A->m;
   APX_REQUIRE(row_offset >= 0 && row_offset + A->m <= m_total, "apx_matrix_fill_uniform: shard outside the global matrix");
   if (A->m == 0 || A->n == 0) return APX_OK;
@@ -357,6 +378,7 @@ int32_t apx_matrix_fill_uniform(apx_matrix* A, uint64_t seed, double lo, double 
 
 int32_t apx_matrix_scale_columns(apx_matrix* A, const double* alpha) {
   APX_REQUIRE(A != nullptr && alpha != nullptr, "apx_matrix_scale_columns: NULL argument");
+  APX_REQUIRE(!A->sparse, "apx_matrix_scale_columns: dense matrices only");
   if (A->m == 0 || A->n == 0) return APX_OK;
   APX_HIP(hipSetDevice(A->ctx->device));
   DBuf d_alpha;
@@ -380,6 +402,7 @@ int32_t apx_matrix_scale_columns(apx_matrix* A, const double* alpha) {
 
 int32_t apx_matrix_fill_column(apx_matrix* A, int64_t j, double value) {
   APX_REQUIRE(A != nullptr, "apx_matrix_fill_column: A is NULL");
+  APX_REQUIRE(!A->sparse, "apx_matrix_fill_column: dense matrices only");
   APX_REQUIRE(j >= 0 && j < A->n, "apx_matrix_fill_column: column out of range");
   if (A->m == 0) return APX_OK;
   APX_HIP(hipSetDevice(A->ctx->device));
@@ -398,12 +421,19 @@ int32_t apx_matrix_sumsq(const apx_matrix* A, double* out) {
   APX_REQUIRE(A != nullptr && out != nullptr, "apx_matrix_sumsq: NULL argument");
   apx_ctx* ctx = A->ctx;
   APX_HIP(hipSetDevice(ctx->device));
-  const int64_t total = A->ld * A->n_pad;
   const int nblk = kMaxRedBlocks;
-  if (A->dtype == APX_F32)
-    hipLaunchKernelGGL(k_sumsq<float>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const float*)A->d, total, ctx->red);
-  else
-    hipLaunchKernelGGL(k_sumsq<double>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const double*)A->d, total, ctx->red);
+  if (A->sparse) {
+    if (A->dtype == APX_F32)
+      hipLaunchKernelGGL(k_sumsq_elems<float>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const float*)A->rval, A->nnz, ctx->red);
+    else
+      hipLaunchKernelGGL(k_sumsq_elems<double>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const double*)A->rval, A->nnz, ctx->red);
+  } else {
+    const int64_t total = A->ld * A->n_pad;
+    if (A->dtype == APX_F32)
+      hipLaunchKernelGGL(k_sumsq<float>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const float*)A->d, total, ctx->red);
+    else
+      hipLaunchKernelGGL(k_sumsq<double>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const double*)A->d, total, ctx->red);
+  }
   APX_HIP(hipGetLastError());
   std::vector<double> h(nblk);
   APX_HIP(hipMemcpyAsync(h.data(), ctx->red, sizeof(double) * nblk, hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,176 @@
+// sparse.hip — compressed sparse storage for the design matrix: the
+// reference's sparse_logreg / dual_svm / LAD experiments load LIBSVM files into a
+// SparseMatrixCSC (experiments/libsvm.jl:3-61) and multiply with it (`f.X * w`, `f.X' * r`,
+// experiments/sparse_logreg/runme.jl:24,31).
+//
+// Both orientations are stored as compressed ROWS (A and A'), built once at upload by a
+// stable counting sort, so that both products are gather-style row dot products: a group of
+// G lanes per row, strided over the row's entries, reduced with width-G shuffles in a fixed
+// order.  No scatter, no atomics => bit-reproducible like the dense path.  Output conventions
+// are those of the dense kernels, so every fused epilogue (residual, logistic link, ...) is
+// shared: spmv_n writes one fp64 "split" into the partial buffer, spmv_t writes T.
+#include <algorithm>
+#include <vector>
+
+#include "apx_internal.h"
+#include "gemv_kernels.h"
+
+namespace apx {
+
+template <typename T, typename OUT, int G>
+__global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ ptr, const int32_t* __restrict__ ind,
+                                                    const T* __restrict__ val, const T* __restrict__ x,
+                                                    OUT* __restrict__ out, int64_t nrows, int64_t nrows_pad,
+                                                    const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  const int lane = threadIdx.x % G;
+  const int64_t groups = (int64_t)gridDim.x * (kBlock / G);
+  for (int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; row < nrows_pad; row += groups) {
+    double s = 0.0;
+    if (row < nrows) {
+      const int64_t k1 = ptr[row + 1];
+      for (int64_t k = ptr[row] + lane; k < k1; k += G) s = fma((double)val[k], (double)x[ind[k]], s);
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    if (lane == 0) out[row] = (OUT)s;     // rows in [nrows, nrows_pad) get exact zeros
+  }
+}
+
+template <typename T, typename OUT>
+static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* ind, const void* val, const void* x,
+                        OUT* out, int64_t nrows, int64_t nrows_pad, const int* done) {
+  const int64_t want = (nrows_pad * G + kBlock - 1) / kBlock;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, 16 * (int64_t)ctx->num_cu));
+#define APX_SPMV(GG)                                                                                      \
+  hipLaunchKernelGGL((spmv_rows<T, OUT, GG>), dim3(grid), dim3(kBlock), 0, ctx->stream, ptr, ind, (const T*)val, \
+                     (const T*)x, out, nrows, nrows_pad, done)
+  switch (G) {
+    case 1: APX_SPMV(1); break;
+    case 2: APX_SPMV(2); break;
+    case 4: APX_SPMV(4); break;
+    case 8: APX_SPMV(8); break;
+    case 16: APX_SPMV(16); break;
+    case 32: APX_SPMV(32); break;
+    default: APX_SPMV(64); break;
+  }
+#undef APX_SPMV
+}
+
+static int group_for(int64_t nnz, int64_t nrows) {
+  const double avg = nrows > 0 ? (double)nnz / (double)nrows : 0.0;
+  int g = 1;
+  while (g < 64 && g * 2 <= avg) g *= 2;      // ~1-2 entries per lane and step
+  return g;
+}
+
+int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
+  APX_TRY(ensure_part(ctx, (size_t)A->ld * sizeof(double)));
+  const int G = group_for(A->nnz, A->m);
+  if (A->dtype == APX_F32)
+    launch_rows<float, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done);
+  else
+    launch_rows<double, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done);
+  APX_HIP(hipGetLastError());
+  *splits_out = 1;
+  return APX_OK;
+}
+
+int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
+  const int G = group_for(A->nnz, A->n);
+  if (A->dtype == APX_F32)
+    launch_rows<float, float>(ctx, G, A->tptr, A->tind, A->tval, r, (float*)out, A->n, A->n_pad, done);
+  else
+    launch_rows<double, double>(ctx, G, A->tptr, A->tind, A->tval, r, (double*)out, A->n, A->n_pad, done);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+// stable transpose of compressed rows (counting sort): entries of each output row keep the
+// order of the input rows => a fixed summation order for A'*y
+template <typename T>
+static void transpose_rows(int64_t nrows, int64_t ncols, const int64_t* ptr, const int32_t* ind, const T* val,
+                           std::vector<int64_t>& tptr, std::vector<int32_t>& tind, std::vector<T>& tval) {
+  const int64_t nnz = ptr[nrows];
+  tptr.assign((size_t)ncols + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) tptr[(size_t)ind[k] + 1]++;
+  for (int64_t j = 0; j < ncols; ++j) tptr[(size_t)j + 1] += tptr[(size_t)j];
+  tind.resize((size_t)nnz);
+  tval.resize((size_t)nnz);
+  std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+  for (int64_t i = 0; i < nrows; ++i)
+    for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) {
+      const int64_t dst = cur[(size_t)ind[k]]++;
+      tind[(size_t)dst] = (int32_t)i;
+      tval[(size_t)dst] = val[k];
+    }
+}
+
+template <typename T>
+static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, const int64_t* ptr, const int32_t* idx,
+                               const T* vals) {
+  // `layout` 0: ptr/idx/vals are the rows of A (CSR); 1: the columns of A (CSC = rows of A')
+  const int64_t nrows_in = layout == 0 ? A->m : A->n, ncols_in = layout == 0 ? A->n : A->m;
+  std::vector<int64_t> tptr;
+  std::vector<int32_t> tind;
+  std::vector<T> tval;
+  transpose_rows<T>(nrows_in, ncols_in, ptr, idx, vals, tptr, tind, tval);
+  const int64_t nnz = A->nnz;
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t {
+    APX_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
+    if (bytes) APX_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return APX_OK;
+  };
+  const void *p0 = ptr, *i0 = idx, *v0 = vals, *p1 = tptr.data(), *i1 = tind.data(), *v1 = tval.data();
+  if (layout == 1) { std::swap(p0, p1); std::swap(i0, i1); std::swap(v0, v1); }
+  APX_TRY(up((void**)&A->rptr, p0, (size_t)(A->m + 1) * sizeof(int64_t)));
+  APX_TRY(up((void**)&A->rind, i0, (size_t)nnz * sizeof(int32_t)));
+  APX_TRY(up(&A->rval, v0, (size_t)nnz * sizeof(T)));
+  APX_TRY(up((void**)&A->tptr, p1, (size_t)(A->n + 1) * sizeof(int64_t)));
+  APX_TRY(up((void**)&A->tind, i1, (size_t)nnz * sizeof(int32_t)));
+  APX_TRY(up(&A->tval, v1, (size_t)nnz * sizeof(T)));
+  APX_HIP(hipStreamSynchronize(ctx->stream));   // the host staging vectors die with this frame
+  return APX_OK;
+}
+
+}  // namespace apx
+
+using namespace apx;
+
+extern "C" {
+
+int32_t apx_matrix_upload_sparse(apx_ctx* ctx, int64_t m, int64_t n, int64_t nnz, int32_t layout, const int64_t* ptr,
+                                 const int32_t* idx, const void* vals, int32_t dtype, apx_matrix** out) {
+  APX_REQUIRE(ctx != nullptr && out != nullptr && ptr != nullptr, "apx_matrix_upload_sparse: NULL argument");
+  APX_REQUIRE(m >= 0 && n >= 0 && nnz >= 0, "apx_matrix_upload_sparse: negative size");
+  APX_REQUIRE(layout == 0 || layout == 1, "apx_matrix_upload_sparse: layout must be 0 (CSR) or 1 (CSC)");
+  APX_REQUIRE(dtype == APX_F64 || dtype == APX_F32, "apx_matrix_upload_sparse: bad dtype");
+  APX_REQUIRE(nnz == 0 || (idx != nullptr && vals != nullptr), "apx_matrix_upload_sparse: NULL index / value array");
+  APX_REQUIRE(m < 2147483647LL && n < 2147483647LL, "apx_matrix_upload_sparse: indices are 32-bit");
+  *out = nullptr;
+  const int64_t nrows_in = layout == 0 ? m : n, ncols_in = layout == 0 ? n : m;
+  APX_REQUIRE(ptr[0] == 0 && ptr[nrows_in] == nnz, "apx_matrix_upload_sparse: pointer array must start at 0 and end at nnz");
+  for (int64_t i = 0; i < nrows_in; ++i) APX_REQUIRE(ptr[i] <= ptr[i + 1], "apx_matrix_upload_sparse: pointer array not monotone");
+  for (int64_t k = 0; k < nnz; ++k) APX_REQUIRE(idx[k] >= 0 && idx[k] < ncols_in, "apx_matrix_upload_sparse: index out of range");
+  APX_HIP(hipSetDevice(ctx->device));
+  apx_matrix* A = new apx_matrix();
+  A->ctx = ctx;
+  A->m = m;
+  A->n = n;
+  A->dtype = dtype;
+  A->ld = round_up(std::max<int64_t>(m, 1), kPad);
+  A->n_pad = round_up(std::max<int64_t>(n, 1), kPad);
+  A->sparse = true;
+  A->nnz = nnz;
+  ctx_retain(ctx);
+  const int32_t rc = dtype == APX_F32 ? upload_sparse_t<float>(ctx, A, layout, ptr, idx, (const float*)vals)
+                                      : upload_sparse_t<double>(ctx, A, layout, ptr, idx, (const double*)vals);
+  if (rc != APX_OK) {
+    apx_matrix_free(A);
+    return rc;
+  }
+  *out = A;
+  return APX_OK;
+}
+
+}  // extern "C"

@@ -203,6 +203,13 @@ int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx
 /* column-major host matrix with leading dimension lda (elements) -> device */
 int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, int64_t lda,
                           int32_t dtype, apx_matrix** out);
+/* sparse design matrix — the `SparseMatrixCSC` the experiments load from LIBSVM files
+ * (experiments/libsvm.jl:3-61; used as `f.X * w`, `f.X' * r` at experiments/sparse_logreg/runme.jl:24,31).
+ * layout 0: CSR (ptr has m+1 entries, idx = column indices); layout 1: CSC (ptr has n+1 entries, idx = row
+ * indices — Julia's colptr/rowval minus 1).  0-based, int64 pointers, int32 indices.  Usable wherever a
+ * dense matrix is (A_f, A_lin, apx_gemv_n/t, apx_matrix_sumsq); element-wise helpers are dense-only. */
+int32_t apx_matrix_upload_sparse(apx_ctx* ctx, int64_t m, int64_t n, int64_t nnz, int32_t layout, const int64_t* ptr,
+                                 const int32_t* idx, const void* vals, int32_t dtype, apx_matrix** out);
 int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda);
 int32_t apx_matrix_free(apx_matrix* A);
 int32_t apx_matrix_shape(const apx_matrix* A, int64_t* m, int64_t* n, int32_t* dtype);

@@ -1,0 +1,99 @@
+"""Sparse design matrices: the products and the solvers on compressed
+storage against scipy / the oracle; the LIBSVM reader mirror of experiments/libsvm.jl."""
+import importlib
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import adaprox_oracle as O
+
+
+@pytest.fixture(scope="module")
+def apx():
+    import adaprox_amd as apx
+    apx.load()
+    return apx
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)))) / \
+        max(float(np.max(np.abs(b))), 1e-300)
+
+
+@pytest.mark.parametrize("m,n,density", [(1, 1, 1.0), (7, 5, 0.5), (300, 1000, 0.01), (5000, 120, 0.15),
+                                         (2000, 3000, 0.002), (64, 64, 0.0), (800, 70, 0.9)])
+@pytest.mark.parametrize("fmt", ["csr", "csc", "coo"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_products(apx, m, n, density, fmt, dtype):
+    rng = np.random.default_rng(m * 31 + n)
+    A = sp.random(m, n, density=density, format=fmt, random_state=rng, dtype=np.float64).astype(dtype)
+    x = rng.standard_normal(n).astype(dtype)
+    r = rng.standard_normal(m).astype(dtype)
+    dA = apx.DeviceMatrix.from_sparse(A)
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    A64 = A.astype(np.float64).tocsr()
+    y_ref, g_ref = A64 @ x.astype(np.float64), A64.T @ r.astype(np.float64)
+    assert np.max(np.abs(dA @ x - y_ref)) <= tol * max(1.0, np.max(np.abs(y_ref)))
+    assert np.max(np.abs(dA.T @ r - g_ref)) <= tol * max(1.0, np.max(np.abs(g_ref)))
+    assert dA.norm() == pytest.approx(np.sqrt(A64.multiply(A64).sum()), rel=1e-6 if dtype == np.float32 else 1e-13)
+    with pytest.raises(apx.ApxError, match="dense matrices only"):
+        dA.to_numpy()
+
+
+def test_sparse_logreg_matches_oracle(apx):
+    """experiments/sparse_logreg/runme.jl:41-63 with a sparse X, Float64 (as the reference runs it)."""
+    rng = np.random.default_rng(0)
+    m, n = 3000, 112                       # mushrooms-like shape (8124 x 112)
+    X = sp.random(m, n, density=0.19, format="csc", random_state=rng, data_rvs=lambda k: np.ones(k))
+    w_true = rng.standard_normal(n) * (rng.uniform(size=n) < 0.2)
+    y = (1 / (1 + np.exp(-(X @ w_true))) > rng.uniform(size=m)).astype(np.float64)
+    X1 = sp.hstack([X, np.ones((m, 1))]).tocsr()
+    Lf = sp.linalg.norm(X1 @ X1.T) / 4 / m                  # :58-59 (Frobenius of the Gram matrix)
+    gam = 1.0 / Lf
+    K = 40
+    orecs, drecs = [], []
+    xo, _ = O.adaptive_proxgrad(np.zeros(n + 1), f=O.LogisticLoss(X.tocsr(), y), g=O.NormL1(0.01),
+                                rule=O.OurRule(gamma=gam), tol=0.0, maxit=K, record=orecs.append)
+    x, _ = apx.adaptive_proxgrad(np.zeros(n + 1), f=apx.LogisticLoss(X, y), g=apx.NormL1(0.01),
+                                 rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, record=drecs.append)
+    assert _rel(x, xo) <= 1e-10
+    for ro, rd in zip(orecs, drecs):
+        assert rd["gamma"] == pytest.approx(ro["gamma"], rel=1e-8)
+        assert rd["objective"] == pytest.approx(ro["objective"], rel=1e-11)
+    # backtracking and the PD loop run on the same storage
+    zo, _ = O.backtracking_proxgrad(np.zeros(n + 1), f=O.LogisticLoss(X.tocsr(), y), g=O.NormL1(0.01), gamma0=gam,
+                                    xi=1.5, tol=0.0, maxit=25)
+    z, _ = apx.backtracking_proxgrad(np.zeros(n + 1), f=apx.LogisticLoss(X, y), g=apx.NormL1(0.01), gamma0=gam, xi=1.5,
+                                     tol=0.0, maxit=25)
+    assert _rel(z, zo) <= 1e-10
+
+
+def test_sparse_lad_condat_vu(apx):
+    rng = np.random.default_rng(5)
+    m, n = 700, 90
+    A = sp.hstack([sp.random(m, n - 1, density=0.1, random_state=rng), np.ones((m, 1))]).tocsr()
+    yv = rng.standard_normal(m)
+    nA = float(sp.linalg.norm(A))
+    kw = dict(Lf=0.0, norm_A=nA, tol=0.0, maxit=150)
+    xo, yo, _ = O.condat_vu(np.zeros(n), np.zeros(m), f=O.Zero(), g=O.NormL1(2.0), h=O.Translate(O.NormL1(1.0), -yv),
+                            A=A, **kw)
+    x, y, _ = apx.condat_vu(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(2.0),
+                            h=apx.Translate(apx.NormL1(1.0), -yv), A=A, **kw)
+    assert _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-10
+
+
+def test_libsvm_reader(apx, tmp_path):
+    lib = importlib.import_module("adaptive-proximal-algorithms_amd.libsvm")
+    path = tmp_path / "toy"
+    path.write_text("1 1:0.5 3:2\n2 2:-1\n1 1:1 4:0.25\n2 \n")
+    X, y = lib.load_libsvm_dataset(str(path), np.float64, labels=[0.0, 1.0])      # sparse_logreg/runme.jl:50
+    assert X.shape == (4, 4) and X.nnz == 5
+    assert np.array_equal(y, [0.0, 1.0, 0.0, 1.0])                                  # labels {1,2} -> {0,1}
+    assert np.array_equal(X.toarray(), [[0.5, 0, 2, 0], [0, -1, 0, 0], [1, 0, 0, 0.25], [0, 0, 0, 0]])
+    X2, y2 = lib.load_libsvm_dataset(str(path), np.float32)
+    assert X2.dtype == np.float32 and np.array_equal(y2, [1, 2, 1, 2])
+    dX = apx.DeviceMatrix.from_sparse(X)
+    assert np.allclose(dX @ np.ones(4), X @ np.ones(4))
