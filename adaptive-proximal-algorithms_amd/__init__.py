@@ -13,7 +13,7 @@ from .api import (  # noqa: F401
     Context, DeviceMatrix, default_context, set_default_context, as_device_matrix,
     Counting, without_counting, is_counting_enabled,
     Zero, IndZero, NormL1, NormL2, IndBox, Translate, ConvexConjugate, convex_conjugate, prox,
-    LinearLeastSquares, LogisticLoss, eval_with_pullback, eval_with_gradient,
+    LinearLeastSquares, LogisticLoss, Quadratic, eval_with_pullback, eval_with_gradient,
     FixedStepsize, MalitskyMishchenkoRule, OurRule, OurRulePlus,
     adaptive_primal_dual, adaptive_proxgrad, fixed_proxgrad, condat_vu, backtracking_proxgrad,
     adaptive_linesearch_primal_dual,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libadaprox_hip.so")
 APX_OK, APX_ERR_INVALID, APX_ERR_HIP, APX_ERR_UNSUPPORTED, APX_ERR_DOMAIN, APX_ERR_CALLBACK = range(6)
 APX_FLAG_TINY_GAMMA, APX_FLAG_NAN_GAMMA, APX_FLAG_DOMAIN = 1, 2, 4
 APX_F64, APX_F32 = 0, 1
-APX_F_ZERO, APX_F_LEAST_SQUARES, APX_F_LOGISTIC, APX_F_CALLBACK = range(4)
+APX_F_ZERO, APX_F_LEAST_SQUARES, APX_F_LOGISTIC, APX_F_CALLBACK, APX_F_QUADRATIC = range(5)
 APX_G_ZERO, APX_G_L1, APX_G_BOX, APX_G_BOXV, APX_G_INDZERO, APX_G_L2 = range(6)
 APX_RULE_FIXED, APX_RULE_MM, APX_RULE_OURS, APX_RULE_OURS_PLUS = range(4)
 APX_KSTAT_GEMV_N, APX_KSTAT_GEMV_T, APX_KSTAT_COUNT = 0, 1, 2

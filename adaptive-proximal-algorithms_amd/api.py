@@ -586,6 +586,31 @@ class LogisticLoss:
         return self.eval_with_pullback(w)[0]
 
 
+class Quadratic:
+    """experiments/dual_svm/runme.jl:19-28: f(x) = 0.5*x'Qx + q'x, pullback `temp + q` with
+    `temp = Q*x` kept from the evaluation (one pass over Q per eval+grad)."""
+
+    def __init__(self, Q, q, ctx: Optional[Context] = None):
+        self.A = as_device_matrix(Q, ctx)
+        if self.A.shape[0] != self.A.shape[1]:
+            raise ValueError("Quadratic: Q must be square")
+        self.b = np.ascontiguousarray(q, dtype=self.A.dtype)
+        if self.b.shape != (self.A.shape[0],):
+            raise ValueError("Quadratic: q must have one entry per row of Q")
+        self.allreduce = None
+        self._op: Optional[_Problem] = None
+
+    @property
+    def n(self):
+        return self.A.shape[1]
+
+    def eval_with_pullback(self, x):
+        return _builtin_eval(self, x)
+
+    def __call__(self, x):
+        return self.eval_with_pullback(x)[0]
+
+
 def _builtin_eval(f, w):
     """`eval_with_pullback` of a built-in f at op level: GEMV-N now, GEMV-T when pb() is called."""
     w = np.ascontiguousarray(w, dtype=f.A.dtype)
@@ -682,11 +707,12 @@ class _Problem:
         d = L.ProblemDesc()
         d.dtype = _code(dtype)
         self._cb_exc: Optional[BaseException] = None
-        if isinstance(fu, (LinearLeastSquares, LogisticLoss)):
+        if isinstance(fu, (LinearLeastSquares, LogisticLoss, Quadratic)):
             ctx = ctx or fu.A.ctx
             if fu.A.dtype != dtype:
                 raise TypeError(f"x is {dtype} but the matrix of f is {fu.A.dtype}")
-            d.f_kind = L.APX_F_LEAST_SQUARES if isinstance(fu, LinearLeastSquares) else L.APX_F_LOGISTIC
+            d.f_kind = (L.APX_F_LEAST_SQUARES if isinstance(fu, LinearLeastSquares) else
+                        L.APX_F_LOGISTIC if isinstance(fu, LogisticLoss) else L.APX_F_QUADRATIC)
             d.A_f = fu.A._h
             d.b = fu.b.ctypes.data
             d.n = fu.n
@@ -810,7 +836,7 @@ def _as_vec(x, dtype=None) -> np.ndarray:
 
 def _problem_dtype(x, f, A):
     fu, Au = _unwrap(f), _unwrap(A)
-    if isinstance(fu, (LinearLeastSquares, LogisticLoss)):
+    if isinstance(fu, (LinearLeastSquares, LogisticLoss, Quadratic)):
         return fu.A.dtype
     if isinstance(Au, DeviceMatrix):
         return Au.dtype

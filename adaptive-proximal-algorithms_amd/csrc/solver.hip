@@ -95,6 +95,13 @@ int32_t eval_f(apx_problem* p, const void* x_dev, bool need_f) {
       }
       break;
     }
+    case APX_F_QUADRATIC: {   // temp = Q*x (kept in `res`), f = 0.5*dot(x, temp) + dot(x, q)
+      int splits = 0;
+      APX_TRY(launch_gemv_n(ctx, p->A_f, x_dev, &splits, p->done_ptr()));
+      APX_TRY(vo_finish_rows(ctx, p->dtype, p->f_kind, splits, p->A_f->ld, p->A_f->m, p->b.p, x_dev, p->n, p->res.p,
+                             p->ctrl(), p->fsc(), true));
+      break;
+    }
     case APX_F_CALLBACK: {
       const size_t bytes = (size_t)p->n * p->es();
       p->hbuf.resize(bytes);
@@ -145,6 +152,9 @@ int32_t pullback_f(apx_problem* p) {
       if (p->f_kind == APX_F_LOGISTIC) APX_TRY(vo_logistic_grad(ctx, p->dtype, p->grad.p, p->n, p->ctrl()));
       break;
     }
+    case APX_F_QUADRATIC:     // quadratic_pullback() = temp + f.q : no second pass over Q
+      APX_TRY(vo_add(ctx, p->dtype, p->grad.p, p->res.p, p->b.p, p->n, p->done_ptr()));
+      break;
     case APX_F_CALLBACK: {
       const size_t bytes = (size_t)p->n * p->es();
       p->hbuf.resize(bytes);
@@ -256,6 +266,16 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
       APX_TRY(p->res.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
       APX_TRY(h2d(ctx, p->b.p, d->b, (size_t)d->A_f->m * es));
       p->n_mean = (double)(d->n_total_rows > 0 ? d->n_total_rows : d->A_f->m);
+      break;
+    }
+    case APX_F_QUADRATIC: {   // Quadratic(Q, q), experiments/dual_svm/runme.jl:19-28
+      APX_REQUIRE(d->A_f != nullptr && d->b != nullptr, "Quadratic needs Q (A_f) and q (b)");
+      APX_REQUIRE(d->A_f->ctx == ctx && d->A_f->dtype == d->dtype, "Q: wrong context or dtype");
+      APX_REQUIRE(d->A_f->m == d->n && d->A_f->n == d->n, "Quadratic: Q must be n x n");
+      APX_REQUIRE(d->allreduce == nullptr, "Quadratic f cannot be row-sharded by the library");
+      APX_TRY(p->b.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
+      APX_TRY(p->res.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
+      APX_TRY(h2d(ctx, p->b.p, d->b, (size_t)d->n * es));
       break;
     }
     case APX_F_CALLBACK:

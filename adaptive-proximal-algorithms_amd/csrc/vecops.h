@@ -32,6 +32,7 @@ int32_t vo_reduce_sums(apx_ctx* ctx, int32_t dtype, const void* x, const void* x
 int32_t vo_dual_trial(apx_ctx* ctx, int32_t dtype, const void* y, const void* ax, const void* axprev, void* ynext,
                       int64_t m, const ProxDev& h, double sigma, double rho, double* out3);
 int32_t vo_diff_sumsq(apx_ctx* ctx, int32_t dtype, const void* a, const void* b, int64_t n, double* out1);
+int32_t vo_add(apx_ctx* ctx, int32_t dtype, void* out, const void* a, const void* b, int64_t n, const int* done);
 // comparison baselines
 int32_t vo_extrap(apx_ctx* ctx, int32_t dtype, void* out, const void* a, const void* b, double c, int64_t n);
 int32_t vo_xbar(apx_ctx* ctx, int32_t dtype, void* xbar, const void* x, double phi, int64_t n);

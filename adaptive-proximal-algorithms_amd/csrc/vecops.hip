@@ -180,6 +180,13 @@ __global__ __launch_bounds__(kBlock) void k_finish_rows(const double* __restrict
       const T r = (T)(s - (double)b[i]);
       res[i] = r;
       q[0] = fma((double)r, (double)r, q[0]);
+    } else if constexpr (FK == APX_F_QUADRATIC) {
+      // temp = Q*x ; f = 0.5*dot(x, temp) + dot(x, q)   (experiments/dual_svm/runme.jl:24-27)
+      const T t = (T)s;
+      res[i] = t;
+      const double xi = (double)x[i];
+      q[0] = fma(xi, (double)t, q[0]);
+      q[1] = fma(xi, (double)b[i], q[1]);
     } else {
       const double logit = s + bias;
       const double u = 1.0 + exp(-logit);
@@ -198,6 +205,8 @@ __device__ __forceinline__ void f_finalize(Ctrl* c, int fk, const double* fsc) {
   if (fk == APX_F_LEAST_SQUARES) {
     const double nr = sqrt(fsc[0]);          // 0.5 * norm(res)^2 : nrm2 THEN square (Appendix A.2)
     c->f_x = 0.5 * (nr * nr);
+  } else if (fk == APX_F_QUADRATIC) {
+    c->f_x = 0.5 * fsc[0] + fsc[1];          // 0.5*dot(x, temp) + dot(x, q)
   } else {
     c->f_x = -(fsc[0] / c->n_mean);          // -mean(...)
     c->bias_grad = fsc[1] / c->n_mean;       // mean(probs - y)
@@ -680,6 +689,14 @@ int32_t vo_finish_rows(apx_ctx* ctx, int32_t dtype, int fk, int splits, int64_t 
                hipLaunchKernelGGL((k_finish_rows<float, APX_F_LEAST_SQUARES>), dim3(g), dim3(kBlock), 0, ctx->stream,
                                   ctx->part, splits, ld, m, (const float*)b, (const float*)x, n, (float*)res,
                                   ctx->red, done));
+  } else if (fk == APX_F_QUADRATIC) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((k_finish_rows<double, APX_F_QUADRATIC>), dim3(g), dim3(kBlock), 0, ctx->stream,
+                                  ctx->part, splits, ld, m, (const double*)b, (const double*)x, n, (double*)res,
+                                  ctx->red, done),
+               hipLaunchKernelGGL((k_finish_rows<float, APX_F_QUADRATIC>), dim3(g), dim3(kBlock), 0, ctx->stream,
+                                  ctx->part, splits, ld, m, (const float*)b, (const float*)x, n, (float*)res,
+                                  ctx->red, done));
   } else {
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((k_finish_rows<double, APX_F_LOGISTIC>), dim3(g), dim3(kBlock), 0, ctx->stream,
@@ -849,6 +866,26 @@ int32_t vo_diff_sumsq(apx_ctx* ctx, int32_t dtype, const void* a, const void* b,
              hipLaunchKernelGGL(k_diff_sumsq<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)a,
                                 (const float*)b, n, ctx->red));
   hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, out1);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+// out = a + b   (`temp + f.q`, the Quadratic pullback of experiments/dual_svm/runme.jl:26)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_add(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                                int64_t n, const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = (T)((double)a[i] + (double)b[i]);
+}
+
+int32_t vo_add(apx_ctx* ctx, int32_t dtype, void* out, const void* a, const void* b, int64_t n, const int* done) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_add<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)out, (const double*)a,
+                                (const double*)b, n, done),
+             hipLaunchKernelGGL(k_add<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)out, (const float*)a,
+                                (const float*)b, n, done));
   APX_HIP(hipGetLastError());
   return APX_OK;
 }

@@ -55,7 +55,8 @@ enum {
   APX_F_ZERO = 0,           /* experiments/least_absolute_deviation/runme.jl:18-21 */
   APX_F_LEAST_SQUARES = 1,  /* LinearLeastSquares, experiments/lasso/runme.jl:16-27 */
   APX_F_LOGISTIC = 2,       /* LogisticLoss, experiments/sparse_logreg/runme.jl:18-39 (bias = last coord) */
-  APX_F_CALLBACK = 3        /* any user f: host callbacks (the f callable convention)  */
+  APX_F_CALLBACK = 3,       /* any user f: host callbacks (the f callable convention)  */
+  APX_F_QUADRATIC = 4       /* Quadratic(Q, q): 0.5 x'Qx + q'x, experiments/dual_svm/runme.jl:19-28 (A_f = Q, b = q) */
 };
 
 /* nonsmooth terms g / h — ProximalOperators.jl / ProximalCore.jl objects */

@@ -1,0 +1,63 @@
+"""experiments/dual_svm/runme.jl:47-76 — the only direct caller of `adaptive_primal_dual` with
+`OurRule(t, norm_A)` in the reference: f = Quadratic(Q, q) (Q = Dy X X' Dy dense N x N),
+g = IndBox(0, C), h = IndZero(), A = y' (1 x N) — natively on the HIP path against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import adaprox_oracle as O
+
+
+@pytest.fixture(scope="module")
+def apx():
+    import adaprox_amd as apx
+    apx.load()
+    return apx
+
+
+def _rel_inf(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / max(float(np.max(np.abs(b))), 1e-300)
+
+
+def _dual_svm(N=400, d=30, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (N, d))
+    y = np.sign(X @ rng.standard_normal(d) + 0.1 * rng.standard_normal(N))
+    Dy = np.diag(y)
+    Q = np.asfortranarray(Dy @ X @ X.T @ Dy)                    # :48
+    q = -np.ones(N)                                             # :49
+    A = np.asfortranarray(y[None, :])                           # :54  A = Matrix(y')
+    return Q, q, A
+
+
+def test_quadratic_eval_pullback(apx):
+    Q, q, _ = _dual_svm()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(Q.shape[0])
+    f_ref, pb_ref = O.Quadratic(Q, q).eval_with_pullback(x)
+    fx, pb = apx.eval_with_pullback(apx.Quadratic(Q, q), x)
+    assert fx == pytest.approx(f_ref, rel=1e-12)
+    assert _rel_inf(pb(), pb_ref()) <= 1e-12
+
+
+@pytest.mark.parametrize("t", [0.01, 0.2, 1.0, 10.0])
+def test_dual_svm_adaptive_primal_dual(apx, t):
+    Q, q, A = _dual_svm()
+    N = Q.shape[0]
+    C = 0.1                                                      # :35
+    norm_A = float(np.linalg.norm(A))
+    K = 200
+    orecs, drecs = [], []
+    of, df = O.Counting(O.Quadratic(Q, q)), apx.Counting(apx.Quadratic(Q, q))
+    xo, yo, _ = O.adaptive_primal_dual(np.zeros(N), np.zeros(1), f=of, g=O.IndBox(0.0, C), h=O.IndZero(), A=A,
+                                       rule=O.OurRule(t=t, norm_A=norm_A), maxit=K, tol=0.0, record=orecs.append)   # :63-76
+    x, y, _ = apx.adaptive_primal_dual(np.zeros(N), np.zeros(1), f=df, g=apx.IndBox(0.0, C), h=apx.IndZero(), A=A,
+                                       rule=apx.OurRule(t=t, norm_A=norm_A), maxit=K, tol=0.0, record=drecs.append)
+    assert _rel_inf(x, xo) <= 1e-10 and _rel_inf(y, yo) <= 1e-9
+    for ro, rd in zip(orecs, drecs):
+        assert rd["gamma"] == pytest.approx(ro["gamma"], rel=1e-8)
+        assert rd["sigma"] == pytest.approx(ro["sigma"], rel=1e-8)
+        assert rd["objective"] == pytest.approx(ro["objective"], rel=1e-10, abs=1e-12)
+    assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
+    assert np.all(x >= 0) and np.all(x <= C)
