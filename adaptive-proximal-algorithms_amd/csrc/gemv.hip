@@ -107,9 +107,16 @@ int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
   if (A->sparse) return launch_spmv_n(ctx, A, x, splits_out, done);
   const int V = A->dtype == APX_F32 ? 4 : 2;
   int vi = ctx->cfg.n_variant;
+  int64_t target = ctx->cfg.n_target_blocks;
+  if (ctx->cfg.n_auto && A->n * (int64_t)dtype_size(A->dtype) <= 256 * 1024) {
+    // short rows (C5: 160 KB, C3: 40 KB per row of A): the narrow 512-row tile with ~8 blocks per
+    // CU measured 4 % (C5) / 1 % (C3) faster than the wide-tile default (gpurun_out/sweep_c5.log)
+    vi = ctx->cfg.n_variant_narrow;
+    target = 8 * (int64_t)ctx->num_cu;
+  }
   int64_t rows_per_block = (int64_t)kBlock * V * kNVars[vi].rpt;
   int64_t row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
-  int64_t S = std::max<int64_t>(1, (ctx->cfg.n_target_blocks + row_tiles - 1) / row_tiles);
+  int64_t S = std::max<int64_t>(1, (target + row_tiles - 1) / row_tiles);
   if (ctx->cfg.n_auto) {
     // every column split writes and re-reads an m-vector of fp64 partials: keep that below ~1 %
     // of the A stream (S*16 B per row against n*sizeof(T)); when that leaves too few blocks for a

@@ -158,7 +158,7 @@ int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
   ctx->cfg.t_variant = 2;
   ctx->cfg.n_target_blocks = 16 * (int64_t)ctx->num_cu;
   ctx->cfg.n_auto = true;
-  ctx->cfg.n_variant_narrow = 3;   // n_rpt1_unr16_nt
+  ctx->cfg.n_variant_narrow = 0;   // n_rpt1_unr8_nt
   ctx->cfg.t_target_blocks = 8 * (int64_t)ctx->num_cu;
   if (const char* s = getenv("APX_GEMV_N_VARIANT")) { ctx->cfg.n_variant = atoi(s); ctx->cfg.n_auto = false; }
   if (const char* s = getenv("APX_GEMV_T_VARIANT")) ctx->cfg.t_variant = atoi(s);

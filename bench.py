@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
-    ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--cpu-iters", type=int, default=30)
     return ap.parse_args()
 
 

@@ -345,3 +345,43 @@ def test_edge_cases(apx, lasso_c1):
     # gamma0 huge on a quadratic makes <dg,dx> overflow-free, so just check the flagless path returns
     xz, itz = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=apx.FixedStepsize(gam), tol=1e-3, maxit=100_000)
     assert itz < 100_000
+
+
+def test_nan_to_zero_path_when_iterates_do_not_move(apx):
+    """lambda > ||A'b||_inf: x stays exactly 0, so dx = dg = 0 and C = L = 0/0 = NaN -> 0 through
+    `nan_to_zero` (src/AdaProx.jl:24, :260-261); D = 0 makes the third candidate of the min
+    gamma1/0 = Inf, and gamma grows by sqrt(1 + gamma1/gamma0) each iteration (:264).  The
+    device scalar code must follow Julia's IEEE semantics exactly."""
+    rng = np.random.default_rng(3)
+    A = np.asfortranarray(rng.uniform(-1, 1, (80, 50)))
+    b = rng.standard_normal(80)
+    lam = 1.01 * np.max(np.abs(A.T @ b))
+    gam = 0.5 / np.linalg.norm(A, 2) ** 2
+    for rule_o, rule_d in ((O.OurRule(gamma=gam), apx.OurRule(gamma=gam)),
+                           (O.OurRulePlus(gamma=gam), apx.OurRulePlus(gamma=gam))):
+        orecs, drecs = [], []
+        xo, _ = O.adaptive_proxgrad(np.zeros(50), f=O.LinearLeastSquares(A, b), g=O.NormL1(lam), rule=rule_o, tol=0.0,
+                                    maxit=30, record=orecs.append)
+        xd, _ = apx.adaptive_proxgrad(np.zeros(50), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(lam), rule=rule_d,
+                                      tol=0.0, maxit=30, record=drecs.append)
+        assert not np.any(xo) and not np.any(xd)
+        assert [r["gamma"] for r in drecs] == pytest.approx([r["gamma"] for r in orecs], rel=1e-14)
+        assert all(np.isfinite(r["gamma"]) for r in drecs)
+    # Malitsky-Mishchenko has no nan_to_zero: L = 0/0 = NaN and Julia's `min` propagates it (:227-228)
+    drecs = []
+    apx.adaptive_proxgrad(np.zeros(50), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(lam),
+                          rule=apx.MalitskyMishchenkoRule(gam), tol=0.0, maxit=3, record=drecs.append)
+    orecs = []
+    O.adaptive_proxgrad(np.zeros(50), f=O.LinearLeastSquares(A, b), g=O.NormL1(lam),
+                        rule=O.MalitskyMishchenkoRule(gam), tol=0.0, maxit=3, record=orecs.append)
+    assert np.isnan(orecs[0]["gamma"]) and np.isnan(drecs[0]["gamma"])
+
+
+def test_start_at_the_solution_terminates_at_first_test(apx, lasso_c1):
+    prob, gam = lasso_c1
+    f, g = apx.LinearLeastSquares(prob.A, prob.b), apx.NormL1(prob.lam)
+    x, it = apx.adaptive_proxgrad(prob.x_star, f=f, g=g, rule=apx.OurRule(gamma=gam), tol=1e-8, maxit=1000)
+    xo, ito = O.adaptive_proxgrad(prob.x_star, f=O.LinearLeastSquares(prob.A, prob.b), g=O.NormL1(prob.lam),
+                                  rule=O.OurRule(gamma=gam), tol=1e-8, maxit=1000)
+    assert it == ito == 1
+    assert np.max(np.abs(x - prob.x_star)) < 1e-12
