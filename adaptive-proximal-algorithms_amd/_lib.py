@@ -92,6 +92,7 @@ PROTOTYPES = {
     "apx_matrix_upload": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, _P(c_void_p)]),
     "apx_matrix_upload_sparse": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                            c_int32, _P(c_void_p)]),
+    "apx_matrix_build_transpose": (c_int32, [c_void_p]),
     "apx_matrix_download": (c_int32, [c_void_p, c_void_p, c_int64]),
     "apx_matrix_free": (c_int32, [c_void_p]),
     "apx_matrix_shape": (c_int32, [c_void_p, _P(c_int64), _P(c_int64), _P(c_int32)]),

@@ -196,6 +196,11 @@ class DeviceMatrix:
     def fill_column(self, j: int, value: float):
         L.check(self._lib.apx_matrix_fill_column(self._h, j, value))
 
+    def build_transpose(self):
+        """Optional dual layout: a transposed copy in HBM so that `A*x` streams contiguously too."""
+        L.check(self._lib.apx_matrix_build_transpose(self._h))
+        return self
+
     def to_numpy(self) -> np.ndarray:
         m, n = self.shape
         out = np.empty((m, n), dtype=self.dtype, order="F")

@@ -106,6 +106,10 @@ struct apx_matrix {
   int64_t m = 0, n = 0, ld = 0, n_pad = 0;
   int32_t dtype = APX_F64;
   void* d = nullptr;           // dense: column-major ld x n_pad
+  // optional second copy, A' column-major (ldT = round_up(n,32) rows x ld columns): with it `A*x`
+  // streams whole rows of A contiguously like `A'*r` streams whole columns (apx_matrix_build_transpose)
+  void* dT = nullptr;
+  int64_t ldT = 0;
   // sparse storage: BOTH orientations are kept, each as compressed rows, so
   // `A*x` and `A'*y` are gather-style row products with a fixed summation order (no atomics)
   bool sparse = false;

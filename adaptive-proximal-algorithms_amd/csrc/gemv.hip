@@ -103,8 +103,14 @@ static int32_t prof_end(apx_ctx* ctx) {
   return APX_OK;
 }
 
+static int32_t launch_t_core(apx_ctx* ctx, const void* d, int64_t ld, int64_t n_pad, int32_t dtype, double bytes,
+                             int stat_kind, const void* r, void* out, int* splits_out, const int* done);
+
 int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
   if (A->sparse) return launch_spmv_n(ctx, A, x, splits_out, done);
+  if (A->dT != nullptr)   // dual layout: A*x as the column-streaming kernel over the transposed copy
+    return launch_t_core(ctx, A->dT, A->ldT, A->ld, A->dtype, (double)A->m * (double)A->n * dtype_size(A->dtype),
+                         APX_KSTAT_GEMV_N, x, nullptr, splits_out, done);
   const int V = A->dtype == APX_F32 ? 4 : 2;
   int vi = ctx->cfg.n_variant;
   int64_t target = ctx->cfg.n_target_blocks;
@@ -152,33 +158,43 @@ int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
   return APX_OK;
 }
 
-int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
-  if (A->sparse) return launch_spmv_t(ctx, A, r, out, done);
+// One launch of the column-streaming kernel on a dense column-major operand (d, ld, rows m_pad,
+// columns n_pad): out != nullptr -> the product as T (gemv_t proper, with a finish pass when the
+// rows are split); out == nullptr -> fp64 partials [splits][n_pad] left in ctx->part for a fused
+// epilogue (used by gemv_n on the transposed copy).
+static int32_t launch_t_core(apx_ctx* ctx, const void* d, int64_t ld, int64_t n_pad, int32_t dtype, double bytes,
+                             int stat_kind, const void* r, void* out, int* splits_out, const int* done) {
   const TVar& v = kTVars[ctx->cfg.t_variant];
-  const int V = A->dtype == APX_F32 ? 4 : 2;
-  const int64_t col_blocks = A->n_pad / v.cpb;
+  const int V = dtype == APX_F32 ? 4 : 2;
+  const int64_t col_blocks = n_pad / v.cpb;
   const int64_t step = (int64_t)kBlock * V * v.unr;
   int64_t SR = std::max<int64_t>(1, ctx->cfg.t_target_blocks / std::max<int64_t>(1, col_blocks));
-  int64_t rps = round_up((A->ld + SR - 1) / SR, step);
-  SR = (A->ld + rps - 1) / rps;
+  int64_t rps = round_up((ld + SR - 1) / SR, step);
+  SR = (ld + rps - 1) / rps;
   APX_REQUIRE(SR <= 65535 && col_blocks <= 2147483647LL, "gemv_t grid too large");
-  if (SR > 1) APX_TRY(ensure_part(ctx, (size_t)SR * A->n_pad * sizeof(double)));
-  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, (double)A->m * (double)A->n * dtype_size(A->dtype)));
+  if (SR > 1 || out == nullptr) APX_TRY(ensure_part(ctx, (size_t)SR * n_pad * sizeof(double)));
+  APX_TRY(prof_begin(ctx, stat_kind, bytes));
   dim3 grid((unsigned)col_blocks, (unsigned)SR);
-  (A->dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, A->d, A->ld, r, out, ctx->part, rps, A->ld, A->n_pad,
-                                         done);
+  (dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, d, ld, r, out, ctx->part, rps, ld, n_pad, done);
   APX_TRY(prof_end(ctx));
-  if (SR > 1) {
-    const unsigned g = (unsigned)((A->n_pad + kBlock - 1) / kBlock);
-    if (A->dtype == APX_F32)
-      hipLaunchKernelGGL(gemv_t_finish<float>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, (int)SR, A->n_pad,
+  if (SR > 1 && out != nullptr) {
+    const unsigned g = (unsigned)((n_pad + kBlock - 1) / kBlock);
+    if (dtype == APX_F32)
+      hipLaunchKernelGGL(gemv_t_finish<float>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, (int)SR, n_pad,
                          (float*)out, done);
     else
-      hipLaunchKernelGGL(gemv_t_finish<double>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, (int)SR,
-                         A->n_pad, (double*)out, done);
+      hipLaunchKernelGGL(gemv_t_finish<double>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, (int)SR, n_pad,
+                         (double*)out, done);
   }
   APX_HIP(hipGetLastError());
+  if (splits_out) *splits_out = (int)SR;
   return APX_OK;
+}
+
+int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
+  if (A->sparse) return launch_spmv_t(ctx, A, r, out, done);
+  return launch_t_core(ctx, A->d, A->ld, A->n_pad, A->dtype, (double)A->m * (double)A->n * dtype_size(A->dtype),
+                       APX_KSTAT_GEMV_T, r, out, nullptr, done);
 }
 
 template <typename T>

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(
     double s = red[0][tid];
 #pragma unroll
     for (int w = 1; w < kBlock / 64; ++w) s += red[w][tid];
-    if (gridDim.y == 1) out[j0 + tid] = (T)s;
-    else part[(int64_t)blockIdx.y * n_pad + j0 + tid] = s;
+    if (gridDim.y == 1 && out != nullptr) out[j0 + tid] = (T)s;
+    else part[(int64_t)blockIdx.y * n_pad + j0 + tid] = s;   // fp64 partials (row splits, or out == nullptr)
   }
 }
 

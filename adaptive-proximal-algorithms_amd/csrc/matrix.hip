@@ -97,6 +97,26 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ A, int64
   }
 }
 
+// out-of-place transpose through a padded LDS tile: B (ldb x ...) = A' ; both sides coalesced
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_transpose(const T* __restrict__ A, int64_t lda, T* __restrict__ B,
+                                                      int64_t ldb, int64_t m, int64_t n) {
+  __shared__ T tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
+  const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 32; k += 8) {
+    const int64_t i = i0 + tx, j = j0 + ty + k;
+    tile[ty + k][tx] = (i < m && j < n) ? A[j * lda + i] : (T)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 32; k += 8) {
+    const int64_t j = j0 + tx, i = i0 + ty + k;
+    if (j < n && i < m) B[i * ldb + j] = tile[tx][ty + k];
+  }
+}
+
 // the same over a plain array of `count` elements (sparse value arrays)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_sumsq_elems(const T* __restrict__ v, int64_t count, double* __restrict__ red) {
@@ -328,11 +348,60 @@ int32_t apx_matrix_free(apx_matrix* A) {
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->stream);
   if (A->d) (void)hipFree(A->d);
+  if (A->dT) (void)hipFree(A->dT);
   for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval})
     if (q) (void)hipFree(q);
   apx_ctx* ctx = A->ctx;
   delete A;
   ctx_release(ctx);
+  return APX_OK;
+}
+
+static void drop_transpose(apx_matrix* A) {
+  if (A->dT == nullptr) return;
+  (void)hipStreamSynchronize(A->ctx->stream);
+  (void)hipFree(A->dT);
+  A->dT = nullptr;
+  A->ldT = 0;
+}
+
+int32_t apx_matrix_build_transpose(apx_matrix* A) {
+  APX_REQUIRE(A != nullptr, "apx_matrix_build_transpose: A is NULL");
+  APX_REQUIRE(!A->sparse, "apx_matrix_build_transpose: dense matrices only (sparse storage keeps both orientations)");
+  apx_ctx* ctx = A->ctx;
+  APX_HIP(hipSetDevice(ctx->device));
+  if (A->dT != nullptr) {
+    APX_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(A->dT);
+    A->dT = nullptr;
+  }
+  const size_t es = dtype_size(A->dtype);
+  const int64_t ldT = round_up(std::max<int64_t>(A->n, 1), kPad);
+  const size_t bytes = (size_t)ldT * (size_t)A->ld * es;      // n_pad(rows of A') x ld(columns = rows of A, padded)
+  void* dT = nullptr;
+  hipError_t e = hipMalloc(&dT, bytes);
+  if (e != hipSuccess)
+    return fail(APX_ERR_HIP, std::string("apx_matrix_build_transpose: hipMalloc of ") + std::to_string(bytes) +
+                                 " B: " + hipGetErrorString(e));
+  APX_HIP(hipMemsetAsync(dT, 0, bytes, ctx->stream));
+  if (A->m > 0 && A->n > 0) {
+    // gridDim.y is limited to 65535 tiles: walk the columns in slabs
+    const int64_t slab = 65535LL * 32;
+    for (int64_t j0 = 0; j0 < A->n; j0 += slab) {
+      const int64_t nj = std::min<int64_t>(slab, A->n - j0);
+      dim3 grid((unsigned)((A->m + 31) / 32), (unsigned)((nj + 31) / 32));
+      if (A->dtype == APX_F32)
+        hipLaunchKernelGGL(k_transpose<float>, grid, dim3(kBlock), 0, ctx->stream,
+                           (const float*)A->d + (size_t)j0 * A->ld, A->ld, (float*)dT + j0, ldT, A->m, nj);
+      else
+        hipLaunchKernelGGL(k_transpose<double>, grid, dim3(kBlock), 0, ctx->stream,
+                           (const double*)A->d + (size_t)j0 * A->ld, A->ld, (double*)dT + j0, ldT, A->m, nj);
+    }
+  }
+  APX_HIP(hipGetLastError());
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  A->dT = dT;
+  A->ldT = ldT;
   return APX_OK;
 }
 
@@ -352,6 +421,7 @@ int32_t apx_matrix_fill_uniform(apx_matrix* A, uint64_t seed, double lo, double 
                                 int64_t m_total) {
   APX_REQUIRE(A != nullptr, "apx_matrix_fill_uniform: A is NULL");
   APX_REQUIRE(!A->sparse, "apx_matrix_fill_uniform: dense matrices only");
+  drop_transpose(A);   // the transposed copy (if any) no longer matches
   if (m_total <= 0) m_total = A->m;
   APX_REQUIRE(row_offset >= 0 && row_offset + A->m <= m_total, "apx_matrix_fill_uniform: shard outside the global matrix");
   if (A->m == 0 || A->n == 0) return APX_OK;
@@ -379,6 +449,7 @@ int32_t apx_matrix_fill_uniform(apx_matrix* A, uint64_t seed, double lo, double 
 int32_t apx_matrix_scale_columns(apx_matrix* A, const double* alpha) {
   APX_REQUIRE(A != nullptr && alpha != nullptr, "apx_matrix_scale_columns: NULL argument");
   APX_REQUIRE(!A->sparse, "apx_matrix_scale_columns: dense matrices only");
+  drop_transpose(A);   // the transposed copy (if any) no longer matches
   if (A->m == 0 || A->n == 0) return APX_OK;
   APX_HIP(hipSetDevice(A->ctx->device));
   DBuf d_alpha;
@@ -403,6 +474,7 @@ int32_t apx_matrix_scale_columns(apx_matrix* A, const double* alpha) {
 int32_t apx_matrix_fill_column(apx_matrix* A, int64_t j, double value) {
   APX_REQUIRE(A != nullptr, "apx_matrix_fill_column: A is NULL");
   APX_REQUIRE(!A->sparse, "apx_matrix_fill_column: dense matrices only");
+  drop_transpose(A);   // the transposed copy (if any) no longer matches
   APX_REQUIRE(j >= 0 && j < A->n, "apx_matrix_fill_column: column out of range");
   if (A->m == 0) return APX_OK;
   APX_HIP(hipSetDevice(A->ctx->device));

@@ -39,7 +39,9 @@ def _ident(v):
 
 def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, lam: float = 1.0, rho: float = 1.0,
                  rank: int = 0, world: int = 1, power_iters: int = 50, ctx: Optional[Context] = None,
-                 allreduce_host: Optional[Callable[[np.ndarray], np.ndarray]] = None) -> DeviceLasso:
+                 allreduce_host: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                 dual_layout: bool = False) -> DeviceLasso:
+    """``dual_layout``: keep the transposed copy of A too (DeviceMatrix.build_transpose)."""
     ar = allreduce_host or _ident
     m_total = m_local * world
     r0 = rank * m_local
@@ -65,6 +67,8 @@ def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, la
     alpha = np.empty(n)
     alpha[perm] = a_sorted
     A.scale_columns(alpha)                                      # :68  A = C * diagm(alpha)
+    if dual_layout:
+        A.build_transpose()                                     # A is final from here on
     # :70-75  x_star
     xs_sorted = np.where(head, r_x * rho / math.sqrt(p) * np.sign(alpha[perm] * cty_signed[perm]), 0.0)
     x_star = np.zeros(n)

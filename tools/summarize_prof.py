@@ -75,7 +75,10 @@ def main():
                      f"{e.get('fetch_bytes_corrected', float('nan')):.4g} | "
                      f"{e.get('WRITE_SIZE_KiB_median', float('nan')):.0f} | {e['hbm_bytes_per_launch']:.4g} |\n")
     # what bench.py reads for roofline.traffic
-    pt = {"gemv_n": traffic.get("gemv_n_kernel", {}), "gemv_t": traffic.get("gemv_t_kernel", {})}
+    # with the dual layout (bench default) A*x runs the column-streaming kernel on the transposed copy,
+    # so both passes appear as gemv_t_kernel in the trace
+    pt = {"gemv_n": traffic.get("gemv_n_kernel") or traffic.get("gemv_t_kernel", {}),
+          "gemv_t": traffic.get("gemv_t_kernel", {})}
     json.dump(pt, open(os.path.join(os.path.dirname(out), "pmc_traffic.json"), "w"), indent=1)
     print(open(out + ".md").read())
 
