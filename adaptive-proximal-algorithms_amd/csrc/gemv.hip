@@ -123,7 +123,8 @@ int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
   int64_t rows_per_block = (int64_t)kBlock * V * kNVars[vi].rpt;
   int64_t row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
   int64_t S = std::max<int64_t>(1, (target + row_tiles - 1) / row_tiles);
-  if (ctx->cfg.n_auto) {
+  if (ctx->cfg.n_auto && (double)A->ld * (double)A->n * (double)dtype_size(A->dtype) > 256e6) {
+    // (cache-resident matrices are latency-bound: there more blocks matter more than partial traffic)
     // every column split writes and re-reads an m-vector of fp64 partials: keep that below ~1 %
     // of the A stream (S*16 B per row against n*sizeof(T)); when that leaves too few blocks for a
     // wide row tile, fall back to the narrow-tile variant (short-and-wide problems such as C3)
@@ -203,9 +204,7 @@ __global__ __launch_bounds__(kBlock) void sum_partials_rows(const double* __rest
                                                             const int* __restrict__ done) {
   if (done != nullptr && *done != 0) return;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-    double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * ld + i];
-    y[i] = (T)s;
+    y[i] = (T)sum_splits(part, splits, ld, i);
   }
 }
 

@@ -174,8 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_rows(const double* __restrict
   double bias = 0.0;
   if constexpr (FK == APX_F_LOGISTIC) bias = (double)x[n - 1];
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-    double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * ld + i];
+    const double s = sum_splits(part, splits, ld, i);
     if constexpr (FK == APX_F_LEAST_SQUARES) {
       const T r = (T)(s - (double)b[i]);
       res[i] = r;

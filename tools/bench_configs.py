@@ -30,6 +30,8 @@ which = sys.argv[1:] or ["c3", "c5", "c2bt", "c1"]
 if "c3" in which:
     m, n = 100_000, 10_000
     p = problems.device_logreg(m, n, seed=0, lam=0.01, dtype=np.float32, ctx=ctx)
+    if os.environ.get("APX_SINGLE_LAYOUT") != "1":
+        p.X.build_transpose()
     f = apx.LogisticLoss(p.X, p.y)
     s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=f, g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
     out["C3 sparse_logreg dense 100000x10000 fp32, adaptive_proxgrad"] = timed(s, 200, 20, 2 * m * n * 4)
@@ -38,6 +40,8 @@ if "c5" in which:
     m, n = 50_000, 20_000
     p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx)
     norm_A = p.norm_A
+    if os.environ.get("APX_SINGLE_LAYOUT") != "1":
+        p.A.build_transpose()
     gamma = 1.0 / (0.0 / 2 + norm_A / 1.0); sigma = 0.99 / (norm_A * 1.0)       # condat_vu, Lf = 0 (src/AdaProx.jl:405-411)
     rule = apx.FixedStepsize(gamma, np.sqrt(sigma / gamma))
     s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=p.A, rule=rule, tol=0.0, ctx=ctx, poll_every=1 << 30)
