@@ -90,6 +90,10 @@ class Context:
     def set_gemv_config(self, n_variant: int = -1, t_variant: int = -1, n_blocks: int = 0, t_blocks: int = 0):
         L.check(self._lib.apx_ctx_set_gemv_config(self._h, n_variant, t_variant, n_blocks, t_blocks))
 
+    def exploit_sparsity(self, enable: bool = True):
+        """Opt-in: `A*x` streams only the columns with x_j != 0 (dense column-major A)."""
+        L.check(self._lib.apx_ctx_exploit_sparsity(self._h, 1 if enable else 0))
+
     def gemv_variants(self, transposed: bool):
         k = self._lib.apx_gemv_variant_count(1 if transposed else 0)
         return [self._lib.apx_gemv_variant_name(1 if transposed else 0, i).decode() for i in range(k)]

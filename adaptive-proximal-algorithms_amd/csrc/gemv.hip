@@ -106,8 +106,47 @@ static int32_t prof_end(apx_ctx* ctx) {
 static int32_t launch_t_core(apx_ctx* ctx, const void* d, int64_t ld, int64_t n_pad, int32_t dtype, double bytes,
                              int stat_kind, const void* r, void* out, int* splits_out, const int* done);
 
+// opt-in sparse-x path: compact the non-zero entries of x, then stream only those columns
+static int32_t launch_gemv_n_nz(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
+  if (ctx->nz_cap < A->n) {
+    APX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->nz_idx) (void)hipFree(ctx->nz_idx);
+    ctx->nz_idx = nullptr;
+    ctx->nz_cap = 0;
+    APX_HIP(hipMalloc((void**)&ctx->nz_idx, (size_t)(A->n + 16) * sizeof(int32_t)));
+    ctx->nz_cap = A->n;
+  }
+  int32_t* count = ctx->nz_idx + ctx->nz_cap;
+  constexpr int RPT = 2, UNR = 8;
+  const int V = A->dtype == APX_F32 ? 4 : 2;
+  const int64_t rows_per_block = (int64_t)kBlock * V * RPT;
+  const int64_t row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
+  int64_t S = std::max<int64_t>(1, (ctx->cfg.n_target_blocks + row_tiles - 1) / row_tiles);
+  S = std::min<int64_t>(S, std::max<int64_t>(1, A->n / UNR));
+  APX_REQUIRE(S <= 65535, "gemv_n grid too large");
+  APX_TRY(ensure_part(ctx, (size_t)S * A->ld * sizeof(double)));
+  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)A->m * (double)A->n * dtype_size(A->dtype)));
+  dim3 grid((unsigned)row_tiles, (unsigned)S);
+  if (A->dtype == APX_F32) {
+    hipLaunchKernelGGL(compact_nonzero_kernel<float>, dim3(1), dim3(1024), 0, ctx->stream, (const float*)x, A->n,
+                       ctx->nz_idx, count, done);
+    hipLaunchKernelGGL((gemv_n_nz_kernel<float, RPT, UNR, true>), grid, dim3(kBlock), 0, ctx->stream,
+                       (const float*)A->d, A->ld, (const float*)x, ctx->nz_idx, count, ctx->part, A->ld, done);
+  } else {
+    hipLaunchKernelGGL(compact_nonzero_kernel<double>, dim3(1), dim3(1024), 0, ctx->stream, (const double*)x, A->n,
+                       ctx->nz_idx, count, done);
+    hipLaunchKernelGGL((gemv_n_nz_kernel<double, RPT, UNR, true>), grid, dim3(kBlock), 0, ctx->stream,
+                       (const double*)A->d, A->ld, (const double*)x, ctx->nz_idx, count, ctx->part, A->ld, done);
+  }
+  APX_TRY(prof_end(ctx));
+  APX_HIP(hipGetLastError());
+  *splits_out = (int)S;
+  return APX_OK;
+}
+
 int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
   if (A->sparse) return launch_spmv_n(ctx, A, x, splits_out, done);
+  if (ctx->skip_zero_cols) return launch_gemv_n_nz(ctx, A, x, splits_out, done);
   if (A->dT != nullptr)   // dual layout: A*x as the column-streaming kernel over the transposed copy
     return launch_t_core(ctx, A->dT, A->ldT, A->ld, A->dtype, (double)A->m * (double)A->n * dtype_size(A->dtype),
                          APX_KSTAT_GEMV_N, x, nullptr, splits_out, done);

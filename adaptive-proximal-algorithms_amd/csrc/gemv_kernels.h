@@ -316,4 +316,128 @@ __global__ __launch_bounds__(kBlock) void gemv_n_il_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------
+// Opt-in: exploit the exact zeros of x (a lasso iterate after the soft-threshold).
+// Reference BLAS `dgemv` itself skips columns with x_j == 0; here a one-block pass compacts
+// the indices of the non-zero entries (ascending) and gemv_n_nz streams only those columns of
+// the column-major A.  Same kernel structure, same partial layout, fixed order.
+// ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void compact_nonzero_kernel(const T* __restrict__ x, int64_t n,
+                                                               int32_t* __restrict__ idx, int32_t* __restrict__ count,
+                                                               const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  __shared__ int32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  int32_t c = 0;
+  for (int64_t i = lo; i < hi; ++i) c += (x[i] != (T)0) ? 1 : 0;
+  int32_t incl = c;                                   // inclusive scan inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int32_t base = 0;
+  for (int w = 0; w < wv; ++w) base += wsum[w];
+  int32_t pos = base + incl - c;
+  for (int64_t i = lo; i < hi; ++i)
+    if (x[i] != (T)0) idx[pos++] = (int32_t)i;
+  if (tid == 1023) *count = base + incl;
+}
+
+template <typename T, int RPT, int UNR, bool NT>
+__global__ __launch_bounds__(kBlock) void gemv_n_nz_kernel(
+    const T* __restrict__ A, int64_t ld, const T* __restrict__ x, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ count, double* __restrict__ part, int64_t m_pad, const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  constexpr int V = V16<T>::N;
+  constexpr int64_t STEP = (int64_t)kBlock * V;
+  constexpr int TILE = 1024;
+  const int tid = threadIdx.x;
+  const int64_t row_base = (int64_t)blockIdx.x * (STEP * RPT) + (int64_t)tid * V;
+  const int64_t total = *count;
+  int64_t cps = (total + gridDim.y - 1) / gridDim.y;
+  cps = (cps + UNR - 1) / UNR * UNR;
+  const int64_t c0 = (int64_t)blockIdx.y * cps;
+  int64_t c1 = c0 + cps;
+  if (c1 > total) c1 = total;
+
+  int64_t rowk[RPT];
+  bool live[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int64_t rr = row_base + k * STEP;
+    live[k] = rr < m_pad;
+    rowk[k] = live[k] ? rr : 0;
+  }
+  double acc[RPT][V];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[k][e] = 0.0;
+
+  __shared__ double xs[TILE];
+  __shared__ int32_t js[TILE];
+  for (int64_t t0 = c0; t0 < c1; t0 += TILE) {
+    int64_t t1 = t0 + TILE;
+    if (t1 > c1) t1 = c1;
+    __syncthreads();
+    for (int64_t j = t0 + tid; j < t1; j += kBlock) {
+      const int32_t col = idx[j];
+      js[j - t0] = col;
+      xs[j - t0] = (double)x[col];
+    }
+    __syncthreads();
+    int64_t j = t0;
+    for (; j + UNR <= t1; j += UNR) {
+      typename V16<T>::type av[UNR][RPT];
+      double xj[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const T* Ac = A + (int64_t)js[j + u - t0] * ld;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) av[u][k] = ld16<T, NT>(Ac + rowk[k]);
+        xj[u] = xs[j + u - t0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[k][e] = fma((double)av[u][k][e], xj[u], acc[k][e]);
+    }
+    for (; j < t1; ++j) {
+      const T* Ac = A + (int64_t)js[j - t0] * ld;
+      const double xj = xs[j - t0];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const auto av = ld16<T, NT>(Ac + rowk[k]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[k][e] = fma((double)av[e], xj, acc[k][e]);
+      }
+    }
+  }
+
+  double* po = part + (int64_t)blockIdx.y * m_pad;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    if (live[k]) {
+      dvec2* dst = reinterpret_cast<dvec2*>(po + row_base + k * STEP);
+#pragma unroll
+      for (int e = 0; e < V; e += 2) {
+        dvec2 o;
+        o[0] = acc[k][e];
+        o[1] = acc[k][e + 1];
+        dst[e / 2] = o;
+      }
+    }
+  }
+}
+
 }  // namespace apx

@@ -208,6 +208,7 @@ static void ctx_free(apx_ctx* ctx) {
   for (auto& ev : ctx->ev_pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : ctx->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (ctx->part) (void)hipFree(ctx->part);
+  if (ctx->nz_idx) (void)hipFree(ctx->nz_idx);
   if (ctx->red) (void)hipFree(ctx->red);
   if (ctx->scal) (void)hipFree(ctx->scal);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
@@ -247,6 +248,12 @@ int32_t apx_ctx_kernel_stats(apx_ctx* ctx, apx_kernel_stat* stats, int32_t reset
   ctx->ev_pending.clear();
   if (stats != nullptr) memcpy(stats, ctx->stats, sizeof(ctx->stats));
   if (reset) memset(ctx->stats, 0, sizeof(ctx->stats));
+  return APX_OK;
+}
+
+int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_exploit_sparsity: ctx is NULL");
+  ctx->skip_zero_cols = enable != 0;
   return APX_OK;
 }
 

@@ -196,6 +196,10 @@ int32_t apx_ctx_kernel_stats(apx_ctx* ctx, apx_kernel_stat* stats /* [APX_KSTAT_
  * measured-best configuration on MI355X. */
 int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_variant, int64_t n_blocks,
                                 int64_t t_blocks);
+/* Opt-in (default off): `A*x` on a dense column-major A streams only the columns with x_j != 0 —
+ * what reference BLAS dgemv does too (`IF (X(JX).NE.ZERO)`), and what a lasso iterate invites
+ * after the soft-threshold.  Same result up to summation order; not used by bench.py's headline. */
+int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
 int32_t apx_gemv_variant_count(int32_t transposed);
 const char* apx_gemv_variant_name(int32_t transposed, int32_t i);
 
