@@ -39,7 +39,7 @@ class ProblemDesc(C.Structure):
                 ("A_f", c_void_p), ("b", c_void_p), ("n_total_rows", c_int64),
                 ("eval_cb", EVAL_FN), ("pullback_cb", PULLBACK_FN), ("cb_user", c_void_p),
                 ("g", ProxDesc), ("h", ProxDesc), ("A_lin", c_void_p),
-                ("allreduce", ALLREDUCE_FN), ("allreduce_user", c_void_p)]
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", c_void_p), ("shard_mask", c_int32), ("_pad2", c_int32)]
 
 
 class Rule(C.Structure):

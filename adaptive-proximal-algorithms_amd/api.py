@@ -709,12 +709,16 @@ class OurRulePlus:
 class _Problem:
     """Owns an apx_problem and everything its descriptor points to."""
 
-    def __init__(self, f, g, h, A, dtype, ctx: Optional[Context]):
+    def __init__(self, f, g, h, A, dtype, ctx: Optional[Context], lin_allreduce=None):
         fu, gu, hu, Au = _unwrap(f), _unwrap(g), _unwrap(h), _unwrap(A)
         self.keep: list = []
         dtype = np.dtype(dtype)
         d = L.ProblemDesc()
         d.dtype = _code(dtype)
+        if lin_allreduce is not None:        # rows of A (hence y, A_x) are sharded over ranks
+            self._ar = L.ALLREDUCE_FN(self._wrap_allreduce(lin_allreduce))
+            d.allreduce = self._ar
+            d.shard_mask = 2
         self._cb_exc: Optional[BaseException] = None
         if isinstance(fu, (LinearLeastSquares, LogisticLoss, Quadratic)):
             ctx = ctx or fu.A.ctx
@@ -728,8 +732,10 @@ class _Problem:
             d.n_total_rows = int(getattr(fu, "n_total_rows", 0) or 0)
             self.keep += [fu.A, fu.b]
             if fu.allreduce is not None:
-                self._ar = L.ALLREDUCE_FN(self._wrap_allreduce(fu.allreduce))
-                d.allreduce = self._ar
+                if lin_allreduce is None:
+                    self._ar = L.ALLREDUCE_FN(self._wrap_allreduce(fu.allreduce))
+                    d.allreduce = self._ar
+                d.shard_mask |= 1            # rows of the matrix of f are sharded (one hook serves both)
         elif isinstance(fu, Zero):
             d.f_kind = L.APX_F_ZERO
             d.n = 0    # filled in below from x / A
@@ -874,14 +880,14 @@ def _nan_none(v):
 # --------------------------------------------------------------------------------------
 def adaptive_primal_dual(x, y, *, f, g, h, A, rule, tol=1e-5, maxit=10_000, name="AdaPDM",
                          record: Record = None, ctx: Optional[Context] = None, poll_every: int = 0,
-                         use_graph: bool = False):
+                         use_graph: bool = False, A_allreduce=None):
     """src/AdaProx.jl:312-364.  Returns (x, y, it).  ``use_graph`` replays the iteration as a
     captured hipGraph (same kernels, same results; pays off for launch-bound small problems)."""
     maxit = int(math.floor(maxit))                     # maxit may be a Float64 in the experiments
     dtype = _problem_dtype(x, f, A)
     x = _as_vec(x, dtype)
     no_lin = A is None or (np.isscalar(_unwrap(A)) and _unwrap(A) == 0)
-    prob = _Problem(f, g, h, None if no_lin else A, dtype, ctx).finalize(x.size)
+    prob = _Problem(f, g, h, None if no_lin else A, dtype, ctx, lin_allreduce=A_allreduce).finalize(x.size)
     try:
         yv = None if no_lin else _as_vec(y, dtype)
         if not no_lin and yv.size != prob._d.m:
@@ -951,8 +957,11 @@ def fixed_proxgrad(x, *, f, g, gamma, tol=1e-5, maxit=100_000, name="Fixed steps
 
 
 def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=1e-5, maxit=10_000,
-              name="Condat-Vu", record: Record = None, ctx: Optional[Context] = None):
-    """src/AdaProx.jl:367-416."""
+              name="Condat-Vu", record: Record = None, ctx: Optional[Context] = None, A_allreduce=None):
+    """src/AdaProx.jl:367-416.  ``A_allreduce``: the rows of A (and y) are sharded over ranks; then
+    ``norm_A`` must be given (the Frobenius norm of the WHOLE matrix)."""
+    if A_allreduce is not None and gamma is None and sigma is None and norm_A is None:
+        raise ValueError("condat_vu with a row-sharded A needs norm_A of the whole matrix")
     if gamma is None and sigma is None:                             # :398
         par, par2 = 5.0, 100.0
         if norm_A is None:                                          # :402-404
@@ -963,7 +972,7 @@ def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=
     assert gamma is not None and sigma is not None                  # :413
     rule = FixedStepsize(gamma, math.sqrt(sigma / gamma))           # :414
     return adaptive_primal_dual(x, y, f=f, g=g, h=h, A=A, rule=rule, tol=tol, maxit=maxit, name=name,
-                                record=record, ctx=ctx)
+                                record=record, ctx=ctx, A_allreduce=A_allreduce)
 
 
 def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=1.0, delta=1e-8, Theta=1.2, r=2,

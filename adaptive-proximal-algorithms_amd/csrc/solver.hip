@@ -85,7 +85,7 @@ int32_t eval_f(apx_problem* p, const void* x_dev, bool need_f) {
     case APX_F_LOGISTIC: {
       int splits = 0;
       APX_TRY(launch_gemv_n(ctx, p->A_f, x_dev, &splits, p->done_ptr()));
-      const bool local_final = p->allreduce == nullptr;
+      const bool local_final = !p->f_sharded;
       APX_TRY(vo_finish_rows(ctx, p->dtype, p->f_kind, splits, p->A_f->ld, p->A_f->m, p->b.p, x_dev, p->n, p->res.p,
                              p->ctrl(), p->fsc(), local_final));
       if (!local_final && need_f) {
@@ -132,7 +132,7 @@ int32_t pullback_f(apx_problem* p) {
     case APX_F_LEAST_SQUARES:
     case APX_F_LOGISTIC: {
       APX_TRY(launch_gemv_t(ctx, p->A_f, p->res.p, p->grad.p, p->done_ptr()));
-      if (p->allreduce != nullptr) {
+      if (p->f_sharded) {
         // [A_k' r_k] summed over the row shards (K12).  In fp64 the two partial f scalars sit
         // right behind the gradient (fsc_packed) and ride along in the SAME collective: one
         // latency-bound 0.8 MB all-reduce per iteration instead of two.
@@ -248,6 +248,9 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   p->A_lin = d->A_lin;
   p->allreduce = d->allreduce;
   p->ar_user = d->allreduce_user;
+  // shard_mask: bit 0 = rows of A_f sharded, bit 1 = rows of A_lin sharded; 0 with a hook = bit 0 (the original ABI)
+  p->f_sharded = d->allreduce != nullptr && (d->shard_mask == 0 || (d->shard_mask & 1) != 0);
+  p->lin_sharded = d->allreduce != nullptr && (d->shard_mask & 2) != 0;
   const size_t es = dtype_size(d->dtype);
 
   switch (d->f_kind) {
@@ -272,7 +275,7 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
       APX_REQUIRE(d->A_f != nullptr && d->b != nullptr, "Quadratic needs Q (A_f) and q (b)");
       APX_REQUIRE(d->A_f->ctx == ctx && d->A_f->dtype == d->dtype, "Q: wrong context or dtype");
       APX_REQUIRE(d->A_f->m == d->n && d->A_f->n == d->n, "Quadratic: Q must be n x n");
-      APX_REQUIRE(d->allreduce == nullptr, "Quadratic f cannot be row-sharded by the library");
+      APX_REQUIRE(!p->f_sharded, "Quadratic f cannot be row-sharded by the library");
       APX_TRY(p->b.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
       APX_TRY(p->res.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
       APX_TRY(h2d(ctx, p->b.p, d->b, (size_t)d->n * es));
@@ -280,7 +283,7 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
     }
     case APX_F_CALLBACK:
       APX_REQUIRE(d->eval_cb != nullptr && d->pullback_cb != nullptr, "callback f needs eval_cb and pullback_cb");
-      APX_REQUIRE(d->allreduce == nullptr, "callback f cannot be row-sharded by the library");
+      APX_REQUIRE(!p->f_sharded, "callback f cannot be row-sharded by the library");
       p->eval_cb = d->eval_cb;
       p->pb_cb = d->pullback_cb;
       p->cb_user = d->cb_user;
@@ -311,7 +314,7 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   APX_TRY(p->xtmp.alloc_zero((size_t)p->n_pad * es, ctx->stream));
   APX_TRY(p->fsc_buf.alloc_zero(sizeof(double) * 8, ctx->stream));
   // n_pad leaves >= 32 spare slots behind A_f->n_pad gradient entries
-  p->fsc_packed = p->allreduce != nullptr && p->dtype == APX_F64 && p->A_f != nullptr &&
+  p->fsc_packed = p->f_sharded && p->dtype == APX_F64 && p->A_f != nullptr &&
                   p->fsc_off() + 2 <= p->n_pad;
   APX_TRY(p->ctrl_buf.alloc_zero(sizeof(Ctrl), ctx->stream));
   apx_rule r{};
@@ -448,7 +451,10 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   }
   APX_TRY(eval_f(p, s->x.p, false));                                           // :328
   APX_TRY(pullback_f(p));
-  if (lin) APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, nullptr));   // :329
+  if (lin) {                                                                   // :329
+    APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, nullptr));
+    if (p->lin_sharded) APX_TRY(do_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));
+  }
   APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
                   p->gd, p->ctrl()));                                          // :330-332
   if (lin)                                                                     // :331  A_x_prev = A_x
@@ -473,9 +479,16 @@ static int32_t enqueue_iteration(apx_solver* s) {
                          lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
                          s->rec_cap));                                         // :338-342
   if (lin) {
-    APX_TRY(vo_dual(ctx, p->dtype, s->y.p, s->ax.p, s->axprev.p, p->m, p->hd, p->ctrl(), (apx_record*)s->recs.p,
-                    s->rec_cap));                                              // :344-354
+    if (p->lin_sharded) {   // y, A_x, dual_res are row shards: their norms / values are all-reduced
+      APX_TRY(vo_dual_sharded(ctx, p->dtype, s->y.p, s->ax.p, s->axprev.p, p->m, p->hd, p->ctrl(),
+                              (apx_record*)s->recs.p, s->rec_cap,
+                              [p](double* buf, int64_t cnt) { return do_allreduce(p, buf, cnt, APX_F64); }));
+    } else {
+      APX_TRY(vo_dual(ctx, p->dtype, s->y.p, s->ax.p, s->axprev.p, p->m, p->hd, p->ctrl(), (apx_record*)s->recs.p,
+                      s->rec_cap));                                            // :344-354
+    }
     APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, p->done_ptr()));    // :358
+    if (p->lin_sharded) APX_TRY(do_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));   // A'y = sum_k A_k' y_k
   }
   APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
                   p->gd, p->ctrl()));                                          // :359-361

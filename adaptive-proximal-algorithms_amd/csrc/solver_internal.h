@@ -18,6 +18,7 @@ struct apx_problem {
   void* cb_user = nullptr;
   apx_allreduce_fn allreduce = nullptr;
   void* ar_user = nullptr;
+  bool f_sharded = false, lin_sharded = false;   // which operand's rows the all-reduce hook sums over
   double n_mean = 0.0;
   apx::DBuf b, res, grad, fsc_buf, xtmp, ctrl_buf;
   apx::DBuf g_lb, g_ub, g_shift, h_lb, h_ub, h_shift;

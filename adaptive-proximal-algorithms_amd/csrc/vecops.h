@@ -1,5 +1,7 @@
 // vecops.h — launchers of the fused vector kernels (vecops.hip).
 #pragma once
+#include <functional>
+
 #include "apx_internal.h"
 
 namespace apx {
@@ -16,6 +18,10 @@ int32_t vo_reduce_rule(apx_ctx* ctx, int32_t dtype, const void* x, const void* x
 // K9 then the end of the iteration
 int32_t vo_dual(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axprev, int64_t m, const ProxDev& h,
                 Ctrl* c, apx_record* recs, int64_t rec_cap);
+// K9 with the rows of A sharded over ranks: `reduce(buf, count)` all-reduces device doubles
+int32_t vo_dual_sharded(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axprev, int64_t m,
+                        const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap,
+                        const std::function<int32_t(double*, int64_t)>& reduce);
 // K5+K6
 int32_t vo_step(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v,
                 const void* aty, int64_t n, const ProxDev& g, const Ctrl* c);

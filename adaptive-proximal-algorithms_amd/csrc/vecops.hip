@@ -764,6 +764,47 @@ int32_t vo_dual(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axpr
   return APX_OK;
 }
 
+// the same with the rows of A (hence y, A_x, dual_res) sharded over ranks: the block partials are
+// summed to device scalars, all-reduced by `reduce`, and the iteration is closed from the global sums
+__global__ void k_dual_pre_final_s(const double* __restrict__ sums, Ctrl* c) {
+  if (c->done != 0) return;
+  if (threadIdx.x == 0 && blockIdx.x == 0) c->h_pre = sqrt(sums[0]);
+}
+__global__ void k_final_s(const double* __restrict__ sums, ProxDev h, Ctrl* c, apx_record* recs, int64_t rec_cap) {
+  if (c->done != 0) return;
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double ndr = sqrt(sums[0]);
+  c->ndr2 = ndr * ndr;
+  c->h_Ax = gval_final(h, sums[1]);
+  finish_iteration(c, recs, rec_cap);
+}
+
+int32_t vo_dual_sharded(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axprev, int64_t m,
+                        const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap,
+                        const std::function<int32_t(double*, int64_t)>& reduce) {
+  const unsigned gr = vgrid(m);
+  if (h.kind == APX_G_L2) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_dual_pre<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const double*)y,
+                                  (const double*)ax, (const double*)axprev, m, h, c, ctx->red),
+               hipLaunchKernelGGL(k_dual_pre<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (const float*)y,
+                                  (const float*)ax, (const float*)axprev, m, h, c, ctx->red));
+    hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 1, ctx->scal + 12);
+    APX_TRY(reduce(ctx->scal + 12, 1));
+    hipLaunchKernelGGL(k_dual_pre_final_s, dim3(1), dim3(64), 0, ctx->stream, ctx->scal + 12, c);
+  }
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_dual<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)y, (const double*)ax,
+                                (double*)axprev, m, h, c, ctx->red),
+             hipLaunchKernelGGL(k_dual<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)y, (const float*)ax,
+                                (float*)axprev, m, h, c, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 2, ctx->scal + 13);
+  APX_TRY(reduce(ctx->scal + 13, 2));
+  hipLaunchKernelGGL(k_final_s, dim3(1), dim3(64), 0, ctx->stream, ctx->scal + 13, h, c, recs, rec_cap);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
 int32_t vo_step(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v,
                 const void* aty, int64_t n, const ProxDev& g, const Ctrl* c) {
   const unsigned gr = vgrid(n);

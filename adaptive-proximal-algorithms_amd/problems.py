@@ -20,6 +20,7 @@ from typing import Callable, Optional
 
 import numpy as np
 
+from ._lib import ApxError
 from .api import Context, DeviceMatrix, _hash_uniform
 
 
@@ -31,6 +32,7 @@ class DeviceLasso:
     lam: float
     optimum: float
     Lf: float
+    dual_layout: bool = False      # a transposed copy of A is resident too
 
 
 def _ident(v):
@@ -67,8 +69,14 @@ def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, la
     alpha = np.empty(n)
     alpha[perm] = a_sorted
     A.scale_columns(alpha)                                      # :68  A = C * diagm(alpha)
-    if dual_layout:
-        A.build_transpose()                                     # A is final from here on
+    have_dual = False
+    if dual_layout:                                             # A is final from here on
+        try:
+            A.build_transpose()
+            have_dual = True
+        except ApxError as e:                                   # e.g. not enough free HBM for the second copy
+            import warnings
+            warnings.warn(f"dual layout not available, continuing with the single layout: {e}")
     # :70-75  x_star
     xs_sorted = np.where(head, r_x * rho / math.sqrt(p) * np.sign(alpha[perm] * cty_signed[perm]), 0.0)
     x_star = np.zeros(n)
@@ -83,7 +91,7 @@ def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, la
         w = ar(A.rmatvec(A.matvec(v)))
         Lf = math.sqrt(float(np.dot(w, w)))
         v = w / Lf
-    return DeviceLasso(A, b, x_star, lam, optimum, Lf)
+    return DeviceLasso(A, b, x_star, lam, optimum, Lf, have_dual)
 
 
 @dataclass

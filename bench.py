@@ -199,7 +199,7 @@ def main():
                                    f"{world} MI355X (GEMV + soft-threshold + stepsize reductions)"
                                    + ("" if world == 1 else f"; row-sharded {args.m * world}x{args.n}, RCCL all-reduce of A'r"),
                        "rows_per_gpu": args.m, "cols": args.n, "rule": "OurRule(gamma=1/Lf)",
-                       "layout": ("single: A column-major, 40 GB" if args.single_layout else
+                       "layout": ("single: A column-major, 40 GB" if not prob.dual_layout else
                                   "dual: A and its transposed copy resident (2 x 40 GB of the 288 GB), "
                                   "each pass still reads 40 GB"),
                        "parallelism": "single" if world == 1 else f"row-shard x{world}"},

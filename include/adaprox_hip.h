@@ -125,6 +125,10 @@ typedef struct {
   const apx_matrix* A_lin; /* linear operator A of h(Ax); NULL <=> `A = 0` (adaptive_proxgrad, :419) */
   apx_allreduce_fn allreduce;  /* row-sharded A_f: all-reduce of [A_k' r_k ; partial f]        */
   void* allreduce_user;
+  int32_t shard_mask;      /* with a hook: bit 0 = rows of A_f are sharded, bit 1 = rows of A_lin are sharded
+                              (y, A_x and the dual residual become shards; A'y and ||dual_res||^2 are all-reduced);
+                              0 means bit 0                                                                       */
+  int32_t _pad2;
 } apx_problem_desc;
 
 typedef struct {

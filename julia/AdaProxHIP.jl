@@ -48,6 +48,7 @@ struct ProblemDesc         # apx_problem_desc
     g::ProxDesc; h::ProxDesc
     A_lin::Ptr{Cvoid}
     allreduce::Ptr{Cvoid}; allreduce_user::Ptr{Cvoid}
+    shard_mask::Int32; _pad2::Int32
 end
 
 struct Rule                # apx_rule
@@ -180,7 +181,7 @@ function with_problem(body, f, g, h, A, ::Type{T}) where {T}
         Af_h, ctx = Af.h, Af.ctx
     end
     desc = ProblemDesc(fk, dtype_code(T), n, m, Af_h, isempty(b) ? C_NULL : pointer(b), 0, C_NULL, C_NULL, C_NULL,
-                       proxdesc(gu, T, keep), proxdesc(hu, T, keep), A_lin, C_NULL, C_NULL)
+                       proxdesc(gu, T, keep), proxdesc(hu, T, keep), A_lin, C_NULL, C_NULL, 0, 0)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve b keep begin
         check(ccall((:apx_problem_create, LIB), Int32, (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), ctx.h, Ref(desc), out))

@@ -38,3 +38,18 @@ def test_two_ranks_reproduce_one_rank():
     assert two["lasso_optimum"] == pytest.approx(one["lasso_optimum"], rel=1e-12)       # same global problem
     assert two["final_objective"] == pytest.approx(one["final_objective"], rel=1e-10)   # same 30 iterations
     assert two["config"]["parallelism"] == "row-shard x2"
+
+
+def test_row_sharded_primal_dual():
+    """A_lin row-sharded over two real ranks (SURVEY §8e "PD (C5-style)"): y, A_x and the dual
+    residual are shards, A'y and the residual norms are all-reduced inside the native loop; the
+    l1 (clamp) and l2-ball conjugate proxes and both the fixed and the adaptive rule must reproduce
+    the single-rank iterates."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "tests", "two_rank_pd_worker.py")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert out.stdout.count("PD-SHARDED") == 2

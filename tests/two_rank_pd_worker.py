@@ -1,0 +1,67 @@
+"""Worker for tests/test_gpu_two_ranks.py::test_row_sharded_primal_dual — launched by
+torch.distributed.run with 2 ranks that share GPU 0 (gloo transport).  Each rank holds a row shard
+of A and of y; A'y and the dual-residual norm are all-reduced by the native loop.  Rank 0 also
+solves the unsharded problem and compares."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import adaprox_amd as apx  # noqa: E402
+from oracle import problems as P  # noqa: E402
+
+sharded = importlib.import_module("adaptive-proximal-algorithms_amd.sharded")
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream(device=0)
+    ok = True
+    with torch.cuda.stream(stream):
+        ctx = apx.Context(device=0, stream=stream.cuda_stream)
+        ar = sharded.device_allreduce(dist, 0)
+        m, n, K = 601, 240, 120
+        r0, ml = sharded.shard_rows(m, rank, world)
+        for hname, lam, hmk in (("l1", 10.0, lambda b: apx.Translate(apx.NormL1(1.0), -b)),
+                                ("l2", 0.05, lambda b: apx.Translate(apx.NormL2(1.0), -b))):
+            lad = P.random_lad(m, n, seed=1, lam=lam)
+            A_k = apx.DeviceMatrix.from_numpy(lad.A[r0:r0 + ml], ctx)
+            x, y_k, it = apx.condat_vu(np.zeros(n), np.zeros(ml), f=apx.Zero(), g=apx.NormL1(lad.lam),
+                                       h=hmk(lad.y[r0:r0 + ml]), A=A_k, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K,
+                                       ctx=ctx, A_allreduce=ar)
+            # adaptive rule with norm_A > 0 on the sharded operator as well
+            xa, ya_k, _ = apx.adaptive_primal_dual(np.zeros(n), np.zeros(ml), f=apx.Zero(), g=apx.NormL1(lad.lam),
+                                                   h=hmk(lad.y[r0:r0 + ml]), A=A_k,
+                                                   rule=apx.OurRule(t=0.5, norm_A=lad.norm_A), tol=0.0, maxit=K,
+                                                   ctx=ctx, A_allreduce=ar)
+            ys = [None] * world
+            dist.all_gather_object(ys, (y_k, ya_k))
+            if rank == 0:
+                A_full = apx.DeviceMatrix.from_numpy(lad.A, ctx)
+                xr, yr, _ = apx.condat_vu(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(lad.lam), h=hmk(lad.y),
+                                          A=A_full, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K, ctx=ctx)
+                xar, yar, _ = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(lad.lam),
+                                                       h=hmk(lad.y), A=A_full, rule=apx.OurRule(t=0.5, norm_A=lad.norm_A),
+                                                       tol=0.0, maxit=K, ctx=ctx)
+                y_cat = np.concatenate([t[0] for t in ys])
+                ya_cat = np.concatenate([t[1] for t in ys])
+                assert np.max(np.abs(xr)) > 0 and np.max(np.abs(xar)) > 0, "degenerate test problem"
+                errs = [np.max(np.abs(x - xr)) / np.max(np.abs(xr)), np.max(np.abs(y_cat - yr)) / np.max(np.abs(yr)),
+                        np.max(np.abs(xa - xar)) / np.max(np.abs(xar)), np.max(np.abs(ya_cat - yar)) / np.max(np.abs(yar))]
+                print(f"PD-SHARDED {hname} errs " + " ".join(f"{e:.3e}" for e in errs), flush=True)
+                ok = ok and all(e <= 1e-10 for e in errs)
+    flag = torch.tensor([1 if ok else 0])
+    dist.broadcast(flag, 0)
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()
