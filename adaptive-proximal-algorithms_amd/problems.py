@@ -42,11 +42,13 @@ def _ident(v):
 def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, lam: float = 1.0, rho: float = 1.0,
                  rank: int = 0, world: int = 1, power_iters: int = 50, ctx: Optional[Context] = None,
                  allreduce_host: Optional[Callable[[np.ndarray], np.ndarray]] = None,
-                 dual_layout: bool = False) -> DeviceLasso:
-    """``dual_layout``: keep the transposed copy of A too (DeviceMatrix.build_transpose)."""
+                 dual_layout: bool = False, m_total: Optional[int] = None,
+                 row_offset: Optional[int] = None) -> DeviceLasso:
+    """``dual_layout``: keep the transposed copy of A too (DeviceMatrix.build_transpose).
+    ``m_total`` / ``row_offset``: an uneven row split (default: ``world`` equal shards of ``m_local`` rows)."""
     ar = allreduce_host or _ident
-    m_total = m_local * world
-    r0 = rank * m_local
+    m_total = m_local * world if m_total is None else m_total
+    r0 = rank * m_local if row_offset is None else row_offset
     # :47-48  y_star = rand(m); y_star ./= norm(y_star)
     y_loc = _hash_uniform(seed + 1, m_total, 0.0, 1.0)[r0:r0 + m_local]
     y_norm = math.sqrt(float(ar(np.array([np.dot(y_loc, y_loc)]))[0]))

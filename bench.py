@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
+HBM_COPY_GBS = 6290.0      # same table: measured float4-copy ceiling (SURVEY.md 8d asks for both)
 
 
 def parse():
@@ -46,6 +47,8 @@ def parse():
                     help="NOT the BASELINE metric: let A*x skip the columns with x_j == 0 (flagged in the JSON line)")
     ap.add_argument("--single-layout", action="store_true",
                     help="do not keep the transposed copy of A (40 GB instead of 80 GB; A*x ~5 %% slower)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --rows is the GLOBAL row count, split over the ranks (default: weak, rows per GPU)")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=30)
     return ap.parse_args()
@@ -123,6 +126,10 @@ def main():
     problems = import_module("adaptive-proximal-algorithms_amd.problems")
     sharded = import_module("adaptive-proximal-algorithms_amd.sharded")
 
+    m_global = args.m if args.strong else args.m * world
+    row0 = rank * args.m
+    if args.strong:
+        row0, args.m = sharded.shard_rows(m_global, rank, world)   # this rank's first row and row count
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx = apx.Context(device=dev, stream=stream.cuda_stream)
@@ -133,7 +140,8 @@ def main():
         t_setup = time.perf_counter()
         prob = problems.device_lasso(args.m, args.n, pfactor=10, seed=args.seed, rank=rank, world=world,
                                      power_iters=30, ctx=ctx, allreduce_host=ar_host,
-                                     dual_layout=not args.single_layout)   # dual: both passes stream contiguously (80 of 288 GB)
+                                     dual_layout=not args.single_layout,   # dual: both passes stream contiguously (80 of 288 GB)
+                                     m_total=m_global, row_offset=row0)
         t_setup = time.perf_counter() - t_setup
 
         if args.exploit_sparsity:
@@ -192,19 +200,20 @@ def main():
                 traffic = None
         out = {
             "metric": "prox-grad iters/sec on dense lasso A 50k x 100k (adaptive_proxgrad, OurRule)",
-            "value": world * iters_per_s, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
+            "value": (1 if args.strong else world) * iters_per_s, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"lasso, dense A {args.m}x{args.n} fp64 per GPU, adaptive_proxgrad on "
                                    f"{world} MI355X (GEMV + soft-threshold + stepsize reductions)"
-                                   + ("" if world == 1 else f"; row-sharded {args.m * world}x{args.n}, RCCL all-reduce of A'r"),
+                                   + ("" if world == 1 else f"; row-sharded {m_global}x{args.n}, RCCL all-reduce of A'r"),
                        "rows_per_gpu": args.m, "cols": args.n, "rule": "OurRule(gamma=1/Lf)",
                        "layout": ("single: A column-major, 40 GB" if not prob.dual_layout else
                                   "dual: A and its transposed copy resident (2 x 40 GB of the 288 GB), "
                                   "each pass still reads 40 GB"),
                        "parallelism": "single" if world == 1 else f"row-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
+                         "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "per_kernel": per_kernel,
                          "iteration_frac": 2 * algo_bytes * iters_per_s / 1e9 / HBM_PEAK_GBS},
             "setup_s": t_setup, "final_objective": res.objective, "lasso_optimum": prob.optimum,

@@ -40,6 +40,17 @@ def test_two_ranks_reproduce_one_rank():
     assert two["config"]["parallelism"] == "row-shard x2"
 
 
+def test_strong_scaling_uneven_split():
+    """`--strong`: --rows is the global row count; 4001 rows over two ranks = 2001 + 2000."""
+    common = ["--rows", "4001", "--cols", "6000", "--steps", "25", "--warmup", "5", "--no-cpu-baseline"]
+    one = _bench(common, {}, 1)
+    two = _bench(common + ["--strong"], {"APX_BENCH_SHARE_GPU": "1"}, 2)
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert two["lasso_optimum"] == pytest.approx(one["lasso_optimum"], rel=1e-12)
+    assert two["final_objective"] == pytest.approx(one["final_objective"], rel=1e-10)
+    assert two["value"] == pytest.approx(1e3 / two["ms_per_step"], rel=1e-9)     # job iterations/s, not x world
+
+
 def test_row_sharded_primal_dual():
     """A_lin row-sharded over two real ranks (SURVEY §8e "PD (C5-style)"): y, A_x and the dual
     residual are shards, A'y and the residual norms are all-reduced inside the native loop; the
