@@ -90,6 +90,10 @@ class Context:
     def set_gemv_config(self, n_variant: int = -1, t_variant: int = -1, n_blocks: int = 0, t_blocks: int = 0):
         L.check(self._lib.apx_ctx_set_gemv_config(self._h, n_variant, t_variant, n_blocks, t_blocks))
 
+    def fused_small(self, enable: bool = True):
+        """Default on: small dense proximal-gradient problems run as two kernels per iteration (csrc/small.hip)."""
+        L.check(self._lib.apx_ctx_fused_small(self._h, 1 if enable else 0))
+
     def exploit_sparsity(self, enable: bool = True):
         """Opt-in: `A*x` streams only the columns with x_j != 0 (dense column-major A)."""
         L.check(self._lib.apx_ctx_exploit_sparsity(self._h, 1 if enable else 0))
@@ -859,9 +863,14 @@ def _problem_dtype(x, f, A):
     return x.dtype if x.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 
 
-def _opts(maxit: int, want_records: bool, poll_every: int = 0, use_graph: bool = False):
+def _graph_flag(use_graph) -> int:
+    """None = the library's choice (eager launches today: replay measured no faster, tools/small_bench.py)."""
+    return 2 if use_graph is None else (1 if use_graph else 0)
+
+
+def _opts(maxit: int, want_records: bool, poll_every: int = 0, use_graph=None):
     o = L.SolveOpts()
-    o.use_graph = 1 if use_graph else 0
+    o.use_graph = _graph_flag(use_graph)
     recs = None
     if want_records and maxit > 0:
         recs = (L.Record * int(maxit))()
@@ -880,7 +889,7 @@ def _nan_none(v):
 # --------------------------------------------------------------------------------------
 def adaptive_primal_dual(x, y, *, f, g, h, A, rule, tol=1e-5, maxit=10_000, name="AdaPDM",
                          record: Record = None, ctx: Optional[Context] = None, poll_every: int = 0,
-                         use_graph: bool = False, A_allreduce=None):
+                         use_graph: Optional[bool] = None, A_allreduce=None):
     """src/AdaProx.jl:312-364.  Returns (x, y, it).  ``use_graph`` replays the iteration as a
     captured hipGraph (same kernels, same results; pays off for launch-bound small problems)."""
     maxit = int(math.floor(maxit))                     # maxit may be a Float64 in the experiments
@@ -941,7 +950,7 @@ def _advance_counts(f, g, h, A, res, f_is_callback):
 
 
 def adaptive_proxgrad(x, *, f, g, rule, tol=1e-5, maxit=100_000, name="AdaPGM", record: Record = None,
-                      ctx: Optional[Context] = None, poll_every: int = 0, use_graph: bool = False):
+                      ctx: Optional[Context] = None, poll_every: int = 0, use_graph: Optional[bool] = None):
     """src/AdaProx.jl:418-421.  Returns (x, numit)."""
     x, _, numit = adaptive_primal_dual(x, None, f=f, g=g, h=Zero(), A=0, rule=rule, tol=tol, maxit=maxit,
                                        name=name, record=record, ctx=ctx, poll_every=poll_every,
@@ -1053,7 +1062,7 @@ def backtracking_proxgrad(x0, *, f, g, gamma0, xi=1.0, shrink=0.5, tol=1e-5, max
 # --------------------------------------------------------------------------------------
 class Solver:
     def __init__(self, x, y=None, *, f, g, h=None, A=None, rule, tol=0.0, ctx: Optional[Context] = None,
-                 poll_every: int = 0, use_graph: bool = False):
+                 poll_every: int = 0, use_graph: Optional[bool] = None):
         dtype = _problem_dtype(x, f, A)
         x = _as_vec(x, dtype)
         no_lin = A is None or (np.isscalar(_unwrap(A)) and _unwrap(A) == 0)
@@ -1062,7 +1071,7 @@ class Solver:
         yv = None if no_lin else _as_vec(y, dtype)
         opts = L.SolveOpts()
         opts.poll_every = poll_every
-        opts.use_graph = 1 if use_graph else 0
+        opts.use_graph = _graph_flag(use_graph)
         h_ = C.c_void_p()
         r = rule._rule()
         self.prob.check(self.prob.lib.apx_solver_create(self.prob.h, C.byref(r), _ptr(x), _ptr(yv), float(tol),

@@ -93,6 +93,7 @@ struct apx_ctx {
   double* scal = nullptr;        // small device scalar scratch (16 doubles)
   double* h_scal = nullptr;      // pinned host scalars (64 doubles): read-backs of scal / Ctrl fields
   // opt-in: A*x streams only the columns with x_j != 0 (apx_ctx_exploit_sparsity)
+  bool fused_small = true;       // small dense proximal-gradient problems run as two kernels per iteration (small.hip)
   bool skip_zero_cols = false;
   int32_t* nz_idx = nullptr;     // compacted column indices + [nz_cap] = count
   int64_t nz_cap = 0;

@@ -257,6 +257,12 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable) {
   return APX_OK;
 }
 
+int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_fused_small: ctx is NULL");
+  ctx->fused_small = enable != 0;
+  return APX_OK;
+}
+
 int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_variant, int64_t n_blocks,
                                 int64_t t_blocks) {
   APX_REQUIRE(ctx != nullptr, "apx_ctx_set_gemv_config: ctx is NULL");
@@ -372,6 +378,31 @@ static void drop_transpose(apx_matrix* A) {
   A->ldT = 0;
 }
 
+}  // extern "C"
+
+namespace apx {
+int32_t transpose_into(apx_ctx* ctx, const apx_matrix* A, void* dT, int64_t ldT) {
+  if (A->m > 0 && A->n > 0) {
+    // gridDim.y is limited to 65535 tiles: walk the columns in slabs
+    const int64_t slab = 65535LL * 32;
+    for (int64_t j0 = 0; j0 < A->n; j0 += slab) {
+      const int64_t nj = std::min<int64_t>(slab, A->n - j0);
+      dim3 grid((unsigned)((A->m + 31) / 32), (unsigned)((nj + 31) / 32));
+      if (A->dtype == APX_F32)
+        hipLaunchKernelGGL(k_transpose<float>, grid, dim3(kBlock), 0, ctx->stream,
+                           (const float*)A->d + (size_t)j0 * A->ld, A->ld, (float*)dT + j0, ldT, A->m, nj);
+      else
+        hipLaunchKernelGGL(k_transpose<double>, grid, dim3(kBlock), 0, ctx->stream,
+                           (const double*)A->d + (size_t)j0 * A->ld, A->ld, (double*)dT + j0, ldT, A->m, nj);
+    }
+  }
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+}  // namespace apx
+
+extern "C" {
+
 int32_t apx_matrix_build_transpose(apx_matrix* A) {
   APX_REQUIRE(A != nullptr, "apx_matrix_build_transpose: A is NULL");
   APX_REQUIRE(!A->sparse, "apx_matrix_build_transpose: dense matrices only (sparse storage keeps both orientations)");
@@ -391,19 +422,9 @@ int32_t apx_matrix_build_transpose(apx_matrix* A) {
     return fail(APX_ERR_HIP, std::string("apx_matrix_build_transpose: hipMalloc of ") + std::to_string(bytes) +
                                  " B: " + hipGetErrorString(e));
   APX_HIP(hipMemsetAsync(dT, 0, bytes, ctx->stream));
-  if (A->m > 0 && A->n > 0) {
-    // gridDim.y is limited to 65535 tiles: walk the columns in slabs
-    const int64_t slab = 65535LL * 32;
-    for (int64_t j0 = 0; j0 < A->n; j0 += slab) {
-      const int64_t nj = std::min<int64_t>(slab, A->n - j0);
-      dim3 grid((unsigned)((A->m + 31) / 32), (unsigned)((nj + 31) / 32));
-      if (A->dtype == APX_F32)
-        hipLaunchKernelGGL(k_transpose<float>, grid, dim3(kBlock), 0, ctx->stream,
-                           (const float*)A->d + (size_t)j0 * A->ld, A->ld, (float*)dT + j0, ldT, A->m, nj);
-      else
-        hipLaunchKernelGGL(k_transpose<double>, grid, dim3(kBlock), 0, ctx->stream,
-                           (const double*)A->d + (size_t)j0 * A->ld, A->ld, (double*)dT + j0, ldT, A->m, nj);
-    }
+  if (int32_t rc = transpose_into(ctx, A, dT, ldT); rc != APX_OK) {
+    (void)hipFree(dT);
+    return rc;
   }
   APX_HIP(hipGetLastError());
   APX_HIP(hipStreamSynchronize(ctx->stream));

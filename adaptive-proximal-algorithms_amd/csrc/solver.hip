@@ -410,7 +410,12 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   *out = nullptr;
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipSetDevice(ctx->device));
-  const bool want_graph = opts != nullptr && opts->use_graph != 0;
+  // use_graph: 0 eager, 1 hipGraph replay, 2 = the library's choice.  Measured on MI355X / ROCm 7.2
+  // (tools/small_bench.py): replay is never faster than eager launches here — the two-kernel small path is
+  // device-bound at ~12 us / iteration eager vs 18+ us replayed, the generic path ~30 us either way — so
+  // the library's choice is eager; replay stays available on request.
+  const bool small = small_eligible(p);
+  const bool want_graph = opts != nullptr && opts->use_graph == 1;
   if (want_graph && (p->f_kind == APX_F_CALLBACK || p->allreduce != nullptr))
     return fail(APX_ERR_UNSUPPORTED,
                 "hipGraph replay needs a device-only iteration: not with a host-callback f or an all-reduce hook");
@@ -444,27 +449,32 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   APX_TRY(h2d(ctx, s->x.p, x0, (size_t)p->n * es));
   if (lin) APX_TRY(h2d(ctx, s->y.p, y0, (size_t)p->m * es));
 
-  if (lin) {                                                                   // :327  A_x = A * x
-    int splits = 0;
-    APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, nullptr));
-    APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, nullptr));
+  if (small) {
+    APX_TRY(small_setup(s.get()));   // small.hip: pre-loop and iteration as fused kernels
+  } else {
+    if (lin) {                                                                   // :327  A_x = A * x
+      int splits = 0;
+      APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, nullptr));
+      APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, nullptr));
+    }
+    APX_TRY(eval_f(p, s->x.p, false));                                           // :328
+    APX_TRY(pullback_f(p));
+    if (lin) {                                                                   // :329
+      APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, nullptr));
+      if (p->lin_sharded) APX_TRY(do_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));
+    }
+    APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
+                    p->gd, p->ctrl()));                                          // :330-332
+    if (lin)                                                                     // :331  A_x_prev = A_x
+      APX_HIP(hipMemcpyAsync(s->axprev.p, s->ax.p, (size_t)p->m_pad * es, hipMemcpyDeviceToDevice, ctx->stream));
   }
-  APX_TRY(eval_f(p, s->x.p, false));                                           // :328
-  APX_TRY(pullback_f(p));
-  if (lin) {                                                                   // :329
-    APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, nullptr));
-    if (p->lin_sharded) APX_TRY(do_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));
-  }
-  APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
-                  p->gd, p->ctrl()));                                          // :330-332
-  if (lin)                                                                     // :331  A_x_prev = A_x
-    APX_HIP(hipMemcpyAsync(s->axprev.p, s->ax.p, (size_t)p->m_pad * es, hipMemcpyDeviceToDevice, ctx->stream));
   p->active = s.get();
   *out = s.release();
   return APX_OK;
 }
 
 static int32_t enqueue_iteration(apx_solver* s) {
+  if (s->small != nullptr) return small_enqueue(s);
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   const bool lin = p->A_lin != nullptr;
@@ -526,7 +536,10 @@ static int32_t capture_iteration(apx_solver* s) {
 static int32_t poll_done(apx_solver* s, bool* done) {
   apx_ctx* ctx = s->p->ctx;
   int32_t* h = (int32_t*)&ctx->h_scal[40];
-  APX_HIP(hipMemcpyAsync(h, s->p->done_ptr(), sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  // small path: the closing state (and its done flag) lives in Ctrl B
+  const int* dp = s->small != nullptr
+                      ? (const int*)((const char*)s->small->cb.p + offsetof(apx::Ctrl, done)) : s->p->done_ptr();
+  APX_HIP(hipMemcpyAsync(h, dp, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   APX_HIP(hipStreamSynchronize(ctx->stream));
   *done = *h != 0;
   return APX_OK;
@@ -557,9 +570,12 @@ int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* r
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipSetDevice(ctx->device));
   Ctrl c;
-  APX_TRY(read_ctrl(p, &c));
+  if (s->small != nullptr) APX_TRY(d2h(ctx, &c, s->small->cb.p, sizeof(Ctrl)));
+  else APX_TRY(read_ctrl(p, &c));
   const bool lin = p->A_lin != nullptr;
-  if (x_out != nullptr) APX_TRY(d2h(ctx, x_out, s->x.p, (size_t)p->n * p->es()));
+  // small path: on convergence x is the tested iterate, otherwise the next one is still staged (Appendix A.8)
+  const void* x_src = (s->small != nullptr && c.done == 0) ? s->small->xn.p : s->x.p;
+  if (x_out != nullptr) APX_TRY(d2h(ctx, x_out, x_src, (size_t)p->n * p->es()));
   if (y_out != nullptr && lin) APX_TRY(d2h(ctx, y_out, s->y.p, (size_t)p->m * p->es()));
   int64_t nrec = 0;
   if (s->host_recs != nullptr) {

@@ -36,6 +36,34 @@ struct apx_problem {
   size_t es() const { return apx::dtype_size(dtype); }
 };
 
+namespace apx {
+
+// ---- small.hip: the two-kernel iteration of small dense problems ---------------------------
+constexpr int kSmallMax = 4096;   // largest m and n (one fp64 vector of that length sits in LDS)
+
+struct SmallDev {
+  const void* A;    // m_pad x ncols, column-major
+  const void* AT;   // ncols_pad x m, column-major (= A')
+  int64_t ld, ldT;
+  int32_t m, ncols, n;   // n = ncols (+1: logistic bias)
+  int32_t w_n, w_t;      // waves per dot product of A x / A' r
+  const void* b;
+  void *X, *XP, *GP, *V;      // state
+  void *XN, *VN, *GN;         // staging (written by k_small_a, rotated in by k_small_b)
+  double *axp, *grp;          // A x [m] and A' r [ncols], fp64
+  Ctrl *ca, *cb;              // A: written by k_small_b ; B: written by k_small_a (the closing state)
+  ProxDev g;
+  apx_record* recs;
+  int64_t rec_cap;
+};
+
+struct SmallState {
+  DBuf xn, vn, gn, axp, grp, at, cb;
+  SmallDev dev{};
+};
+
+}  // namespace apx
+
 struct apx_solver {
   apx_problem* p = nullptr;
   apx_rule rule{};
@@ -49,6 +77,8 @@ struct apx_solver {
   bool use_graph = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  apx::SmallState* small = nullptr;   // non-null: the iteration runs as small.hip's two kernels
+  ~apx_solver() { delete small; }
 };
 
 namespace apx {
@@ -63,5 +93,11 @@ int32_t init_ctrl(apx_problem* p, const apx_rule* rule, double tol);
 int32_t read_ctrl(apx_problem* p, Ctrl* out);
 // A_x = A_lin * x  into ax (T, length m_pad)
 int32_t mul_A_lin(apx_problem* p, const void* x_dev, void* ax);
+// matrix.hip: dT (ldT x A->ld, zero-initialised by the caller) = A'
+int32_t transpose_into(apx_ctx* ctx, const apx_matrix* A, void* dT, int64_t ldT);
+// small.hip
+bool small_eligible(const apx_problem* p);
+int32_t small_setup(apx_solver* s);      // after the generic pre-loop of apx_solver_create
+int32_t small_enqueue(apx_solver* s);    // one iteration
 
 }  // namespace apx

@@ -135,6 +135,9 @@ def test_native_allreduce_hook_world_size_one(apx):
         gam = 1.0 / P.opnorm_sq_power(prob.A, iters=30)
         ar = sharded.device_allreduce(dist, 0)
         x0 = np.zeros(700)
+        # the un-hooked run on the same (generic) kernels the hooked one uses: small problems would
+        # otherwise take the two-kernel path of csrc/small.hip, which has no all-reduce hook
+        apx.default_context().fused_small(False)
         f_plain = apx.LinearLeastSquares(prob.A, prob.b)
         f_hook = apx.LinearLeastSquares(prob.A, prob.b, allreduce=ar)
         xa, _ = apx.adaptive_proxgrad(x0, f=f_plain, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=40)
@@ -144,5 +147,6 @@ def test_native_allreduce_hook_world_size_one(apx):
         zb, _ = apx.backtracking_proxgrad(x0, f=f_hook, g=apx.NormL1(1.0), gamma0=gam, xi=1.5, tol=0.0, maxit=15)
         assert np.array_equal(za, zb)
     finally:
+        apx.default_context().fused_small(True)
         if created:
             dist.destroy_process_group()

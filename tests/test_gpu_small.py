@@ -1,0 +1,175 @@
+"""The two-kernel small-problem iteration (csrc/small.hip, default for dense proximal-gradient
+problems with m, n <= 4096) against the oracle and against the generic kernels: the reference's
+own lasso sizes (experiments/lasso/runme.jl:191-195), every rule, box / l1 / translated prox,
+logistic fp64 and fp32, termination, records, counters, the stepping interface and the size
+limits.  Tolerance: rtol 1e-10 (fp64) inside the drift window DESIGN.md §2 documents."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import adaprox_oracle as O
+from oracle import problems as P
+
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def apx():
+    import adaprox_amd as apx
+    apx.load()
+    return apx
+
+
+@pytest.fixture(scope="module")
+def generic_ctx(apx):
+    ctx = apx.Context(0)
+    ctx.fused_small(False)
+    return ctx
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+@pytest.mark.parametrize("m,n,K", [(100, 300, 60), (500, 1000, 100), (4000, 1000, 100), (64, 17, 15), (1, 5, 10),
+                                   (7, 1, 10)])
+def test_lasso_reference_sizes_vs_oracle_and_generic(apx, generic_ctx, m, n, K):
+    prob = P.random_lasso(m, n, pfactor=10, seed=0) if n >= 10 else None
+    if prob is None:
+        rng = np.random.default_rng(5)
+        A, b, lam = rng.uniform(-1, 1, (m, n)), rng.uniform(-1, 1, m), 0.1
+    else:
+        A, b, lam = prob.A, prob.b, prob.lam
+    gam = 1.0 / max(1e-12, P.opnorm_sq_power(A, iters=30))
+    ro, rf, rg = [], [], []
+    xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(A, b), g=O.NormL1(lam), rule=O.OurRule(gamma=gam),
+                                tol=0.0, maxit=K, record=ro.append)
+    xf, itf = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(lam),
+                                    rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, record=rf.append)
+    xg, itg = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A, generic_ctx), b),
+                                    g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, ctx=generic_ctx,
+                                    record=rg.append)
+    if min(m, n) == 1:
+        # an exactly solved tiny problem reaches norm_res == 0 <= tol = 0 and stops early, in the oracle
+        # too; WHEN the residual rounds to exactly zero depends on the last bits of the gradient
+        assert itf <= len(ro) + 2 and itg <= len(ro) + 2 and len(rf) == itf
+    else:
+        assert itf == itg == len(ro) == K and len(rf) == len(rg) == K
+    assert _rel(xf, xo) <= RTOL and _rel(xf, xg) <= RTOL
+    for a, b_ in zip(rf, [] if min(m, n) == 1 else ro):     # (n = 1: the rule's ratios turn into 0/0 noise)
+        assert a["it"] == b_["it"]
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-8)
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10)
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7, abs=1e-13)
+
+
+@pytest.mark.parametrize("rule_name", ["fixed", "mm", "ours", "ours_plus"])
+def test_every_rule(apx, rule_name):
+    m, n = 300, 500
+    prob = P.random_lasso(m, n, pfactor=10, seed=2)
+    Lf = P.opnorm_sq_power(prob.A, iters=50)
+    mk = {"fixed": lambda M: M.FixedStepsize(1.0 / Lf, 1.0), "mm": lambda M: M.MalitskyMishchenkoRule(gamma=1.0 / Lf),
+          "ours": lambda M: M.OurRule(gamma=1.0 / Lf), "ours_plus": lambda M: M.OurRulePlus(gamma=1.0 / Lf)}[rule_name]
+    K = 25 if rule_name == "mm" else 50     # drift horizon: tools/drift_probe.py (generic kernels: 3.6e-10 at 80 too)
+    xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(prob.A, prob.b), g=O.NormL1(1.0), rule=mk(O),
+                                tol=0.0, maxit=K)
+    xf, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(prob.A, prob.b), g=apx.NormL1(1.0), rule=mk(apx),
+                                  tol=0.0, maxit=K)
+    assert _rel(xf, xo) <= RTOL
+
+
+def test_box_and_translated_prox(apx):
+    rng = np.random.default_rng(11)
+    m, n = 200, 120
+    A, b = rng.uniform(-1, 1, (m, n)), rng.uniform(-1, 1, m)
+    gam = 1.0 / P.opnorm_sq_power(A, iters=50)
+    shift = rng.uniform(-0.2, 0.2, n)
+    lb, ub = -0.05 * np.ones(n), rng.uniform(0.01, 0.1, n)
+    for go, ga in ((O.IndBox(-0.05, 0.08), apx.IndBox(-0.05, 0.08)), (O.IndBox(lb, ub), apx.IndBox(lb, ub)),
+                   (O.Translate(O.NormL1(0.3), shift), apx.Translate(apx.NormL1(0.3), shift)), (O.Zero(), apx.Zero())):
+        xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(A, b), g=go, rule=O.OurRule(gamma=gam), tol=0.0,
+                                    maxit=60)
+        xf, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A, b), g=ga, rule=apx.OurRule(gamma=gam),
+                                      tol=0.0, maxit=60)
+        assert _rel(xf, xo) <= RTOL
+
+
+@pytest.mark.parametrize("dtype,tol_x,K", [(np.float64, 1e-10, 30), (np.float32, 2e-3, 30)])
+def test_logistic(apx, generic_ctx, dtype, tol_x, K):
+    lr = P.random_logreg(900, 70, seed=4, dtype=dtype)
+    n = 71
+    xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LogisticLoss(lr.X.astype(np.float64), lr.y.astype(np.float64)),
+                                g=O.NormL1(lr.lam), rule=O.OurRule(gamma=lr.gamma0), tol=0.0, maxit=K)
+    rf = []
+    xf, _ = apx.adaptive_proxgrad(np.zeros(n, dtype=dtype), f=apx.LogisticLoss(lr.X, lr.y), g=apx.NormL1(lr.lam),
+                                  rule=apx.OurRule(gamma=lr.gamma0), tol=0.0, maxit=K, record=rf.append)
+    xg, _ = apx.adaptive_proxgrad(np.zeros(n, dtype=dtype),
+                                  f=apx.LogisticLoss(apx.DeviceMatrix.from_numpy(lr.X, generic_ctx), lr.y),
+                                  g=apx.NormL1(lr.lam), rule=apx.OurRule(gamma=lr.gamma0), tol=0.0, maxit=K, ctx=generic_ctx)
+    assert xf.dtype == dtype
+    assert _rel(xf, xo) <= tol_x and _rel(xf, xg) <= tol_x
+    assert np.isfinite(rf[-1]["objective"]) and rf[-1]["objective"] < rf[0]["objective"]
+
+
+def test_termination_counters_and_tested_iterate(apx, generic_ctx):
+    prob = P.random_lasso(500, 1000, pfactor=10, seed=0)
+    gam = 1.0 / P.opnorm_sq_power(prob.A, iters=30)
+    tol = 1e-6
+    fo = O.Counting(O.LinearLeastSquares(prob.A, prob.b))
+    xo, ito = O.adaptive_proxgrad(np.zeros(1000), f=fo, g=O.NormL1(1.0), rule=O.OurRule(gamma=gam), tol=tol, maxit=20000)
+    ff = apx.Counting(apx.LinearLeastSquares(prob.A, prob.b))
+    gf = apx.Counting(apx.NormL1(1.0))
+    xf, itf = apx.adaptive_proxgrad(np.zeros(1000), f=ff, g=gf, rule=apx.OurRule(gamma=gam), tol=tol, maxit=20000,
+                                    poll_every=7)
+    fg = apx.Counting(apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(prob.A, generic_ctx), prob.b))
+    xg, itg = apx.adaptive_proxgrad(np.zeros(1000), f=fg, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=gam), tol=tol,
+                                    maxit=20000, ctx=generic_ctx)
+    assert ito < 20000 and abs(itf - ito) <= max(3, ito // 20) and abs(itf - itg) <= max(3, ito // 20)
+    # SURVEY 3.4 identities on convergence at iteration k: f k+1, grad k+1, prox_g k
+    assert ff.eval_count == itf + 1 and ff.grad_count == itf + 1 and gf.prox_count == itf
+    assert _rel(xf, prob.x_star) < 1e-4 and _rel(xf, xo) < 1e-5
+    obj = 0.5 * np.linalg.norm(prob.A @ xf - prob.b) ** 2 + np.sum(np.abs(xf))
+    assert obj == pytest.approx(prob.optimum, rel=1e-9)
+
+
+def test_stepping_interface_matches_one_shot(apx):
+    prob = P.random_lasso(200, 400, pfactor=10, seed=1)
+    gam = 1.0 / P.opnorm_sq_power(prob.A, iters=30)
+    f, g = apx.LinearLeastSquares(prob.A, prob.b), apx.NormL1(1.0)
+    x1, _ = apx.adaptive_proxgrad(np.zeros(400), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, maxit=90)
+    x30, _ = apx.adaptive_proxgrad(np.zeros(400), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, maxit=30)
+    for ug in (False, True):
+        s = apx.Solver(np.zeros(400), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, use_graph=ug)
+        s.step(30)
+        xa, _, ra = s.result()          # reading the staged iterate must not disturb the run
+        s.step(45)
+        s.step(15)
+        xb, _, rb = s.result()
+        s.close()
+        assert np.array_equal(xa, x30) and np.array_equal(xb, x1)
+        assert ra.numit == 30 and rb.numit == 90 and not rb.converged
+
+
+def test_size_limits_fall_back_to_generic_kernels(apx):
+    rng = np.random.default_rng(3)
+    for m, n in ((4096, 64), (64, 4096), (4097, 40), (40, 4097)):
+        A, b = rng.uniform(-1, 1, (m, n)), rng.uniform(-1, 1, m)
+        gam = 1.0 / P.opnorm_sq_power(A, iters=30)
+        xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(A, b), g=O.NormL1(0.5), rule=O.OurRule(gamma=gam),
+                                    tol=0.0, maxit=40)
+        xf, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(0.5),
+                                      rule=apx.OurRule(gamma=gam), tol=0.0, maxit=40)
+        assert _rel(xf, xo) <= RTOL
+
+
+def test_domain_error_and_nan_flags_survive(apx):
+    """OurRule with norm_A > 0 and a huge gamma: sqrt of a negative number inside the rule (Julia: DomainError)."""
+    rng = np.random.default_rng(8)
+    A, b = rng.uniform(-1, 1, (50, 30)), rng.uniform(-1, 1, 50)
+    with pytest.raises(apx.DomainError):
+        apx.adaptive_proxgrad(np.zeros(30), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(0.1),
+                              rule=apx.OurRule(gamma=10.0, norm_A=5.0, t=1.0), tol=0.0, maxit=5)
+    with pytest.raises(ValueError):
+        O.adaptive_proxgrad(np.zeros(30), f=O.LinearLeastSquares(A, b), g=O.NormL1(0.1),
+                            rule=O.OurRule(gamma=10.0, norm_A=5.0, t=1.0), tol=0.0, maxit=5)

@@ -365,7 +365,11 @@ def test_nan_to_zero_path_when_iterates_do_not_move(apx):
         xd, _ = apx.adaptive_proxgrad(np.zeros(50), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(lam), rule=rule_d,
                                       tol=0.0, maxit=30, record=drecs.append)
         assert not np.any(xo) and not np.any(xd)
-        assert [r["gamma"] for r in drecs] == pytest.approx([r["gamma"] for r in orecs], rel=1e-14)
+        # the run ends when (v - x)/gamma + grad rounds to exactly 0 in every coordinate, which depends on the
+        # last bits of grad (summation order): compare the common prefix of the step-size sequence
+        k = min(len(drecs), len(orecs))
+        assert k >= 10
+        assert [r["gamma"] for r in drecs[:k]] == pytest.approx([r["gamma"] for r in orecs[:k]], rel=1e-14)
         assert all(np.isfinite(r["gamma"]) for r in drecs)
     # Malitsky-Mishchenko has no nan_to_zero: L = 0/0 = NaN and Julia's `min` propagates it (:227-228)
     drecs = []

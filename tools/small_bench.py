@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Iteration latency of the reference's own experiment sizes (experiments/lasso/runme.jl:191-195 and a
+small logistic problem): two-kernel small path (csrc/small.hip) vs the generic kernels, eager vs hipGraph.
+`python tools/small_bench.py` on an MI355X; prints one JSON line per configuration."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import adaprox_amd as apx  # noqa: E402
+from oracle import problems as P  # noqa: E402  (problem generator only)
+
+
+def run(label, ctx, f, g, n, gam, graph, iters=2000, dtype=np.float64):
+    s = apx.Solver(np.zeros(n, dtype=dtype), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, ctx=ctx, use_graph=graph,
+                   poll_every=1 << 30)
+    s.step(200, sync=True)
+    t0 = time.perf_counter()
+    s.step(iters, sync=False)
+    t_enq = time.perf_counter() - t0          # host time to enqueue: ~ the total when the host is the bottleneck
+    s.step(0, sync=True)
+    dt = time.perf_counter() - t0
+    s.close()
+    print(json.dumps({"config": label, "graph": graph, "us_per_iteration": round(dt / iters * 1e6, 2),
+                      "host_enqueue_us_per_iteration": round(t_enq / iters * 1e6, 2),
+                      "iters_per_sec": round(iters / dt)}), flush=True)
+
+
+def main():
+    fused, generic = apx.Context(0), apx.Context(0)
+    generic.fused_small(False)
+    for m, n in ((100, 300), (500, 1000), (4000, 1000), (4000, 4000)):
+        prob = P.random_lasso(m, n, pfactor=10, seed=0)
+        gam = 1.0 / P.opnorm_sq_power(prob.A, iters=30)
+        for name, ctx in (("small.hip", fused), ("generic", generic)):
+            f = apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(prob.A, ctx), prob.b, ctx=ctx)
+            for graph in (False, True):
+                run(f"lasso {m}x{n} fp64 {name}", ctx, f, apx.NormL1(1.0), n, gam, graph)
+    lr = P.random_logreg(2000, 120, seed=2, dtype=np.float32)
+    for name, ctx in (("small.hip", fused), ("generic", generic)):
+        f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(lr.X, ctx), lr.y, ctx=ctx)
+        for graph in (False, True):
+            run(f"logreg 2000x120 fp32 {name}", ctx, f, apx.NormL1(lr.lam), 121, lr.gamma0, graph, dtype=np.float32)
+
+
+if __name__ == "__main__":
+    main()
