@@ -966,7 +966,8 @@ def fixed_proxgrad(x, *, f, g, gamma, tol=1e-5, maxit=100_000, name="Fixed steps
 
 
 def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=1e-5, maxit=10_000,
-              name="Condat-Vu", record: Record = None, ctx: Optional[Context] = None, A_allreduce=None):
+              name="Condat-Vu", record: Record = None, ctx: Optional[Context] = None, A_allreduce=None,
+              poll_every: int = 0, use_graph: Optional[bool] = None):
     """src/AdaProx.jl:367-416.  ``A_allreduce``: the rows of A (and y) are sharded over ranks; then
     ``norm_A`` must be given (the Frobenius norm of the WHOLE matrix)."""
     if A_allreduce is not None and gamma is None and sigma is None and norm_A is None:
@@ -981,7 +982,8 @@ def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=
     assert gamma is not None and sigma is not None                  # :413
     rule = FixedStepsize(gamma, math.sqrt(sigma / gamma))           # :414
     return adaptive_primal_dual(x, y, f=f, g=g, h=h, A=A, rule=rule, tol=tol, maxit=maxit, name=name,
-                                record=record, ctx=ctx, A_allreduce=A_allreduce)
+                                record=record, ctx=ctx, A_allreduce=A_allreduce, poll_every=poll_every,
+                                use_graph=use_graph)
 
 
 def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=1.0, delta=1e-8, Theta=1.2, r=2,

@@ -416,6 +416,7 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   // the library's choice is eager; replay stays available on request.
   const bool small = small_eligible(p);
   const bool want_graph = opts != nullptr && opts->use_graph == 1;
+  const bool small_pd = !want_graph && small_pd_eligible(p);   // (its buffer roles rotate on the host: no replay)
   if (want_graph && (p->f_kind == APX_F_CALLBACK || p->allreduce != nullptr))
     return fail(APX_ERR_UNSUPPORTED,
                 "hipGraph replay needs a device-only iteration: not with a host-callback f or an all-reduce hook");
@@ -451,6 +452,8 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
 
   if (small) {
     APX_TRY(small_setup(s.get()));   // small.hip: pre-loop and iteration as fused kernels
+  } else if (small_pd) {
+    APX_TRY(small_pd_setup(s.get(), x0, y0));
   } else {
     if (lin) {                                                                   // :327  A_x = A * x
       int splits = 0;
@@ -475,6 +478,7 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
 
 static int32_t enqueue_iteration(apx_solver* s) {
   if (s->small != nullptr) return small_enqueue(s);
+  if (s->small_pd != nullptr) return small_pd_enqueue(s);
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   const bool lin = p->A_lin != nullptr;
@@ -537,8 +541,8 @@ static int32_t poll_done(apx_solver* s, bool* done) {
   apx_ctx* ctx = s->p->ctx;
   int32_t* h = (int32_t*)&ctx->h_scal[40];
   // small path: the closing state (and its done flag) lives in Ctrl B
-  const int* dp = s->small != nullptr
-                      ? (const int*)((const char*)s->small->cb.p + offsetof(apx::Ctrl, done)) : s->p->done_ptr();
+  const void* cp = s->small != nullptr ? s->small->cb.p : (s->small_pd != nullptr ? small_pd_ctrl(s) : nullptr);
+  const int* dp = cp != nullptr ? (const int*)((const char*)cp + offsetof(apx::Ctrl, done)) : s->p->done_ptr();
   APX_HIP(hipMemcpyAsync(h, dp, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   APX_HIP(hipStreamSynchronize(ctx->stream));
   *done = *h != 0;
@@ -571,12 +575,15 @@ int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* r
   APX_HIP(hipSetDevice(ctx->device));
   Ctrl c;
   if (s->small != nullptr) APX_TRY(d2h(ctx, &c, s->small->cb.p, sizeof(Ctrl)));
+  else if (s->small_pd != nullptr) APX_TRY(d2h(ctx, &c, small_pd_ctrl(s), sizeof(Ctrl)));
   else APX_TRY(read_ctrl(p, &c));
   const bool lin = p->A_lin != nullptr;
   // small path: on convergence x is the tested iterate, otherwise the next one is still staged (Appendix A.8)
   const void* x_src = (s->small != nullptr && c.done == 0) ? s->small->xn.p : s->x.p;
+  const void* y_src = s->y.p;
+  if (s->small_pd != nullptr) small_pd_result_ptrs(s, c, &x_src, &y_src);
   if (x_out != nullptr) APX_TRY(d2h(ctx, x_out, x_src, (size_t)p->n * p->es()));
-  if (y_out != nullptr && lin) APX_TRY(d2h(ctx, y_out, s->y.p, (size_t)p->m * p->es()));
+  if (y_out != nullptr && lin) APX_TRY(d2h(ctx, y_out, y_src, (size_t)p->m * p->es()));
   int64_t nrec = 0;
   if (s->host_recs != nullptr) {
     nrec = std::min<int64_t>(c.it, s->rec_cap);

@@ -62,6 +62,36 @@ struct SmallState {
   SmallDev dev{};
 };
 
+// ---- small_pd.hip: the same for the primal-dual loop (f = Zero, dense A) ----------------------
+struct PdDev {
+  const void* A;    // m_pad x n, column-major
+  const void* AT;   // n_pad x m (= A')
+  int64_t ld, ldT;
+  int32_t m, n, w_n, w_t;
+  const void *x_prev, *x_cur;
+  void* x_next;
+  const void* v_cur;
+  void* v_next;
+  const void* y_cur;
+  void* y_next;
+  const double *ax_prev, *ax_cur;
+  double* ax_next;
+  const double* aty_cur;
+  double* aty_next;
+  const Ctrl* c_cur;
+  Ctrl* c_next;
+  ProxDev g, h;
+  apx_record* recs;
+  int64_t rec_cap;
+};
+
+struct SmallPdState {
+  DBuf xb[3], axb[3];                 // prev / cur / next, roles rotate with the iteration index
+  DBuf vb[2], yb[2], atyb[2], cb[2];  // cur / next
+  DBuf at;
+  PdDev base{};                       // the loop-invariant fields
+};
+
 }  // namespace apx
 
 struct apx_solver {
@@ -78,7 +108,11 @@ struct apx_solver {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   apx::SmallState* small = nullptr;   // non-null: the iteration runs as small.hip's two kernels
-  ~apx_solver() { delete small; }
+  apx::SmallPdState* small_pd = nullptr;   // non-null: ... as small_pd.hip's two kernels
+  ~apx_solver() {
+    delete small;
+    delete small_pd;
+  }
 };
 
 namespace apx {
@@ -99,5 +133,11 @@ int32_t transpose_into(apx_ctx* ctx, const apx_matrix* A, void* dT, int64_t ldT)
 bool small_eligible(const apx_problem* p);
 int32_t small_setup(apx_solver* s);      // after the generic pre-loop of apx_solver_create
 int32_t small_enqueue(apx_solver* s);    // one iteration
+// small_pd.hip
+bool small_pd_eligible(const apx_problem* p);
+int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0);
+int32_t small_pd_enqueue(apx_solver* s);
+const void* small_pd_ctrl(const apx_solver* s);
+void small_pd_result_ptrs(const apx_solver* s, const Ctrl& c, const void** x, const void** y);
 
 }  // namespace apx

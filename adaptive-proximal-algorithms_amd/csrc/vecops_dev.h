@@ -89,26 +89,33 @@ __device__ __forceinline__ double prox_core(const ProxDev& g, double z, double g
   }
 }
 
-// Translate(g, b): z = v + b ; y = prox_g(z) ; y -= b
+// Translate(g, b): z = v + b ; y = prox_g(z) ; y -= b.  The `_s` forms take the shift value b_i already
+// loaded (0 without a Translate) so that callers can batch that load with their other operands.
+template <typename T>
+__device__ __forceinline__ double prox_elem_s(const ProxDev& g, double v, double gamma, int64_t i, double aux, double b) {
+  if (g.has_shift) return prox_core<T>(g, v + b, gamma, i, aux) - b;
+  return prox_core<T>(g, v, gamma, i, aux);
+}
 template <typename T>
 __device__ __forceinline__ double prox_elem(const ProxDev& g, double v, double gamma, int64_t i, double aux) {
-  if (g.has_shift) {
-    const double b = shift_at<T>(g, i);
-    return prox_core<T>(g, v + b, gamma, i, aux) - b;
-  }
-  return prox_core<T>(g, v, gamma, i, aux);
+  return prox_elem_s<T>(g, v, gamma, i, aux, shift_at<T>(g, i));
 }
 
 // prox of convex_conjugate(h) at w with step sigma (src/AdaProx.jl:325,345):
 //   Zero -> IndZero (0) ; IndZero -> Zero (w) ; otherwise Moreau:
 //   u = w/sigma ; p = prox_{h,1/sigma}(u) ; y = w - sigma*p      (ProximalCore prox_conjugate!)
 template <typename T>
-__device__ __forceinline__ double prox_conj_elem(const ProxDev& h, double w, double sigma, int64_t i, double aux) {
+__device__ __forceinline__ double prox_conj_elem_s(const ProxDev& h, double w, double sigma, int64_t i, double aux,
+                                                   double b) {
   if (h.kind == APX_G_ZERO && !h.has_shift) return 0.0;
   if (h.kind == APX_G_INDZERO && !h.has_shift) return w;
   const double u = w / sigma;
-  const double p = prox_elem<T>(h, u, 1.0 / sigma, i, aux);
+  const double p = prox_elem_s<T>(h, u, 1.0 / sigma, i, aux, b);
   return w - sigma * p;
+}
+template <typename T>
+__device__ __forceinline__ double prox_conj_elem(const ProxDev& h, double w, double sigma, int64_t i, double aux) {
+  return prox_conj_elem_s<T>(h, w, sigma, i, aux, shift_at<T>(h, i));
 }
 
 // value g(x): accumulate `gval_elem`, finish with `gval_final`.  gval_core is the
@@ -131,6 +138,10 @@ __device__ __forceinline__ double gval_core(const ProxDev& g, double z, int64_t 
 template <typename T>
 __device__ __forceinline__ double gval_elem(const ProxDev& g, double x, int64_t i) {
   return gval_core<T>(g, x + shift_at<T>(g, i), i);
+}
+template <typename T>
+__device__ __forceinline__ double gval_elem_s(const ProxDev& g, double x, int64_t i, double b) {
+  return gval_core<T>(g, x + b, i);
 }
 // prox that also accumulates the value the prox call returns: for Translate that is the
 // value of the INNER prox at the inner point (`v = prox!(y, f.f, z, gamma)`), not g(y + b)

@@ -206,11 +206,12 @@ int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_varia
  * what reference BLAS dgemv does too (`IF (X(JX).NE.ZERO)`), and what a lasso iterate invites
  * after the soft-threshold.  Same result up to summation order; not used by bench.py's headline. */
 int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
-/* Default ON: a dense proximal-gradient problem (LinearLeastSquares or LogisticLoss, no linear
- * operator, no all-reduce hook) with m, n <= 4096 — the sizes of the reference's own experiments,
- * experiments/lasso/runme.jl:191-195 — runs each iteration of src/AdaProx.jl:334-362 as two kernels
- * in which every workgroup redundantly does the O(m + n) work (csrc/small.hip).  Same arithmetic,
- * different summation order than the generic path; 0 switches back to the generic kernels. */
+/* Default ON: a dense problem with m, n <= 4096 and no all-reduce hook — the sizes of the reference's
+ * own experiments (experiments/lasso/runme.jl:191-195, least_absolute_deviation/runme.jl:39-62) —
+ * runs each iteration of src/AdaProx.jl:334-362 as two kernels in which every workgroup redundantly
+ * does the O(m + n) work: proximal gradient with LinearLeastSquares / LogisticLoss (csrc/small.hip)
+ * and the primal-dual loop with f = Zero (csrc/small_pd.hip).  Same arithmetic, different summation
+ * order than the generic path; 0 switches back to the generic kernels. */
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
 int32_t apx_gemv_variant_count(int32_t transposed);
 const char* apx_gemv_variant_name(int32_t transposed, int32_t i);

@@ -29,8 +29,11 @@ def test_graph_replay_is_bit_identical(apx):
                                        record=rb.append, use_graph=True)
         assert ia == ib and np.array_equal(xa, xb) and ra == rb
     lad = P.random_lad(400, 150, seed=1, lam=5.0)
-    kw = dict(f=apx.Zero(), g=apx.NormL1(lad.lam), h=apx.Translate(apx.NormL2(1.0), -lad.y), A=lad.A,
-              rule=apx.OurRule(t=0.7, norm_A=lad.norm_A), tol=0.0, maxit=120)
+    gctx = apx.Context()
+    gctx.fused_small(False)       # (the small primal-dual path rotates its buffers on the host: no replay)
+    kw = dict(f=apx.Zero(), g=apx.NormL1(lad.lam), h=apx.Translate(apx.NormL2(1.0), -lad.y),
+              A=apx.DeviceMatrix.from_numpy(lad.A, gctx), rule=apx.OurRule(t=0.7, norm_A=lad.norm_A), tol=0.0,
+              maxit=120, ctx=gctx)
     xa, ya, _ = apx.adaptive_primal_dual(np.zeros(150), np.zeros(400), use_graph=False, **kw)
     xb, yb, _ = apx.adaptive_primal_dual(np.zeros(150), np.zeros(400), use_graph=True, **kw)
     assert np.array_equal(xa, xb) and np.array_equal(ya, yb)

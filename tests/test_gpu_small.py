@@ -173,3 +173,78 @@ def test_domain_error_and_nan_flags_survive(apx):
     with pytest.raises(ValueError):
         O.adaptive_proxgrad(np.zeros(30), f=O.LinearLeastSquares(A, b), g=O.NormL1(0.1),
                             rule=O.OurRule(gamma=10.0, norm_A=5.0, t=1.0), tol=0.0, maxit=5)
+
+
+# ---------------------------------------------------------------------------------------
+# primal-dual loop (csrc/small_pd.hip): f = Zero, dense A, the reference's LAD / sqrt-lasso shapes
+# ---------------------------------------------------------------------------------------
+def _lad_terms(M, lad, hkind):
+    h = M.Translate(M.NormL1(1.0) if hkind == "l1" else M.NormL2(1.0), -lad.y)
+    return dict(f=M.Zero(), g=M.NormL1(lad.lam), h=h)
+
+
+@pytest.mark.parametrize("m,n,lam,hkind,K", [(506, 14, 10.0, "l1", 150), (400, 150, 5.0, "l2", 100), (300, 1200, 2.0, "l1", 80),
+                                             (1500, 40, 1.0, "l2", 80), (3, 2, 0.1, "l1", 20)])
+def test_pd_condat_vu_and_adaptive_vs_oracle_and_generic(apx, generic_ctx, m, n, lam, hkind, K):
+    lad = P.random_lad(m, n, seed=1, lam=lam)
+    Ag = apx.DeviceMatrix.from_numpy(lad.A, generic_ctx)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    ro, rf = [], []
+    xo, yo, ito = O.condat_vu(x0, y0, A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K, record=ro.append,
+                              **_lad_terms(O, lad, hkind))
+    xf, yf, itf = apx.condat_vu(x0, y0, A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K, record=rf.append,
+                                **_lad_terms(apx, lad, hkind))
+    xg, yg, itg = apx.condat_vu(x0, y0, A=Ag, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K, ctx=generic_ctx,
+                                **_lad_terms(apx, lad, hkind))
+    assert ito == itf == itg == K and len(rf) == K
+    assert _rel(xf, xo) <= RTOL and _rel(yf, yo) <= RTOL and _rel(xf, xg) <= RTOL and _rel(yf, yg) <= RTOL
+    for a, b_ in zip(rf, ro):
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-12) and a["sigma"] == pytest.approx(b_["sigma"], rel=1e-12)
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-9)
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7, abs=1e-12)
+    # the adaptive rule with a linear operator (norm_A > 0 enters xi and the second candidate of the min)
+    Ka = min(K, 60)
+    xo, yo, _ = O.adaptive_primal_dual(x0, y0, A=lad.A, rule=O.OurRule(t=0.8, norm_A=lad.norm_A), tol=0.0, maxit=Ka,
+                                       **_lad_terms(O, lad, hkind))
+    xf, yf, _ = apx.adaptive_primal_dual(x0, y0, A=lad.A, rule=apx.OurRule(t=0.8, norm_A=lad.norm_A), tol=0.0, maxit=Ka,
+                                         **_lad_terms(apx, lad, hkind))
+    assert _rel(xf, xo) <= 1e-9 and _rel(yf, yo) <= 1e-9
+
+
+def test_pd_termination_returns_tested_x_and_updated_y(apx, generic_ctx):
+    lad = P.random_lad(506, 14, seed=3, lam=10.0)
+    x0, y0 = np.zeros(14), np.zeros(506)
+    tol = 1e-5
+    xo, yo, ito = O.condat_vu(x0, y0, A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=tol, maxit=200000, **_lad_terms(O, lad, "l1"))
+    cA = apx.Counting(apx.DeviceMatrix.from_numpy(lad.A))
+    terms = _lad_terms(apx, lad, "l1")
+    terms["h"] = apx.Counting(terms["h"])
+    for poll in (1, 16, 1000):
+        xf, yf, itf = apx.condat_vu(x0, y0, A=cA, Lf=0.0, norm_A=lad.norm_A, tol=tol, maxit=200000, poll_every=poll,
+                                    **terms)
+        assert ito < 200000 and itf == ito
+        assert _rel(xf, xo) <= 1e-8 and _rel(yf, yo) <= 1e-8
+    # converged at k: A k+1, A' k, prox_h k  (three runs accumulated)
+    assert cA.mul_count == 3 * (ito + 1) and cA.amul_count == 3 * ito and terms["h"].prox_count == 3 * ito
+
+
+def test_pd_stepping_and_fp32(apx):
+    lad = P.random_lad(400, 150, seed=5, lam=5.0)
+    terms = _lad_terms(apx, lad, "l2")
+    rule = apx.OurRule(t=1.0, norm_A=lad.norm_A)
+    x1, y1, _ = apx.adaptive_primal_dual(np.zeros(150), np.zeros(400), A=lad.A, rule=rule, tol=0.0, maxit=77, **terms)
+    s = apx.Solver(np.zeros(150), np.zeros(400), A=lad.A, rule=rule, tol=0.0, **terms)
+    for k in (1, 2, 3, 30, 41):          # every residue of the 6-cycle of buffer roles
+        s.step(k)
+        s.result()
+    xs, ys, res = s.result()
+    s.close()
+    assert res.numit == 77 and np.array_equal(xs, x1) and np.array_equal(ys, y1)
+    # fp32 end to end
+    A32, y32 = lad.A.astype(np.float32), lad.y.astype(np.float32)
+    t32 = dict(f=apx.Zero(), g=apx.NormL1(lad.lam), h=apx.Translate(apx.NormL1(1.0), -y32))
+    xo, yo, _ = O.condat_vu(np.zeros(150), np.zeros(400), A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=40,
+                            **_lad_terms(O, lad, "l1"))
+    xf, yf, _ = apx.condat_vu(np.zeros(150, dtype=np.float32), np.zeros(400, dtype=np.float32), A=A32, Lf=0.0,
+                              norm_A=lad.norm_A, tol=0.0, maxit=40, **t32)
+    assert xf.dtype == np.float32 and _rel(xf, xo) <= 5e-3 and _rel(yf, yo) <= 5e-3

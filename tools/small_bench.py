@@ -14,15 +14,23 @@ import adaprox_amd as apx  # noqa: E402
 from oracle import problems as P  # noqa: E402  (problem generator only)
 
 
-def run(label, ctx, f, g, n, gam, graph, iters=2000, dtype=np.float64):
-    s = apx.Solver(np.zeros(n, dtype=dtype), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, ctx=ctx, use_graph=graph,
-                   poll_every=1 << 30)
+def run(label, ctx, f, g, n, gam, graph, iters=2000, dtype=np.float64, pd=None):
+    if pd is None:
+        s = apx.Solver(np.zeros(n, dtype=dtype), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, ctx=ctx,
+                       use_graph=graph, poll_every=1 << 30)
+    else:       # primal-dual: pd = (A, h, m, rule)
+        s = apx.Solver(np.zeros(n, dtype=dtype), np.zeros(pd[2], dtype=dtype), f=f, g=g, h=pd[1], A=pd[0], rule=pd[3],
+                       tol=0.0, ctx=ctx, use_graph=graph, poll_every=1 << 30)
     s.step(200, sync=True)
-    t0 = time.perf_counter()
-    s.step(iters, sync=False)
-    t_enq = time.perf_counter() - t0          # host time to enqueue: ~ the total when the host is the bottleneck
-    s.step(0, sync=True)
-    dt = time.perf_counter() - t0
+    dt, t_enq = 1e9, 0.0
+    for _ in range(5):                            # best of 5: the boxes are noisy at this time scale
+        t0 = time.perf_counter()
+        s.step(iters, sync=False)
+        te = time.perf_counter() - t0             # host time to enqueue: ~ the total when the host is the bottleneck
+        s.step(0, sync=True)
+        d1 = time.perf_counter() - t0
+        if d1 < dt:
+            dt, t_enq = d1, te
     s.close()
     print(json.dumps({"config": label, "graph": graph, "us_per_iteration": round(dt / iters * 1e6, 2),
                       "host_enqueue_us_per_iteration": round(t_enq / iters * 1e6, 2),
@@ -44,6 +52,17 @@ def main():
         f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(lr.X, ctx), lr.y, ctx=ctx)
         for graph in (False, True):
             run(f"logreg 2000x120 fp32 {name}", ctx, f, apx.NormL1(lr.lam), 121, lr.gamma0, graph, dtype=np.float32)
+
+
+    # primal-dual (LAD shapes of experiments/least_absolute_deviation: housing is 506 x 14)
+    for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1")):
+        lad = P.random_lad(m, n, seed=1, lam=5.0)
+        for name, ctx in (("small_pd.hip", fused), ("generic", generic)):
+            A = apx.DeviceMatrix.from_numpy(lad.A, ctx)
+            h = apx.Translate(apx.NormL1(1.0) if hk == "l1" else apx.NormL2(1.0), -lad.y)
+            for graph in ((False,) if name == "small_pd.hip" else (False, True)):
+                run(f"LAD-{hk} {m}x{n} fp64 adaptive PD {name}", ctx, apx.Zero(), apx.NormL1(lad.lam), n, None, graph,
+                    pd=(A, h, m, apx.OurRule(t=1.0, norm_A=lad.norm_A)))
 
 
 if __name__ == "__main__":
