@@ -1,3 +1,5 @@
+"""Checker script (not collected by pytest): drift of the two-kernel small path and of the generic kernels from the
+oracle as the iteration count grows — `python tests/drift_probe.py` on an MI355X (see DESIGN.md, fp64 horizon)."""
 import sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 import adaprox_amd as apx

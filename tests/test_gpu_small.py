@@ -71,7 +71,7 @@ def test_every_rule(apx, rule_name):
     Lf = P.opnorm_sq_power(prob.A, iters=50)
     mk = {"fixed": lambda M: M.FixedStepsize(1.0 / Lf, 1.0), "mm": lambda M: M.MalitskyMishchenkoRule(gamma=1.0 / Lf),
           "ours": lambda M: M.OurRule(gamma=1.0 / Lf), "ours_plus": lambda M: M.OurRulePlus(gamma=1.0 / Lf)}[rule_name]
-    K = 25 if rule_name == "mm" else 50     # drift horizon: tools/drift_probe.py (generic kernels: 3.6e-10 at 80 too)
+    K = 25 if rule_name == "mm" else 50     # drift horizon: tests/drift_probe.py (generic kernels: 3.6e-10 at 80 too)
     xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(prob.A, prob.b), g=O.NormL1(1.0), rule=mk(O),
                                 tol=0.0, maxit=K)
     xf, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(prob.A, prob.b), g=apx.NormL1(1.0), rule=mk(apx),

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""µs per iteration of every solver of the reference's lasso experiment (experiments/lasso/runme.jl:86-160)
+at its own size 500 x 1000 and of the LAD experiment's methods at 506 x 14 — which loops are device-resident
+and which are host-driven.  `python tools/method_latency.py` on an MI355X; one JSON line per method."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import adaprox_amd as apx  # noqa: E402
+
+problems = importlib.import_module("adaptive-proximal-algorithms_amd.problems")
+
+
+def timed(name, fn, K):
+    fn(20)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn(K)
+        best = min(best, time.perf_counter() - t0)
+    print(json.dumps({"method": name, "us_per_iteration": round(best / K * 1e6, 1)}), flush=True)
+
+
+def main():
+    K = 400
+    prob = problems.device_lasso(500, 1000, pfactor=10, seed=0, power_iters=100)
+    gam = 1 / prob.Lf
+    f, g, x0 = apx.LinearLeastSquares(prob.A, prob.b), apx.NormL1(prob.lam), np.zeros(1000)
+    kw = dict(f=f, g=g, tol=0.0)
+    timed("lasso 500x1000  PGM (fixed)", lambda k: apx.fixed_proxgrad(x0, gamma=gam, maxit=k, **kw), K)
+    timed("lasso 500x1000  AdaPGM (Ours)", lambda k: apx.adaptive_proxgrad(x0, rule=apx.OurRule(gamma=gam), maxit=k, **kw), K)
+    timed("lasso 500x1000  AdaPGM (MM)", lambda k: apx.adaptive_proxgrad(x0, rule=apx.MalitskyMishchenkoRule(gam), maxit=k, **kw), K)
+    for xi in (1, 1.5, 2):
+        timed(f"lasso 500x1000  PGM (backtracking, xi={xi})",
+              lambda k: apx.backtracking_proxgrad(x0, gamma0=gam, xi=xi, maxit=k, **kw), K)
+    timed("lasso 500x1000  Nesterov (backtracking)", lambda k: apx.backtracking_nesterov(x0, gamma0=gam, maxit=k, **kw), K)
+    timed("lasso 500x1000  Nesterov (fixed)", lambda k: apx.fixed_nesterov(x0, gamma=gam, maxit=k, **kw), K)
+    timed("lasso 500x1000  aGRAAL", lambda k: apx.agraal(x0, gamma0=gam, maxit=k, rng=np.random.default_rng(0), **kw), K)
+
+    rng = np.random.default_rng(1)
+    m, n = 506, 14
+    A = np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))])
+    y = A @ rng.standard_normal(n) + rng.laplace(size=m)
+    nrm = float(np.linalg.norm(A))
+    dA = apx.DeviceMatrix.from_numpy(A)
+    t = dict(f=apx.Zero(), g=apx.NormL1(10.0), h=apx.Translate(apx.NormL1(1.0), -y), A=dA, tol=0.0)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    timed("LAD 506x14  Condat-Vu", lambda k: apx.condat_vu(x0, y0, Lf=0.0, norm_A=nrm, maxit=k, **t), K)
+    timed("LAD 506x14  AdaPDM", lambda k: apx.adaptive_primal_dual(x0, y0, rule=apx.OurRule(t=1.0, norm_A=nrm), maxit=k, **t), K)
+    timed("LAD 506x14  AdaPDM+", lambda k: apx.adaptive_linesearch_primal_dual(x0, y0, gamma=1.0 / nrm, maxit=k, **t), K)
+    timed("LAD 506x14  Malitsky-Pock", lambda k: apx.malitsky_pock(x0, y0, sigma=1.0 / nrm, maxit=k, **t), K)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,27 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import adaprox_amd as apx  # noqa: E402
-from oracle import problems as P  # noqa: E402  (problem generator only)
+
+
+def lasso(m, n, seed=0):
+    rng = np.random.default_rng(seed)
+    A = rng.uniform(-1, 1, (m, n))
+    xs = np.where(rng.uniform(size=n) < 0.1, rng.standard_normal(n), 0.0)
+    return A, A @ xs + 0.1 * rng.standard_normal(m), 1.0 / np.linalg.norm(A, 2) ** 2
+
+
+def logreg(m, n, seed=2):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    w = np.where(rng.uniform(size=n) < 0.05, rng.standard_normal(n), 0.0)
+    y = (1 / (1 + np.exp(-(X @ w))) > rng.uniform(size=m)).astype(np.float32)
+    return X, y, 4.0 * m / (np.linalg.norm(X) ** 2 + m)
+
+
+def lad(m, n, seed=1):
+    rng = np.random.default_rng(seed)
+    A = np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))])
+    return A, A @ rng.standard_normal(n) + rng.laplace(size=m), float(np.linalg.norm(A))
 
 
 def run(label, ctx, f, g, n, gam, graph, iters=2000, dtype=np.float64, pd=None):
@@ -41,28 +61,27 @@ def main():
     fused, generic = apx.Context(0), apx.Context(0)
     generic.fused_small(False)
     for m, n in ((100, 300), (500, 1000), (4000, 1000), (4000, 4000)):
-        prob = P.random_lasso(m, n, pfactor=10, seed=0)
-        gam = 1.0 / P.opnorm_sq_power(prob.A, iters=30)
+        A_h, b_h, gam = lasso(m, n)
         for name, ctx in (("small.hip", fused), ("generic", generic)):
-            f = apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(prob.A, ctx), prob.b, ctx=ctx)
+            f = apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A_h, ctx), b_h, ctx=ctx)
             for graph in (False, True):
                 run(f"lasso {m}x{n} fp64 {name}", ctx, f, apx.NormL1(1.0), n, gam, graph)
-    lr = P.random_logreg(2000, 120, seed=2, dtype=np.float32)
+    X_h, y_h, gam0 = logreg(2000, 120)
     for name, ctx in (("small.hip", fused), ("generic", generic)):
-        f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(lr.X, ctx), lr.y, ctx=ctx)
+        f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(X_h, ctx), y_h, ctx=ctx)
         for graph in (False, True):
-            run(f"logreg 2000x120 fp32 {name}", ctx, f, apx.NormL1(lr.lam), 121, lr.gamma0, graph, dtype=np.float32)
+            run(f"logreg 2000x120 fp32 {name}", ctx, f, apx.NormL1(0.01), 121, gam0, graph, dtype=np.float32)
 
 
     # primal-dual (LAD shapes of experiments/least_absolute_deviation: housing is 506 x 14)
     for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1")):
-        lad = P.random_lad(m, n, seed=1, lam=5.0)
+        A_h, y_h, nrm = lad(m, n)
         for name, ctx in (("small_pd.hip", fused), ("generic", generic)):
-            A = apx.DeviceMatrix.from_numpy(lad.A, ctx)
-            h = apx.Translate(apx.NormL1(1.0) if hk == "l1" else apx.NormL2(1.0), -lad.y)
+            A = apx.DeviceMatrix.from_numpy(A_h, ctx)
+            h = apx.Translate(apx.NormL1(1.0) if hk == "l1" else apx.NormL2(1.0), -y_h)
             for graph in ((False,) if name == "small_pd.hip" else (False, True)):
-                run(f"LAD-{hk} {m}x{n} fp64 adaptive PD {name}", ctx, apx.Zero(), apx.NormL1(lad.lam), n, None, graph,
-                    pd=(A, h, m, apx.OurRule(t=1.0, norm_A=lad.norm_A)))
+                run(f"LAD-{hk} {m}x{n} fp64 adaptive PD {name}", ctx, apx.Zero(), apx.NormL1(5.0), n, None, graph,
+                    pd=(A, h, m, apx.OurRule(t=1.0, norm_A=nrm)))
 
 
 if __name__ == "__main__":
