@@ -195,7 +195,9 @@ def main():
         # default per-GPU shape only
         if os.path.exists(tpath) and (args.m, args.n) == (50_000, 100_000) and not share_gpu:
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                # with the dual layout both passes run the column-streaming kernel (the "gemv_t" entry)
+                tkey = "gemv_t" if prob.dual_layout else dom
+                traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
