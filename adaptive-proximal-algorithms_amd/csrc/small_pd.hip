@@ -1,7 +1,9 @@
 // small_pd.hip — the primal-dual iteration (src/AdaProx.jl:334-362 with a linear operator) of a SMALL
 // dense problem in TWO kernels, for the sizes of the reference's own LAD / square-root-lasso experiments
 // (experiments/least_absolute_deviation/runme.jl:39-62: f = Zero, g = NormL1, h = Translate(NormL1 |
-// NormL2, -b), A dense with a few hundred rows).  Same idea as small.hip: every workgroup redundantly does
+// NormL2, -b), A dense with a few hundred rows) and of its dual SVM (experiments/dual_svm/runme.jl:47-76:
+// f = Quadratic(Q, q), g = IndBox, h = IndZero, A = y' — the third product Q x+ rides in kernel A, its
+// output rotating through three buffers like A x).  Same idea as small.hip: every workgroup redundantly does
 // the O(m + n) work, the two products are in-block dot products, nothing else crosses blocks.
 //
 //   k_small_pd_b (iteration k): primal_res = (v - x)/gamma + A'y (:338) ; ||dx||^2 ... (:260-261, grad f = 0)
@@ -24,7 +26,7 @@ namespace apx {
 
 
 // MODE 0: only A' y_cur -> aty_next (pre-loop, :329) ; MODE 2: the loop body
-template <typename T, int MODE>
+template <typename T, int MODE, int FK>
 __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
   __shared__ double ys[kSmallMax];
   if constexpr (MODE == 0) {
@@ -44,11 +46,15 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
     const T* __restrict__ XP = (const T*)d.x_prev;
     const T* __restrict__ V = (const T*)d.v_cur;
     const T* __restrict__ Y = (const T*)d.y_cur;
-    // ---- n side: primal residual and the rule's sums (grad f == 0: dg == 0) --------------------
+    // ---- n side: primal residual and the rule's sums (f = Zero: grad f == 0, dg == 0 ; Quadratic:
+    //      grad = Q x + q from kernel A's third product, f = 0.5 <x, Q x> + <x, q>) -----------------
     double q[5] = {0, 0, 0, 0, 0};
+    double fq[2] = {0.0, 0.0};
+    [[maybe_unused]] const T* __restrict__ QV = (const T*)d.qvec;
     const int per_n = (d.n + kBlock - 1) / kBlock;
     for (int k0 = 0; k0 < per_n; k0 += 4) {
       double x4[4], xp4[4], v4[4], a4[4], gb4[4];
+      [[maybe_unused]] double t4[4], tp4[4], qv4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ic = min((int)threadIdx.x + (k0 + u) * kBlock, d.n - 1);
@@ -57,15 +63,30 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
         v4[u] = (double)V[ic];
         a4[u] = (double)(T)d.aty_cur[ic];
         gb4[u] = shift_at<T>(d.g, ic);
+        if constexpr (FK == APX_F_QUADRATIC) {
+          t4[u] = (double)(T)d.qx_cur[ic];
+          tp4[u] = (double)(T)d.qx_prev[ic];
+          qv4[u] = (double)QV[ic];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = threadIdx.x + (k0 + u) * kBlock;
         if (i < d.n) {
-          double pr = (v4[u] - x4[u]) / gamma + 0.0;     // (v - x)/gamma + grad_x   (:338)
+          double gi = 0.0, gp = 0.0;
+          if constexpr (FK == APX_F_QUADRATIC) {         // quadratic_pullback() = temp + q  (dual_svm/runme.jl:24-27)
+            gi = (double)(T)(t4[u] + qv4[u]);
+            gp = (double)(T)(tp4[u] + qv4[u]);
+            fq[0] = fma(x4[u], t4[u], fq[0]);
+            fq[1] = fma(x4[u], qv4[u], fq[1]);
+          }
+          double pr = (v4[u] - x4[u]) / gamma + gi;      // (v - x)/gamma + grad_x   (:338)
           pr = pr + a4[u];                               //                + At_y
+          const double dg = gi - gp;
           const double dx = x4[u] - xp4[u];
           q[0] = fma(pr, pr, q[0]);
+          q[1] = fma(dg, dg, q[1]);
+          q[2] = fma(dg, dx, q[2]);
           q[3] = fma(dx, dx, q[3]);
           q[4] += gval_elem_s<T>(d.g, x4[u], i, gb4[u]);
         }
@@ -86,11 +107,16 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
       }
     }
     block_sums_t0<5>(q);
+    if constexpr (FK == APX_F_QUADRATIC) {
+      __syncthreads();
+      block_sums_t0<2>(fq);
+    }
     if (threadIdx.x == 0) {
       if (done_in != 0) {
         lc.done = 2;                                     // already converged: forward the control block
       } else {
         lc = t;
+        if constexpr (FK == APX_F_QUADRATIC) lc.f_x = 0.5 * fq[0] + fq[1];
         lc.it += 1;
         const double npr = sqrt(q[0]);
         lc.npr2 = npr * npr;
@@ -152,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
 }
 
 // MODE 0: only A x_cur -> ax_next (pre-loop, :327) ; MODE 2: x+ and A x+
-template <typename T, int MODE>
+template <typename T, int MODE, int FK>
 __global__ __launch_bounds__(kBlock) void k_small_pd_a(PdDev d) {
   __shared__ double xs[kSmallMax];
   const T* __restrict__ X = (const T*)d.x_cur;
@@ -160,6 +186,8 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_a(PdDev d) {
     for (int i = threadIdx.x; i < d.n; i += kBlock) xs[i] = (double)X[i];
     __syncthreads();
     small_dots_w<T>(d.w_n, (const T*)d.AT, d.ldT, d.m, d.n, xs, d.ax_next, true);
+    if constexpr (FK == APX_F_QUADRATIC)
+      small_dots_w<T>(d.w_n, (const T*)d.QT, d.ldQ, d.n, d.n, xs, d.qx_next, true);   // temp = Q * x
     return;
   } else {
     const int done = d.c_next->done;            // written by the previous kernel: block-uniform
@@ -169,19 +197,26 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_a(PdDev d) {
     const int per_n = (d.n + kBlock - 1) / kBlock;
     for (int k0 = 0; k0 < per_n; k0 += 4) {
       double x4[4], a4[4], gb4[4];
+      [[maybe_unused]] double t4[4], qv4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ic = min((int)threadIdx.x + (k0 + u) * kBlock, d.n - 1);
         x4[u] = (double)X[ic];
         a4[u] = (double)(T)d.aty_next[ic];
         gb4[u] = shift_at<T>(d.g, ic);
+        if constexpr (FK == APX_F_QUADRATIC) {
+          t4[u] = (double)(T)d.qx_cur[ic];
+          qv4[u] = (double)((const T*)d.qvec)[ic];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k = k0 + u;
         const int i = threadIdx.x + k * kBlock;
         if (i < d.n) {
-          const double gs = 0.0 + a4[u];                                     // grad_x + At_y
+          double gi = 0.0;
+          if constexpr (FK == APX_F_QUADRATIC) gi = (double)(T)(t4[u] + qv4[u]);
+          const double gs = gi + a4[u];                                      // grad_x + At_y
           const T vi = (T)(x4[u] - gamma * gs);                              // :359
           const T xn = (T)prox_elem_s<T>(d.g, (double)vi, gamma, i, 0.0, gb4[u]);   // :361
           xs[i] = (double)xn;
@@ -194,6 +229,8 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_a(PdDev d) {
     }
     __syncthreads();
     small_dots_w<T>(d.w_n, (const T*)d.AT, d.ldT, d.m, d.n, xs, d.ax_next, done == 0);   // :335 of the next iteration
+    if constexpr (FK == APX_F_QUADRATIC)
+      small_dots_w<T>(d.w_n, (const T*)d.QT, d.ldQ, d.n, d.n, xs, d.qx_next, done == 0);  // :336  temp = Q * x+
   }
 }
 
@@ -202,7 +239,9 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_a(PdDev d) {
 // ---------------------------------------------------------------------------------------
 bool small_pd_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
-  if (p->A_lin == nullptr || p->allreduce != nullptr || p->f_kind != APX_F_ZERO) return false;
+  if (p->A_lin == nullptr || p->allreduce != nullptr) return false;
+  if (p->f_kind != APX_F_ZERO && p->f_kind != APX_F_QUADRATIC) return false;
+  if (p->f_kind == APX_F_QUADRATIC && (p->A_f == nullptr || p->A_f->sparse)) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   return p->n <= kSmallMax && p->A_lin->m <= kSmallMax && p->A_lin->m > 0;
 }
@@ -218,6 +257,9 @@ static PdDev roles(const apx_solver* s, int64_t k) {
   d.ax_prev = (const double*)st->axb[k3].p;
   d.ax_cur = (const double*)st->axb[(k3 + 1) % 3].p;
   d.ax_next = (double*)st->axb[(k3 + 2) % 3].p;
+  d.qx_prev = (const double*)st->qxb[k3].p;
+  d.qx_cur = (const double*)st->qxb[(k3 + 1) % 3].p;
+  d.qx_next = (double*)st->qxb[(k3 + 2) % 3].p;
   d.v_cur = st->vb[k2].p;
   d.v_next = st->vb[1 - k2].p;
   d.y_cur = st->yb[k2].p;
@@ -232,14 +274,26 @@ static PdDev roles(const apx_solver* s, int64_t k) {
 template <int MODE>
 static void launch_pd_b(const PdDev& d, int32_t dtype, hipStream_t q) {
   const dim3 grid(pick_grid(d.n, d.w_t));
-  if (dtype == APX_F32) hipLaunchKernelGGL((k_small_pd_b<float, MODE>), grid, dim3(kBlock), 0, q, d);
-  else hipLaunchKernelGGL((k_small_pd_b<double, MODE>), grid, dim3(kBlock), 0, q, d);
+  const bool quad = d.fk == APX_F_QUADRATIC;
+  if (dtype == APX_F32) {
+    if (quad) hipLaunchKernelGGL((k_small_pd_b<float, MODE, APX_F_QUADRATIC>), grid, dim3(kBlock), 0, q, d);
+    else hipLaunchKernelGGL((k_small_pd_b<float, MODE, APX_F_ZERO>), grid, dim3(kBlock), 0, q, d);
+  } else {
+    if (quad) hipLaunchKernelGGL((k_small_pd_b<double, MODE, APX_F_QUADRATIC>), grid, dim3(kBlock), 0, q, d);
+    else hipLaunchKernelGGL((k_small_pd_b<double, MODE, APX_F_ZERO>), grid, dim3(kBlock), 0, q, d);
+  }
 }
 template <int MODE>
 static void launch_pd_a(const PdDev& d, int32_t dtype, hipStream_t q) {
-  const dim3 grid(pick_grid(d.m, d.w_n));
-  if (dtype == APX_F32) hipLaunchKernelGGL((k_small_pd_a<float, MODE>), grid, dim3(kBlock), 0, q, d);
-  else hipLaunchKernelGGL((k_small_pd_a<double, MODE>), grid, dim3(kBlock), 0, q, d);
+  const bool quad = d.fk == APX_F_QUADRATIC;
+  const dim3 grid(pick_grid(quad ? std::max(d.m, d.n) : d.m, d.w_n));     // (the Q x product has n outputs)
+  if (dtype == APX_F32) {
+    if (quad) hipLaunchKernelGGL((k_small_pd_a<float, MODE, APX_F_QUADRATIC>), grid, dim3(kBlock), 0, q, d);
+    else hipLaunchKernelGGL((k_small_pd_a<float, MODE, APX_F_ZERO>), grid, dim3(kBlock), 0, q, d);
+  } else {
+    if (quad) hipLaunchKernelGGL((k_small_pd_a<double, MODE, APX_F_QUADRATIC>), grid, dim3(kBlock), 0, q, d);
+    else hipLaunchKernelGGL((k_small_pd_a<double, MODE, APX_F_ZERO>), grid, dim3(kBlock), 0, q, d);
+  }
 }
 
 // called by apx_solver_create instead of the generic pre-loop (:324-332); Ctrl is initialised in p->ctrl_buf
@@ -254,6 +308,7 @@ int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0) {
   for (auto& b : st->vb) APX_TRY(b.alloc_zero(nb, ctx->stream));
   for (auto& b : st->yb) APX_TRY(b.alloc_zero(mb, ctx->stream));
   for (auto& b : st->axb) APX_TRY(b.alloc_zero((size_t)p->m_pad * sizeof(double), ctx->stream));
+  for (auto& b : st->qxb) APX_TRY(b.alloc_zero((size_t)p->n_pad * sizeof(double), ctx->stream));
   for (auto& b : st->atyb) APX_TRY(b.alloc_zero((size_t)p->n_pad * sizeof(double), ctx->stream));
   for (auto& b : st->cb) APX_TRY(b.alloc_zero(sizeof(Ctrl), ctx->stream));
   PdDev d{};
@@ -267,6 +322,20 @@ int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0) {
     APX_TRY(st->at.alloc_zero((size_t)d.ldT * (size_t)A->ld * es, ctx->stream));
     APX_TRY(transpose_into(ctx, A, st->at.p, d.ldT));
     d.AT = st->at.p;
+  }
+  d.fk = p->f_kind;
+  if (p->f_kind == APX_F_QUADRATIC) {   // rows of Q as contiguous columns: (Q x)_i = <Q[i, :], x> exactly as gemv_n forms it
+    const apx_matrix* Q = p->A_f;
+    if (Q->dT != nullptr) {
+      d.QT = Q->dT;
+      d.ldQ = Q->ldT;
+    } else {
+      d.ldQ = round_up(Q->n, kPad);
+      APX_TRY(st->qt.alloc_zero((size_t)d.ldQ * (size_t)Q->ld * es, ctx->stream));
+      APX_TRY(transpose_into(ctx, Q, st->qt.p, d.ldQ));
+      d.QT = st->qt.p;
+    }
+    d.qvec = p->b.p;
   }
   d.m = (int32_t)A->m;
   d.n = (int32_t)p->n;
@@ -285,8 +354,9 @@ int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0) {
   APX_TRY(h2d(ctx, S->yb[1].p, y0, (size_t)p->m * es));
   APX_HIP(hipMemcpyAsync(S->cb[1].p, p->ctrl_buf.p, sizeof(Ctrl), hipMemcpyDeviceToDevice, ctx->stream));
   PdDev pre = S->base;
-  pre.x_cur = S->xb[1].p;                                  // :327  A_x = A * x0
+  pre.x_cur = S->xb[1].p;                                  // :327-328  A_x = A * x0 (and Q * x0)
   pre.ax_next = (double*)S->axb[1].p;
+  pre.qx_next = (double*)S->qxb[1].p;
   launch_pd_a<0>(pre, p->dtype, ctx->stream);
   pre.y_cur = S->yb[1].p;                                  // :329  At_y = A' * y0
   pre.aty_next = (double*)S->atyb[1].p;
@@ -295,6 +365,8 @@ int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0) {
   pre.x_next = S->xb[2].p;
   pre.v_next = S->vb[1].p;
   pre.ax_next = (double*)S->axb[2].p;
+  pre.qx_cur = (const double*)S->qxb[1].p;
+  pre.qx_next = (double*)S->qxb[2].p;
   launch_pd_a<2>(pre, p->dtype, ctx->stream);
   APX_HIP(hipGetLastError());
   return APX_OK;

@@ -68,6 +68,12 @@ struct PdDev {
   const void* AT;   // n_pad x m (= A')
   int64_t ld, ldT;
   int32_t m, n, w_n, w_t;
+  int32_t fk, _pad;          // APX_F_ZERO or APX_F_QUADRATIC
+  const void* QT;            // Quadratic: Q' (n_pad x n) ; q
+  int64_t ldQ;
+  const void* qvec;
+  const double *qx_prev, *qx_cur;   // Q x, rotating like A x
+  double* qx_next;
   const void *x_prev, *x_cur;
   void* x_next;
   const void* v_cur;
@@ -86,9 +92,9 @@ struct PdDev {
 };
 
 struct SmallPdState {
-  DBuf xb[3], axb[3];                 // prev / cur / next, roles rotate with the iteration index
+  DBuf xb[3], axb[3], qxb[3];         // prev / cur / next, roles rotate with the iteration index
   DBuf vb[2], yb[2], atyb[2], cb[2];  // cur / next
-  DBuf at;
+  DBuf at, qt;
   PdDev base{};                       // the loop-invariant fields
 };
 

@@ -248,3 +248,34 @@ def test_pd_stepping_and_fp32(apx):
     xf, yf, _ = apx.condat_vu(np.zeros(150, dtype=np.float32), np.zeros(400, dtype=np.float32), A=A32, Lf=0.0,
                               norm_A=lad.norm_A, tol=0.0, maxit=40, **t32)
     assert xf.dtype == np.float32 and _rel(xf, xo) <= 5e-3 and _rel(yf, yo) <= 5e-3
+
+
+def test_pd_dual_svm_quadratic(apx, generic_ctx):
+    """experiments/dual_svm/runme.jl:47-76 on the two-kernel path: f = Quadratic(Q, q) (the third product Q x
+    rides in kernel A), g = IndBox(0, C), h = IndZero, A = y'."""
+    rng = np.random.default_rng(0)
+    N, dfeat, C = 700, 25, 0.1
+    X = rng.uniform(-1, 1, (N, dfeat))
+    yl = np.sign(X @ rng.standard_normal(dfeat) + 0.1 * rng.standard_normal(N))
+    Q = np.asfortranarray((yl[:, None] * X) @ (yl[:, None] * X).T)
+    Q[3, 5] += 1e-3                                  # not symmetric: rows of Q, not its columns, must be used
+    q = -np.ones(N)
+    A = np.asfortranarray(yl[None, :])
+    nrm = float(np.linalg.norm(A))
+    for t in (0.05, 1.0, 5.0):
+        K = 120
+        ro, rf = [], []
+        fo, ff = O.Counting(O.Quadratic(Q, q)), apx.Counting(apx.Quadratic(Q, q))
+        xo, yo, _ = O.adaptive_primal_dual(np.zeros(N), np.zeros(1), f=fo, g=O.IndBox(0.0, C), h=O.IndZero(), A=A,
+                                           rule=O.OurRule(t=t, norm_A=nrm), maxit=K, tol=0.0, record=ro.append)
+        xf, yf, _ = apx.adaptive_primal_dual(np.zeros(N), np.zeros(1), f=ff, g=apx.IndBox(0.0, C), h=apx.IndZero(), A=A,
+                                             rule=apx.OurRule(t=t, norm_A=nrm), maxit=K, tol=0.0, record=rf.append)
+        fg = apx.Quadratic(apx.DeviceMatrix.from_numpy(Q, generic_ctx), q, ctx=generic_ctx)
+        xg, yg, _ = apx.adaptive_primal_dual(np.zeros(N), np.zeros(1), f=fg, g=apx.IndBox(0.0, C), h=apx.IndZero(),
+                                             A=apx.DeviceMatrix.from_numpy(A, generic_ctx), ctx=generic_ctx,
+                                             rule=apx.OurRule(t=t, norm_A=nrm), maxit=K, tol=0.0)
+        assert _rel(xf, xo) <= RTOL and _rel(yf, yo) <= 1e-9 and _rel(xf, xg) <= RTOL
+        assert (ff.eval_count, ff.grad_count) == (fo.eval_count, fo.grad_count)
+        for a, b_ in zip(rf, ro):
+            assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-8)
+            assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10, abs=1e-12)
