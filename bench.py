@@ -30,6 +30,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY_GBS = 6290.0      # same table: measured float4-copy ceiling (SURVEY.md 8d asks for both)
+HBM_READ_GBS = 7211.0      # fastest pure 40 GB read found on this part over access pattern / unroll / grid / cache
+                           # policy (tools/read_ceiling.hip, profiles/r01e_read_ceiling_40GB.log)
 
 
 def parse():
@@ -215,6 +217,7 @@ def main():
                        "parallelism": "single" if world == 1 else f"row-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
+                         "frac_of_measured_read_ceiling": achieved / HBM_READ_GBS,
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "per_kernel": per_kernel,
                          "iteration_frac": 2 * algo_bytes * iters_per_s / 1e9 / HBM_PEAK_GBS},
