@@ -7,7 +7,9 @@ imported from here).
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadaprox_hip.so")
@@ -151,6 +153,29 @@ class DomainError(ApxError, ValueError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """Two HIP runtimes in one process do not share the GPU: whichever initialises second sees "no
+    ROCm-capable device".  PyTorch-ROCm bundles its own libamdhip64; if it is already imported the loader
+    resolves this library's DT_NEEDED to that copy by soname, but if THIS library were loaded first it would
+    pull the system copy and a later `import torch` (the torch.distributed plumbing of the sharded path) would
+    lose the device.  So when an installed torch ships a libamdhip64, map that copy first — without importing
+    torch — and both libraries share one runtime whatever the import order."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Loads libadaprox_hip.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -161,6 +186,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build the HIP extension first "
             f"(`make -C {os.path.join(_HERE, 'csrc')}` or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "This package has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol

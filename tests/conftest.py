@@ -11,14 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
-    # The HIP extension is built in-tree and is git-ignored: (re)build it when it is missing or
-    # older than its sources, so a fresh checkout tests the real library, never a stand-in.
-    csrc = os.path.join(ROOT, "adaptive-proximal-algorithms_amd", "csrc")
-    lib = os.path.join(csrc, "libadaprox_hip.so")
-    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(ROOT, "include", "adaprox_hip.h"))
-    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
-        import __graft_entry__
+    # The HIP extension is built in-tree and is git-ignored: (re)build it when it is missing or was
+    # built from other sources (content hash), so a fresh checkout tests the real library, never a stand-in.
+    import __graft_entry__
+    if __graft_entry__.is_stale():
         __graft_entry__.build()
 
 
