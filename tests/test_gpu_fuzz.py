@@ -65,3 +65,157 @@ def test_lasso_iterations_fuzz(m, n, lam, k, rule, seed):
                                   maxit=k, ctx=ctx)
     assert it == k
     assert np.max(np.abs(x - xo)) <= 1e-10 * max(1.0, np.max(np.abs(xo)))
+
+
+# ---------------------------------------------------------------------------------------
+# the two-kernel small-problem paths (csrc/small.hip, small_pd.hip) against the generic kernels
+# ---------------------------------------------------------------------------------------
+def _generic_ctx():
+    apx, _ = _apx()
+    if "generic" not in _ctx:
+        _ctx["generic"] = apx.Context(0)
+        _ctx["generic"].fused_small(False)
+    return _ctx["generic"]
+
+
+small_dims = st.one_of(st.integers(1, 40), st.integers(60, 700), st.sampled_from([255, 256, 257, 1023, 1024, 1025, 2048,
+                                                                                  2049, 3000, 4095, 4096]))
+
+
+def _g_term(apx, kind, n, rng):
+    if kind == "l1":
+        return apx.NormL1(float(rng.uniform(0.01, 1.0)))
+    if kind == "box":
+        return apx.IndBox(-0.3, 0.5)
+    if kind == "boxv":
+        lb = -rng.uniform(0.1, 1.0, n)
+        return apx.IndBox(lb, lb + rng.uniform(0.1, 2.0, n))
+    if kind == "tl1":
+        return apx.Translate(apx.NormL1(0.2), rng.uniform(-0.5, 0.5, n))
+    return apx.Zero()
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(m=small_dims, n=small_dims, logistic=st.booleans(), f32=st.booleans(),
+       gk=st.sampled_from(["l1", "box", "boxv", "tl1", "zero"]), rule=st.sampled_from(["ours", "fixed", "plus", "mm"]),
+       k=st.integers(0, 14), seed=st.integers(0, 2**31 - 1))
+def test_small_proxgrad_vs_generic_fuzz(m, n, logistic, f32, gk, rule, k, seed):
+    apx, _ = _apx()
+    g_ctx = _generic_ctx()
+    if m * n > 3_000_000:
+        m = max(1, 3_000_000 // n)
+    dtype = np.float32 if f32 else np.float64
+    rng = np.random.default_rng(seed)
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
+    nx = n + 1 if logistic else n
+    if logistic:
+        b = (rng.uniform(size=m) < 0.5).astype(dtype)
+        gam = 4.0 * m / (np.linalg.norm(A.astype(np.float64)) ** 2 + m)
+    else:
+        b = rng.standard_normal(m).astype(dtype)
+        gam = 0.9 / max(np.linalg.norm(A.astype(np.float64), 2) ** 2, 1e-12)
+    mk = {"ours": lambda: apx.OurRule(gamma=gam), "fixed": lambda: apx.FixedStepsize(gam),
+          "plus": lambda: apx.OurRulePlus(gamma=gam), "mm": lambda: apx.MalitskyMishchenkoRule(gam)}[rule]
+    x0 = (0.1 * rng.standard_normal(nx)).astype(dtype)
+    out = []
+    for ctx in (apx.default_context(), g_ctx):
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        f = apx.LogisticLoss(dA, b, ctx=ctx) if logistic else apx.LinearLeastSquares(dA, b, ctx=ctx)
+        recs = []
+        x, it = apx.adaptive_proxgrad(x0, f=f, g=_g_term(apx, gk, nx, np.random.default_rng(seed + 1)), rule=mk(), tol=0.0,
+                                      maxit=k, ctx=ctx, record=recs.append)
+        out.append((x, it, recs))
+        dA.free()
+    (xs, its, rs), (xg, itg, rg) = out
+    tol = 5e-4 if f32 else 1e-9
+    assert its == itg or min(m, n) == 1
+    assert np.all(np.isfinite(xs)) == np.all(np.isfinite(xg))
+    if np.all(np.isfinite(xg)):
+        assert np.max(np.abs(xs - xg)) <= tol * max(1.0, np.max(np.abs(xg)))
+        for a, b_ in zip(rs, rg):
+            if np.isfinite(b_["objective"]):
+                assert a["objective"] == pytest.approx(b_["objective"], rel=10 * tol, abs=10 * tol)
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(m=small_dims, n=small_dims, quad=st.booleans(), hk=st.sampled_from(["l1", "l2", "tl1", "tl2", "indzero", "box"]),
+       gk=st.sampled_from(["l1", "box", "zero"]), rule=st.sampled_from(["ours", "fixed"]), k=st.integers(0, 14),
+       seed=st.integers(0, 2**31 - 1))
+def test_small_primal_dual_vs_generic_fuzz(m, n, quad, hk, gk, rule, k, seed):
+    apx, _ = _apx()
+    g_ctx = _generic_ctx()
+    if quad:
+        n = min(n, 1500)
+    if m * n > 3_000_000:
+        m = max(1, 3_000_000 // n)
+    rng = np.random.default_rng(seed)
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    nrm = float(np.linalg.norm(A))
+    bvec = rng.standard_normal(m)
+    hmk = {"l1": lambda: apx.NormL1(0.7), "l2": lambda: apx.NormL2(1.3), "tl1": lambda: apx.Translate(apx.NormL1(1.0), -bvec),
+           "tl2": lambda: apx.Translate(apx.NormL2(1.0), -bvec), "indzero": lambda: apx.IndZero(),
+           "box": lambda: apx.IndBox(-0.5, 0.5)}[hk]
+    if quad:
+        B = rng.uniform(-1, 1, (n, max(2, n // 3)))
+        Q = np.asfortranarray(B @ B.T / n)
+        qv = rng.standard_normal(n)
+        Lf = float(np.linalg.norm(Q, 2))
+    else:
+        Lf = 0.0
+    t = 1.0
+    gam = 1.0 / (2.0 * 1.2 * t * max(nrm, 1e-12) + Lf)
+    mk = {"ours": lambda: apx.OurRule(gamma=gam, t=t, norm_A=nrm), "fixed": lambda: apx.FixedStepsize(gam, t)}[rule]
+    x0, y0 = 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(m)
+    out = []
+    for ctx in (apx.default_context(), g_ctx):
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        f = apx.Quadratic(apx.DeviceMatrix.from_numpy(Q, ctx), qv, ctx=ctx) if quad else apx.Zero()
+        recs = []
+        x, y, it = apx.adaptive_primal_dual(x0, y0, f=f, g=_g_term(apx, gk, n, np.random.default_rng(seed + 1)), h=hmk(),
+                                            A=dA, rule=mk(), tol=0.0, maxit=k, ctx=ctx, record=recs.append)
+        out.append((x, y, it, recs))
+    (xs, ys, its, rs), (xg, yg, itg, rg) = out
+    assert its == itg
+    assert np.max(np.abs(xs - xg)) <= 1e-9 * max(1.0, np.max(np.abs(xg)))
+    assert np.max(np.abs(ys - yg)) <= 1e-9 * max(1.0, np.max(np.abs(yg)))
+    for a, b_ in zip(rs, rg):
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-6, abs=1e-9)
+        if np.isfinite(b_["objective"]):
+            assert a["objective"] == pytest.approx(b_["objective"], rel=1e-8, abs=1e-8)
+        else:
+            assert a["objective"] == b_["objective"]
+
+
+def test_small_path_soak_long_run():
+    """60 000 iterations through the two-kernel path: the buffer rotation and the control blocks stay consistent
+    (same converged point as the generic kernels, objective at the optimum), and a converged run stays frozen."""
+    apx, _ = _apx()
+    g_ctx = _generic_ctx()
+    rng = np.random.default_rng(5)
+    A = np.asfortranarray(rng.uniform(-1, 1, (150, 260)))
+    b = rng.standard_normal(150)
+    gam = 1.0 / np.linalg.norm(A, 2) ** 2
+    # (fixed step: with tol = 0 an adaptive rule keeps growing gamma once the iterate is exactly stationary —
+    #  dx = dg = 0 makes C = L = D = 0 — until it overflows, in the reference as well)
+    s = apx.Solver(np.zeros(260), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(0.5), rule=apx.FixedStepsize(gam), tol=0.0)
+    s.step(60_000, sync=True)
+    xs, _, res = s.result()
+    s.close()
+    xg, _ = apx.adaptive_proxgrad(np.zeros(260), f=apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A, g_ctx), b, ctx=g_ctx),
+                                  g=apx.NormL1(0.5), rule=apx.OurRule(gamma=gam), tol=1e-12, maxit=60_000, ctx=g_ctx)
+    obj = lambda x: 0.5 * np.linalg.norm(A @ x - b) ** 2 + 0.5 * np.sum(np.abs(x))   # noqa: E731
+    assert res.numit == 60_000 and np.all(np.isfinite(xs))
+    assert obj(xs) == pytest.approx(obj(xg), rel=1e-10) and np.max(np.abs(xs - xg)) < 1e-7
+    # tol > 0: converges early, later iterations are no-ops, the tested iterate is returned
+    x1, it1 = apx.adaptive_proxgrad(np.zeros(260), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(0.5),
+                                    rule=apx.OurRule(gamma=gam), tol=1e-9, maxit=60_000, poll_every=5000)
+    assert it1 < 60_000 and np.max(np.abs(x1 - xg)) < 1e-6
+    lad_A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (300, 9)), np.ones((300, 1))]))
+    yv = lad_A @ rng.standard_normal(10) + rng.laplace(size=300)
+    nrm = float(np.linalg.norm(lad_A))
+    kw = dict(f=apx.Zero(), g=apx.NormL1(1.0), h=apx.Translate(apx.NormL1(1.0), -yv), Lf=0.0, norm_A=nrm, tol=1e-7,
+              maxit=300_000)
+    xa, ya, ita = apx.condat_vu(np.zeros(10), np.zeros(300), A=lad_A, poll_every=4096, **kw)
+    xb, yb, itb = apx.condat_vu(np.zeros(10), np.zeros(300), A=apx.DeviceMatrix.from_numpy(lad_A, g_ctx), ctx=g_ctx, **kw)
+    assert ita < 300_000 and abs(ita - itb) <= max(5, itb // 20)
+    assert np.max(np.abs(xa - xb)) < 1e-5 * max(1.0, np.max(np.abs(xb)))
