@@ -37,8 +37,9 @@ HBM_READ_GBS = 7211.0      # fastest pure 40 GB read found on this part over acc
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults = SURVEY.md 8(d): 200 timed iterations after 10 warm-up iterations (2.4 s at 11.3 ms each)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     # (long names: torch.distributed.run's own parser treats a bare `--m` after the script as an
     # ambiguous abbreviation of its options)
     ap.add_argument("--rows", dest="m", type=int, default=50_000, help="rows per GPU")
