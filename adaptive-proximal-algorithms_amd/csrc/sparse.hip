@@ -17,23 +17,80 @@
 
 namespace apx {
 
+// A group of G lanes per row; every group works on R rows at once (row, row + groups, ...): their pointer
+// pairs are loaded together, then the first U strides of all R rows (R*U independent index / value loads
+// per lane), then the R*U gathers; rows longer than U*G entries finish in a 4-way unrolled remainder loop.
+// The summation order per row is fixed (stride-major, then the width-G shuffle tree): bit-reproducible.
+// Measured (tools/sparse_bench.py, profiles/r01e_sparse_*): LIBSVM-sized matrices are cache-resident and the
+// iteration is launch-bound (~25 us); a 60 M-entry matrix with a 100 000-long gathered operand runs at
+// 1.1 - 1.7 TB/s of value + index bytes whatever the loads in flight — every random 8-byte gather moves a
+// whole cache line from L2, which is what bounds it; an operand that fits LDS / a row-blocked layout is the
+// next step for that regime, not this kernel's schedule.
 template <typename T, typename OUT, int G>
 __global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ ptr, const int32_t* __restrict__ ind,
                                                     const T* __restrict__ val, const T* __restrict__ x,
                                                     OUT* __restrict__ out, int64_t nrows, int64_t nrows_pad,
                                                     const int* __restrict__ done) {
   if (done != nullptr && *done != 0) return;
+  constexpr int R = 4, U = 2;
   const int lane = threadIdx.x % G;
   const int64_t groups = (int64_t)gridDim.x * (kBlock / G);
-  for (int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; row < nrows_pad; row += groups) {
-    double s = 0.0;
-    if (row < nrows) {
-      const int64_t k1 = ptr[row + 1];
-      for (int64_t k = ptr[row] + lane; k < k1; k += G) s = fma((double)val[k], (double)x[ind[k]], s);
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; base < nrows_pad; base += R * groups) {
+    int64_t k0[R], k1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = base + r * groups;
+      const bool ok = row < nrows;
+      k0[r] = ok ? ptr[row] : 0;
+      k1[r] = ok ? ptr[row + 1] : 0;
+    }
+    int32_t j[R][U];
+    double v[R][U], xv[R][U], s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t kk = k0[r] + lane + (int64_t)u * G;
+        const bool ok = kk < k1[r];
+        j[r][u] = ok ? ind[kk] : 0;
+        v[r][u] = ok ? (double)val[kk] : 0.0;
+      }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv[r][u] = (double)x[j[r][u]];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s[r] = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) s[r] = fma(v[r][u], xv[r][u], s[r]);
     }
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
-    if (lane == 0) out[row] = (OUT)s;     // rows in [nrows, nrows_pad) get exact zeros
+    for (int r = 0; r < R; ++r) {
+      for (int64_t k = k0[r] + lane + (int64_t)U * G; k < k1[r]; k += 4 * G) {     // long rows
+        int32_t jj[4];
+        double vv[4], xx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t kk = k + (int64_t)u * G;
+          const bool ok = kk < k1[r];
+          jj[u] = ok ? ind[kk] : 0;
+          vv[u] = ok ? (double)val[kk] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xx[u] = (double)x[jj[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[r] = fma(vv[u], xx[u], s[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double t = s[r];
+#pragma unroll
+      for (int off = G / 2; off > 0; off >>= 1) t += __shfl_down(t, off, G);
+      const int64_t row = base + r * groups;
+      if (lane == 0 && row < nrows_pad) out[row] = (OUT)t;     // rows in [nrows, nrows_pad) get exact zeros
+    }
   }
 }
 
