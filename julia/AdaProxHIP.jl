@@ -93,6 +93,10 @@ mutable struct Context
     end
 end
 
+"Execution policy: the two-kernel iteration for small dense problems (default on) and the opt-in sparse-iterate product."
+fused_small!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_fused_small, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
+exploit_sparsity!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_exploit_sparsity, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
+
 dtype_code(::Type{Float64}) = APX_F64
 dtype_code(::Type{Float32}) = APX_F32
 
