@@ -44,3 +44,35 @@ def test_lad_experiment_runs(tmp_path):
     assert len(out) == 7
     objs = {k: 3.0 * np.sum(np.abs(x)) + np.sum(np.abs(p.A.matvec(x) - p.y)) for k, (x, y, it) in out.items()}
     assert min(objs.values()) > 0 and max(objs.values()) < 1.5 * min(objs.values())
+
+
+def test_square_root_lasso_experiment_runs():
+    ex = _load("square_root_lasso_experiment")
+    p, out = ex.run_square_root_lasso(400, 9, lam=2.0, maxit=3000, tol=1e-6, t_values=[0.1, 1, 10])
+    assert len(out) == 7
+    objs = {k: ex.objective(p, 2.0, x) for k, (x, y, it) in out.items()}
+    best = min(objs.values())
+    assert best > 0
+    # every method that met the tolerance sits at the same optimum; the dual iterate lies in the unit l2 ball
+    for k, (x, y, it) in out.items():
+        if it < 3000:
+            assert objs[k] == pytest.approx(best, rel=1e-4), k
+        assert np.linalg.norm(y) <= 1.0 + 1e-9, k
+    assert sum(it < 3000 for (_, _, it) in out.values()) >= 3
+
+
+def test_dual_svm_experiment_runs():
+    ex = _load("dual_svm_experiment")
+    X, y = ex.make_data(300, 10, seed=1)
+    (Q, q, yl, C), out = ex.run_dsvm(X, y, C=0.1, maxit=4000, tol=1e-6, t_values=[0.1, 1.0])
+    assert len(out) == 6
+    objs = {}
+    for k, (x, yd, it) in out.items():
+        assert np.all(x >= -1e-12) and np.all(x <= C + 1e-12), k           # box constraint (g)
+        objs[k] = ex.dual_objective(Q, q, x)
+        if it < 4000:
+            assert abs(yl @ x) <= 1e-4, k                                     # equality constraint y'x = 0 (h = IndZero)
+    done = [k for k, (_, _, it) in out.items() if it < 4000]
+    assert len(done) >= 2
+    ref = min(objs[k] for k in done)
+    assert all(objs[k] == pytest.approx(ref, rel=1e-3, abs=1e-6) for k in done)
