@@ -41,12 +41,12 @@ namespace apx {
 
 // k_small_b: blocks [0, dot_blocks) finish A x and form A' r ; the blocks behind them rotate the staged
 // iterate in (x_prev = x ; x = x+ ; grad_prev = grad ; v = v+, :359-361), one element per thread
-template <typename T, int FK>
-__global__ __launch_bounds__(kBlock) void k_small_b(SmallDev d, int dot_blocks) {
-  __shared__ double rs[kSmallMax];
+template <typename T, int FK, int BS>
+__global__ __launch_bounds__(BS) void k_small_b(SmallDev d, int dot_blocks) {
+  extern __shared__ double rs[];              // the residual, m doubles (dynamic: up to 128 KB)
   const bool live = d.cb->done == 0;          // Ctrl B is not written by this kernel: block-uniform
   if ((int)blockIdx.x >= dot_blocks) {
-    const int i = ((int)blockIdx.x - dot_blocks) * kBlock + threadIdx.x;
+    const int i = ((int)blockIdx.x - dot_blocks) * BS + threadIdx.x;
     if (live && i < d.n) {
       T* __restrict__ X = (T*)d.X;
       const T xo = X[i], xn = ((const T*)d.XN)[i], gn = ((const T*)d.GN)[i], vn = ((const T*)d.VN)[i];
@@ -64,18 +64,19 @@ __global__ __launch_bounds__(kBlock) void k_small_b(SmallDev d, int dot_blocks) 
   double bias = 0.0;
   if constexpr (FK == APX_F_LOGISTIC) bias = (double)((const T*)d.XN)[d.n - 1];
   double q[2] = {0.0, 0.0};
-  const int per = (d.m + kBlock - 1) / kBlock;
-  for (int k0 = 0; k0 < per; k0 += 4) {
-    double s4[4], b4[4];
+  const int per = (d.m + BS - 1) / BS;
+  constexpr int MB = 8;             // chunks per batch (16 loads in flight per lane)
+  for (int k0 = 0; k0 < per; k0 += MB) {
+    double s4[MB], b4[MB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int ic = min((int)threadIdx.x + (k0 + u) * kBlock, d.m - 1);
+    for (int u = 0; u < MB; ++u) {
+      const int ic = min((int)threadIdx.x + (k0 + u) * BS, d.m - 1);
       s4[u] = d.axp[ic];
       b4[u] = (double)b[ic];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = threadIdx.x + (k0 + u) * kBlock;
+    for (int u = 0; u < MB; ++u) {
+      const int i = threadIdx.x + (k0 + u) * BS;
       if (i < d.m) {
         if constexpr (FK == APX_F_LEAST_SQUARES) {        // res = A*w - b ; sum res^2   (lasso/runme.jl:22,24)
           const T r = (T)(s4[u] - b4[u]);
@@ -92,12 +93,12 @@ __global__ __launch_bounds__(kBlock) void k_small_b(SmallDev d, int dot_blocks) 
       }
     }
   }
-  block_sums_t0<2>(q);             // (barrier inside: rs is complete behind it)
+  block_sums_t0<2, BS>(q);             // (barrier inside: rs is complete behind it)
   if (writer && live) {
     f_finalize(&t, FK, q);
     *d.ca = t;
   }
-  small_dots_w<T>(d.w_t, (const T*)d.A, d.ld, d.ncols, d.m, rs, d.grp, live);       // A' r: columns of A
+  small_dots_w<T, BS>(d.w_t, (const T*)d.A, d.ld, d.ncols, d.m, rs, d.grp, live);       // A' r: columns of A
 }
 
 // MODE 0: only A x for the staged x (start of the pre-loop, :327-328)
@@ -235,17 +236,27 @@ bool small_eligible(const apx_problem* p) {
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
   if (p->A_f == nullptr || p->A_f->sparse) return false;
   if (p->ctx->skip_zero_cols) return false;
-  return p->n <= kSmallMax && p->A_f->m <= kSmallMax && p->A_f->m > 0 && p->A_f->n > 0;
+  return small_shape_ok(p->A_f->m, p->n) && p->A_f->n > 0;
+}
+
+template <typename T, int BS>
+static void launch_b_inst(const SmallDev& d, int fk, hipStream_t st) {
+  const int dot_blocks = (int)pick_grid(d.ncols, d.w_t, BS);
+  const dim3 grid((unsigned)(dot_blocks + (d.n + BS - 1) / BS));   // + the rotation blocks
+  const size_t lds = m_vector_lds_bytes(d.m);
+  if (fk == APX_F_LEAST_SQUARES) {
+    allow_big_lds<k_small_b<T, APX_F_LEAST_SQUARES, BS>>();
+    hipLaunchKernelGGL((k_small_b<T, APX_F_LEAST_SQUARES, BS>), grid, dim3(BS), lds, st, d, dot_blocks);
+  } else {
+    allow_big_lds<k_small_b<T, APX_F_LOGISTIC, BS>>();
+    hipLaunchKernelGGL((k_small_b<T, APX_F_LOGISTIC, BS>), grid, dim3(BS), lds, st, d, dot_blocks);
+  }
 }
 
 template <typename T>
 static void launch_b(const SmallDev& d, int fk, hipStream_t st) {
-  const int dot_blocks = (int)pick_grid(d.ncols, d.w_t);
-  const dim3 grid((unsigned)(dot_blocks + (d.n + kBlock - 1) / kBlock));   // + the rotation blocks
-  if (fk == APX_F_LEAST_SQUARES)
-    hipLaunchKernelGGL((k_small_b<T, APX_F_LEAST_SQUARES>), grid, dim3(kBlock), 0, st, d, dot_blocks);
-  else
-    hipLaunchKernelGGL((k_small_b<T, APX_F_LOGISTIC>), grid, dim3(kBlock), 0, st, d, dot_blocks);
+  if (d.m > kSmallMax) launch_b_inst<T, kTallBlock>(d, fk, st);
+  else launch_b_inst<T, kBlock>(d, fk, st);
 }
 
 template <typename T, int MODE>
@@ -287,7 +298,7 @@ int32_t small_setup(apx_solver* s) {
   d.ncols = (int32_t)A->n;
   d.n = (int32_t)p->n;
   d.w_n = pick_waves(d.ncols);
-  d.w_t = pick_waves(d.m);
+  d.w_t = pick_waves(d.m, m_side_block(d.m));
   APX_TRY(st->axp.alloc_zero((size_t)A->ld * sizeof(double), ctx->stream));
   APX_TRY(st->grp.alloc_zero((size_t)p->n_pad * sizeof(double), ctx->stream));
   d.b = p->b.p;

@@ -18,11 +18,11 @@ constexpr int kSmallPer = kSmallMax / kBlock;
 // is finished inside its block — no split partials, no second stage.
 constexpr int kDotUnroll = 16;   // loads in flight per lane: a 1024-element dot product is one round trip
 
-template <typename T, int W>
+template <typename T, int W, int BS = kBlock>
 __device__ __forceinline__ void small_dots(const T* __restrict__ M, int64_t ld, int n_out, int len,
                                            const double* __restrict__ vec, double* __restrict__ out, bool live) {
-  constexpr int DPB = (kBlock / 64) / W;
-  __shared__ double wsum[kBlock / 64];
+  constexpr int DPB = (BS / 64) / W;
+  __shared__ double wsum[BS / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int part = wv % W;
   constexpr int step = W * 64;
@@ -62,18 +62,22 @@ __device__ __forceinline__ void small_dots(const T* __restrict__ M, int64_t ld, 
   }
 }
 
-template <typename T>
+template <typename T, int BS = kBlock>
 __device__ __forceinline__ void small_dots_w(int W, const T* __restrict__ M, int64_t ld, int n_out, int len,
                                              const double* __restrict__ vec, double* __restrict__ out, bool live) {
-  if (W == 1) small_dots<T, 1>(M, ld, n_out, len, vec, out, live);
-  else if (W == 2) small_dots<T, 2>(M, ld, n_out, len, vec, out, live);
-  else small_dots<T, 4>(M, ld, n_out, len, vec, out, live);
+  if (W == 1) small_dots<T, 1, BS>(M, ld, n_out, len, vec, out, live);
+  else if (W == 2) small_dots<T, 2, BS>(M, ld, n_out, len, vec, out, live);
+  else if (W == 4 || BS / 64 <= 4) small_dots<T, 4, BS>(M, ld, n_out, len, vec, out, live);
+  else if constexpr (BS / 64 >= 16) {         // 1024-thread blocks (tall matrices): up to 16 waves per dot
+    if (W == 8) small_dots<T, 8, BS>(M, ld, n_out, len, vec, out, live);
+    else small_dots<T, 16, BS>(M, ld, n_out, len, vec, out, live);
+  }
 }
 
 // block-wide sums of Q quantities, valid on thread 0 only
-template <int Q>
+template <int Q, int BS = kBlock>
 __device__ __forceinline__ void block_sums_t0(double (&v)[Q]) {
-  __shared__ double sh[kBlock / 64][Q];
+  __shared__ double sh[BS / 64][Q];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
@@ -83,15 +87,46 @@ __device__ __forceinline__ void block_sums_t0(double (&v)[Q]) {
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) v[q] = ((sh[0][q] + sh[1][q]) + sh[2][q]) + sh[3][q];
+    for (int q = 0; q < Q; ++q) {
+      double t = sh[0][q];
+#pragma unroll
+      for (int w = 1; w < BS / 64; ++w) t += sh[w][q];
+      v[q] = t;
+    }
   }
 }
 
+// a workgroup of gfx950 may allocate all 160 KB of LDS (tools/lds_probe.hip); dynamic allocations above 64 KB
+// are opted into per kernel — 144 KB: the kernels also hold a few KB of static LDS, and dynamic + static
+// beyond 160 KB is refused
+template <auto KERNEL>
+inline void allow_big_lds() {
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+      (void)hipGetLastError();       // (not sticky: a launch that really needs more than the default fails by itself)
+    done = true;
+  }
+}
+inline size_t m_vector_lds_bytes(int m) { return (size_t)round_up(m, 32) * sizeof(double); }
+// tall matrices are taken while they stay small in bytes (beyond that the products are bandwidth-bound and
+// the generic kernels are the right tool)
+inline bool small_shape_ok(int64_t m, int64_t n) {
+  return m > 0 && n > 0 && n <= kSmallMax && m <= kSmallMaxM && (m <= kSmallMax || m * n <= (int64_t)1 << 22);
+}
+
 // waves per dot product: <= 16 loads per lane
-inline int pick_waves(int len) { return len > 2048 ? 4 : (len > 1024 ? 2 : 1); }   // (64 * kDotUnroll per wave)
-inline unsigned pick_grid(int n_out, int W) {
-  const int dpb = (kBlock / 64) / W;
+inline int pick_waves(int len, int bs = kBlock) {      // (64 * kDotUnroll elements per wave and round trip)
+  int w = 1;
+  while (w < bs / 64 && len > 64 * kDotUnroll * w) w *= 2;
+  return w;
+}
+inline unsigned pick_grid(int n_out, int W, int bs = kBlock) {
+  const int dpb = (bs / 64) / W;
   return (unsigned)std::max(1, std::min(1024, (n_out + dpb - 1) / dpb));
 }
+// tall matrices (m > kSmallMax): the kernel that does the O(m) work redundantly runs 1024-thread blocks
+constexpr int kTallBlock = 1024;
+inline int m_side_block(int m) { return m > kSmallMax ? kTallBlock : kBlock; }
 
 }  // namespace apx

@@ -26,14 +26,16 @@ namespace apx {
 
 
 // MODE 0: only A' y_cur -> aty_next (pre-loop, :329) ; MODE 2: the loop body
-template <typename T, int MODE, int FK>
-__global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
-  __shared__ double ys[kSmallMax];
+// MREG: m <= 4096, the m-side operands stay in registers between the passes (their loads are in flight during
+// the rule); otherwise they are re-read per pass (L2 hits) and only y+ lives on chip
+template <typename T, int MODE, int FK, bool MREG, int BS>
+__global__ __launch_bounds__(BS) void k_small_pd_b(PdDev d) {
+  extern __shared__ double ys[];              // y (MODE 0) / y+ : m doubles (dynamic: up to 128 KB)
   if constexpr (MODE == 0) {
     const T* __restrict__ Y = (const T*)d.y_cur;
-    for (int i = threadIdx.x; i < d.m; i += kBlock) ys[i] = (double)Y[i];
+    for (int i = threadIdx.x; i < d.m; i += BS) ys[i] = (double)Y[i];
     __syncthreads();
-    small_dots_w<T>(d.w_t, (const T*)d.A, d.ld, d.n, d.m, ys, d.aty_next, true);
+    small_dots_w<T, BS>(d.w_t, (const T*)d.A, d.ld, d.n, d.m, ys, d.aty_next, true);
     return;
   } else {
     __shared__ Ctrl lc;
@@ -51,13 +53,13 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
     double q[5] = {0, 0, 0, 0, 0};
     double fq[2] = {0.0, 0.0};
     [[maybe_unused]] const T* __restrict__ QV = (const T*)d.qvec;
-    const int per_n = (d.n + kBlock - 1) / kBlock;
+    const int per_n = (d.n + BS - 1) / BS;
     for (int k0 = 0; k0 < per_n; k0 += 4) {
       double x4[4], xp4[4], v4[4], a4[4], gb4[4];
       [[maybe_unused]] double t4[4], tp4[4], qv4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int ic = min((int)threadIdx.x + (k0 + u) * kBlock, d.n - 1);
+        const int ic = min((int)threadIdx.x + (k0 + u) * BS, d.n - 1);
         x4[u] = (double)X[ic];
         xp4[u] = (double)XP[ic];
         v4[u] = (double)V[ic];
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + (k0 + u) * kBlock;
+        const int i = threadIdx.x + (k0 + u) * BS;
         if (i < d.n) {
           double gi = 0.0, gp = 0.0;
           if constexpr (FK == APX_F_QUADRATIC) {         // quadratic_pullback() = temp + q  (dual_svm/runme.jl:24-27)
@@ -93,23 +95,27 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
       }
     }
     // ---- m side operands, loaded now so that they are in flight during the rule ----------------
-    double yl[kSmallPer], al[kSmallPer], apl[kSmallPer], hb[kSmallPer];
-    const int per_m = (d.m + kBlock - 1) / kBlock;
+    static_assert(!MREG || BS == kBlock, "the register-resident m side is written for 256-thread blocks");
+    constexpr int MP = MREG ? kSmallPer : 1;
+    [[maybe_unused]] double yl[MP], al[MP], apl[MP], hb[MP];
+    const int per_m = (d.m + BS - 1) / BS;
+    if constexpr (MREG) {
 #pragma unroll
-    for (int k = 0; k < kSmallPer; ++k) {
-      yl[k] = al[k] = apl[k] = hb[k] = 0.0;
-      if (k < per_m) {
-        const int ic = min((int)threadIdx.x + k * kBlock, d.m - 1);
-        yl[k] = (double)Y[ic];
-        al[k] = (double)(T)d.ax_cur[ic];
-        apl[k] = (double)(T)d.ax_prev[ic];
-        hb[k] = shift_at<T>(d.h, ic);                    // Translate(h, -b): the data vector
+      for (int k = 0; k < kSmallPer; ++k) {
+        yl[k] = al[k] = apl[k] = hb[k] = 0.0;
+        if (k < per_m) {
+          const int ic = min((int)threadIdx.x + k * BS, d.m - 1);
+          yl[k] = (double)Y[ic];
+          al[k] = (double)(T)d.ax_cur[ic];
+          apl[k] = (double)(T)d.ax_prev[ic];
+          hb[k] = shift_at<T>(d.h, ic);                    // Translate(h, -b): the data vector
+        }
       }
     }
-    block_sums_t0<5>(q);
+    block_sums_t0<5, BS>(q);
     if constexpr (FK == APX_F_QUADRATIC) {
       __syncthreads();
-      block_sums_t0<2>(fq);
+      block_sums_t0<2, BS>(fq);
     }
     if (threadIdx.x == 0) {
       if (done_in != 0) {
@@ -130,40 +136,85 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
       return;
     }
     const double sigma = lc.sigma, rho = lc.rho;
-    // ---- m side: w, (l2: its norm), y+ = prox_{sigma h*}(w), dual residual ---------------------
-    if (d.h.kind == APX_G_L2) {
-      double z2[1] = {0.0};
+    T* __restrict__ YN = (T*)d.y_next;
+    double r2[2] = {0.0, 0.0};
+    // one element of the dual update: w (:344), y+ = prox_{sigma h*}(w) (:345), dual residual (:347)
+    auto dual_elem = [&](int i, int k, double yv, double a, double ap, double b, double aux) {
+      const double w = yv + sigma * ((1.0 + rho) * a - rho * ap);
+      const T yn = (T)prox_conj_elem_s<T>(d.h, w, sigma, i, aux, b);
+      const double dr = (w - (double)yn) / sigma - a;
+      r2[0] = fma(dr, dr, r2[0]);
+      r2[1] += gval_elem_s<T>(d.h, a, i, b);
+      ys[i] = (double)yn;
+      if ((unsigned)k % gridDim.x == blockIdx.x) YN[i] = yn;       // chunk k is written by one block
+    };
+    if constexpr (MREG) {
+      if (d.h.kind == APX_G_L2) {                // the l2 ball needs ||w/sigma + shift|| first
+        double z2[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < kSmallPer; ++k) {
+          const int i = threadIdx.x + k * BS;
+          if (i < d.m) {
+            const double w = yl[k] + sigma * ((1.0 + rho) * al[k] - rho * apl[k]);
+            const double z = w / sigma + hb[k];
+            z2[0] = fma(z, z, z2[0]);
+          }
+        }
+        block_sums_t0<1, BS>(z2);
+        if (threadIdx.x == 0) lc.h_pre = sqrt(z2[0]);
+        __syncthreads();
+      }
+      const double aux = lc.h_pre;
 #pragma unroll
       for (int k = 0; k < kSmallPer; ++k) {
-        const int i = threadIdx.x + k * kBlock;
-        if (i < d.m) {
-          const double w = yl[k] + sigma * ((1.0 + rho) * al[k] - rho * apl[k]);
-          const double z = w / sigma + hb[k];
-          z2[0] = fma(z, z, z2[0]);
+        const int i = threadIdx.x + k * BS;
+        if (i < d.m) dual_elem(i, k, yl[k], al[k], apl[k], hb[k], aux);
+      }
+    } else {
+      constexpr int MB = 8;       // chunks per batch: 32 loads in flight per lane, 4 batches at m = 8192
+      if (d.h.kind == APX_G_L2) {
+        double z2[1] = {0.0};
+        for (int k0 = 0; k0 < per_m; k0 += MB) {
+          double y4[MB], a4[MB], p4[MB], b4[MB];
+#pragma unroll
+          for (int u = 0; u < MB; ++u) {
+            const int ic = min((int)threadIdx.x + (k0 + u) * BS, d.m - 1);
+            y4[u] = (double)Y[ic];
+            a4[u] = (double)(T)d.ax_cur[ic];
+            p4[u] = (double)(T)d.ax_prev[ic];
+            b4[u] = shift_at<T>(d.h, ic);
+          }
+#pragma unroll
+          for (int u = 0; u < MB; ++u)
+            if ((int)threadIdx.x + (k0 + u) * BS < d.m) {
+              const double w = y4[u] + sigma * ((1.0 + rho) * a4[u] - rho * p4[u]);
+              const double z = w / sigma + b4[u];
+              z2[0] = fma(z, z, z2[0]);
+            }
+        }
+        block_sums_t0<1, BS>(z2);
+        if (threadIdx.x == 0) lc.h_pre = sqrt(z2[0]);
+        __syncthreads();
+      }
+      const double aux = lc.h_pre;
+      for (int k0 = 0; k0 < per_m; k0 += MB) {
+        double y4[MB], a4[MB], p4[MB], b4[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          const int ic = min((int)threadIdx.x + (k0 + u) * BS, d.m - 1);
+          y4[u] = (double)Y[ic];
+          a4[u] = (double)(T)d.ax_cur[ic];
+          p4[u] = (double)(T)d.ax_prev[ic];
+          b4[u] = shift_at<T>(d.h, ic);
+        }
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          const int i = threadIdx.x + (k0 + u) * BS;
+          if (i < d.m) dual_elem(i, k0 + u, y4[u], a4[u], p4[u], b4[u], aux);
         }
       }
-      block_sums_t0<1>(z2);
-      if (threadIdx.x == 0) lc.h_pre = sqrt(z2[0]);
-      __syncthreads();
     }
-    const double aux = lc.h_pre;
-    double r2[2] = {0.0, 0.0};
-    T* __restrict__ YN = (T*)d.y_next;
-#pragma unroll
-    for (int k = 0; k < kSmallPer; ++k) {
-      const int i = threadIdx.x + k * kBlock;
-      if (i < d.m) {
-        const double a = al[k];
-        const double w = yl[k] + sigma * ((1.0 + rho) * a - rho * apl[k]);     // :344
-        const T yn = (T)prox_conj_elem_s<T>(d.h, w, sigma, i, aux, hb[k]);       // :345
-        const double dr = (w - (double)yn) / sigma - a;                          // :347
-        r2[0] = fma(dr, dr, r2[0]);
-        r2[1] += gval_elem_s<T>(d.h, a, i, hb[k]);
-        ys[i] = (double)yn;
-        if ((unsigned)k % gridDim.x == blockIdx.x) YN[i] = yn;     // chunk k is written by one block
-      }
-    }
-    block_sums_t0<2>(r2);
+    block_sums_t0<2, BS>(r2);
     if (threadIdx.x == 0) {
       const double ndr = sqrt(r2[0]);
       lc.ndr2 = ndr * ndr;
@@ -173,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_b(PdDev d) {
     }
     __syncthreads();
     if (lc.done != 0) return;      // converged: (x, y+) is what the reference returns (:355)
-    small_dots_w<T>(d.w_t, (const T*)d.A, d.ld, d.n, d.m, ys, d.aty_next, true);    // :358  At_y = A' * y
+    small_dots_w<T, BS>(d.w_t, (const T*)d.A, d.ld, d.n, d.m, ys, d.aty_next, true);    // :358  At_y = A' * y
   }
 }
 
@@ -243,7 +294,7 @@ bool small_pd_eligible(const apx_problem* p) {
   if (p->f_kind != APX_F_ZERO && p->f_kind != APX_F_QUADRATIC) return false;
   if (p->f_kind == APX_F_QUADRATIC && (p->A_f == nullptr || p->A_f->sparse)) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
-  return p->n <= kSmallMax && p->A_lin->m <= kSmallMax && p->A_lin->m > 0;
+  return small_shape_ok(p->A_lin->m, p->n);
 }
 
 // roles of the rotating buffers in loop iteration k (1-based)
@@ -271,17 +322,28 @@ static PdDev roles(const apx_solver* s, int64_t k) {
   return d;
 }
 
+template <typename T, int MODE, int FK, bool MREG>
+static void launch_pd_b_inst(const PdDev& d, hipStream_t q) {
+  constexpr int BS = MREG ? kBlock : kTallBlock;
+  allow_big_lds<k_small_pd_b<T, MODE, FK, MREG, BS>>();
+  hipLaunchKernelGGL((k_small_pd_b<T, MODE, FK, MREG, BS>), dim3(pick_grid(d.n, d.w_t, BS)), dim3(BS), m_vector_lds_bytes(d.m),
+                     q, d);
+}
+template <typename T, int MODE>
+static void launch_pd_b_t(const PdDev& d, hipStream_t q) {
+  const bool quad = d.fk == APX_F_QUADRATIC, mreg = d.m <= kSmallMax;
+  if (quad) {
+    if (mreg) launch_pd_b_inst<T, MODE, APX_F_QUADRATIC, true>(d, q);
+    else launch_pd_b_inst<T, MODE, APX_F_QUADRATIC, false>(d, q);
+  } else {
+    if (mreg) launch_pd_b_inst<T, MODE, APX_F_ZERO, true>(d, q);
+    else launch_pd_b_inst<T, MODE, APX_F_ZERO, false>(d, q);
+  }
+}
 template <int MODE>
 static void launch_pd_b(const PdDev& d, int32_t dtype, hipStream_t q) {
-  const dim3 grid(pick_grid(d.n, d.w_t));
-  const bool quad = d.fk == APX_F_QUADRATIC;
-  if (dtype == APX_F32) {
-    if (quad) hipLaunchKernelGGL((k_small_pd_b<float, MODE, APX_F_QUADRATIC>), grid, dim3(kBlock), 0, q, d);
-    else hipLaunchKernelGGL((k_small_pd_b<float, MODE, APX_F_ZERO>), grid, dim3(kBlock), 0, q, d);
-  } else {
-    if (quad) hipLaunchKernelGGL((k_small_pd_b<double, MODE, APX_F_QUADRATIC>), grid, dim3(kBlock), 0, q, d);
-    else hipLaunchKernelGGL((k_small_pd_b<double, MODE, APX_F_ZERO>), grid, dim3(kBlock), 0, q, d);
-  }
+  if (dtype == APX_F32) launch_pd_b_t<float, MODE>(d, q);
+  else launch_pd_b_t<double, MODE>(d, q);
 }
 template <int MODE>
 static void launch_pd_a(const PdDev& d, int32_t dtype, hipStream_t q) {
@@ -340,7 +402,7 @@ int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0) {
   d.m = (int32_t)A->m;
   d.n = (int32_t)p->n;
   d.w_n = pick_waves(d.n);
-  d.w_t = pick_waves(d.m);
+  d.w_t = pick_waves(d.m, m_side_block(d.m));
   d.g = p->gd;
   d.h = p->hd;
   d.recs = (apx_record*)s->recs.p;

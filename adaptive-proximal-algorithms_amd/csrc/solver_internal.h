@@ -39,7 +39,8 @@ struct apx_problem {
 namespace apx {
 
 // ---- small.hip: the two-kernel iteration of small dense problems ---------------------------
-constexpr int kSmallMax = 4096;   // largest m and n (one fp64 vector of that length sits in LDS)
+constexpr int kSmallMax = 4096;    // largest n: x sits in static LDS and in per-thread register chunks
+constexpr int kSmallMaxM = 16384;  // largest m: the m-vector (r or y) sits in dynamic LDS (128 of the 160 KB)
 
 struct SmallDev {
   const void* A;    // m_pad x ncols, column-major

@@ -279,3 +279,47 @@ def test_pd_dual_svm_quadratic(apx, generic_ctx):
         for a, b_ in zip(rf, ro):
             assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-8)
             assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10, abs=1e-12)
+
+
+# ---------------------------------------------------------------------------------------
+# tall matrices (4096 < m <= 16384): the m-vector in dynamic LDS, m-side operands re-read per pass —
+# the shapes of the reference's own datasets: cpusmall_scale 8192 x 12(+1), abalone 4177 x 8(+1) (LAD,
+# square-root lasso), mushrooms 8124 x 112, phishing 11055 x 68 (logistic regression, loaded dense)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,hkind", [(8192, 13, "l1"), (8192, 13, "l2"), (4177, 9, "l2"), (16384, 40, "l1")])
+def test_pd_tall_dataset_shapes(apx, generic_ctx, m, n, hkind):
+    lad = P.random_lad(m, n, seed=2, lam=10.0)
+    Ag = apx.DeviceMatrix.from_numpy(lad.A, generic_ctx)
+    x0, y0, K = np.zeros(n), np.zeros(m), 80
+    xo, yo, _ = O.condat_vu(x0, y0, A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K, **_lad_terms(O, lad, hkind))
+    xf, yf, _ = apx.condat_vu(x0, y0, A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K, **_lad_terms(apx, lad, hkind))
+    xg, yg, _ = apx.condat_vu(x0, y0, A=Ag, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=K, ctx=generic_ctx,
+                              **_lad_terms(apx, lad, hkind))
+    assert _rel(xf, xo) <= RTOL and _rel(yf, yo) <= RTOL and _rel(xf, xg) <= RTOL and _rel(yf, yg) <= RTOL
+    xo, yo, _ = O.adaptive_primal_dual(x0, y0, A=lad.A, rule=O.OurRule(t=0.8, norm_A=lad.norm_A), tol=0.0, maxit=50,
+                                       **_lad_terms(O, lad, hkind))
+    xf, yf, _ = apx.adaptive_primal_dual(x0, y0, A=lad.A, rule=apx.OurRule(t=0.8, norm_A=lad.norm_A), tol=0.0, maxit=50,
+                                         **_lad_terms(apx, lad, hkind))
+    assert _rel(xf, xo) <= 1e-9 and _rel(yf, yo) <= 1e-9
+
+
+@pytest.mark.parametrize("m,n,logistic", [(8124, 112, True), (11055, 68, True), (6414, 123, False), (16384, 200, False)])
+def test_proxgrad_tall_dataset_shapes(apx, generic_ctx, m, n, logistic):
+    rng = np.random.default_rng(m + n)
+    if logistic:
+        lr = P.random_logreg(m, n, seed=3, dtype=np.float64)
+        A, b, lam, gam, nx = lr.X, lr.y, lr.lam, lr.gamma0, n + 1
+        fo, mkf = O.LogisticLoss(A, b), apx.LogisticLoss
+    else:
+        A, b, lam, nx = rng.uniform(-1, 1, (m, n)), rng.standard_normal(m), 0.5, n
+        gam = 1.0 / P.opnorm_sq_power(A, iters=30)
+        fo, mkf = O.LinearLeastSquares(A, b), apx.LinearLeastSquares
+    K = 30
+    xo, _ = O.adaptive_proxgrad(np.zeros(nx), f=fo, g=O.NormL1(lam), rule=O.OurRule(gamma=gam), tol=0.0, maxit=K)
+    rf = []
+    xf, _ = apx.adaptive_proxgrad(np.zeros(nx), f=mkf(A, b), g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0,
+                                  maxit=K, record=rf.append)
+    xg, _ = apx.adaptive_proxgrad(np.zeros(nx), f=mkf(apx.DeviceMatrix.from_numpy(A, generic_ctx), b, ctx=generic_ctx),
+                                  g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, ctx=generic_ctx)
+    assert _rel(xf, xo) <= RTOL and _rel(xf, xg) <= RTOL
+    assert len(rf) == K and rf[-1]["objective"] < rf[0]["objective"]

@@ -66,15 +66,16 @@ def main():
             f = apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A_h, ctx), b_h, ctx=ctx)
             for graph in (False, True):
                 run(f"lasso {m}x{n} fp64 {name}", ctx, f, apx.NormL1(1.0), n, gam, graph)
-    X_h, y_h, gam0 = logreg(2000, 120)
-    for name, ctx in (("small.hip", fused), ("generic", generic)):
-        f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(X_h, ctx), y_h, ctx=ctx)
-        for graph in (False, True):
-            run(f"logreg 2000x120 fp32 {name}", ctx, f, apx.NormL1(0.01), 121, gam0, graph, dtype=np.float32)
+    for lm, ln in ((2000, 120), (8124, 112)):              # (mushrooms is 8124 x 112)
+        X_h, y_h, gam0 = logreg(lm, ln)
+        for name, ctx in (("small.hip", fused), ("generic", generic)):
+            f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(X_h, ctx), y_h, ctx=ctx)
+            for graph in (False, True):
+                run(f"logreg {lm}x{ln} fp32 {name}", ctx, f, apx.NormL1(0.01), ln + 1, gam0, graph, dtype=np.float32)
 
 
     # primal-dual (LAD shapes of experiments/least_absolute_deviation: housing is 506 x 14)
-    for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1")):
+    for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1"), (4177, 9, "l1"), (8192, 13, "l2")):
         A_h, y_h, nrm = lad(m, n)
         for name, ctx in (("small_pd.hip", fused), ("generic", generic)):
             A = apx.DeviceMatrix.from_numpy(A_h, ctx)
