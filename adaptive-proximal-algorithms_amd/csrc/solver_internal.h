@@ -40,7 +40,8 @@ namespace apx {
 
 // ---- small.hip: the two-kernel iteration of small dense problems ---------------------------
 constexpr int kSmallMax = 4096;    // largest n: x sits in static LDS and in per-thread register chunks
-constexpr int kSmallMaxM = 16384;  // largest m: the m-vector (r or y) sits in dynamic LDS (128 of the 160 KB)
+constexpr int kSmallMaxM = 8192;   // largest m: the m-vector (r or y) sits in dynamic LDS; measured break-even with the
+                                   // generic kernels (beyond it the redundant O(m) elementwise work costs more than it saves)
 
 struct SmallDev {
   const void* A;    // m_pad x ncols, column-major

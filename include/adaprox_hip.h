@@ -206,7 +206,7 @@ int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_varia
  * what reference BLAS dgemv does too (`IF (X(JX).NE.ZERO)`), and what a lasso iterate invites
  * after the soft-threshold.  Same result up to summation order; not used by bench.py's headline. */
 int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
-/* Default ON: a dense problem with n <= 4096, m <= 4096 (or m <= 16384 with m*n <= 4 M elements) and no
+/* Default ON: a dense problem with n <= 4096, m <= 4096 (or m <= 8192 with m*n <= 4 M elements) and no
  * all-reduce hook — the sizes of the reference's
  * own experiments (experiments/lasso/runme.jl:191-195, least_absolute_deviation/runme.jl:39-62) —
  * runs each iteration of src/AdaProx.jl:334-362 as two kernels in which every workgroup redundantly

@@ -282,7 +282,8 @@ def test_pd_dual_svm_quadratic(apx, generic_ctx):
 
 
 # ---------------------------------------------------------------------------------------
-# tall matrices (4096 < m <= 16384): the m-vector in dynamic LDS, m-side operands re-read per pass —
+# tall matrices (4096 < m <= 8192; the larger shapes below fall back to the generic kernels): the m-vector in
+# dynamic LDS, m-side operands re-read per pass —
 # the shapes of the reference's own datasets: cpusmall_scale 8192 x 12(+1), abalone 4177 x 8(+1) (LAD,
 # square-root lasso), mushrooms 8124 x 112, phishing 11055 x 68 (logistic regression, loaded dense)
 # ---------------------------------------------------------------------------------------
