@@ -416,7 +416,8 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   // the library's choice is eager; replay stays available on request.
   const bool small = small_eligible(p);
   const bool want_graph = opts != nullptr && opts->use_graph == 1;
-  const bool small_pd = !want_graph && small_pd_eligible(p);   // (its buffer roles rotate on the host: no replay)
+  const bool skinny = skinny_pd_eligible(p);                   // tall, skinny A: row kernel + closing kernel
+  const bool small_pd = !skinny && !want_graph && small_pd_eligible(p);   // (its buffer roles rotate on the host: no replay)
   if (want_graph && (p->f_kind == APX_F_CALLBACK || p->allreduce != nullptr))
     return fail(APX_ERR_UNSUPPORTED,
                 "hipGraph replay needs a device-only iteration: not with a host-callback f or an all-reduce hook");
@@ -452,6 +453,8 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
 
   if (small) {
     APX_TRY(small_setup(s.get()));   // small.hip: pre-loop and iteration as fused kernels
+  } else if (skinny) {
+    APX_TRY(skinny_pd_setup(s.get(), x0, y0));
   } else if (small_pd) {
     APX_TRY(small_pd_setup(s.get(), x0, y0));
   } else {
@@ -479,6 +482,7 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
 static int32_t enqueue_iteration(apx_solver* s) {
   if (s->small != nullptr) return small_enqueue(s);
   if (s->small_pd != nullptr) return small_pd_enqueue(s);
+  if (s->skinny != nullptr) return skinny_pd_enqueue(s);
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   const bool lin = p->A_lin != nullptr;
@@ -582,6 +586,10 @@ int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* r
   const void* x_src = (s->small != nullptr && c.done == 0) ? s->small->xn.p : s->x.p;
   const void* y_src = s->y.p;
   if (s->small_pd != nullptr) small_pd_result_ptrs(s, c, &x_src, &y_src);
+  if (s->skinny != nullptr) {      // x: the tested iterate on convergence, else the next one ; y updated in place
+    x_src = s->skinny->x.p;
+    y_src = s->skinny->y.p;
+  }
   if (x_out != nullptr) APX_TRY(d2h(ctx, x_out, x_src, (size_t)p->n * p->es()));
   if (y_out != nullptr && lin) APX_TRY(d2h(ctx, y_out, y_src, (size_t)p->m * p->es()));
   int64_t nrec = 0;

@@ -100,6 +100,31 @@ struct SmallPdState {
   PdDev base{};                       // the loop-invariant fields
 };
 
+// ---- skinny_pd.hip: primal-dual loop for tall, skinny dense A (n <= 120, f = Zero) --------------
+constexpr int kSkinnyMaxN = 120;
+
+struct SkinnyDev {
+  const void* A;          // m_pad x n, column-major
+  int64_t ld;
+  int32_t m, n, npow, _pad;
+  int64_t ldpart;
+  void *X, *XP, *V;       // x, x_prev, v  (n, written by k_skinny_close only)
+  double* aty;            // A'y (n)
+  void* Y;                // y (m), updated in place by the row kernel
+  double *ax, *axn, *wbuf;   // A_x of the previous iteration (m) ; l2 scratch: A_x and w of this one
+  double* part;           // [blocks][ldpart]: n partials of A'y+, ||dual_res||^2, h(A_x), ||w/sigma + shift||^2
+  Ctrl *c, *cs;           // control block ; staging written by block 0 of the row kernel
+  ProxDev g, h;
+  apx_record* recs;
+  int64_t rec_cap;
+};
+
+struct SkinnyState {
+  DBuf x, xp, v, aty, y, ax, axn, wbuf, part, cs;
+  SkinnyDev dev{};
+  int B = 0;              // row blocks
+};
+
 }  // namespace apx
 
 struct apx_solver {
@@ -117,9 +142,11 @@ struct apx_solver {
   hipGraphExec_t graph_exec = nullptr;
   apx::SmallState* small = nullptr;   // non-null: the iteration runs as small.hip's two kernels
   apx::SmallPdState* small_pd = nullptr;   // non-null: ... as small_pd.hip's two kernels
+  apx::SkinnyState* skinny = nullptr;      // non-null: ... as skinny_pd.hip's row + closing kernels
   ~apx_solver() {
     delete small;
     delete small_pd;
+    delete skinny;
   }
 };
 
@@ -146,6 +173,10 @@ bool small_pd_eligible(const apx_problem* p);
 int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0);
 int32_t small_pd_enqueue(apx_solver* s);
 const void* small_pd_ctrl(const apx_solver* s);
+// skinny_pd.hip
+bool skinny_pd_eligible(const apx_problem* p);
+int32_t skinny_pd_setup(apx_solver* s, const void* x0, const void* y0);
+int32_t skinny_pd_enqueue(apx_solver* s);
 void small_pd_result_ptrs(const apx_solver* s, const Ctrl& c, const void** x, const void** y);
 
 }  // namespace apx

@@ -211,7 +211,8 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  * own experiments (experiments/lasso/runme.jl:191-195, least_absolute_deviation/runme.jl:39-62) —
  * runs each iteration of src/AdaProx.jl:334-362 as two kernels in which every workgroup redundantly
  * does the O(m + n) work: proximal gradient with LinearLeastSquares / LogisticLoss (csrc/small.hip)
- * and the primal-dual loop with f = Zero or Quadratic (csrc/small_pd.hip).  Same arithmetic, different summation
+ * and the primal-dual loop with f = Zero or Quadratic (csrc/small_pd.hip; tall, skinny A with n <= 120:
+ * csrc/skinny_pd.hip, a thread per row and a closing block).  Same arithmetic, different summation
  * order than the generic path; 0 switches back to the generic kernels. */
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
 int32_t apx_gemv_variant_count(int32_t transposed);

@@ -324,3 +324,72 @@ def test_proxgrad_tall_dataset_shapes(apx, generic_ctx, m, n, logistic):
                                   g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, ctx=generic_ctx)
     assert _rel(xf, xo) <= RTOL and _rel(xf, xg) <= RTOL
     assert len(rf) == K and rf[-1]["objective"] < rf[0]["objective"]
+
+
+# ---------------------------------------------------------------------------------------
+# tall, skinny A (csrc/skinny_pd.hip: n <= 120, m >= 4 n): one thread per row, a closing block
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,hkind", [(1024, 14, "l1"), (3072, 14, "l2"), (1025, 1, "l1"), (3500, 120, "l2"), (40000, 30, "l1"),
+                                       (262144, 6, "l2"), (9000, 120, "l1")])
+def test_skinny_pd_shapes(apx, generic_ctx, m, n, hkind):
+    lad = P.random_lad(m, n, seed=4, lam=5.0)
+    Ag = apx.DeviceMatrix.from_numpy(lad.A, generic_ctx)
+    x0, y0, K = np.zeros(n), np.zeros(m), 60
+    rf, rg = [], []
+    xf, yf, itf = apx.adaptive_primal_dual(x0, y0, A=lad.A, rule=apx.OurRule(t=1.0, norm_A=lad.norm_A), tol=0.0, maxit=K,
+                                           record=rf.append, **_lad_terms(apx, lad, hkind))
+    xg, yg, itg = apx.adaptive_primal_dual(x0, y0, A=Ag, rule=apx.OurRule(t=1.0, norm_A=lad.norm_A), tol=0.0, maxit=K,
+                                           ctx=generic_ctx, record=rg.append, **_lad_terms(apx, lad, hkind))
+    assert itf == itg == K and len(rf) == K
+    assert _rel(xf, xg) <= 1e-9 and _rel(yf, yg) <= 1e-9
+    for a, b_ in zip(rf, rg):
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-8) and a["sigma"] == pytest.approx(b_["sigma"], rel=1e-8)
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-6, abs=1e-10)
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-9)
+    if m <= 50000:
+        xo, yo, _ = O.adaptive_primal_dual(x0, y0, A=lad.A, rule=O.OurRule(t=1.0, norm_A=lad.norm_A), tol=0.0, maxit=K,
+                                           **_lad_terms(O, lad, hkind))
+        assert _rel(xf, xo) <= 1e-9 and _rel(yf, yo) <= 1e-9
+
+
+def test_skinny_pd_graph_stepping_fp32_and_termination(apx):
+    lad = P.random_lad(3200, 11, seed=6, lam=5.0)
+    terms = _lad_terms(apx, lad, "l2")
+    rule = apx.OurRule(t=1.0, norm_A=lad.norm_A)
+    x1, y1, _ = apx.adaptive_primal_dual(np.zeros(11), np.zeros(3200), A=lad.A, rule=rule, tol=0.0, maxit=70, **terms)
+    x2, y2, _ = apx.adaptive_primal_dual(np.zeros(11), np.zeros(3200), A=lad.A, rule=rule, tol=0.0, maxit=70,
+                                         use_graph=True, **terms)
+    assert np.array_equal(x1, x2) and np.array_equal(y1, y2)            # fixed pointers: replayable, identical kernels
+    s = apx.Solver(np.zeros(11), np.zeros(3200), A=lad.A, rule=rule, tol=0.0, **terms)
+    for k in (1, 2, 30, 37):
+        s.step(k)
+        s.result()
+    xs, ys, res = s.result()
+    s.close()
+    assert res.numit == 70 and np.array_equal(xs, x1) and np.array_equal(ys, y1)
+    # termination: a tolerance that the residual first reaches at a known iteration k* of the run above;
+    # the run must stop there whatever the polling period and return x_k* with the already updated y
+    t1 = _lad_terms(apx, lad, "l1")
+    recs = []
+    apx.adaptive_primal_dual(np.zeros(11), np.zeros(3200), A=lad.A, rule=rule, tol=0.0, maxit=300, record=recs.append, **t1)
+    res_k = [r["norm_res"] for r in recs]
+    tol = res_k[249] * (1 + 1e-9)
+    kstar = 1 + next(k for k, v in enumerate(res_k) if v <= tol)
+    s = apx.Solver(np.zeros(11), np.zeros(3200), A=lad.A, rule=rule, tol=0.0, **t1)
+    s.step(kstar - 1)
+    x_prev_iter, _, _ = s.result()            # x_k* (the iterate that iteration k* tests)
+    s.step(1)
+    _, y_after, _ = s.result()                # y after the dual update of iteration k*
+    s.close()
+    for poll in (1, 64):
+        xf, yf, itf = apx.adaptive_primal_dual(np.zeros(11), np.zeros(3200), A=lad.A, rule=rule, tol=tol, maxit=5000,
+                                               poll_every=poll, **t1)
+        assert itf == kstar <= 250 and np.array_equal(xf, x_prev_iter) and np.array_equal(yf, y_after)
+    # fp32
+    A32, y32 = lad.A.astype(np.float32), lad.y.astype(np.float32)
+    xf, yf, _ = apx.condat_vu(np.zeros(11, dtype=np.float32), np.zeros(3200, dtype=np.float32), A=A32, Lf=0.0,
+                              norm_A=lad.norm_A, tol=0.0, maxit=40, f=apx.Zero(), g=apx.NormL1(lad.lam),
+                              h=apx.Translate(apx.NormL1(1.0), -y32))
+    xo, yo, _ = O.condat_vu(np.zeros(11), np.zeros(3200), A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=40,
+                            **_lad_terms(O, lad, "l1"))
+    assert xf.dtype == np.float32 and _rel(xf, xo) <= 5e-3 and _rel(yf, yo) <= 5e-3

@@ -77,10 +77,10 @@ def main():
     # primal-dual (LAD shapes of experiments/least_absolute_deviation: housing is 506 x 14)
     for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1"), (4177, 9, "l1"), (8192, 13, "l2")):
         A_h, y_h, nrm = lad(m, n)
-        for name, ctx in (("small_pd.hip", fused), ("generic", generic)):
+        for name, ctx in (("small_pd.hip / skinny_pd.hip", fused), ("generic", generic)):
             A = apx.DeviceMatrix.from_numpy(A_h, ctx)
             h = apx.Translate(apx.NormL1(1.0) if hk == "l1" else apx.NormL2(1.0), -y_h)
-            for graph in ((False,) if name == "small_pd.hip" else (False, True)):
+            for graph in ((False,) if name != "generic" else (False, True)):
                 run(f"LAD-{hk} {m}x{n} fp64 adaptive PD {name}", ctx, apx.Zero(), apx.NormL1(5.0), n, None, graph,
                     pd=(A, h, m, apx.OurRule(t=1.0, norm_A=nrm)))
     # dual SVM (experiments/dual_svm/runme.jl:47-76): f = Quadratic(Q, q), g = IndBox, h = IndZero, A = y'
