@@ -707,6 +707,8 @@ int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch
 
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipSetDevice(ctx->device));
+  // tall, skinny dense A with f = Zero (the reference's LAD / square-root-lasso data): device-resident linesearch
+  if (skinny_ls_eligible(p)) return skinny_ls_run(p, prm, gamma, x0, y0, tol, maxit, opts, x_out, y_out, res);
   const size_t es = p->es();
   const size_t nb = (size_t)p->n_pad * es, mb = (size_t)p->m_pad * es;
   DBuf bx, bxprev, bgprev, bv, baty, baty2, by, by2, bax, baxprev;

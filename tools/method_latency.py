@@ -52,7 +52,15 @@ def main():
     x0, y0 = np.zeros(n), np.zeros(m)
     timed("LAD 506x14  Condat-Vu", lambda k: apx.condat_vu(x0, y0, Lf=0.0, norm_A=nrm, maxit=k, **t), K)
     timed("LAD 506x14  AdaPDM", lambda k: apx.adaptive_primal_dual(x0, y0, rule=apx.OurRule(t=1.0, norm_A=nrm), maxit=k, **t), K)
-    timed("LAD 506x14  AdaPDM+", lambda k: apx.adaptive_linesearch_primal_dual(x0, y0, gamma=1.0 / nrm, maxit=k, **t), K)
+    timed("LAD 506x14  AdaPDM+", lambda k: apx.adaptive_linesearch_primal_dual(x0, y0, eta=nrm, maxit=k, **t), K)
+    for mm, nn in ((4177, 9), (8192, 13)):
+        A2 = np.hstack([rng.uniform(-1, 1, (mm, nn - 1)), np.ones((mm, 1))])
+        y2 = A2 @ rng.standard_normal(nn) + rng.laplace(size=mm)
+        t2 = dict(f=apx.Zero(), g=apx.NormL1(10.0), h=apx.Translate(apx.NormL1(1.0), -y2), A=apx.DeviceMatrix.from_numpy(A2),
+                  tol=0.0)
+        n2 = float(np.linalg.norm(A2))
+        timed(f"LAD {mm}x{nn}  AdaPDM+", lambda k: apx.adaptive_linesearch_primal_dual(np.zeros(nn), np.zeros(mm), eta=n2,
+                                                                                        maxit=k, **t2), K)
     timed("LAD 506x14  Malitsky-Pock", lambda k: apx.malitsky_pock(x0, y0, sigma=1.0 / nrm, maxit=k, **t), K)
 
 
