@@ -177,6 +177,10 @@ const void* small_pd_ctrl(const apx_solver* s);
 bool skinny_pd_eligible(const apx_problem* p);
 int32_t skinny_pd_setup(apx_solver* s, const void* x0, const void* y0);
 int32_t skinny_pd_enqueue(apx_solver* s);
+// skinny_mp.hip: Malitsky-Pock with its linesearch as a device-side state machine
+bool skinny_mp_eligible(const apx_problem* p);
+int32_t skinny_mp_run(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol, int64_t maxit,
+                      const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res);
 // skinny_ls.hip: AdaPDM+ with the linesearch as a device-side state machine
 bool skinny_ls_eligible(const apx_problem* p);
 int32_t skinny_ls_run(apx_problem* p, const apx_linesearch_params* prm, double gamma, const void* x0, const void* y0,

@@ -129,3 +129,43 @@ def test_malitsky_pock_with_smooth_f(apx):
                                 h=apx.Translate(apx.NormL1(1.0), -yv), A=A, **kw)
     assert _rel_inf(x, xo) <= 1e-9 and _rel_inf(y, yo) <= 1e-9
     assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
+
+
+# ---------------------------------------------------------------------------------------
+# tall, skinny A: Malitsky-Pock with the device-resident linesearch of csrc/skinny_mp.hip
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,hkind,t", [(506, 14, "l1", 0.1), (506, 14, "l1", 10.0), (506, 14, "l2", 1.0), (4177, 9, "l1", 1.0),
+                                         (8192, 13, "l2", 0.5), (300, 1, "l1", 1.0), (1000, 120, "l2", 2.0)])
+def test_malitsky_pock_skinny_vs_oracle(apx, m, n, hkind, t):
+    prob = P.random_lad(m, n, seed=7, lam=10.0 if hkind == "l1" else 0.05)
+    mkh = (lambda M: M.Translate(M.NormL1(1.0), -prob.y)) if hkind == "l1" else (lambda M: M.Translate(M.NormL2(1.0), -prob.y))
+    K = 60      # (a linesearch decision is a comparison of two nearly equal numbers once the iterates settle)
+    oA, dA = O.Counting(prob.A), apx.Counting(apx.DeviceMatrix.from_numpy(prob.A))
+    og, dg = O.Counting(O.NormL1(prob.lam)), apx.Counting(apx.NormL1(prob.lam))
+    orecs, drecs = [], []
+    xo, yo, ito = O.malitsky_pock(np.zeros(n), np.zeros(m), f=O.Zero(), g=og, h=mkh(O), A=oA, sigma=1.0, t=t, tol=0.0,
+                                  maxit=K, record=orecs.append)
+    x, y, it = apx.malitsky_pock(np.zeros(n), np.zeros(m), f=apx.Zero(), g=dg, h=mkh(apx), A=dA, sigma=1.0, t=t, tol=0.0,
+                                 maxit=K, record=drecs.append)
+    assert it == ito == K and len(drecs) == K
+    assert _rel_inf(x, xo) <= 1e-9 and _rel_inf(y, yo) <= 1e-9
+    _compare(orecs, drecs, ("gamma", "sigma", "norm_res", "objective"), 1e-7)
+    for ro, rd in zip(orecs, drecs):
+        assert (rd["A_evals"], rd["At_evals"], rd["prox_g_evals"]) == (ro["A_evals"], ro["At_evals"], ro["prox_g_evals"])
+    assert (dA.mul_count, dA.amul_count, dg.prox_count) == (oA.mul_count, oA.amul_count, og.prox_count)
+
+
+def test_malitsky_pock_skinny_termination_and_maxit(apx):
+    prob = P.random_lad(2000, 10, seed=9, lam=5.0)
+    terms = lambda M: dict(f=M.Zero(), g=M.NormL1(prob.lam), h=M.Translate(M.NormL1(1.0), -prob.y))   # noqa: E731
+    orecs = []
+    O.malitsky_pock(np.zeros(10), np.zeros(2000), A=prob.A, sigma=1.0, t=1.0, tol=0.0, maxit=150, record=orecs.append,
+                    **terms(O))
+    tol = orecs[99]["norm_res"] * (1 + 1e-7)
+    xo, yo, ito = O.malitsky_pock(np.zeros(10), np.zeros(2000), A=prob.A, sigma=1.0, t=1.0, tol=tol, maxit=5000, **terms(O))
+    x, y, it = apx.malitsky_pock(np.zeros(10), np.zeros(2000), A=prob.A, sigma=1.0, t=1.0, tol=tol, maxit=5000, **terms(apx))
+    assert it == ito <= 100 and _rel_inf(x, xo) <= 1e-9 and _rel_inf(y, yo) <= 1e-9
+    for K in (0, 1, 49, 97):
+        xo, yo, _ = O.malitsky_pock(np.zeros(10), np.zeros(2000), A=prob.A, sigma=1.0, t=0.3, tol=0.0, maxit=K, **terms(O))
+        x, y, it = apx.malitsky_pock(np.zeros(10), np.zeros(2000), A=prob.A, sigma=1.0, t=0.3, tol=0.0, maxit=K, **terms(apx))
+        assert it == K and _rel_inf(x, xo) <= 1e-8 and (K == 0 or _rel_inf(y, yo) <= 1e-8)
