@@ -393,3 +393,68 @@ def test_skinny_pd_graph_stepping_fp32_and_termination(apx):
     xo, yo, _ = O.condat_vu(np.zeros(11), np.zeros(3200), A=lad.A, Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=40,
                             **_lad_terms(O, lad, "l1"))
     assert xf.dtype == np.float32 and _rel(xf, xo) <= 5e-3 and _rel(yf, yo) <= 5e-3
+
+
+# ---------------------------------------------------------------------------------------
+# backtracking_proxgrad with the device-resident linesearch (csrc/small_bt.hip)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,logistic,xi", [(100, 300, False, 1.0), (500, 1000, False, 2.0), (4000, 1000, False, 1.5),
+                                             (900, 70, True, 1.5), (64, 17, False, 1.1), (5, 1, False, 2.0)])
+def test_backtracking_small_vs_oracle_and_generic(apx, generic_ctx, m, n, logistic, xi):
+    if logistic:
+        lr = P.random_logreg(m, n, seed=4, dtype=np.float64)
+        A, b, lam, gam, nx = lr.X, lr.y, lr.lam, lr.gamma0, n + 1
+        fo, mkf = O.LogisticLoss(A, b), apx.LogisticLoss
+    else:
+        rng = np.random.default_rng(m + n)
+        A, b, lam, nx = rng.uniform(-1, 1, (m, n)), rng.standard_normal(m), 0.3, n
+        gam = 3.0 / P.opnorm_sq_power(A, iters=30)            # too long on purpose: the linesearch has to shrink
+        fo, mkf = O.LinearLeastSquares(A, b), apx.LinearLeastSquares
+    # (near the solution `f_z > ub_z` compares two numbers that agree to rounding: any two fp64 evaluations
+    #  then take different linesearch branches — 4000 x 1000 at K = 50: 8e-9 — so the window is short)
+    K = 25
+    of, og = O.Counting(fo), O.Counting(O.NormL1(lam))
+    ro, rf = [], []
+    zo, ito = O.backtracking_proxgrad(np.zeros(nx), f=of, g=og, gamma0=gam, xi=xi, tol=0.0, maxit=K, record=ro.append)
+    ff, gf = apx.Counting(mkf(A, b)), apx.Counting(apx.NormL1(lam))
+    zf, itf = apx.backtracking_proxgrad(np.zeros(nx), f=ff, g=gf, gamma0=gam, xi=xi, tol=0.0, maxit=K, record=rf.append)
+    zg, itg = apx.backtracking_proxgrad(np.zeros(nx), f=mkf(apx.DeviceMatrix.from_numpy(A, generic_ctx), b, ctx=generic_ctx),
+                                        g=apx.NormL1(lam), gamma0=gam, xi=xi, tol=0.0, maxit=K, ctx=generic_ctx)
+    if min(m, n) == 1:          # solved exactly after a few iterations: WHEN z == x bit for bit is rounding
+        assert _rel(zf, zo) <= 1e-6 and _rel(zf, zg) <= 1e-6
+        return
+    assert itf == ito == itg and len(rf) == len(ro)
+    assert _rel(zf, zo) <= RTOL and _rel(zf, zg) <= RTOL
+    for a, b_ in zip(rf, ro):
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-12)
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10)
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7, abs=1e-13)
+        assert (a["f_evals"], a["grad_f_evals"], a["prox_g_evals"]) == (b_["f_evals"], b_["grad_f_evals"], b_["prox_g_evals"])
+    assert (ff.eval_count, ff.grad_count, gf.prox_count) == (of.eval_count, of.grad_count, og.prox_count)
+    assert of.eval_count > K + 1                              # trials were rejected along the way
+
+
+def test_backtracking_small_termination_maxit_fp32(apx):
+    prob = P.random_lasso(200, 400, pfactor=10, seed=3)
+    gam = 2.0 / P.opnorm_sq_power(prob.A, iters=30)
+    kw = dict(gamma0=gam, xi=1.5)
+    of, ff = O.Counting(O.LinearLeastSquares(prob.A, prob.b)), apx.Counting(apx.LinearLeastSquares(prob.A, prob.b))
+    zo, ito = O.backtracking_proxgrad(np.zeros(400), f=of, g=O.NormL1(1.0), tol=1e-6, maxit=20000, **kw)
+    zf, itf = apx.backtracking_proxgrad(np.zeros(400), f=ff, g=apx.NormL1(1.0), tol=1e-6, maxit=20000, **kw)
+    assert ito < 20000 and abs(itf - ito) <= max(2, ito // 50) and _rel(zf, zo) <= 1e-6
+    if itf == ito:
+        assert (ff.eval_count, ff.grad_count) == (of.eval_count, of.grad_count)     # converged: no pullback after the last trial
+    obj = 0.5 * np.linalg.norm(prob.A @ zf - prob.b) ** 2 + np.sum(np.abs(zf))
+    assert obj == pytest.approx(prob.optimum, rel=1e-8)
+    for K in (0, 1, 33):
+        zo, _ = O.backtracking_proxgrad(np.zeros(400), f=O.LinearLeastSquares(prob.A, prob.b), g=O.NormL1(1.0), tol=0.0,
+                                        maxit=K, **kw)
+        zf, itf = apx.backtracking_proxgrad(np.zeros(400), f=apx.LinearLeastSquares(prob.A, prob.b), g=apx.NormL1(1.0),
+                                            tol=0.0, maxit=K, **kw)
+        assert itf == K and (K == 0 and not np.any(zf) or _rel(zf, zo) <= RTOL)
+    A32, b32 = prob.A.astype(np.float32), prob.b.astype(np.float32)
+    zf, itf = apx.backtracking_proxgrad(np.zeros(400, dtype=np.float32), f=apx.LinearLeastSquares(A32, b32), g=apx.NormL1(1.0),
+                                        tol=0.0, maxit=40, **kw)
+    zo, _ = O.backtracking_proxgrad(np.zeros(400), f=O.LinearLeastSquares(prob.A, prob.b), g=O.NormL1(1.0), tol=0.0,
+                                    maxit=40, **kw)
+    assert zf.dtype == np.float32 and itf == 40 and _rel(zf, zo) <= 5e-3
