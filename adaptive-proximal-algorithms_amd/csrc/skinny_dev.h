@@ -1,0 +1,85 @@
+// skinny_dev.h — pieces shared by the tall-skinny kernels (skinny_pd.hip, skinny_ls.hip, skinny_mp.hip): a thread
+// per row of A, block partials of A'y and of a few scalars, and their fixed-order sum in the one-block closing kernels.
+#pragma once
+#include "small_dev.h"
+
+namespace apx {
+
+constexpr int kSkinnyExtra = 4;                       // scalar partial columns behind the n columns of A'y
+using SkinnyRed = double[kSkinnyMaxN + kSkinnyExtra];
+
+// <A[i,:], x> for row ic, rounded to T like every stored A_x: neighbouring lanes hold neighbouring rows, so each
+// column load is coalesced; 8 columns in flight
+template <typename T>
+__device__ __forceinline__ double skinny_row_dot(const T* __restrict__ A, int64_t ld, int ic, int n,
+                                                 const double* __restrict__ xs) {
+  const T* __restrict__ row = A + ic;
+  double a = 0.0;
+  int j = 0;
+  for (; j + 8 <= n; j += 8) {
+    T av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = row[(int64_t)(j + u) * ld];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a = fma((double)av[u], xs[j + u], a);
+  }
+  for (; j < n; ++j) a = fma((double)row[(int64_t)j * ld], xs[j], a);
+  return (double)(T)a;
+}
+
+// Block totals of A[i,j] * yn over the block's rows (j < n, when with_aty) and of the kSkinnyExtra scalars ex[]:
+// wave shuffles, one LDS row per wave, a barrier, then thread c < n + kSkinnyExtra returns the total of column c
+// (waves summed in order).  Threads of rows beyond m pass yn = 0 and zeros.
+template <typename T>
+__device__ __forceinline__ double skinny_block_partials(const T* __restrict__ A, int64_t ld, int ic, int n, double yn,
+                                                        bool with_aty, const double (&ex)[kSkinnyExtra],
+                                                        SkinnyRed* wred) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (with_aty) {
+    const T* __restrict__ row = A + ic;
+    for (int j = 0; j < n; ++j) {
+      const double p = wave_sum((double)row[(int64_t)j * ld] * yn);
+      if (lane == 0) wred[wv][j] = p;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < kSkinnyExtra; ++e) {
+    const double p = wave_sum(ex[e]);
+    if (lane == 0) wred[wv][n + e] = p;
+  }
+  __syncthreads();
+  double s = 0.0;
+  if (tid < n + kSkinnyExtra) {
+    s = wred[0][tid];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) s += wred[w][tid];
+  }
+  return s;
+}
+
+// Column c of the block partials summed over the B blocks in a fixed order by all 256 threads: thread (c, s) takes
+// blocks s, s + S, ... (S = 256 / npow <= 16), then thread c < nc adds the S sub-sums in order and returns the total.
+__device__ __forceinline__ double skinny_colsum(const double* __restrict__ part, int64_t ldpart, int nc, int npow, int B,
+                                                SkinnyRed* red) {
+  const int tid = threadIdx.x;
+  const int S = kBlock / npow;
+  const int c = tid % npow, s = tid / npow;
+  if (c < nc) {
+    double acc = 0.0;
+    for (int b = s; b < B; b += S) acc += part[(int64_t)b * ldpart + c];
+    red[s][c] = acc;
+  }
+  __syncthreads();
+  double tot = 0.0;
+  if (tid < nc)
+    for (int k = 0; k < S; ++k) tot += red[k][tid];
+  return tot;
+}
+
+inline int skinny_npow(int n) {
+  int npow = 16;
+  while (npow < n + kSkinnyExtra) npow *= 2;
+  return npow;
+}
+
+}  // namespace apx

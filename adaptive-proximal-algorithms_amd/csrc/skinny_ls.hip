@@ -20,7 +20,7 @@
 #include <cstring>
 #include <memory>
 
-#include "small_dev.h"
+#include "skinny_dev.h"
 
 namespace apx {
 
@@ -67,7 +67,6 @@ __device__ __forceinline__ double ls_sqrt(double v, int32_t* fl) {
   return sqrt(v);
 }
 
-constexpr int kLsExtra = 4;   // partial columns behind the n of A'y_next
 
 // PHASE 0: pre-loop (:494-496): A x0 -> axc, block partials of A'y0
 // PHASE 1: a whole trial (elementwise conjugate prox)
@@ -77,8 +76,8 @@ template <typename T, int PHASE>
 __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
   __shared__ double xs[kSkinnyMaxN];
   __shared__ LsCtrl lc;
-  __shared__ double wred[kBlock / 64][kSkinnyMaxN + kLsExtra];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ SkinnyRed wred[kBlock / 64];
+  const int tid = threadIdx.x;
   const T* __restrict__ A = (const T*)d.A;
   const int i = blockIdx.x * kBlock + tid;
   const bool row_ok = i < d.m;
@@ -149,26 +148,14 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
   // ---- this thread's row ------------------------------------------------------------------------
   double a = 0.0, yv = 0.0, yn = 0.0, sdr = 0.0, shv = 0.0, sz = 0.0, sdy = 0.0;
   if constexpr (PHASE == 0) {
-    const T* __restrict__ row = A + ic;
-    for (int j = 0; j < d.n; ++j) a = fma((double)row[(int64_t)j * d.ld], xs[j], a);
-    a = (double)(T)a;
+    a = skinny_row_dot<T>(A, d.ld, ic, d.n, xs);
     if (row_ok) d.axc[i] = a;
     yn = row_ok ? (double)Y[ic] : 0.0;
   } else {
     if constexpr (PHASE != 3) {
       if (lc.ycommit != 0 && row_ok) Y[i] = YT[i];          // the y accepted by the previous tick
       if (lc.phase == 0) {                                   // first trial: A_x_prev = A_x (:546), new A_x (:502)
-        const T* __restrict__ row = A + ic;
-        int j = 0;
-        for (; j + 8 <= d.n; j += 8) {
-          T av[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) av[u] = row[(int64_t)(j + u) * d.ld];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) a = fma((double)av[u], xs[j + u], a);
-        }
-        for (; j < d.n; ++j) a = fma((double)row[(int64_t)j * d.ld], xs[j], a);
-        a = (double)(T)a;
+        a = skinny_row_dot<T>(A, d.ld, ic, d.n, xs);
         if (row_ok) {
           d.axp[i] = d.axc[i];
           d.axc[i] = a;
@@ -205,48 +192,13 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
     }
   }
 
-  // ---- block partials --------------------------------------------------------------------------------
-  if constexpr (PHASE != 2) {
-    const T* __restrict__ row = A + ic;
-    for (int j = 0; j < d.n; ++j) {
-      const double p = wave_sum((double)row[(int64_t)j * d.ld] * yn);
-      if (lane == 0) wred[wv][j] = p;
-    }
-  }
-  {
-    const double p0 = wave_sum(sdr), p1 = wave_sum(shv), p2 = wave_sum(sz), p3 = wave_sum(sdy);
-    if (lane == 0) {
-      wred[wv][d.n] = p0;
-      wred[wv][d.n + 1] = p1;
-      wred[wv][d.n + 2] = p2;
-      wred[wv][d.n + 3] = p3;
-    }
-  }
-  __syncthreads();
-  if (tid < d.n + kLsExtra) {
-    double s = wred[0][tid];
-#pragma unroll
-    for (int w = 1; w < kBlock / 64; ++w) s += wred[w][tid];
+  // ---- block partials: A'y_next, ||dual_res||^2, h(A_x), ||z||^2, ||y_next - y||^2 -----------------------
+  const double ex[kSkinnyExtra] = {sdr, shv, sz, sdy};
+  const double tot = skinny_block_partials<T>(A, d.ld, ic, d.n, yn, PHASE != 2, ex, wred);
+  if (tid < d.n + kSkinnyExtra) {
     const bool is_z = tid == d.n + 2;
-    if (PHASE == 2 ? is_z : (PHASE == 3 ? !is_z : true)) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = s;
+    if (PHASE == 2 ? is_z : (PHASE == 3 ? !is_z : true)) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = tot;
   }
-}
-
-__device__ __forceinline__ double ls_colsum(const LsDev& d, int B, double (*red)[kSkinnyMaxN + kLsExtra]) {
-  const int tid = threadIdx.x;
-  const int npow = d.npow, S = kBlock / npow;      // npow >= 16: at most 16 sub-sums per column
-  const int c = tid % npow, s = tid / npow;
-  const int nc = d.n + kLsExtra;
-  if (c < nc) {
-    double acc = 0.0;
-    for (int b = s; b < B; b += S) acc += d.part[(int64_t)b * d.ldpart + c];
-    red[s][c] = acc;
-  }
-  __syncthreads();
-  double tot = 0.0;
-  if (tid < nc)
-    for (int k = 0; k < S; ++k) tot += red[k][tid];
-  return tot;
 }
 
 // MODE 0: pre-loop  v = x0 - gamma A'y0 ; x1 = prox(v)  (:497-499)
@@ -254,17 +206,17 @@ __device__ __forceinline__ double ls_colsum(const LsDev& d, int B, double (*red)
 // MODE 2: l2 ball: ||w/sigma + shift|| -> staging
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void k_ls_close(LsDev d, int B) {
-  __shared__ double red[kBlock / 16][kSkinnyMaxN + kLsExtra];
+  __shared__ SkinnyRed red[kBlock / 16];
   __shared__ LsCtrl lc;
   __shared__ double fin[6];
   const int tid = threadIdx.x;
   if (MODE != 0 && (d.c->done != 0 || d.c->it >= d.c->maxit)) return;
-  const double tot = ls_colsum(d, B, red);
+  const double tot = skinny_colsum(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
   if constexpr (MODE == 2) {
     if (tid == d.n + 2) d.cs->h_pre = sqrt(tot);
     return;
   } else {
-    if (tid >= d.n && tid < d.n + kLsExtra) fin[tid - d.n] = tot;
+    if (tid >= d.n && tid < d.n + kSkinnyExtra) fin[tid - d.n] = tot;
     // ||A'y_next - A'y||^2 over the n columns (:527)
     double q[1] = {0.0};
     if (MODE == 1 && tid < d.n) {
@@ -370,10 +322,8 @@ int32_t skinny_ls_run(apx_problem* p, const apx_linesearch_params* prm, double g
   d.ld = A->ld;
   d.m = (int32_t)A->m;
   d.n = (int32_t)p->n;
-  int npow = 16;
-  while (npow < d.n + kLsExtra) npow *= 2;
-  d.npow = npow;
-  d.ldpart = round_up(d.n + kLsExtra, 8);
+  d.npow = skinny_npow(d.n);
+  d.ldpart = round_up(d.n + kSkinnyExtra, 8);
   for (DBuf* b : {&bx, &bxp, &bv}) APX_TRY(b->alloc_zero(nb, ctx->stream));
   APX_TRY(baty.alloc_zero((size_t)p->n_pad * sizeof(double), ctx->stream));
   for (DBuf* b : {&by, &byt}) APX_TRY(b->alloc_zero(mb, ctx->stream));

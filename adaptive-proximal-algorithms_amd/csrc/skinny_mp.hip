@@ -17,7 +17,7 @@
 #include <cstring>
 #include <memory>
 
-#include "small_dev.h"
+#include "skinny_dev.h"
 
 namespace apx {
 
@@ -47,16 +47,14 @@ struct MpDev {
   apx_record* recs;
 };
 
-constexpr int kMpExtra = 4;
-
 // STAGE 0: pre-loop (:597-598): A x0 -> axc, partials of A'y0
 // STAGE 1: dual tick: the whole row work (l2: only w and ||z||^2) ; primal tick: the whole row work
 // STAGE 3: dual tick, l2 only: y from w, partials of A'y
 template <typename T, int STAGE>
 __global__ __launch_bounds__(kBlock) void k_mp_rows(MpDev d) {
   __shared__ double xs[kSkinnyMaxN];
-  __shared__ double wred[kBlock / 64][kSkinnyMaxN + kMpExtra];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ SkinnyRed wred[kBlock / 64];
+  const int tid = threadIdx.x;
   const T* __restrict__ A = (const T*)d.A;
   const int i = blockIdx.x * kBlock + tid;
   const bool row_ok = i < d.m;
@@ -78,18 +76,7 @@ __global__ __launch_bounds__(kBlock) void k_mp_rows(MpDev d) {
     const T* __restrict__ xsrc = (const T*)(STAGE == 0 ? d.X : d.XT);
     if (tid < d.n) xs[tid] = (double)xsrc[tid];
     __syncthreads();
-    const T* __restrict__ row = A + ic;
-    double a = 0.0;
-    int j = 0;
-    for (; j + 8 <= d.n; j += 8) {
-      T av[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) av[u] = row[(int64_t)(j + u) * d.ld];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a = fma((double)av[u], xs[j + u], a);
-    }
-    for (; j < d.n; ++j) a = fma((double)row[(int64_t)j * d.ld], xs[j], a);
-    a = (double)(T)a;
+    const double a = skinny_row_dot<T>(A, d.ld, ic, d.n, xs);
     if constexpr (STAGE == 0) {
       if (row_ok) d.axc[i] = a;
       yn = row_ok ? (double)Y[ic] : 0.0;
@@ -134,47 +121,10 @@ __global__ __launch_bounds__(kBlock) void k_mp_rows(MpDev d) {
     aty_partials = true;
   }
 
-  // ---- block partials (uniform branches) -----------------------------------------------------------
-  if (aty_partials) {
-    const T* __restrict__ row = A + ic;
-    for (int j = 0; j < d.n; ++j) {
-      const double p = wave_sum((double)row[(int64_t)j * d.ld] * yn);
-      if (lane == 0) wred[wv][j] = p;
-    }
-  }
-  {
-    const double p0 = wave_sum(s0), p1 = wave_sum(s1), p2 = wave_sum(s2), p3 = wave_sum(s3);
-    if (lane == 0) {
-      wred[wv][d.n] = p0;
-      wred[wv][d.n + 1] = p1;
-      wred[wv][d.n + 2] = p2;
-      wred[wv][d.n + 3] = p3;
-    }
-  }
-  __syncthreads();
-  if (tid < d.n + kMpExtra) {
-    double s = wred[0][tid];
-#pragma unroll
-    for (int w = 1; w < kBlock / 64; ++w) s += wred[w][tid];
-    if (tid >= d.n || aty_partials) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = s;
-  }
-}
-
-__device__ __forceinline__ double mp_colsum(const MpDev& d, int B, double (*red)[kSkinnyMaxN + kMpExtra]) {
-  const int tid = threadIdx.x;
-  const int npow = d.npow, S = kBlock / npow;      // npow >= 16: at most 16 sub-sums per column
-  const int c = tid % npow, s = tid / npow;
-  const int nc = d.n + kMpExtra;
-  if (c < nc) {
-    double acc = 0.0;
-    for (int b = s; b < B; b += S) acc += d.part[(int64_t)b * d.ldpart + c];
-    red[s][c] = acc;
-  }
-  __syncthreads();
-  double tot = 0.0;
-  if (tid < nc)
-    for (int k = 0; k < S; ++k) tot += red[k][tid];
-  return tot;
+  // ---- block partials (aty_partials is uniform over the launch) -----------------------------------------
+  const double ex[kSkinnyExtra] = {s0, s1, s2, s3};
+  const double tot = skinny_block_partials<T>(A, d.ld, ic, d.n, yn, aty_partials, ex, wred);
+  if (tid < d.n + kSkinnyExtra && (tid >= d.n || aty_partials)) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = tot;
 }
 
 // the primal trial for the current sigma (:556-560): theta, gamma, A'ybar, v, x+ ; returns ||x+ - x||^2 on thread 0
@@ -204,15 +154,15 @@ __device__ __forceinline__ void mp_trial(const MpDev& d, MpCtrl& lc, double* ndx
 // STAGE 0: pre-loop: A'y0 ; STAGE 2: l2 norm of the dual tick ; STAGE 1: close a dual or a primal tick
 template <typename T, int STAGE>
 __global__ __launch_bounds__(kBlock) void k_mp_close(MpDev d, int B) {
-  __shared__ double red[kBlock / 16][kSkinnyMaxN + kMpExtra];
+  __shared__ SkinnyRed red[kBlock / 16];
   __shared__ MpCtrl lc;
-  __shared__ double fin[kMpExtra + 2];
+  __shared__ double fin[kSkinnyExtra + 2];
   const int tid = threadIdx.x;
   if constexpr (STAGE != 0) {
     if (d.c->done != 0 || d.c->it >= d.c->maxit) return;
     if (STAGE == 2 && (d.c->phase != 0 || d.h.kind != APX_G_L2)) return;
   }
-  const double tot = mp_colsum(d, B, red);
+  const double tot = skinny_colsum(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
   if constexpr (STAGE == 2) {
     if (tid == d.n + 3) d.c->h_pre = sqrt(tot);
     return;
@@ -221,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_mp_close(MpDev d, int B) {
     return;
   } else {
     if (tid == 0) lc = *d.c;
-    if (tid >= d.n && tid < d.n + kMpExtra) fin[tid - d.n] = tot;
+    if (tid >= d.n && tid < d.n + kSkinnyExtra) fin[tid - d.n] = tot;
     __syncthreads();
     if (lc.phase == 0) {
       // ---- close the dual tick --------------------------------------------------------------------
@@ -236,9 +186,9 @@ __global__ __launch_bounds__(kBlock) void k_mp_close(MpDev d, int B) {
         lc.axcommit = 0;
       }
       __syncthreads();
-      mp_trial<T>(d, lc, &fin[kMpExtra]);
+      mp_trial<T>(d, lc, &fin[kSkinnyExtra]);
       if (tid == 0) {
-        lc.ndx2 = fin[kMpExtra];
+        lc.ndx2 = fin[kSkinnyExtra];
         lc.phase = 1;
         *d.c = lc;
       }
@@ -258,9 +208,9 @@ __global__ __launch_bounds__(kBlock) void k_mp_close(MpDev d, int B) {
     }
     __syncthreads();
     if (!accept) {
-      mp_trial<T>(d, lc, &fin[kMpExtra]);
+      mp_trial<T>(d, lc, &fin[kSkinnyExtra]);
       if (tid == 0) {
-        lc.ndx2 = fin[kMpExtra];
+        lc.ndx2 = fin[kSkinnyExtra];
         *d.c = lc;
       }
       return;
@@ -330,10 +280,8 @@ int32_t skinny_mp_run(apx_problem* p, const void* x0, const void* y0, double sig
   d.ld = A->ld;
   d.m = (int32_t)A->m;
   d.n = (int32_t)p->n;
-  int npow = 16;
-  while (npow < d.n + kMpExtra) npow *= 2;
-  d.npow = npow;
-  d.ldpart = round_up(d.n + kMpExtra, 8);
+  d.npow = skinny_npow(d.n);
+  d.ldpart = round_up(d.n + kSkinnyExtra, 8);
   for (DBuf* b : {&bx, &bxt, &bv}) APX_TRY(b->alloc_zero(nb, ctx->stream));
   for (DBuf* b : {&baty, &batyp}) APX_TRY(b->alloc_zero((size_t)p->n_pad * sizeof(double), ctx->stream));
   APX_TRY(by.alloc_zero(mb, ctx->stream));

@@ -19,7 +19,7 @@
 #include <cstdlib>
 #include <memory>
 
-#include "small_dev.h"
+#include "skinny_dev.h"
 
 namespace apx {
 
@@ -31,8 +31,8 @@ template <typename T, int PHASE>
 __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
   __shared__ double xs[kSkinnyMaxN];
   __shared__ Ctrl lc;
-  __shared__ double wred[kBlock / 64][kSkinnyMaxN + 4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ SkinnyRed wred[kBlock / 64];
+  const int tid = threadIdx.x;
   const T* __restrict__ A = (const T*)d.A;
   const int i = blockIdx.x * kBlock + tid;
   const bool row_ok = i < d.m;
@@ -78,19 +78,7 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
 
   // ---- this thread's row ------------------------------------------------------------------------
   double a = 0.0;
-  if constexpr (PHASE != 3) {
-    const T* __restrict__ row = A + ic;
-    int j = 0;
-    for (; j + 8 <= d.n; j += 8) {                           // A_x[i] = <A[i,:], x>, 8 columns in flight
-      T av[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) av[u] = row[(int64_t)(j + u) * d.ld];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a = fma((double)av[u], xs[j + u], a);
-    }
-    for (; j < d.n; ++j) a = fma((double)row[(int64_t)j * d.ld], xs[j], a);
-    a = (double)(T)a;
-  }
+  if constexpr (PHASE != 3) a = skinny_row_dot<T>(A, d.ld, ic, d.n, xs);            // A_x[i] = <A[i,:], x>
   double yn = 0.0, sdr = 0.0, shv = 0.0, sz = 0.0;
   if constexpr (PHASE == 0) {
     if (row_ok) d.ax[i] = a;
@@ -129,53 +117,12 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
   }
 
   // ---- block partials: A' y (n numbers, A re-read from L1 / L2), ||dual_res||^2, h(A_x), ||z||^2 ------
-  if constexpr (PHASE != 2) {
-    const T* __restrict__ row = A + ic;
-    for (int j = 0; j < d.n; ++j) {
-      const double p = wave_sum((double)row[(int64_t)j * d.ld] * yn);
-      if (lane == 0) wred[wv][j] = p;
-    }
+  const double ex[kSkinnyExtra] = {sdr, shv, sz, 0.0};
+  const double tot = skinny_block_partials<T>(A, d.ld, ic, d.n, yn, PHASE != 2, ex, wred);
+  if (tid < d.n + kSkinnyExtra) {
+    const bool is_z = tid == d.n + 2;
+    if (PHASE == 2 ? is_z : (PHASE == 3 ? !is_z : true)) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = tot;
   }
-  {
-    const double p0 = wave_sum(sdr), p1 = wave_sum(shv), p2 = wave_sum(sz);
-    if (lane == 0) {
-      wred[wv][d.n] = p0;
-      wred[wv][d.n + 1] = p1;
-      wred[wv][d.n + 2] = p2;
-    }
-  }
-  __syncthreads();
-  const int nc = d.n + 3;
-  if (tid < nc) {
-    double s = wred[0][tid];
-#pragma unroll
-    for (int w = 1; w < kBlock / 64; ++w) s += wred[w][tid];
-    if (PHASE == 2) {
-      if (tid == d.n + 2) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = s;
-    } else if (PHASE == 3) {
-      if (tid != d.n + 2) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = s;
-    } else {
-      d.part[(int64_t)blockIdx.x * d.ldpart + tid] = s;
-    }
-  }
-}
-
-// column c of the block partials, summed over the B blocks in a fixed order by all 256 threads:
-// thread (c, s) takes blocks s, s + S, ... ; then the S sub-sums of each column in order
-__device__ __forceinline__ double skinny_colsum(const SkinnyDev& d, int B, double (*red)[kSkinnyMaxN + 4]) {
-  const int tid = threadIdx.x;
-  const int npow = d.npow, S = kBlock / npow;      // npow >= 16: at most 16 sub-sums per column
-  const int c = tid % npow, s = tid / npow;
-  if (c < d.n + 3) {
-    double acc = 0.0;
-    for (int b = s; b < B; b += S) acc += d.part[(int64_t)b * d.ldpart + c];
-    red[s][c] = acc;
-  }
-  __syncthreads();
-  double tot = 0.0;
-  if (tid < d.n + 3)
-    for (int k = 0; k < S; ++k) tot += red[k][tid];
-  return tot;
 }
 
 // MODE 0: pre-loop  v = x0 - gamma A'y0 ; x1 = prox(v)  (:330-332)
@@ -183,12 +130,12 @@ __device__ __forceinline__ double skinny_colsum(const SkinnyDev& d, int B, doubl
 // MODE 2: l2 ball: only ||w/sigma + shift|| -> Ctrl staging (between the two row kernels)
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void k_skinny_close(SkinnyDev d, int B) {
-  __shared__ double red[kBlock / 16][kSkinnyMaxN + 4];
+  __shared__ SkinnyRed red[kBlock / 16];
   __shared__ Ctrl lc;
   __shared__ double fin[4];
   const int tid = threadIdx.x;
   if (MODE != 0 && d.c->done != 0) return;
-  const double tot = skinny_colsum(d, B, red);
+  const double tot = skinny_colsum(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
   if constexpr (MODE == 2) {
     if (tid == d.n + 2) d.cs->h_pre = sqrt(tot);
     return;
@@ -265,10 +212,8 @@ int32_t skinny_pd_setup(apx_solver* s, const void* x0, const void* y0) {
   d.ld = A->ld;
   d.m = (int32_t)A->m;
   d.n = (int32_t)p->n;
-  int npow = 16;
-  while (npow < d.n + 3) npow *= 2;
-  d.npow = npow;
-  d.ldpart = round_up(d.n + 3, 8);
+  d.npow = skinny_npow(d.n);
+  d.ldpart = round_up(d.n + kSkinnyExtra, 8);
   APX_TRY(st->x.alloc_zero(nb, ctx->stream));
   APX_TRY(st->xp.alloc_zero(nb, ctx->stream));
   APX_TRY(st->v.alloc_zero(nb, ctx->stream));
