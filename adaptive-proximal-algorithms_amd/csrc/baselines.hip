@@ -176,6 +176,18 @@ int32_t apx_fixed_nesterov(apx_problem* p, const void* x0, double gamma, double 
   APX_REQUIRE(q < 1, "fixed_nesterov: assertion q < 1 failed");                         // :110
   if (theta < 0) theta = q > 0 ? 1.0 / std::sqrt(q) : 0.0;                              // :111-117
   APX_REQUIRE(theta >= 0 && theta <= 1.0 / std::sqrt(q), "fixed_nesterov: assertion 0 <= theta <= 1/sqrt(q) failed");
+  if (small_mom_eligible(p)) {      // small dense problems: the loop stays on the device (csrc/small_mom.hip)
+    MomCtrl c0;
+    memset(&c0, 0, sizeof(c0));
+    c0.tol = tol;
+    c0.gamma = gamma;
+    c0.theta = theta;
+    c0.q = q;
+    c0.mu = mu;
+    c0.muf = muf;
+    c0.mug = mug;
+    return small_mom_run(p, MOM_NESTEROV, c0, x0, x0, maxit, opts, x_out, res);
+  }
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es;
   DBuf b0, b1, b2, b3;
@@ -232,6 +244,18 @@ int32_t apx_agraal(apx_problem* p, const void* x1, const void* x0, double gamma0
                    double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_TRY(begin(p, maxit, false));
   APX_REQUIRE(x1 != nullptr && x0 != nullptr && x_out != nullptr, "apx_agraal: NULL argument");
+  if (small_mom_eligible(p)) {      // small dense problems: the loop stays on the device (csrc/small_mom.hip)
+    MomCtrl c0;
+    memset(&c0, 0, sizeof(c0));
+    c0.tol = tol;
+    c0.gamma = gamma0 > 0 ? gamma0 : 0.0;
+    c0.need_gamma0 = gamma0 > 0 ? 0 : 1;                    // :168-170
+    c0.theta = 1.0;                                          // :173
+    c0.phi = phi;
+    c0.rho = 1.0 / phi + 1.0 / (phi * phi);                  // :172
+    c0.gamma_max = gamma_max;
+    return small_mom_run(p, MOM_AGRAAL, c0, x1, x0, maxit, opts, x_out, res);
+  }
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es;
   DBuf b0, b1, b2, b3, b4;

@@ -125,6 +125,23 @@ struct SkinnyState {
   int B = 0;              // row blocks
 };
 
+// ---- small_mom.hip: fixed Nesterov and aGRAAL as device-resident loops (small dense problems) ---------
+enum { MOM_AGRAAL = 0, MOM_NESTEROV = 1 };
+
+struct MomCtrl {
+  double tol, n_mean;
+  int64_t maxit, rec_cap;
+  // aGRAAL (:172-178)
+  double gamma, theta, rho, phi, gamma_max;
+  // Nesterov (:108-128)
+  double q, mu, muf, mug;
+  double bias[3];                   // logistic: mean(probs - y) belonging to gradient buffer 0 / 1 / 2
+  double norm_res, g_raw, f_new, objective;
+  int64_t it;                       // finished iterations
+  int32_t need_gamma0, stop_after, done, flags;
+  int32_t frozen, _pad;             // set in block B by a k_mom_a that found nothing left to do
+};
+
 }  // namespace apx
 
 struct apx_solver {
@@ -177,6 +194,10 @@ const void* small_pd_ctrl(const apx_solver* s);
 bool skinny_pd_eligible(const apx_problem* p);
 int32_t skinny_pd_setup(apx_solver* s, const void* x0, const void* y0);
 int32_t skinny_pd_enqueue(apx_solver* s);
+// small_mom.hip (the caller fills the method's parameters into c0)
+bool small_mom_eligible(const apx_problem* p);
+int32_t small_mom_run(apx_problem* p, int method, const MomCtrl& c0, const void* x1, const void* x0, int64_t maxit,
+                      const apx_solve_opts* opts, void* x_out, apx_result* res);
 // small_bt.hip: backtracking_proxgrad with its linesearch as a device-side state machine (small dense problems)
 bool small_bt_eligible(const apx_problem* p);
 int32_t small_bt_run(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol, int64_t maxit,

@@ -169,3 +169,50 @@ def test_malitsky_pock_skinny_termination_and_maxit(apx):
         xo, yo, _ = O.malitsky_pock(np.zeros(10), np.zeros(2000), A=prob.A, sigma=1.0, t=0.3, tol=0.0, maxit=K, **terms(O))
         x, y, it = apx.malitsky_pock(np.zeros(10), np.zeros(2000), A=prob.A, sigma=1.0, t=0.3, tol=0.0, maxit=K, **terms(apx))
         assert it == K and _rel_inf(x, xo) <= 1e-8 and (K == 0 or _rel_inf(y, yo) <= 1e-8)
+
+
+# ---------------------------------------------------------------------------------------
+# fixed Nesterov and aGRAAL as device-resident loops (csrc/small_mom.hip): more shapes, logistic, edge cases
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,logistic", [(100, 300, False), (4000, 1000, False), (900, 70, True), (64, 17, False)])
+def test_small_mom_shapes(apx, m, n, logistic):
+    if logistic:
+        lr = P.random_logreg(m, n, seed=4, dtype=np.float64)
+        A, b, lam, gam, nx = lr.X, lr.y, lr.lam, lr.gamma0, n + 1
+        mkf = lambda M: M.LogisticLoss(A, b)      # noqa: E731
+    else:
+        rng = np.random.default_rng(m + n)
+        A, b, lam, nx = rng.uniform(-1, 1, (m, n)), rng.standard_normal(m), 0.3, n
+        gam = 1.0 / P.opnorm_sq_power(A, iters=30)
+        mkf = lambda M: M.LinearLeastSquares(A, b)      # noqa: E731
+    K = 40
+    ro, rd = [], []
+    xo, ito = O.fixed_nesterov(np.zeros(nx), f=mkf(O), g=O.NormL1(lam), gamma=gam, tol=0.0, maxit=K, record=ro.append)
+    x, it = apx.fixed_nesterov(np.zeros(nx), f=mkf(apx), g=apx.NormL1(lam), gamma=gam, tol=0.0, maxit=K, record=rd.append)
+    assert it == ito == K and _rel_inf(x, xo) <= 1e-10
+    _compare(ro, rd, ("gamma", "norm_res", "objective"), 1e-8)
+    x0 = 0.01 * np.cos(np.arange(nx))
+    ro, rd = [], []
+    xo, ito = O.agraal(np.zeros(nx), f=mkf(O), g=O.NormL1(lam), x0=x0, tol=0.0, maxit=K, record=ro.append)
+    x, it = apx.agraal(np.zeros(nx), f=mkf(apx), g=apx.NormL1(lam), x0=x0, tol=0.0, maxit=K, record=rd.append)
+    assert it == ito == K and _rel_inf(x, xo) <= 1e-9
+    _compare(ro, rd, ("gamma", "norm_res", "objective"), 1e-7)
+
+
+def test_small_mom_termination_and_maxit(apx, lasso):
+    prob, gam = lasso
+    f_o, f_d = O.LinearLeastSquares(prob.A, prob.b), apx.LinearLeastSquares(prob.A, prob.b)
+    x0 = 0.01 * np.cos(np.arange(1000))
+    for name, kw in (("fixed_nesterov", dict(gamma=gam)), ("agraal", dict(x0=x0, gamma0=gam))):
+        ro = []
+        getattr(O, name)(np.zeros(1000), f=f_o, g=O.NormL1(1.0), tol=0.0, maxit=60, record=ro.append, **kw)
+        tol = min(r["norm_res"] for r in ro[:40]) * (1 + 1e-7)
+        of, df = O.Counting(f_o), apx.Counting(f_d)
+        xo, ito = getattr(O, name)(np.zeros(1000), f=of, g=O.NormL1(1.0), tol=tol, maxit=5000, **kw)
+        x, it = getattr(apx, name)(np.zeros(1000), f=df, g=apx.NormL1(1.0), tol=tol, maxit=5000, **kw)
+        assert it == ito <= 40 and _rel_inf(x, xo) <= 1e-10
+        assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
+        for K in (0, 1, 2, 65):
+            xo, _ = getattr(O, name)(np.zeros(1000), f=f_o, g=O.NormL1(1.0), tol=0.0, maxit=K, **kw)
+            x, it = getattr(apx, name)(np.zeros(1000), f=f_d, g=apx.NormL1(1.0), tol=0.0, maxit=K, **kw)
+            assert it == K and (np.max(np.abs(x - xo)) <= 1e-9 * max(1.0, np.max(np.abs(xo))))
