@@ -95,6 +95,8 @@ int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0,
                                   int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_TRY(begin(p, maxit, false));
   APX_REQUIRE(x0 != nullptr && x_out != nullptr, "apx_backtracking_nesterov: NULL argument");
+  // small dense problems: the linesearch stays on the device (csrc/small_bt.hip)
+  if (small_bt_eligible(p)) return small_bt_run(p, true, x0, gamma0, 1.0, shrink, tol, maxit, opts, x_out, res);
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es;
   DBuf bx, bz0, bz1, bz2;

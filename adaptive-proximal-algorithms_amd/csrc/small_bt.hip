@@ -9,6 +9,10 @@
 //            rejected: gamma *= shrink, the next tick retries ; accepted: norm_res, record, termination
 //            (:55-59), x = z ; and — speculatively, for every trial — A' res, the gradient at z (:61)
 //
+// `backtracking_nesterov` (:66-84) runs on the same kernels: its trial ticks start from the extrapolated point,
+// need no gradient at z, and every accepted trial is followed by an extrapolation tick (k_bt_a: x = z +
+// (theta_prev - 1)/theta (z - z_prev), A x ; k_bt_b: f_x and grad f(x), :78-81).
+//
 // x / z and grad_x / grad_z live in two buffers each and the control block holds the index of the current one:
 // accepting a trial flips the index, nothing is copied.  Two control blocks (A read by k_bt_a and written by
 // k_bt_b, B the other way round), so no kernel writes what its own blocks read.  The host enqueues ticks in
@@ -29,8 +33,11 @@ struct BtCtrl {
   double bias[2];                   // logistic: mean(probs - y) belonging to grad buffer 0 / 1
   double norm_res, objective;
   int64_t it, trials_total;
-  int32_t cur;                      // which of the two x / grad buffers is current
-  int32_t done, flags, _pad;
+  int32_t cur;                      // which of the two x / grad buffers (Nesterov: z buffers) is current
+  int32_t done, flags;
+  int32_t nesterov;                 // backtracking_nesterov (:66-84): trial ticks and extrapolation ticks alternate
+  int32_t phase, _pad;              // Nesterov: 0 trial tick, 1 extrapolation tick
+  double theta, beta;               // :78-80
 };
 
 struct BtDev {
@@ -39,8 +46,9 @@ struct BtDev {
   int64_t ld, ldT;
   int32_t m, ncols, n, w_n, w_t, _pad;
   const void* b;
-  void* P[2];          // x / z
-  double* G[2];        // A' res at P[k] (fp64, as the dots leave it)
+  void* P[2];          // x / z  (Nesterov: z / z_prev)
+  void* XB;            // Nesterov: the extrapolated point x the trials start from
+  double* G[2];        // A' res at P[k] (Nesterov: G[0] = A' res at XB), fp64 as the dots leave it
   double* az;          // A z
   BtCtrl *ca, *cb;
   ProxDev g;
@@ -55,7 +63,8 @@ __global__ __launch_bounds__(kBlock) void k_bt_a(BtDev d) {
   if (threadIdx.x == 0) lc = *d.ca;
   __syncthreads();
   const int cur = lc.cur;
-  const T* __restrict__ X = (const T*)d.P[cur];
+  const bool nes = lc.nesterov != 0;
+  const T* __restrict__ X = (const T*)(nes ? d.XB : d.P[cur]);
   if constexpr (MODE == 0) {
     for (int i = threadIdx.x; i < d.n; i += kBlock) zs[i] = (double)X[i];
     __syncthreads();
@@ -66,11 +75,31 @@ __global__ __launch_bounds__(kBlock) void k_bt_a(BtDev d) {
       if (blockIdx.x == 0 && threadIdx.x == 0) *d.cb = lc;
       return;
     }
+    const int per = (d.n + kBlock - 1) / kBlock;
+    if (nes && lc.phase == 1) {                     // extrapolation tick: x = z + beta (z - z_prev) (:80) ; A x
+      const T* __restrict__ Zc = (const T*)d.P[cur];
+      const T* __restrict__ Zq = (const T*)d.P[1 - cur];
+      T* __restrict__ XW = (T*)d.XB;
+      const double beta = lc.beta;
+      for (int k = 0; k < per; ++k) {
+        const int i = threadIdx.x + k * kBlock;
+        if (i < d.n) {
+          const double zc = (double)Zc[i];
+          const T xn = (T)(zc + beta * (zc - (double)Zq[i]));
+          zs[i] = (double)xn;
+          if ((unsigned)k % gridDim.x == blockIdx.x) XW[i] = xn;
+        }
+      }
+      __syncthreads();
+      if (blockIdx.x == 0 && threadIdx.x == 0) *d.cb = lc;
+      small_dots_w<T>(d.w_n, (const T*)d.AT, d.ldT, d.m, d.ncols, zs, d.az, true);
+      return;
+    }
+    const int gi_buf = nes ? 0 : cur;
     const double gamma = lc.gamma_try;
-    const double* __restrict__ G = d.G[cur];
+    const double* __restrict__ G = d.G[gi_buf];
     T* __restrict__ Z = (T*)d.P[1 - cur];
     double q[3] = {0.0, 0.0, 0.0};
-    const int per = (d.n + kBlock - 1) / kBlock;
     for (int k0 = 0; k0 < per; k0 += 4) {
       double x4[4], g4[4];
 #pragma unroll
@@ -86,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_bt_a(BtDev d) {
         if (i < d.n) {
           double gi;
           if (FK == APX_F_LOGISTIC && i == d.n - 1) {
-            gi = (double)(T)lc.bias[cur];                                  // grad[end] = mean(probs - y)
+            gi = (double)(T)lc.bias[gi_buf];                               // grad[end] = mean(probs - y)
           } else {
             const T gs = (T)g4[u];                                         // A' * res
             gi = FK == APX_F_LOGISTIC ? (double)(T)((double)gs / lc.n_mean) : (double)gs;
@@ -121,9 +150,12 @@ __global__ __launch_bounds__(kBlock) void k_bt_b(BtDev d) {
   __syncthreads();
   if (MODE == 2 && (lc.done != 0 || lc.it >= lc.maxit)) return;
   const int cur = lc.cur;
+  const bool nes = lc.nesterov != 0;
+  const bool extrap = nes && (MODE == 0 || lc.phase == 1);          // the point is XB, its gradient goes to G[0]
   const int tgt = MODE == 0 ? cur : 1 - cur;              // the buffers of the point whose gradient is formed here
+  const int gbuf = nes ? 0 : tgt;
   const T* __restrict__ b = (const T*)d.b;
-  const T* __restrict__ Zp = (const T*)d.P[tgt];
+  const T* __restrict__ Zp = (const T*)(extrap ? d.XB : d.P[tgt]);
   double bias = 0.0;
   if constexpr (FK == APX_F_LOGISTIC) bias = (double)Zp[d.n - 1];
   double q[2] = {0.0, 0.0};
@@ -163,10 +195,13 @@ __global__ __launch_bounds__(kBlock) void k_bt_b(BtDev d) {
       f_z = 0.5 * (nr * nr);
     } else {
       f_z = -(q[0] / lc.n_mean);
-      lc.bias[tgt] = q[1] / lc.n_mean;
+      if (!nes || extrap) lc.bias[gbuf] = q[1] / lc.n_mean;
     }
-    if constexpr (MODE == 0) {
-      lc.f_x = f_z;                                       // :52
+    if (MODE == 0) {
+      lc.f_x = f_z;                                       // :52 / :69
+    } else if (extrap) {
+      lc.f_x = f_z;                                       // :81  f_x, grad_x = eval_with_gradient(f, x)
+      lc.phase = 0;
     } else {
       const double gamma = lc.gamma_try;
       const double nrm = sqrt(lc.s_ss);
@@ -186,14 +221,22 @@ __global__ __launch_bounds__(kBlock) void k_bt_b(BtDev d) {
           r.norm_res = lc.norm_res;
           r.objective = lc.objective;
           r.f_x = f_z;
-          r.f_evals = 1 + lc.trials_total;
+          r.f_evals = 1 + lc.trials_total + (nes ? lc.it - 1 : 0);                      // (+ the evaluations at the extrapolated points)
           r.grad_evals = lc.it;
           d.recs[lc.it - 1] = r;
         }
-        lc.f_x = f_z;                                                                   // :60
-        lc.cur = tgt;                                                                   //      x = z (and its gradient)
-        if (lc.norm_res <= lc.tol) lc.done = 1;                                         // :57-59
-        lc.gamma_try = lc.xi * gamma;                                                   // :54 of the next iteration
+        lc.cur = tgt;                                                                   // :60  x = z (Nesterov: z_prev = z ; z)
+        if (lc.norm_res <= lc.tol) lc.done = 1;                                         // :57-59 / :75-77
+        if (nes) {
+          const double theta_prev = lc.theta;                                           // :78
+          lc.theta = (1.0 + sqrt(1.0 + 4.0 * (theta_prev * theta_prev))) / 2.0;         // :79
+          lc.beta = (theta_prev - 1.0) / lc.theta;
+          lc.gamma_try = gamma;                                                         // (no xi in backtracking_nesterov)
+          lc.phase = 1;
+        } else {
+          lc.f_x = f_z;
+          lc.gamma_try = lc.xi * gamma;                                                 // :54 of the next iteration
+        }
       } else {
         lc.gamma_try = gamma * lc.shrink;                                               // :39
         if (lc.gamma_try < 1e-12) lc.flags |= APX_FLAG_TINY_GAMMA;                      // :40-42 (logs, continues)
@@ -201,8 +244,9 @@ __global__ __launch_bounds__(kBlock) void k_bt_b(BtDev d) {
     }
     *d.ca = lc;
   }
-  // grad at the trial point, speculatively (:61) — rs is complete behind the barrier of block_sums_t0
-  small_dots_w<T>(d.w_t, (const T*)d.A, d.ld, d.ncols, d.m, rs, d.G[tgt], true);
+  // grad at the trial point, speculatively (:61) — rs is complete behind the barrier of block_sums_t0.
+  // Nesterov never needs the gradient at z: only the extrapolation ticks (and the pre-loop) form one.
+  if (!nes || extrap) small_dots_w<T>(d.w_t, (const T*)d.A, d.ld, d.ncols, d.m, rs, d.G[gbuf], true);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -228,13 +272,13 @@ static void bt_launch(const BtDev& d, int fk, hipStream_t q) {
   }
 }
 
-int32_t small_bt_run(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol, int64_t maxit,
-                     const apx_solve_opts* opts, void* x_out, apx_result* res) {
+int32_t small_bt_run(apx_problem* p, bool nesterov, const void* x0, double gamma0, double xi, double shrink, double tol,
+                     int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   apx_ctx* ctx = p->ctx;
   const apx_matrix* A = p->A_f;
   const size_t es = p->es();
   const size_t nb = (size_t)p->n_pad * es, nd = (size_t)p->n_pad * sizeof(double);
-  DBuf p0, p1, g0, g1, baz, bat, bca, bcb, brecs;
+  DBuf p0, p1, bxb, g0, g1, baz, bat, bca, bcb, brecs;
   BtDev d{};
   d.A = A->d;
   d.ld = A->ld;
@@ -255,6 +299,7 @@ int32_t small_bt_run(apx_problem* p, const void* x0, double gamma0, double xi, d
   d.b = p->b.p;
   APX_TRY(p0.alloc_zero(nb, ctx->stream));
   APX_TRY(p1.alloc_zero(nb, ctx->stream));
+  APX_TRY(bxb.alloc_zero(nb, ctx->stream));
   APX_TRY(g0.alloc_zero(nd, ctx->stream));
   APX_TRY(g1.alloc_zero(nd, ctx->stream));
   APX_TRY(baz.alloc_zero((size_t)A->ld * sizeof(double), ctx->stream));
@@ -265,6 +310,7 @@ int32_t small_bt_run(apx_problem* p, const void* x0, double gamma0, double xi, d
   if (rec_cap > 0) APX_TRY(brecs.alloc_zero((size_t)rec_cap * sizeof(apx_record), ctx->stream));
   d.P[0] = p0.p;
   d.P[1] = p1.p;
+  d.XB = bxb.p;
   d.G[0] = (double*)g0.p;
   d.G[1] = (double*)g1.p;
   d.az = (double*)baz.p;
@@ -281,18 +327,21 @@ int32_t small_bt_run(apx_problem* p, const void* x0, double gamma0, double xi, d
   c.n_mean = p->n_mean;
   c.maxit = maxit;
   c.rec_cap = rec_cap;
-  c.gamma = gamma0;                                  // :51
-  c.gamma_try = xi * gamma0;                         // :54
+  c.gamma = gamma0;                                  // :51 / :67
+  c.gamma_try = nesterov ? gamma0 : xi * gamma0;     // :54 / :72
+  c.nesterov = nesterov ? 1 : 0;
+  c.theta = 1.0;                                     // :68
   c.norm_res = c.objective = std::numeric_limits<double>::quiet_NaN();
   APX_TRY(h2d(ctx, bca.p, &c, sizeof(c)));
-  APX_TRY(h2d(ctx, p0.p, x0, (size_t)p->n * es));
+  APX_TRY(h2d(ctx, p0.p, x0, (size_t)p->n * es));       // x (Nesterov: z) = x0
+  if (nesterov) APX_TRY(h2d(ctx, bxb.p, x0, (size_t)p->n * es));
   hipStream_t q = ctx->stream;
   const bool f32 = p->dtype == APX_F32;
   if (f32) bt_launch<float, 0>(d, p->f_kind, q);     // :52  f_x, grad_x = eval_with_gradient(f, x)
   else bt_launch<double, 0>(d, p->f_kind, q);
   APX_HIP(hipGetLastError());
-  while (maxit > 0) {                                // every iteration takes at least one tick
-    const int64_t missing = maxit - c.it;
+  while (maxit > 0) {                                // every iteration takes at least one tick (Nesterov: two)
+    const int64_t missing = (maxit - c.it) * (nesterov ? 2 : 1);
     const int chunk = (int)std::min<int64_t>(64, std::max<int64_t>(missing, 1));
     for (int k = 0; k < chunk; ++k) {
       if (f32) bt_launch<float, 2>(d, p->f_kind, q);
@@ -318,8 +367,10 @@ int32_t small_bt_run(apx_problem* p, const void* x0, double gamma0, double xi, d
     res->sigma = std::numeric_limits<double>::quiet_NaN();
     res->norm_res = c.norm_res;
     res->objective = c.objective;
-    res->f_evals = 1 + c.trials_total;
-    res->grad_f_evals = conv ? k : k + 1;            // the pullback after the last accepted trial only if the loop went on
+    // evaluations after an accepted trial happen only if the loop went on (:60-61 / :80-81)
+    const int64_t cont = conv ? k - 1 : k;
+    res->f_evals = 1 + c.trials_total + (nesterov ? std::max<int64_t>(cont, 0) : 0);
+    res->grad_f_evals = 1 + std::max<int64_t>(cont, 0);
     res->prox_g_evals = c.trials_total;
     res->prox_h_evals = -1;
     res->A_evals = -1;

@@ -200,8 +200,8 @@ int32_t small_mom_run(apx_problem* p, int method, const MomCtrl& c0, const void*
                       const apx_solve_opts* opts, void* x_out, apx_result* res);
 // small_bt.hip: backtracking_proxgrad with its linesearch as a device-side state machine (small dense problems)
 bool small_bt_eligible(const apx_problem* p);
-int32_t small_bt_run(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol, int64_t maxit,
-                     const apx_solve_opts* opts, void* x_out, apx_result* res);
+int32_t small_bt_run(apx_problem* p, bool nesterov, const void* x0, double gamma0, double xi, double shrink, double tol,
+                     int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
 // skinny_mp.hip: Malitsky-Pock with its linesearch as a device-side state machine
 bool skinny_mp_eligible(const apx_problem* p);
 int32_t skinny_mp_run(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol, int64_t maxit,

@@ -216,3 +216,37 @@ def test_small_mom_termination_and_maxit(apx, lasso):
             xo, _ = getattr(O, name)(np.zeros(1000), f=f_o, g=O.NormL1(1.0), tol=0.0, maxit=K, **kw)
             x, it = getattr(apx, name)(np.zeros(1000), f=f_d, g=apx.NormL1(1.0), tol=0.0, maxit=K, **kw)
             assert it == K and (np.max(np.abs(x - xo)) <= 1e-9 * max(1.0, np.max(np.abs(xo))))
+
+
+@pytest.mark.parametrize("m,n,logistic", [(100, 300, False), (4000, 1000, False), (900, 70, True)])
+def test_backtracking_nesterov_small_shapes(apx, m, n, logistic):
+    if logistic:
+        lr = P.random_logreg(m, n, seed=4, dtype=np.float64)
+        A, b, lam, gam, nx = lr.X, lr.y, lr.lam, 4 * lr.gamma0, n + 1
+        mkf = lambda M: M.LogisticLoss(A, b)      # noqa: E731
+    else:
+        rng = np.random.default_rng(m + n)
+        A, b, lam, nx = rng.uniform(-1, 1, (m, n)), rng.standard_normal(m), 0.3, n
+        gam = 6.0 / P.opnorm_sq_power(A, iters=30)
+        mkf = lambda M: M.LinearLeastSquares(A, b)      # noqa: E731
+    K = 30
+    of, df = O.Counting(mkf(O)), apx.Counting(mkf(apx))
+    og, dg = O.Counting(O.NormL1(lam)), apx.Counting(apx.NormL1(lam))
+    ro, rd = [], []
+    zo, ito = O.backtracking_nesterov(np.zeros(nx), f=of, g=og, gamma0=gam, tol=0.0, maxit=K, record=ro.append)
+    z, it = apx.backtracking_nesterov(np.zeros(nx), f=df, g=dg, gamma0=gam, tol=0.0, maxit=K, record=rd.append)
+    assert it == ito == K and _rel_inf(z, zo) <= 1e-10
+    _compare(ro, rd, ("gamma", "norm_res", "objective"), 1e-8)
+    assert (df.eval_count, df.grad_count, dg.prox_count) == (of.eval_count, of.grad_count, og.prox_count)
+    assert logistic or any(r["gamma"] < gam for r in rd)          # (least squares: the linesearch did backtrack)
+    # termination at a known iteration, and maxit edge cases
+    tol = min(r["norm_res"] for r in ro[:20]) * (1 + 1e-7)
+    of, df = O.Counting(mkf(O)), apx.Counting(mkf(apx))
+    zo, ito = O.backtracking_nesterov(np.zeros(nx), f=of, g=O.NormL1(lam), gamma0=gam, tol=tol, maxit=500)
+    z, it = apx.backtracking_nesterov(np.zeros(nx), f=df, g=apx.NormL1(lam), gamma0=gam, tol=tol, maxit=500)
+    assert it == ito <= 20 and _rel_inf(z, zo) <= 1e-10
+    assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
+    for K2 in (0, 1, 2):
+        zo, _ = O.backtracking_nesterov(np.zeros(nx), f=mkf(O), g=O.NormL1(lam), gamma0=gam, tol=0.0, maxit=K2)
+        z, it = apx.backtracking_nesterov(np.zeros(nx), f=mkf(apx), g=apx.NormL1(lam), gamma0=gam, tol=0.0, maxit=K2)
+        assert it == K2 and np.max(np.abs(z - zo)) <= 1e-10 * max(1.0, np.max(np.abs(zo)))
