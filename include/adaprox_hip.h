@@ -206,14 +206,17 @@ int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_varia
  * what reference BLAS dgemv does too (`IF (X(JX).NE.ZERO)`), and what a lasso iterate invites
  * after the soft-threshold.  Same result up to summation order; not used by bench.py's headline. */
 int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
-/* Default ON: a dense problem with n <= 4096, m <= 4096 (or m <= 8192 with m*n <= 4 M elements) and no
- * all-reduce hook — the sizes of the reference's
- * own experiments (experiments/lasso/runme.jl:191-195, least_absolute_deviation/runme.jl:39-62) —
- * runs each iteration of src/AdaProx.jl:334-362 as two kernels in which every workgroup redundantly
- * does the O(m + n) work: proximal gradient with LinearLeastSquares / LogisticLoss (csrc/small.hip)
- * and the primal-dual loop with f = Zero or Quadratic (csrc/small_pd.hip; tall, skinny A with n <= 120:
- * csrc/skinny_pd.hip, a thread per row and a closing block).  Same arithmetic, different summation
- * order than the generic path; 0 switches back to the generic kernels. */
+/* Default ON: execution policy for the reference's own small experiment sizes (experiments/lasso/runme.jl:191-195,
+ * least_absolute_deviation/runme.jl:128-160, dual_svm/runme.jl:140-180) — no all-reduce hook, dense matrices:
+ *   - n <= 4096, m <= 4096 (m <= 8192 with m*n <= 4 M): every iteration of src/AdaProx.jl:334-362 as two kernels in
+ *     which each workgroup redundantly does the O(m + n) work (csrc/small.hip: proximal gradient with
+ *     LinearLeastSquares / LogisticLoss ; csrc/small_pd.hip: primal-dual with f = Zero or Quadratic);
+ *   - tall, skinny A (n <= 120, f = Zero): a thread per row and a one-block closing kernel (csrc/skinny_pd.hip);
+ *   - the linesearch methods as state machines in device memory, no read-back per trial: backtracking_proxgrad,
+ *     backtracking_nesterov (csrc/small_bt.hip), adaptive_linesearch_primal_dual, malitsky_pock on tall-skinny A
+ *     (csrc/skinny_ls.hip, csrc/skinny_mp.hip); fixed_nesterov and agraal likewise (csrc/small_mom.hip).
+ * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and
+ * the host-driven loops. */
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
 int32_t apx_gemv_variant_count(int32_t transposed);
 const char* apx_gemv_variant_name(int32_t transposed, int32_t i);
