@@ -57,23 +57,58 @@ __device__ __forceinline__ double skinny_block_partials(const T* __restrict__ A,
   return s;
 }
 
-// Column c of the block partials summed over the B blocks in a fixed order by all 256 threads: thread (c, s) takes
-// blocks s, s + S, ... (S = 256 / npow <= 16), then thread c < nc adds the S sub-sums in order and returns the total.
+// Blocks s, s + S, s + 2 S, ... of column c summed with eight independent accumulators (a plain running sum is a
+// chain of dependent L2 round trips, ~0.7 us each); the order is fixed: accumulator u takes every eighth term, then
+// a fixed tree.
+__device__ __forceinline__ double skinny_strided_sum(const double* __restrict__ part, int64_t ldpart, int c, int s, int S,
+                                                     int B) {
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int b = s;
+  for (; b + 7 * S < B; b += 8 * S) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += part[(int64_t)(b + u * S) * ldpart + c];
+  }
+  double tail = 0.0;
+  for (; b < B; b += S) tail += part[(int64_t)b * ldpart + c];
+  return (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + tail;
+}
+
+// Column c of the block partials summed over the B blocks in a fixed order by all BS threads: thread (c, s) takes
+// blocks s, s + S, ... (S = min(BS / npow, 16)), then thread c < nc adds the S sub-sums in order and returns the total.
+template <int BS = kBlock>
 __device__ __forceinline__ double skinny_colsum(const double* __restrict__ part, int64_t ldpart, int nc, int npow, int B,
                                                 SkinnyRed* red) {
   const int tid = threadIdx.x;
-  const int S = kBlock / npow;
+  const int S = min(BS / npow, 16);
   const int c = tid % npow, s = tid / npow;
-  if (c < nc) {
-    double acc = 0.0;
-    for (int b = s; b < B; b += S) acc += part[(int64_t)b * ldpart + c];
-    red[s][c] = acc;
-  }
+  if (c < nc && s < S) red[s][c] = skinny_strided_sum(part, ldpart, c, s, S, B);
   __syncthreads();
   double tot = 0.0;
   if (tid < nc)
     for (int k = 0; k < S; ++k) tot += red[k][tid];
   return tot;
+}
+
+// Wave totals of N per-lane values with N - 1 + log2(64 / N) exchanges instead of 6 N: at each of the first log2 N
+// steps a lane keeps half of its values and hands the other half to its partner.  Afterwards v[0] of lane l is the
+// total of value l / (64 / N).
+template <int N>
+__device__ __forceinline__ void wave_sum_multi(double (&v)[N]) {
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32, "power of two");
+  const int lane = threadIdx.x & 63;
+  int off = 32;
+#pragma unroll
+  for (int h = N / 2; h >= 1; h >>= 1) {
+    const bool upper = (lane & off) != 0;
+#pragma unroll
+    for (int u = 0; u < h; ++u) {
+      const double send = upper ? v[u] : v[u + h];
+      const double keep = upper ? v[u + h] : v[u];
+      v[u] = keep + __shfl_xor(send, off, 64);
+    }
+    off >>= 1;
+  }
+  for (; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
 }
 
 inline int skinny_npow(int n) {

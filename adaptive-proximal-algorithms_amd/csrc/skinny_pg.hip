@@ -1,0 +1,293 @@
+// skinny_pg.hip — the proximal-gradient iteration (`adaptive_proxgrad` / `fixed_proxgrad`, src/AdaProx.jl:418-421,
+// 457-459 over the loop :334-362) for TALL, SKINNY dense A: at most 120 unknowns, thousands of rows — the shape of the
+// reference's logistic-regression data once densified (mushrooms 8124 x 112, phishing 11055 x 68,
+// experiments/sparse_logreg/runme.jl:177-204) and of any tall least-squares problem.  With so few columns the
+// gradient is n block-partial sums and the whole n side fits one workgroup:
+//
+//   k_spg_rows  a block owns groups of 64 rows (lane = row) and splits the COLUMNS over its waves, CPW per wave:
+//               every wave loads its CPW entries of the row once, into registers (coalesced down each column, all
+//               loads in flight together) ; the waves' partial dots meet in LDS -> A_x[i] (+ bias) ; res = A_x - b
+//               or the logistic link (lasso/runme.jl:22 ; sparse_logreg/runme.jl:24-36) ; A' res is accumulated
+//               per lane from the SAME registers and wave-summed once per block ; block partials of ||res||^2
+//               or the loss terms, of sum(res)
+//   k_spg_close (one block of 1024): partials summed in a fixed order -> f(x), grad f(x) ; primal residual and
+//               the step-size sums (:338, :260-261) ; rule (:340) ; termination, record (:348-354) ;
+//               v = x - gamma grad ; x+ = prox_{gamma g}(v) (:359-361)
+//
+// Two launches per iteration, A read once, no redundant work, every sum in a fixed order (bit-reproducible); the
+// control block is the generic one (`Ctrl`), so polling, results and hipGraph replay work as in the generic path.
+// (A thread per whole row — skinny_pd.hip's scheme, right for n ~ 10 — leaves a chain of n dependent loads and n
+//  wave sums per thread: 51 us per iteration at 8124 x 112.)
+#include <cstdlib>
+#include <memory>
+
+#include "skinny_dev.h"
+
+namespace apx {
+
+constexpr int kSpgMaxWaves = 8;       // column slices per block
+constexpr int kSpgCloseBlock = 1024;
+constexpr int kSpgMaxBlocks = 512;    // row blocks: what the closing block sums per column
+
+// (Every dependent trip to memory costs 1-2 us here — the partials and the control block were written by the previous
+//  launch, on other XCDs — so both kernels issue ALL their loads first, the done flag among them, and only then branch.)
+template <typename T, int FK, int CPW>
+__global__ __launch_bounds__(64 * kSpgMaxWaves) void k_spg_rows(SkinnyPgDev d) {
+  __shared__ double xs[kSkinnyMaxN + 8];
+  __shared__ double pd[2][kSpgMaxWaves][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int W = blockDim.x >> 6;
+  const T* __restrict__ A = (const T*)d.A;
+  const T* __restrict__ bv = (const T*)d.b;
+  const int done = d.c->done;                  // written by an earlier launch: block-uniform
+  const T xv = tid < d.n ? ((const T*)d.X)[tid] : (T)0;
+  const int c0 = wv * CPW;
+  int64_t co[CPW];
+#pragma unroll
+  for (int u = 0; u < CPW; ++u) co[u] = (int64_t)min(c0 + u, d.ncols - 1) * d.ld;   // clamped: a valid address, weight 0
+  const int row0 = blockIdx.x * d.groups * 64 + lane;
+  T av[CPW], nv[CPW] = {};
+  T bi, nb = (T)0;
+  {
+    const int ic = min(row0, d.m - 1);
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) av[u] = A[co[u] + ic];
+    bi = bv[ic];
+  }
+  if (done != 0) return;
+  if (tid < d.n) xs[tid] = (double)xv;
+  __syncthreads();
+  double xr[CPW], acc[CPW];
+#pragma unroll
+  for (int u = 0; u < CPW; ++u) {
+    xr[u] = c0 + u < d.ncols ? xs[c0 + u] : 0.0;
+    acc[u] = 0.0;
+  }
+  double ex[2] = {0.0, 0.0};
+  for (int g = 0; g < d.groups; ++g) {
+    const int i = row0 + g * 64;
+    if (g + 1 < d.groups) {                    // the next group's loads go out before this group's arithmetic
+      const int ic = min(i + 64, d.m - 1);
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) nv[u] = A[co[u] + ic];
+      nb = bv[ic];
+    }
+    double part = 0.0;
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) part = fma((double)av[u], xr[u], part);
+    pd[g & 1][wv][lane] = part;
+    __syncthreads();                           // (two buffers: one barrier per group is enough)
+    double a = pd[g & 1][0][lane];
+    for (int w = 1; w < W; ++w) a += pd[g & 1][w][lane];
+    a = (double)(T)a;                          // A_x rounded to T like every stored A x
+    double res = 0.0;
+    if (i < d.m) {
+      if constexpr (FK == APX_F_LEAST_SQUARES) {
+        res = (double)(T)(a - (double)bi);
+        ex[0] += res * res;
+      } else {
+        const double logit = a + xs[d.n - 1];
+        const double e = 1.0 + exp(-logit);
+        ex[0] += ((double)bi - 1.0) * logit - log(e);
+        res = (double)(T)(1.0 / e - (double)bi);
+        ex[1] += res;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      acc[u] = fma((double)av[u], res, acc[u]);
+      av[u] = nv[u];
+    }
+    bi = nb;
+  }
+  double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
+  wave_sum_multi<CPW>(acc);                    // lane l: the total of column c0 + l / (64 / CPW)
+  if (wv == 0) wave_sum_multi<2>(ex);          // (every wave holds the same two sums) lane l: ex[l / 32]
+  constexpr int kPer = 64 / CPW;
+  const int col = c0 + lane / kPer;
+  if (lane % kPer == 0 && col < d.ncols) out[col] = acc[0];
+  if (wv == 0 && (lane & 31) == 0) out[d.ncols + (lane >> 5)] = ex[0];
+}
+
+// MODE 0: pre-loop (:328-332) grad f(x0) ; v = x0 - gamma grad ; x1 = prox(v)   MODE 1: close iteration k and step
+template <typename T, int FK, int MODE>
+__global__ __launch_bounds__(kSpgCloseBlock) void k_spg_close(SkinnyPgDev d, int B) {
+  __shared__ SkinnyRed red[16];
+  __shared__ Ctrl lc;
+  __shared__ double fin[2];
+  __shared__ double qs[2][8];
+  const int tid = threadIdx.x;
+  T* __restrict__ X = (T*)d.X;
+  T* __restrict__ XP = (T*)d.XP;
+  T* __restrict__ GP = (T*)d.GP;
+  T* __restrict__ V = (T*)d.V;
+  // ---- every load of this kernel -------------------------------------------------------------------
+  const int done = d.c->done;
+  const int nc = d.ncols + 2;
+  const int S = min(kSpgCloseBlock / d.npow, 16);
+  const int c = tid % d.npow, sg = tid / d.npow;
+  const bool summing = c < nc && sg < S;
+  double pa[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {               // blocks sg, sg + S, ...: sixteen loads in flight
+    const int b = sg + u * S;
+    pa[u] = summing && b < B ? d.part[(int64_t)b * d.ldpart + c] : 0.0;
+  }
+  const bool mine = tid < d.n;
+  const T x_t = mine ? X[tid] : (T)0, v_t = mine ? V[tid] : (T)0, gp_t = mine ? GP[tid] : (T)0, xp_t = mine ? XP[tid] : (T)0;
+  if (tid == 0) lc = *d.c;
+  if (done != 0) return;
+  // ---- column sums of the block partials, in a fixed order --------------------------------------------
+  if (summing) {
+    double t = (((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pa[4] + pa[5]) + (pa[6] + pa[7]))) +
+               (((pa[8] + pa[9]) + (pa[10] + pa[11])) + ((pa[12] + pa[13]) + (pa[14] + pa[15])));
+    if (B > 16 * S) t += skinny_strided_sum(d.part, d.ldpart, c, sg + 16 * S, S, B);
+    red[sg][c] = t;
+  }
+  __syncthreads();
+  double tot = 0.0;
+  if (tid < nc)
+    for (int k = 0; k < S; ++k) tot += red[k][tid];
+  if (tid == d.ncols) fin[0] = tot;
+  if (tid == d.ncols + 1) fin[1] = tot;
+  __syncthreads();
+  // the gradient entry of this thread
+  double gj = 0.0;
+  if (mine) {
+    if (FK == APX_F_LOGISTIC && tid == d.n - 1) {
+      gj = (double)(T)(fin[1] / lc.n_mean);                        // grad[end] = mean(probs - y)
+    } else {
+      const T gs = (T)tot;                                          // A' * res
+      gj = FK == APX_F_LOGISTIC ? (double)(T)((double)gs / lc.n_mean) : (double)gs;
+    }
+  }
+  const double xj = (double)x_t;
+  if constexpr (MODE == 1) {
+    if (tid < 128) {                                                // n <= 120: the first two waves hold it all
+      double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (mine) {
+        const double pr = ((double)v_t - xj) / lc.gamma + gj;      // :338 (A'y == 0)
+        const double dg = gj - (double)gp_t;
+        const double dx = xj - (double)xp_t;
+        q[0] = pr * pr;
+        q[1] = dg * dg;
+        q[2] = dg * dx;
+        q[3] = dx * dx;
+        q[4] = gval_elem<T>(d.g, xj, tid);
+      }
+      wave_sum_multi<8>(q);                                         // lane l: sum l / 8
+      if ((tid & 7) == 0) qs[tid >> 6][(tid & 63) >> 3] = q[0];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if constexpr (FK == APX_F_LEAST_SQUARES) {
+        const double nr = sqrt(fin[0]);                             // 0.5 * norm(res)^2 : nrm2 THEN square
+        lc.f_x = 0.5 * (nr * nr);
+      } else {
+        lc.f_x = -(fin[0] / lc.n_mean);
+        lc.bias_grad = fin[1] / lc.n_mean;
+      }
+      lc.it += 1;
+      const double npr = sqrt(qs[0][0] + qs[1][0]);
+      lc.npr2 = npr * npr;
+      lc.g_x = gval_final(d.g, qs[0][4] + qs[1][4]);
+      rule_update(&lc, qs[0][1] + qs[1][1], qs[0][2] + qs[1][2], qs[0][3] + qs[1][3]);   // :340-342
+      lc.ndr2 = 0.0;                                                // h = Zero, A = 0: dual_res == 0
+      lc.h_Ax = 0.0;
+      finish_iteration(&lc, d.recs, d.rec_cap);                     // :348-354
+      *d.c = lc;
+    }
+    __syncthreads();
+    if (lc.done != 0) return;      // converged: x is the tested iterate, nothing moves (:355)
+  }
+  if (mine) {
+    const double gamma = lc.gamma;
+    const T vj = (T)(xj - gamma * gj);                              // :330 / :359
+    const T xn = (T)prox_elem<T>(d.g, (double)vj, gamma, tid, 0.0); // :332 / :361
+    XP[tid] = x_t;
+    GP[tid] = (T)gj;
+    V[tid] = vj;
+    X[tid] = xn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+bool skinny_pg_eligible(const apx_problem* p) {
+  if (!p->ctx->fused_small) return false;
+  if (p->A_lin != nullptr || p->allreduce != nullptr) return false;
+  if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
+  if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
+  const int64_t m = p->A_f->m;
+  // below ~2000 rows small.hip's redundant scheme is as fast (logistic 2000 x 120: 14.8 us)
+  return p->n <= kSkinnyMaxN && p->A_f->n > 0 && m >= 2048 && m <= 256 * 1024 && p->n * 4 <= m;
+}
+
+template <typename T, int FK, int MODE>
+static void spg_tick_t(const SkinnyPgState* st, hipStream_t q) {
+  const SkinnyPgDev& d = st->dev;
+  if (st->cpw == 4) hipLaunchKernelGGL((k_spg_rows<T, FK, 4>), dim3(st->B), dim3(64 * st->waves), 0, q, d);
+  else hipLaunchKernelGGL((k_spg_rows<T, FK, 16>), dim3(st->B), dim3(64 * st->waves), 0, q, d);
+  hipLaunchKernelGGL((k_spg_close<T, FK, MODE>), dim3(1), dim3(kSpgCloseBlock), 0, q, d, st->B);
+}
+template <int MODE>
+static void spg_tick(const SkinnyPgState* st, int32_t dtype, int fk, hipStream_t q) {
+  const bool ls = fk == APX_F_LEAST_SQUARES;
+  if (dtype == APX_F32) {
+    if (ls) spg_tick_t<float, APX_F_LEAST_SQUARES, MODE>(st, q);
+    else spg_tick_t<float, APX_F_LOGISTIC, MODE>(st, q);
+  } else {
+    if (ls) spg_tick_t<double, APX_F_LEAST_SQUARES, MODE>(st, q);
+    else spg_tick_t<double, APX_F_LOGISTIC, MODE>(st, q);
+  }
+}
+
+// called by apx_solver_create instead of the generic pre-loop (:324-332); Ctrl is initialised in p->ctrl_buf, x0 in s->x
+int32_t skinny_pg_setup(apx_solver* s) {
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  const apx_matrix* A = p->A_f;
+  std::unique_ptr<SkinnyPgState> st(new SkinnyPgState());
+  // columns per wave: 4 up to 32 columns (more waves per row group), else 16 ; row groups per block so that at
+  // most kSpgMaxBlocks partial rows are left for the closing block
+  st->cpw = A->n <= 4 * kSpgMaxWaves ? 4 : 16;
+  st->waves = (int)((A->n + st->cpw - 1) / st->cpw);
+  const int64_t ngroups = (A->m + 63) / 64;
+  const int groups = (int)((ngroups + kSpgMaxBlocks - 1) / kSpgMaxBlocks);
+  st->B = (int)((ngroups + groups - 1) / groups);
+  SkinnyPgDev d{};
+  d.groups = groups;
+  d.A = A->d;
+  d.ld = A->ld;
+  d.m = (int32_t)A->m;
+  d.ncols = (int32_t)A->n;
+  d.n = (int32_t)p->n;
+  d.npow = skinny_npow(d.ncols);          // (>= ncols + 4 >= the ncols + 2 partial columns used here)
+  d.ldpart = round_up(d.ncols + kSkinnyExtra, 8);
+  APX_TRY(st->part.alloc_zero((size_t)st->B * d.ldpart * sizeof(double), ctx->stream));
+  d.b = p->b.p;
+  d.X = s->x.p;                 // the solver's own n-vectors: results and stepping work as in the generic path
+  d.XP = s->xprev.p;
+  d.GP = s->gprev.p;
+  d.V = s->v.p;
+  d.part = (double*)st->part.p;
+  d.c = p->ctrl();
+  d.g = p->gd;
+  d.recs = (apx_record*)s->recs.p;
+  d.rec_cap = s->rec_cap;
+  st->dev = d;
+  spg_tick<0>(st.get(), p->dtype, p->f_kind, ctx->stream);
+  APX_HIP(hipGetLastError());
+  s->skinny_pg = st.release();
+  return APX_OK;
+}
+
+int32_t skinny_pg_enqueue(apx_solver* s) {
+  const SkinnyPgState* st = s->skinny_pg;
+  spg_tick<1>(st, s->p->dtype, s->p->f_kind, s->p->ctx->stream);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+}  // namespace apx

@@ -414,7 +414,8 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   // (tools/small_bench.py): replay is never faster than eager launches here — the two-kernel small path is
   // device-bound at ~12 us / iteration eager vs 18+ us replayed, the generic path ~30 us either way — so
   // the library's choice is eager; replay stays available on request.
-  const bool small = small_eligible(p);
+  const bool skinny_pg = skinny_pg_eligible(p);                // tall, skinny A_f: row kernel + closing kernel
+  const bool small = !skinny_pg && small_eligible(p);
   const bool want_graph = opts != nullptr && opts->use_graph == 1;
   const bool skinny = skinny_pd_eligible(p);                   // tall, skinny A: row kernel + closing kernel
   const bool small_pd = !skinny && !want_graph && small_pd_eligible(p);   // (its buffer roles rotate on the host: no replay)
@@ -451,7 +452,9 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   APX_TRY(h2d(ctx, s->x.p, x0, (size_t)p->n * es));
   if (lin) APX_TRY(h2d(ctx, s->y.p, y0, (size_t)p->m * es));
 
-  if (small) {
+  if (skinny_pg) {
+    APX_TRY(skinny_pg_setup(s.get()));
+  } else if (small) {
     APX_TRY(small_setup(s.get()));   // small.hip: pre-loop and iteration as fused kernels
   } else if (skinny) {
     APX_TRY(skinny_pd_setup(s.get(), x0, y0));
@@ -483,6 +486,7 @@ static int32_t enqueue_iteration(apx_solver* s) {
   if (s->small != nullptr) return small_enqueue(s);
   if (s->small_pd != nullptr) return small_pd_enqueue(s);
   if (s->skinny != nullptr) return skinny_pd_enqueue(s);
+  if (s->skinny_pg != nullptr) return skinny_pg_enqueue(s);
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   const bool lin = p->A_lin != nullptr;

@@ -125,6 +125,28 @@ struct SkinnyState {
   int B = 0;              // row blocks
 };
 
+// ---- skinny_pg.hip: proximal-gradient loop for tall, skinny dense A (LinearLeastSquares / LogisticLoss) --------
+struct SkinnyPgDev {
+  const void* A;          // m_pad x ncols, column-major
+  int64_t ld;
+  int32_t m, ncols, n, npow;
+  int32_t groups;         // groups of 64 rows per block
+  int64_t ldpart;
+  const void* b;
+  void *X, *XP, *GP, *V;  // the solver's n-vectors, written by k_spg_close only
+  double* part;           // [blocks][ldpart]: ncols partials of A' res, ||res||^2 or the loss sum, sum(res)
+  Ctrl* c;
+  ProxDev g;
+  apx_record* recs;
+  int64_t rec_cap;
+};
+
+struct SkinnyPgState {
+  DBuf part;
+  SkinnyPgDev dev{};
+  int B = 0, waves = 0, cpw = 0;
+};
+
 // ---- small_mom.hip: fixed Nesterov and aGRAAL as device-resident loops (small dense problems) ---------
 enum { MOM_AGRAAL = 0, MOM_NESTEROV = 1 };
 
@@ -160,10 +182,12 @@ struct apx_solver {
   apx::SmallState* small = nullptr;   // non-null: the iteration runs as small.hip's two kernels
   apx::SmallPdState* small_pd = nullptr;   // non-null: ... as small_pd.hip's two kernels
   apx::SkinnyState* skinny = nullptr;      // non-null: ... as skinny_pd.hip's row + closing kernels
+  apx::SkinnyPgState* skinny_pg = nullptr; // non-null: ... as skinny_pg.hip's row + closing kernels
   ~apx_solver() {
     delete small;
     delete small_pd;
     delete skinny;
+    delete skinny_pg;
   }
 };
 
@@ -190,6 +214,10 @@ bool small_pd_eligible(const apx_problem* p);
 int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0);
 int32_t small_pd_enqueue(apx_solver* s);
 const void* small_pd_ctrl(const apx_solver* s);
+// skinny_pg.hip
+bool skinny_pg_eligible(const apx_problem* p);
+int32_t skinny_pg_setup(apx_solver* s);
+int32_t skinny_pg_enqueue(apx_solver* s);
 // skinny_pd.hip
 bool skinny_pd_eligible(const apx_problem* p);
 int32_t skinny_pd_setup(apx_solver* s, const void* x0, const void* y0);

@@ -156,10 +156,11 @@ def test_size_limits_fall_back_to_generic_kernels(apx):
     for m, n in ((4096, 64), (64, 4096), (4097, 40), (40, 4097)):
         A, b = rng.uniform(-1, 1, (m, n)), rng.uniform(-1, 1, m)
         gam = 1.0 / P.opnorm_sq_power(A, iters=30)
+        K = 14 if m > n else 40            # (the tall ones are at rounding level after ~20 iterations)
         xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(A, b), g=O.NormL1(0.5), rule=O.OurRule(gamma=gam),
-                                    tol=0.0, maxit=40)
+                                    tol=0.0, maxit=K)
         xf, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(0.5),
-                                      rule=apx.OurRule(gamma=gam), tol=0.0, maxit=40)
+                                      rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K)
         assert _rel(xf, xo) <= RTOL
 
 
@@ -332,7 +333,9 @@ def test_proxgrad_tall_dataset_shapes(apx, generic_ctx, m, n, logistic):
 @pytest.mark.parametrize("m,n,hkind", [(1024, 14, "l1"), (3072, 14, "l2"), (1025, 1, "l1"), (3500, 120, "l2"), (40000, 30, "l1"),
                                        (262144, 6, "l2"), (9000, 120, "l1")])
 def test_skinny_pd_shapes(apx, generic_ctx, m, n, hkind):
-    lad = P.random_lad(m, n, seed=4, lam=5.0)
+    # (lam = 5 at 262144 x 6 with the l2 ball has the solution x = 0: the residual is at rounding level after five
+    #  iterations and reaches 0.0 exactly a few later, whenever the summation order lets it)
+    lad = P.random_lad(m, n, seed=4, lam=0.05 if (m, hkind) == (262144, "l2") else 5.0)
     Ag = apx.DeviceMatrix.from_numpy(lad.A, generic_ctx)
     x0, y0, K = np.zeros(n), np.zeros(m), 60
     rf, rg = [], []
@@ -458,3 +461,79 @@ def test_backtracking_small_termination_maxit_fp32(apx):
     zo, _ = O.backtracking_proxgrad(np.zeros(400), f=O.LinearLeastSquares(prob.A, prob.b), g=O.NormL1(1.0), tol=0.0,
                                     maxit=40, **kw)
     assert zf.dtype == np.float32 and itf == 40 and _rel(zf, zo) <= 5e-3
+
+
+# ---------------------------------------------------------------------------------------
+# tall, skinny A in the proximal-gradient loop (csrc/skinny_pg.hip: n <= 120, m >= 2048)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,logistic,dtype", [(8124, 112, True, np.float64), (11055, 68, True, np.float64),
+                                                (2048, 119, True, np.float64), (6000, 40, False, np.float64),
+                                                (100000, 7, False, np.float64), (2049, 2, False, np.float64),
+                                                (8124, 112, True, np.float32)])
+def test_skinny_pg_shapes(apx, generic_ctx, m, n, logistic, dtype):
+    if logistic:
+        lr = P.random_logreg(m, n, seed=5, dtype=dtype)
+        A, b, lam, gam, nx = lr.X, lr.y, lr.lam, lr.gamma0, n + 1
+        mko, mkf = (lambda: O.LogisticLoss(A.astype(np.float64), b.astype(np.float64))), apx.LogisticLoss
+    else:
+        rng = np.random.default_rng(m + n)
+        A, b, lam, nx = rng.uniform(-1, 1, (m, n)).astype(dtype), rng.standard_normal(m).astype(dtype), 0.5, n
+        gam = 1.0 / P.opnorm_sq_power(A.astype(np.float64), iters=30)
+        mko, mkf = (lambda: O.LinearLeastSquares(A.astype(np.float64), b.astype(np.float64))), apx.LinearLeastSquares
+    # (these tall problems are well conditioned: the residual reaches rounding level after ~20 iterations and every
+    #  later step size is a ratio of rounding errors, so the compared window ends before that)
+    K = 12
+    tol_x = 1e-10 if dtype == np.float64 else 2e-3
+    ro, rf = [], []
+    xo, _ = O.adaptive_proxgrad(np.zeros(nx), f=mko(), g=O.NormL1(lam), rule=O.OurRule(gamma=gam), tol=0.0, maxit=K,
+                                record=ro.append)
+    ff = apx.Counting(mkf(A, b))
+    xf, itf = apx.adaptive_proxgrad(np.zeros(nx, dtype=dtype), f=ff, g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0,
+                                    maxit=K, record=rf.append)
+    xg, _ = apx.adaptive_proxgrad(np.zeros(nx, dtype=dtype), f=mkf(apx.DeviceMatrix.from_numpy(A, generic_ctx), b, ctx=generic_ctx),
+                                  g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, ctx=generic_ctx)
+    assert itf == K and len(rf) == K and (ff.eval_count, ff.grad_count) == (K + 1, K + 1)
+    assert _rel(xf, xo) <= tol_x and _rel(xf, xg) <= tol_x
+    if dtype == np.float64:
+        for a, b_ in zip(rf, ro):
+            # (the step size is a ratio of differences of iterates: its relative accuracy is eps * |x| / |dx|, and
+            #  these problems contract by 10x per iteration)
+            if b_["norm_res"] <= 1e-4 * ro[0]["norm_res"]:
+                break
+            assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-8)
+            assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10)
+            assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7, abs=1e-13)
+
+
+def test_skinny_pg_rules_graph_stepping_termination(apx):
+    lr = P.random_logreg(5000, 60, seed=8, dtype=np.float64)
+    f, g = apx.LogisticLoss(lr.X, lr.y), apx.NormL1(lr.lam)
+    fo, go = O.LogisticLoss(lr.X, lr.y), O.NormL1(lr.lam)
+    for mk in (lambda M: M.FixedStepsize(lr.gamma0, 1.0), lambda M: M.MalitskyMishchenkoRule(gamma=lr.gamma0),
+               lambda M: M.OurRulePlus(gamma=lr.gamma0)):
+        xo, _ = O.adaptive_proxgrad(np.zeros(61), f=fo, g=go, rule=mk(O), tol=0.0, maxit=14)
+        xf, _ = apx.adaptive_proxgrad(np.zeros(61), f=f, g=g, rule=mk(apx), tol=0.0, maxit=14)
+        assert _rel(xf, xo) <= RTOL
+    rule = apx.OurRule(gamma=lr.gamma0)
+    # (20 iterations: past ~24 the residual of this problem is at rounding level and may hit 0.0, which terminates)
+    x1, _ = apx.adaptive_proxgrad(np.zeros(61), f=f, g=g, rule=rule, tol=0.0, maxit=20)
+    x2, _ = apx.adaptive_proxgrad(np.zeros(61), f=f, g=g, rule=rule, tol=0.0, maxit=20, use_graph=True)
+    assert np.array_equal(x1, x2)
+    s = apx.Solver(np.zeros(61), f=f, g=g, rule=rule, tol=0.0)
+    for k in (1, 9, 10):
+        s.step(k)
+        s.result()
+    xs, _, res = s.result()
+    s.close()
+    assert res.numit == 20 and np.array_equal(xs, x1)
+    # termination: tolerance reached at a known iteration
+    recs = []
+    apx.adaptive_proxgrad(np.zeros(61), f=f, g=g, rule=rule, tol=0.0, maxit=20, record=recs.append)
+    res_k = [r["norm_res"] for r in recs]
+    tol = res_k[11] * (1 + 1e-9)            # (rounding level is reached near iteration 24)
+    kstar = 1 + next(k for k, v in enumerate(res_k) if v <= tol)
+    xo, ito = O.adaptive_proxgrad(np.zeros(61), f=fo, g=go, rule=O.OurRule(gamma=lr.gamma0), tol=tol, maxit=1000)
+    for poll in (1, 64):
+        ff = apx.Counting(f)
+        xf, itf = apx.adaptive_proxgrad(np.zeros(61), f=ff, g=g, rule=rule, tol=tol, maxit=1000, poll_every=poll)
+        assert itf == kstar == ito and _rel(xf, xo) <= RTOL and (ff.eval_count, ff.grad_count) == (itf + 1, itf + 1)

@@ -66,13 +66,18 @@ def main():
             f = apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A_h, ctx), b_h, ctx=ctx)
             for graph in (False, True):
                 run(f"lasso {m}x{n} fp64 {name}", ctx, f, apx.NormL1(1.0), n, gam, graph)
-    for lm, ln in ((2000, 120), (8124, 112)):              # (mushrooms is 8124 x 112)
+    # (mushrooms is 8124 x 112, phishing 11055 x 68: from 2048 rows on, n <= 120 runs in skinny_pg.hip)
+    for lm, ln in ((2000, 120), (8124, 112), (11055, 68), (65536, 32)):
         X_h, y_h, gam0 = logreg(lm, ln)
-        for name, ctx in (("small.hip", fused), ("generic", generic)):
+        for name, ctx in (("small.hip / skinny_pg.hip", fused), ("generic", generic)):
             f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(X_h, ctx), y_h, ctx=ctx)
             for graph in (False, True):
                 run(f"logreg {lm}x{ln} fp32 {name}", ctx, f, apx.NormL1(0.01), ln + 1, gam0, graph, dtype=np.float32)
-
+    for m, n in ((8124, 112), (100000, 20)):
+        A_h, b_h, gam = lasso(m, n)
+        for name, ctx in (("skinny_pg.hip", fused), ("generic", generic)):
+            f = apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A_h, ctx), b_h, ctx=ctx)
+            run(f"lasso {m}x{n} fp64 {name}", ctx, f, apx.NormL1(1.0), n, gam, False)
 
     # primal-dual (LAD shapes of experiments/least_absolute_deviation: housing is 506 x 14)
     for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1"), (4177, 9, "l1"), (8192, 13, "l2")):
