@@ -92,23 +92,26 @@ __device__ __forceinline__ double skinny_colsum(const double* __restrict__ part,
 // Wave totals of N per-lane values with N - 1 + log2(64 / N) exchanges instead of 6 N: at each of the first log2 N
 // steps a lane keeps half of its values and hands the other half to its partner.  Afterwards v[0] of lane l is the
 // total of value l / (64 / N).
+template <int H, int N>
+__device__ __forceinline__ void wave_sum_multi_step(double (&v)[N], int lane) {
+  if constexpr (H >= 1) {                      // (a template per step: every register index is a constant)
+    constexpr int kOff = 64 * H / N;
+    const bool upper = (lane & kOff) != 0;
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+      const double send = upper ? v[u] : v[u + H];
+      const double keep = upper ? v[u + H] : v[u];
+      v[u] = keep + __shfl_xor(send, kOff, 64);
+    }
+    wave_sum_multi_step<H / 2, N>(v, lane);
+  }
+}
 template <int N>
 __device__ __forceinline__ void wave_sum_multi(double (&v)[N]) {
   static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32, "power of two");
-  const int lane = threadIdx.x & 63;
-  int off = 32;
+  wave_sum_multi_step<N / 2, N>(v, threadIdx.x & 63);
 #pragma unroll
-  for (int h = N / 2; h >= 1; h >>= 1) {
-    const bool upper = (lane & off) != 0;
-#pragma unroll
-    for (int u = 0; u < h; ++u) {
-      const double send = upper ? v[u] : v[u + h];
-      const double keep = upper ? v[u + h] : v[u];
-      v[u] = keep + __shfl_xor(send, off, 64);
-    }
-    off >>= 1;
-  }
-  for (; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
+  for (int off = 32 / N; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
 }
 
 inline int skinny_npow(int n) {

@@ -43,17 +43,23 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
     if (tid < d.n) xs[tid] = (double)((const T*)d.X)[tid];
     __syncthreads();
   } else {
-    if (d.c->done != 0) return;                // written by an earlier launch: block-uniform
+    // (every load goes out before the branch on the done flag, and the control block goes straight to LDS behind
+    //  them: each dependent round trip to memory costs 1-2 us here, and a private copy would live in scratch)
+    const int done = d.c->done;                // written by an earlier launch: block-uniform
     if constexpr (PHASE == 1 || PHASE == 2) {
       // ---- n side, redundantly per block (n <= 120 values): residual, rule ------------------------
-      Ctrl t;
-      if (tid == 0) t = *d.c;
       const double gamma = d.c->gamma;
+      const bool mine = tid < d.n;
+      const T x_t = mine ? ((const T*)d.X)[tid] : (T)0, v_t = mine ? ((const T*)d.V)[tid] : (T)0,
+              xp_t = mine ? ((const T*)d.XP)[tid] : (T)0;
+      const double aty_t = mine ? d.aty[tid] : 0.0;
+      if (tid == 0) lc = *d.c;
+      if (done != 0) return;
       double q[5] = {0, 0, 0, 0, 0};
-      if (tid < d.n) {
-        const double xj = (double)((const T*)d.X)[tid];
-        const double pr = ((double)((const T*)d.V)[tid] - xj) / gamma + 0.0 + (double)(T)d.aty[tid];   // :338
-        const double dx = xj - (double)((const T*)d.XP)[tid];
+      if (mine) {
+        const double xj = (double)x_t;
+        const double pr = ((double)v_t - xj) / gamma + 0.0 + (double)(T)aty_t;   // :338
+        const double dx = xj - (double)xp_t;
         q[0] = pr * pr;
         q[3] = dx * dx;
         q[4] = gval_elem<T>(d.g, xj, tid);
@@ -61,7 +67,6 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
       }
       block_sums_t0<5>(q);
       if (tid == 0) {
-        lc = t;
         lc.it += 1;
         const double npr = sqrt(q[0]);
         lc.npr2 = npr * npr;
@@ -72,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
       __syncthreads();
     } else {
       if (tid == 0) lc = *d.cs;
+      if (done != 0) return;
       __syncthreads();
     }
   }

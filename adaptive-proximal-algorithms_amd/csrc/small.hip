@@ -58,9 +58,8 @@ __global__ __launch_bounds__(BS) void k_small_b(SmallDev d, int dot_blocks) {
     return;
   }
   const T* __restrict__ b = (const T*)d.b;
-  Ctrl t;
+  __shared__ Ctrl lt;
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
-  if (writer) t = *d.cb;
   double bias = 0.0;
   if constexpr (FK == APX_F_LOGISTIC) bias = (double)((const T*)d.XN)[d.n - 1];
   double q[2] = {0.0, 0.0};
@@ -74,6 +73,9 @@ __global__ __launch_bounds__(BS) void k_small_b(SmallDev d, int dot_blocks) {
       s4[u] = d.axp[ic];
       b4[u] = (double)b[ic];
     }
+    // the control block goes straight to LDS, BEHIND the first batch of loads: a private copy would live in
+    // scratch, and its wave would wait a whole round trip for it before issuing anything else
+    if (k0 == 0 && writer) lt = *d.cb;
 #pragma unroll
     for (int u = 0; u < MB; ++u) {
       const int i = threadIdx.x + (k0 + u) * BS;
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(BS) void k_small_b(SmallDev d, int dot_blocks) {
   }
   block_sums_t0<2, BS>(q);             // (barrier inside: rs is complete behind it)
   if (writer && live) {
-    f_finalize(&t, FK, q);
-    *d.ca = t;
+    f_finalize(&lt, FK, q);
+    *d.ca = lt;
   }
   small_dots_w<T, BS>(d.w_t, (const T*)d.A, d.ld, d.ncols, d.m, rs, d.grp, live);       // A' r: columns of A
 }
@@ -118,11 +120,6 @@ __global__ __launch_bounds__(kBlock) void k_small_a(SmallDev d) {
     // thread 0 alone reads the done flag (block 0 of THIS launch may set it while a later block starts:
     // that block then leaves, which is what it would decide for itself anyway) and the control block
     int done_in = 0;
-    Ctrl t;
-    if (threadIdx.x == 0) {
-      done_in = d.cb->done;
-      if constexpr (MODE == 2) t = *d.ca;
-    }
     const T* __restrict__ X = (const T*)d.X;
     [[maybe_unused]] const T* __restrict__ XP = (const T*)d.XP;
     [[maybe_unused]] const T* __restrict__ GP = (const T*)d.GP;
@@ -153,6 +150,10 @@ __global__ __launch_bounds__(kBlock) void k_small_a(SmallDev d) {
             gp4[u] = (double)GP[ic];
             xp4[u] = (double)XP[ic];
           }
+        }
+        if (k0 == 0 && threadIdx.x == 0) {     // behind the first batch of loads, straight to LDS (see k_small_b)
+          done_in = d.cb->done;
+          if constexpr (MODE == 2) lc = *d.ca;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -190,7 +191,6 @@ __global__ __launch_bounds__(kBlock) void k_small_a(SmallDev d) {
         lc.done = 0;
         lc.gamma = gamma;
       } else {
-        lc = t;
         lc.it += 1;
         const double npr = sqrt(q[0]);
         lc.npr2 = npr * npr;

@@ -40,8 +40,6 @@ __global__ __launch_bounds__(BS) void k_small_pd_b(PdDev d) {
   } else {
     __shared__ Ctrl lc;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
-    Ctrl t;
-    if (threadIdx.x == 0) t = *d.c_cur;
     const int done_in = d.c_cur->done;          // c_cur is not written by this kernel: block-uniform
     const double gamma = d.c_cur->gamma;
     const T* __restrict__ X = (const T*)d.x_cur;
@@ -71,6 +69,9 @@ __global__ __launch_bounds__(BS) void k_small_pd_b(PdDev d) {
           qv4[u] = (double)QV[ic];
         }
       }
+      // the control block goes straight to LDS, BEHIND the first batch of loads: a private copy would live in
+      // scratch, and its wave would wait a whole round trip for it before issuing anything else
+      if (k0 == 0 && threadIdx.x == 0) lc = *d.c_cur;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = threadIdx.x + (k0 + u) * BS;
@@ -121,7 +122,6 @@ __global__ __launch_bounds__(BS) void k_small_pd_b(PdDev d) {
       if (done_in != 0) {
         lc.done = 2;                                     // already converged: forward the control block
       } else {
-        lc = t;
         if constexpr (FK == APX_F_QUADRATIC) lc.f_x = 0.5 * fq[0] + fq[1];
         lc.it += 1;
         const double npr = sqrt(q[0]);
@@ -132,7 +132,10 @@ __global__ __launch_bounds__(BS) void k_small_pd_b(PdDev d) {
     }
     __syncthreads();
     if (lc.done == 2) {
-      if (writer) *d.c_next = t;
+      if (writer) {
+        *d.c_next = lc;
+        d.c_next->done = done_in;                        // (lc.done is the marker 2 here)
+      }
       return;
     }
     const double sigma = lc.sigma, rho = lc.rho;
