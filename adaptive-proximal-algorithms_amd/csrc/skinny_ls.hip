@@ -205,13 +205,13 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
 // MODE 1: the linesearch test and, when it passes, the rest of the iteration
 // MODE 2: l2 ball: ||w/sigma + shift|| -> staging
 template <typename T, int MODE>
-__global__ __launch_bounds__(kBlock) void k_ls_close(LsDev d, int B) {
-  __shared__ SkinnyRed red[kBlock / 16];
+__global__ __launch_bounds__(kSkinnyCloseBlock) void k_ls_close(LsDev d, int B) {
+  __shared__ SkinnyRed red[16];
   __shared__ LsCtrl lc;
   __shared__ double fin[6];
   const int tid = threadIdx.x;
   if (MODE != 0 && (d.c->done != 0 || d.c->it >= d.c->maxit)) return;
-  const double tot = skinny_colsum(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
+  const double tot = skinny_colsum<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
   if constexpr (MODE == 2) {
     if (tid == d.n + 2) d.cs->h_pre = sqrt(tot);
     return;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_ls_close(LsDev d, int B) {
       const double da = (double)(T)tot - (double)(T)d.aty[tid];
       q[0] = da * da;
     }
-    block_sums_t0<1>(q);
+    block_sums_t0<1, kSkinnyCloseBlock>(q);
     if (tid == 0) {
       if constexpr (MODE == 1) {
         lc = *d.cs;
@@ -305,8 +305,8 @@ static void ls_rows(const LsDev& d, int32_t dtype, int B, hipStream_t q) {
 }
 template <int MODE>
 static void ls_close(const LsDev& d, int32_t dtype, int B, hipStream_t q) {
-  if (dtype == APX_F32) hipLaunchKernelGGL((k_ls_close<float, MODE>), dim3(1), dim3(kBlock), 0, q, d, B);
-  else hipLaunchKernelGGL((k_ls_close<double, MODE>), dim3(1), dim3(kBlock), 0, q, d, B);
+  if (dtype == APX_F32) hipLaunchKernelGGL((k_ls_close<float, MODE>), dim3(1), dim3(kSkinnyCloseBlock), 0, q, d, B);
+  else hipLaunchKernelGGL((k_ls_close<double, MODE>), dim3(1), dim3(kSkinnyCloseBlock), 0, q, d, B);
 }
 
 int32_t skinny_ls_run(apx_problem* p, const apx_linesearch_params* prm, double gamma, const void* x0, const void* y0,

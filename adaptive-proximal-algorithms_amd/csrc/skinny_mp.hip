@@ -153,8 +153,8 @@ __device__ __forceinline__ void mp_trial(const MpDev& d, MpCtrl& lc, double* ndx
 
 // STAGE 0: pre-loop: A'y0 ; STAGE 2: l2 norm of the dual tick ; STAGE 1: close a dual or a primal tick
 template <typename T, int STAGE>
-__global__ __launch_bounds__(kBlock) void k_mp_close(MpDev d, int B) {
-  __shared__ SkinnyRed red[kBlock / 16];
+__global__ __launch_bounds__(kSkinnyCloseBlock) void k_mp_close(MpDev d, int B) {
+  __shared__ SkinnyRed red[16];
   __shared__ MpCtrl lc;
   __shared__ double fin[kSkinnyExtra + 2];
   const int tid = threadIdx.x;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_mp_close(MpDev d, int B) {
     if (d.c->done != 0 || d.c->it >= d.c->maxit) return;
     if (STAGE == 2 && (d.c->phase != 0 || d.h.kind != APX_G_L2)) return;
   }
-  const double tot = skinny_colsum(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
+  const double tot = skinny_colsum<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
   if constexpr (STAGE == 2) {
     if (tid == d.n + 3) d.c->h_pre = sqrt(tot);
     return;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_mp_close(MpDev d, int B) {
       q[1] = gval_elem<T>(d.g, xi, tid);
       ((T*)d.X)[tid] = (T)xi;
     }
-    block_sums_t0<2>(q);
+    block_sums_t0<2, kSkinnyCloseBlock>(q);
     if (tid == 0) {
       const double npr = sqrt(q[0]), ndr = sqrt(fin[1]);
       lc.norm_res = sqrt(npr * npr + ndr * ndr);                         // :618
@@ -263,8 +263,8 @@ static void mp_rows(const MpDev& d, int32_t dtype, int B, hipStream_t q) {
 }
 template <int STAGE>
 static void mp_close(const MpDev& d, int32_t dtype, int B, hipStream_t q) {
-  if (dtype == APX_F32) hipLaunchKernelGGL((k_mp_close<float, STAGE>), dim3(1), dim3(kBlock), 0, q, d, B);
-  else hipLaunchKernelGGL((k_mp_close<double, STAGE>), dim3(1), dim3(kBlock), 0, q, d, B);
+  if (dtype == APX_F32) hipLaunchKernelGGL((k_mp_close<float, STAGE>), dim3(1), dim3(kSkinnyCloseBlock), 0, q, d, B);
+  else hipLaunchKernelGGL((k_mp_close<double, STAGE>), dim3(1), dim3(kSkinnyCloseBlock), 0, q, d, B);
 }
 
 int32_t skinny_mp_run(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol, int64_t maxit,

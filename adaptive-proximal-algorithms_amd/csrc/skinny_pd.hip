@@ -135,13 +135,20 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
 // MODE 1: close the iteration and take the primal step
 // MODE 2: l2 ball: only ||w/sigma + shift|| -> Ctrl staging (between the two row kernels)
 template <typename T, int MODE>
-__global__ __launch_bounds__(kBlock) void k_skinny_close(SkinnyDev d, int B) {
-  __shared__ SkinnyRed red[kBlock / 16];
+__global__ __launch_bounds__(kSkinnyCloseBlock) void k_skinny_close(SkinnyDev d, int B) {
+  __shared__ SkinnyRed red[16];
   __shared__ Ctrl lc;
   __shared__ double fin[4];
   const int tid = threadIdx.x;
-  if (MODE != 0 && d.c->done != 0) return;
-  const double tot = skinny_colsum(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
+  // every load first (the done flag, the partials, x, the control block), then the branch
+  const int done = MODE != 0 ? d.c->done : 0;
+  SkinnyColLoads L;
+  skinny_colsum_issue<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, L);
+  T* __restrict__ X = (T*)d.X;
+  const T x_t = MODE != 2 && tid < d.n ? X[tid] : (T)0;
+  if (MODE != 2 && tid == 0) lc = MODE == 1 ? *d.cs : *d.c;
+  if (done != 0) return;
+  const double tot = skinny_colsum_finish(d.part, d.ldpart, d.n + kSkinnyExtra, B, L, red);
   if constexpr (MODE == 2) {
     if (tid == d.n + 2) d.cs->h_pre = sqrt(tot);
     return;
@@ -151,7 +158,6 @@ __global__ __launch_bounds__(kBlock) void k_skinny_close(SkinnyDev d, int B) {
     __syncthreads();
     if constexpr (MODE == 1) {
       if (tid == 0) {
-        lc = *d.cs;
         const double ndr = sqrt(fin[0]);
         lc.ndr2 = ndr * ndr;
         lc.h_Ax = gval_final(d.h, fin[1]);
@@ -160,18 +166,14 @@ __global__ __launch_bounds__(kBlock) void k_skinny_close(SkinnyDev d, int B) {
       }
       __syncthreads();
       if (lc.done != 0) return;                              // (x, y+) is what the reference returns (:355)
-    } else {
-      if (tid == 0) lc = *d.c;
-      __syncthreads();
     }
     if (tid < d.n) {
-      T* __restrict__ X = (T*)d.X;
       const double gamma = lc.gamma;
-      const double xj = (double)X[tid];
+      const double xj = (double)x_t;
       const T aty = (T)tot;                                  // :358  At_y = A' * y
       const T vj = (T)(xj - gamma * (0.0 + (double)aty));    // :359
       const T xn = (T)prox_elem<T>(d.g, (double)vj, gamma, tid, 0.0);     // :361
-      ((T*)d.XP)[tid] = (T)xj;
+      ((T*)d.XP)[tid] = x_t;
       X[tid] = xn;
       ((T*)d.V)[tid] = vj;
       d.aty[tid] = (double)aty;
@@ -200,8 +202,8 @@ static void launch_rows(const SkinnyDev& d, int32_t dtype, int B, hipStream_t q)
 }
 template <int MODE>
 static void launch_close(const SkinnyDev& d, int32_t dtype, int B, hipStream_t q) {
-  if (dtype == APX_F32) hipLaunchKernelGGL((k_skinny_close<float, MODE>), dim3(1), dim3(kBlock), 0, q, d, B);
-  else hipLaunchKernelGGL((k_skinny_close<double, MODE>), dim3(1), dim3(kBlock), 0, q, d, B);
+  if (dtype == APX_F32) hipLaunchKernelGGL((k_skinny_close<float, MODE>), dim3(1), dim3(kSkinnyCloseBlock), 0, q, d, B);
+  else hipLaunchKernelGGL((k_skinny_close<double, MODE>), dim3(1), dim3(kSkinnyCloseBlock), 0, q, d, B);
 }
 
 // called by apx_solver_create instead of the generic pre-loop (:324-332); Ctrl is initialised in p->ctrl_buf

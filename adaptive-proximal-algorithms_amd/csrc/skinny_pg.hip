@@ -124,30 +124,14 @@ __global__ __launch_bounds__(kSpgCloseBlock) void k_spg_close(SkinnyPgDev d, int
   // ---- every load of this kernel -------------------------------------------------------------------
   const int done = d.c->done;
   const int nc = d.ncols + 2;
-  const int S = min(kSpgCloseBlock / d.npow, 16);
-  const int c = tid % d.npow, sg = tid / d.npow;
-  const bool summing = c < nc && sg < S;
-  double pa[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {               // blocks sg, sg + S, ...: sixteen loads in flight
-    const int b = sg + u * S;
-    pa[u] = summing && b < B ? d.part[(int64_t)b * d.ldpart + c] : 0.0;
-  }
+  SkinnyColLoads L;
+  skinny_colsum_issue<kSpgCloseBlock>(d.part, d.ldpart, nc, d.npow, B, L);
   const bool mine = tid < d.n;
   const T x_t = mine ? X[tid] : (T)0, v_t = mine ? V[tid] : (T)0, gp_t = mine ? GP[tid] : (T)0, xp_t = mine ? XP[tid] : (T)0;
   if (tid == 0) lc = *d.c;
   if (done != 0) return;
   // ---- column sums of the block partials, in a fixed order --------------------------------------------
-  if (summing) {
-    double t = (((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pa[4] + pa[5]) + (pa[6] + pa[7]))) +
-               (((pa[8] + pa[9]) + (pa[10] + pa[11])) + ((pa[12] + pa[13]) + (pa[14] + pa[15])));
-    if (B > 16 * S) t += skinny_strided_sum(d.part, d.ldpart, c, sg + 16 * S, S, B);
-    red[sg][c] = t;
-  }
-  __syncthreads();
-  double tot = 0.0;
-  if (tid < nc)
-    for (int k = 0; k < S; ++k) tot += red[k][tid];
+  const double tot = skinny_colsum_finish(d.part, d.ldpart, nc, B, L, red);
   if (tid == d.ncols) fin[0] = tot;
   if (tid == d.ncols + 1) fin[1] = tot;
   __syncthreads();

@@ -80,7 +80,8 @@ def main():
             run(f"lasso {m}x{n} fp64 {name}", ctx, f, apx.NormL1(1.0), n, gam, False)
 
     # primal-dual (LAD shapes of experiments/least_absolute_deviation: housing is 506 x 14)
-    for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1"), (4177, 9, "l1"), (8192, 13, "l2")):
+    for m, n, hk in ((506, 14, "l1"), (400, 150, "l2"), (2000, 500, "l1"), (4177, 9, "l1"), (8192, 13, "l2"),
+                     (9000, 120, "l1"), (20000, 60, "l1"), (100000, 30, "l1")):
         A_h, y_h, nrm = lad(m, n)
         for name, ctx in (("small_pd.hip / skinny_pd.hip", fused), ("generic", generic)):
             A = apx.DeviceMatrix.from_numpy(A_h, ctx)
