@@ -166,6 +166,28 @@ __device__ __forceinline__ double skinny_colsum(const double* __restrict__ part,
   return skinny_colsum_finish(part, ldpart, nc, B, L, red);
 }
 
+// sqrt of the sum over the B blocks of column `col` of the block partials (the l2 ball's ||w/sigma + shift||),
+// formed by a 256-thread block itself in a fixed order — every block of a launch gets the same bits, and the norm
+// needs no launch of its own.  `issue` puts the loads in flight, `finish` (barriers inside) returns it to all threads.
+__device__ __forceinline__ void skinny_partial_norm_issue(const double* __restrict__ part, int64_t ldpart, int col, int B,
+                                                          double (&z4)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int b = (int)threadIdx.x + u * kBlock;
+    z4[u] = b < B ? part[(int64_t)b * ldpart + col] : 0.0;
+  }
+}
+__device__ __forceinline__ double skinny_partial_norm_finish(const double* __restrict__ part, int64_t ldpart, int col, int B,
+                                                             const double (&z4)[4]) {
+  __shared__ double out;
+  double zz[1] = {(z4[0] + z4[1]) + (z4[2] + z4[3])};
+  for (int b = (int)threadIdx.x + 4 * kBlock; b < B; b += kBlock) zz[0] += part[(int64_t)b * ldpart + col];
+  block_sums_t0<1>(zz);
+  if (threadIdx.x == 0) out = sqrt(zz[0]);
+  __syncthreads();
+  return out;
+}
+
 inline int skinny_npow(int n) {
   int npow = 16;
   while (npow < n + kSkinnyExtra) npow *= 2;

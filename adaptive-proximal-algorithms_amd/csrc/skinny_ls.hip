@@ -5,7 +5,7 @@
 // ~75 us per iteration at these sizes.  Here the linesearch is a small state machine in device memory:
 //
 //   one TICK = one linesearch trial (:516-533) = k_ls_rows + k_ls_close  (the l2 ball needs its norm first:
-//   k_ls_rows<2>, k_ls_close<2>, k_ls_rows<3>, k_ls_close<1>)
+//   k_ls_rows<2>, k_ls_rows<3>, k_ls_close<1>)
 //     k_ls_rows : first trial of an iteration: primal residual (:505), Delta / xi_bar (:507-511, grad f = 0),
 //                 eta = R eta (:513), A_x = <A[i,:], x> (cached for the retries) ; every trial: gamma_next
 //                 (:517-521), rho, sigma, w (:524), y_next (:525) into a trial buffer, block partials of
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
   const int ic = row_ok ? i : d.m - 1;
   T* __restrict__ Y = (T*)d.Y;
   T* __restrict__ YT = (T*)d.YT;
+  [[maybe_unused]] double h_pre = 0.0;
 
   if constexpr (PHASE == 0) {
     if (tid < d.n) xs[tid] = (double)((const T*)d.X)[tid];
@@ -92,8 +93,11 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
     // the control block is only written by k_ls_close: block-uniform
     if (d.c->done != 0 || d.c->it >= d.c->maxit) return;
     if constexpr (PHASE == 3) {
+      // ||w/sigma + shift|| from the first half's block partials, summed by every block itself
       if (tid == 0) lc = *d.cs;
-      __syncthreads();
+      double z4[4];
+      skinny_partial_norm_issue(d.part, d.ldpart, d.n + 2, (int)gridDim.x, z4);
+      h_pre = skinny_partial_norm_finish(d.part, d.ldpart, d.n + 2, (int)gridDim.x, z4);   // (lc is visible behind it)
     } else {
       if (tid == 0) lc = *d.c;
       __syncthreads();
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
         sz = z * z;
       }
     } else {
-      const T ynt = (T)prox_conj_elem_s<T>(d.h, w, sigma, ic, PHASE == 3 ? lc.h_pre : 0.0, b);   // :525
+      const T ynt = (T)prox_conj_elem_s<T>(d.h, w, sigma, ic, h_pre, b);   // :525
       if (row_ok) {
         yn = (double)ynt;
         YT[i] = ynt;
@@ -203,7 +207,6 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
 
 // MODE 0: pre-loop  v = x0 - gamma A'y0 ; x1 = prox(v)  (:497-499)
 // MODE 1: the linesearch test and, when it passes, the rest of the iteration
-// MODE 2: l2 ball: ||w/sigma + shift|| -> staging
 template <typename T, int MODE>
 __global__ __launch_bounds__(kSkinnyCloseBlock) void k_ls_close(LsDev d, int B) {
   __shared__ SkinnyRed red[16];
@@ -212,10 +215,7 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_ls_close(LsDev d, int B) 
   const int tid = threadIdx.x;
   if (MODE != 0 && (d.c->done != 0 || d.c->it >= d.c->maxit)) return;
   const double tot = skinny_colsum<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
-  if constexpr (MODE == 2) {
-    if (tid == d.n + 2) d.cs->h_pre = sqrt(tot);
-    return;
-  } else {
+  {
     if (tid >= d.n && tid < d.n + kSkinnyExtra) fin[tid - d.n] = tot;
     // ||A'y_next - A'y||^2 over the n columns (:527)
     double q[1] = {0.0};
@@ -379,7 +379,6 @@ int32_t skinny_ls_run(apx_problem* p, const apx_linesearch_params* prm, double g
   auto tick = [&]() {
     if (l2) {
       ls_rows<2>(d, dt, B, q);
-      ls_close<2>(d, dt, B, q);
       ls_rows<3>(d, dt, B, q);
     } else {
       ls_rows<1>(d, dt, B, q);

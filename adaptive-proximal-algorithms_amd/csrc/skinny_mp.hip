@@ -111,9 +111,14 @@ __global__ __launch_bounds__(kBlock) void k_mp_rows(MpDev d) {
       aty_partials = true;
     }
   } else {                              // STAGE 3: l2 ball, second half of the dual tick
+    // ||w/sigma + shift|| from the first half's block partials, summed by every block itself
+    double z4[4];
+    skinny_partial_norm_issue(d.part, d.ldpart, d.n + 3, (int)gridDim.x, z4);
     const double sigma = d.c->sigma;
     const double b = shift_at<T>(d.h, ic);
-    const T ynt = (T)prox_conj_elem_s<T>(d.h, d.w[ic], sigma, ic, d.c->h_pre, b);
+    const double wv = d.w[ic];
+    const double h_pre = skinny_partial_norm_finish(d.part, d.ldpart, d.n + 3, (int)gridDim.x, z4);
+    const T ynt = (T)prox_conj_elem_s<T>(d.h, wv, sigma, ic, h_pre, b);
     if (row_ok) {
       Y[i] = ynt;
       yn = (double)ynt;
@@ -124,7 +129,9 @@ __global__ __launch_bounds__(kBlock) void k_mp_rows(MpDev d) {
   // ---- block partials (aty_partials is uniform over the launch) -----------------------------------------
   const double ex[kSkinnyExtra] = {s0, s1, s2, s3};
   const double tot = skinny_block_partials<T>(A, d.ld, ic, d.n, yn, aty_partials, ex, wred);
-  if (tid < d.n + kSkinnyExtra && (tid >= d.n || aty_partials)) d.part[(int64_t)blockIdx.x * d.ldpart + tid] = tot;
+  // (STAGE 3 leaves column n + 3 alone: the other blocks of its launch are still reading it)
+  if (tid < d.n + kSkinnyExtra && (tid >= d.n || aty_partials) && !(STAGE == 3 && tid == d.n + 3))
+    d.part[(int64_t)blockIdx.x * d.ldpart + tid] = tot;
 }
 
 // the primal trial for the current sigma (:556-560): theta, gamma, A'ybar, v, x+ ; returns ||x+ - x||^2 on thread 0
@@ -151,7 +158,7 @@ __device__ __forceinline__ void mp_trial(const MpDev& d, MpCtrl& lc, double* ndx
   }
 }
 
-// STAGE 0: pre-loop: A'y0 ; STAGE 2: l2 norm of the dual tick ; STAGE 1: close a dual or a primal tick
+// STAGE 0: pre-loop: A'y0 ; STAGE 1: close a dual or a primal tick
 template <typename T, int STAGE>
 __global__ __launch_bounds__(kSkinnyCloseBlock) void k_mp_close(MpDev d, int B) {
   __shared__ SkinnyRed red[16];
@@ -160,13 +167,9 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_mp_close(MpDev d, int B) 
   const int tid = threadIdx.x;
   if constexpr (STAGE != 0) {
     if (d.c->done != 0 || d.c->it >= d.c->maxit) return;
-    if (STAGE == 2 && (d.c->phase != 0 || d.h.kind != APX_G_L2)) return;
   }
   const double tot = skinny_colsum<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
-  if constexpr (STAGE == 2) {
-    if (tid == d.n + 3) d.c->h_pre = sqrt(tot);
-    return;
-  } else if constexpr (STAGE == 0) {
+  if constexpr (STAGE == 0) {
     if (tid < d.n) d.aty[tid] = (double)(T)tot;                          // :598
     return;
   } else {
@@ -328,10 +331,7 @@ int32_t skinny_mp_run(apx_problem* p, const void* x0, const void* y0, double sig
   const bool l2 = d.h.kind == APX_G_L2;
   auto tick = [&]() {
     mp_rows<1>(d, dt, B, q);
-    if (l2) {
-      mp_close<2>(d, dt, B, q);
-      mp_rows<3>(d, dt, B, q);
-    }
+    if (l2) mp_rows<3>(d, dt, B, q);
     mp_close<1>(d, dt, B, q);
   };
   while (maxit > 0) {                                // every iteration takes at least two ticks

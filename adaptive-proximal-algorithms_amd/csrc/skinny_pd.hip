@@ -14,7 +14,8 @@
 //        v = x - gamma A'y+ ; x+ = prox_{gamma g}(v) (:358-361)
 //
 // For h = NormL2 the projection needs ||w/sigma + shift|| over all rows before any y+ exists, so the row
-// kernel is split in two (w and its partial norms ; then the prox).  Two (three) launches per iteration, the
+// kernel is split in two (w and its partial norms ; then every block sums those partials itself and applies the
+// prox).  Two (three) launches per iteration, the
 // control block is written by one thread, every sum has a fixed order: bit-reproducible, no atomics.
 #include <cstdlib>
 #include <memory>
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
   const bool row_ok = i < d.m;
   const int ic = row_ok ? i : d.m - 1;
   T* __restrict__ Y = (T*)d.Y;
+  [[maybe_unused]] double h_pre = 0.0;
 
   if constexpr (PHASE == 0) {
     if (tid < d.n) xs[tid] = (double)((const T*)d.X)[tid];
@@ -76,9 +78,13 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
       }
       __syncthreads();
     } else {
+      // l2 ball, second half: ||w/sigma + shift|| from the first half's block partials, summed by every block in
+      // the same fixed order (no launch of its own for it)
       if (tid == 0) lc = *d.cs;
+      double z4[4];
+      skinny_partial_norm_issue(d.part, d.ldpart, d.n + 2, (int)gridDim.x, z4);
       if (done != 0) return;
-      __syncthreads();
+      h_pre = skinny_partial_norm_finish(d.part, d.ldpart, d.n + 2, (int)gridDim.x, z4);   // (lc is visible behind it)
     }
   }
 
@@ -108,8 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
         w = d.wbuf[ic];
         a = d.axn[ic];
       }
-      double aux = 0.0;
-      if constexpr (PHASE == 3) aux = lc.h_pre;
+      const double aux = h_pre;
       const T ynt = (T)prox_conj_elem_s<T>(d.h, w, sigma, ic, aux, b);                  // :345
       if (row_ok) {
         yn = (double)ynt;
@@ -133,7 +138,6 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
 
 // MODE 0: pre-loop  v = x0 - gamma A'y0 ; x1 = prox(v)  (:330-332)
 // MODE 1: close the iteration and take the primal step
-// MODE 2: l2 ball: only ||w/sigma + shift|| -> Ctrl staging (between the two row kernels)
 template <typename T, int MODE>
 __global__ __launch_bounds__(kSkinnyCloseBlock) void k_skinny_close(SkinnyDev d, int B) {
   __shared__ SkinnyRed red[16];
@@ -145,14 +149,11 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_skinny_close(SkinnyDev d,
   SkinnyColLoads L;
   skinny_colsum_issue<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, L);
   T* __restrict__ X = (T*)d.X;
-  const T x_t = MODE != 2 && tid < d.n ? X[tid] : (T)0;
-  if (MODE != 2 && tid == 0) lc = MODE == 1 ? *d.cs : *d.c;
+  const T x_t = tid < d.n ? X[tid] : (T)0;
+  if (tid == 0) lc = MODE == 1 ? *d.cs : *d.c;
   if (done != 0) return;
   const double tot = skinny_colsum_finish(d.part, d.ldpart, d.n + kSkinnyExtra, B, L, red);
-  if constexpr (MODE == 2) {
-    if (tid == d.n + 2) d.cs->h_pre = sqrt(tot);
-    return;
-  } else {
+  {
     if (tid == d.n) fin[0] = tot;
     if (tid == d.n + 1) fin[1] = tot;
     __syncthreads();
@@ -264,7 +265,6 @@ int32_t skinny_pd_enqueue(apx_solver* s) {
   const int32_t dt = s->p->dtype;
   if (d.h.kind == APX_G_L2) {
     launch_rows<2>(d, dt, st->B, q);
-    launch_close<2>(d, dt, st->B, q);
     launch_rows<3>(d, dt, st->B, q);
   } else {
     launch_rows<1>(d, dt, st->B, q);
