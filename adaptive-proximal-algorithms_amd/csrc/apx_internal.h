@@ -125,6 +125,10 @@ struct apx_matrix {
   int64_t* tptr = nullptr;     // rows of A'     : n + 1
   int32_t* tind = nullptr;     //                  nnz row indices
   void* tval = nullptr;
+  // a small sparse matrix also keeps a dense copy, built on first use (apx::small_dense_view): the small-size
+  // execution policy (apx_ctx_fused_small) runs on dense storage
+  int64_t r_maxlen = 0, t_maxlen = 0;   // longest row of A / of A' (entries)
+  mutable apx_matrix* dense_view = nullptr;
 };
 
 namespace apx {
@@ -143,6 +147,8 @@ int32_t launch_sum_partials_rows(apx_ctx* ctx, int32_t dtype, int splits, int64_
                                  const int* done);
 // sparse.hip: the same two products for compressed storage (same output conventions)
 int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done);
+// A itself, or — for a sparse A small enough for the small-size paths — its dense copy (owned by A)
+int32_t small_dense_view(const apx_matrix* A, const apx_matrix** out);
 int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done);
 int gemv_n_variant_count();
 int gemv_t_variant_count();

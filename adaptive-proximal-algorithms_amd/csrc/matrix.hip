@@ -360,6 +360,7 @@ int32_t apx_matrix_free(apx_matrix* A) {
   if (A == nullptr) return APX_OK;
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->stream);
+  if (A->dense_view) apx_matrix_free(A->dense_view);
   if (A->d) (void)hipFree(A->d);
   if (A->dT) (void)hipFree(A->dT);
   for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval})

@@ -90,27 +90,34 @@ __global__ __launch_bounds__(kBlock) void k_ls_rows(LsDev d) {
     if (tid < d.n) xs[tid] = (double)((const T*)d.X)[tid];
     __syncthreads();
   } else {
-    // the control block is only written by k_ls_close: block-uniform
-    if (d.c->done != 0 || d.c->it >= d.c->maxit) return;
+    // the control block is only written by k_ls_close: block-uniform.  Every load of this part goes out before
+    // the branch on it (each dependent round trip to memory costs 1-2 us here)
+    const bool dead = d.c->done != 0 || d.c->it >= d.c->maxit;
     if constexpr (PHASE == 3) {
       // ||w/sigma + shift|| from the first half's block partials, summed by every block itself
       if (tid == 0) lc = *d.cs;
       double z4[4];
       skinny_partial_norm_issue(d.part, d.ldpart, d.n + 2, (int)gridDim.x, z4);
+      if (dead) return;
       h_pre = skinny_partial_norm_finish(d.part, d.ldpart, d.n + 2, (int)gridDim.x, z4);   // (lc is visible behind it)
     } else {
+      const bool mine = tid < d.n;
+      const T x_t = mine ? ((const T*)d.X)[tid] : (T)0, v_t = mine ? ((const T*)d.V)[tid] : (T)0,
+              xp_t = mine ? ((const T*)d.XP)[tid] : (T)0;
+      const double aty_t = mine ? d.aty[tid] : 0.0;
       if (tid == 0) lc = *d.c;
+      if (dead) return;
       __syncthreads();
       const bool fresh = lc.phase == 0;
       // ---- n side (redundantly per block): only the first trial of an iteration has work here ----------
       double q[3] = {0, 0, 0};
-      if (tid < d.n) {
-        const double xj = (double)((const T*)d.X)[tid];
+      if (mine) {
+        const double xj = (double)x_t;
         xs[tid] = xj;
         if (fresh) {
           const double gam = lc.gamma;
-          const double pr = ((double)((const T*)d.V)[tid] - xj) / gam + 0.0 + (double)(T)d.aty[tid];   // :505
-          const double dx = xj - (double)((const T*)d.XP)[tid];
+          const double pr = ((double)v_t - xj) / gam + 0.0 + (double)(T)aty_t;   // :505
+          const double dx = xj - (double)xp_t;
           q[0] = pr * pr;
           q[1] = dx * dx;
           q[2] = gval_elem<T>(d.g, xj, tid);
@@ -213,20 +220,27 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_ls_close(LsDev d, int B) 
   __shared__ LsCtrl lc;
   __shared__ double fin[6];
   const int tid = threadIdx.x;
-  if (MODE != 0 && (d.c->done != 0 || d.c->it >= d.c->maxit)) return;
-  const double tot = skinny_colsum<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, red);
+  // every load first (the flags, the partials, A'y, x, the control block), then the branch
+  const bool dead = MODE != 0 && (d.c->done != 0 || d.c->it >= d.c->maxit);
+  SkinnyColLoads L;
+  skinny_colsum_issue<kSkinnyCloseBlock>(d.part, d.ldpart, d.n + kSkinnyExtra, d.npow, B, L);
+  T* __restrict__ X = (T*)d.X;
+  const double aty_t = MODE == 1 && tid < d.n ? d.aty[tid] : 0.0;
+  const T x_t = tid < d.n ? X[tid] : (T)0;
+  if (tid == 0) lc = MODE == 1 ? *d.cs : *d.c;
+  if (dead) return;
+  const double tot = skinny_colsum_finish(d.part, d.ldpart, d.n + kSkinnyExtra, B, L, red);
   {
     if (tid >= d.n && tid < d.n + kSkinnyExtra) fin[tid - d.n] = tot;
     // ||A'y_next - A'y||^2 over the n columns (:527)
     double q[1] = {0.0};
     if (MODE == 1 && tid < d.n) {
-      const double da = (double)(T)tot - (double)(T)d.aty[tid];
+      const double da = (double)(T)tot - (double)(T)aty_t;
       q[0] = da * da;
     }
     block_sums_t0<1, kSkinnyCloseBlock>(q);
     if (tid == 0) {
       if constexpr (MODE == 1) {
-        lc = *d.cs;
         const double ratio = sqrt(q[0]) / sqrt(fin[3]);
         lc.trials_total += 1;
         if (lc.eta >= ratio) {                                     // :527  accepted
@@ -264,7 +278,6 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_ls_close(LsDev d, int B) 
         }
         *d.c = lc;
       } else {
-        lc = *d.c;
         fin[4] = 1.0;
       }
     }
@@ -274,12 +287,11 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_ls_close(LsDev d, int B) 
       const T aty = (T)tot;
       d.aty[tid] = (double)aty;                  // :529  At_y = At_y_next
       if (lc.done == 0) {                        // :545-547
-        T* __restrict__ X = (T*)d.X;
         const double gamma = lc.gamma;
-        const double xj = (double)X[tid];
+        const double xj = (double)x_t;
         const T vj = (T)(xj - gamma * (0.0 + (double)aty));
         const T xn = (T)prox_elem<T>(d.g, (double)vj, gamma, tid, 0.0);
-        ((T*)d.XP)[tid] = (T)xj;
+        ((T*)d.XP)[tid] = x_t;
         X[tid] = xn;
         ((T*)d.V)[tid] = vj;
       }

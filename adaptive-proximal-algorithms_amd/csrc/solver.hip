@@ -246,6 +246,10 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   p->n_pad = round_up(d->n, kPad) + kPad;   // room for a logistic X with n-1 == k*32 columns
   p->A_f = d->A_f;
   p->A_lin = d->A_lin;
+  if (d->allreduce == nullptr) {        // small sparse matrices: the problem runs on their dense copies
+    APX_TRY(small_dense_view(d->A_f, &p->A_f));
+    APX_TRY(small_dense_view(d->A_lin, &p->A_lin));
+  }
   p->allreduce = d->allreduce;
   p->ar_user = d->allreduce_user;
   // shard_mask: bit 0 = rows of A_f sharded, bit 1 = rows of A_lin sharded; 0 with a hook = bit 0 (the original ABI)
@@ -264,20 +268,20 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
       APX_REQUIRE(d->A_f->n == ncol, d->f_kind == APX_F_LOGISTIC
                                          ? "LogisticLoss: n must be columns(X) + 1 (bias is the last coordinate)"
                                          : "LinearLeastSquares: n must equal columns(A)");
-      APX_REQUIRE(d->A_f->n_pad <= p->n_pad, "internal: gradient buffer too small");
-      APX_TRY(p->b.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
-      APX_TRY(p->res.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
-      APX_TRY(h2d(ctx, p->b.p, d->b, (size_t)d->A_f->m * es));
-      p->n_mean = (double)(d->n_total_rows > 0 ? d->n_total_rows : d->A_f->m);
+      APX_REQUIRE(p->A_f->n_pad <= p->n_pad, "internal: gradient buffer too small");
+      APX_TRY(p->b.alloc_zero((size_t)p->A_f->ld * es, ctx->stream));
+      APX_TRY(p->res.alloc_zero((size_t)p->A_f->ld * es, ctx->stream));
+      APX_TRY(h2d(ctx, p->b.p, d->b, (size_t)p->A_f->m * es));
+      p->n_mean = (double)(d->n_total_rows > 0 ? d->n_total_rows : p->A_f->m);
       break;
     }
     case APX_F_QUADRATIC: {   // Quadratic(Q, q), experiments/dual_svm/runme.jl:19-28
       APX_REQUIRE(d->A_f != nullptr && d->b != nullptr, "Quadratic needs Q (A_f) and q (b)");
       APX_REQUIRE(d->A_f->ctx == ctx && d->A_f->dtype == d->dtype, "Q: wrong context or dtype");
-      APX_REQUIRE(d->A_f->m == d->n && d->A_f->n == d->n, "Quadratic: Q must be n x n");
+      APX_REQUIRE(p->A_f->m == d->n && d->A_f->n == d->n, "Quadratic: Q must be n x n");
       APX_REQUIRE(!p->f_sharded, "Quadratic f cannot be row-sharded by the library");
-      APX_TRY(p->b.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
-      APX_TRY(p->res.alloc_zero((size_t)d->A_f->ld * es, ctx->stream));
+      APX_TRY(p->b.alloc_zero((size_t)p->A_f->ld * es, ctx->stream));
+      APX_TRY(p->res.alloc_zero((size_t)p->A_f->ld * es, ctx->stream));
       APX_TRY(h2d(ctx, p->b.p, d->b, (size_t)d->n * es));
       break;
     }
@@ -295,9 +299,9 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   if (d->A_lin != nullptr) {
     APX_REQUIRE(d->A_lin->ctx == ctx && d->A_lin->dtype == d->dtype, "A_lin: wrong context or dtype");
     APX_REQUIRE(d->A_lin->n == d->n, "A_lin: columns must equal n");
-    APX_REQUIRE(d->m == 0 || d->m == d->A_lin->m, "m must equal rows(A_lin)");
-    p->m = d->A_lin->m;
-    p->m_pad = d->A_lin->ld;
+    APX_REQUIRE(d->m == 0 || d->m == p->A_lin->m, "m must equal rows(A_lin)");
+    p->m = p->A_lin->m;
+    p->m_pad = p->A_lin->ld;
   } else {
     // `A = 0`, `h = Zero()` — adaptive_proxgrad (src/AdaProx.jl:419)
     APX_REQUIRE(d->h.kind == APX_G_ZERO && d->h.shift == nullptr, "h must be Zero when there is no linear operator");

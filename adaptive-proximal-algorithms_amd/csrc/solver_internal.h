@@ -101,7 +101,7 @@ struct SmallPdState {
 };
 
 // ---- skinny_pd.hip: primal-dual loop for tall, skinny dense A (n <= 120, f = Zero) --------------
-constexpr int kSkinnyMaxN = 120;
+constexpr int kSkinnyMaxN = 124;     // n + 4 scalar partial columns <= 128 (a5a: 123 features + the bias)
 
 struct SkinnyDev {
   const void* A;          // m_pad x n, column-major

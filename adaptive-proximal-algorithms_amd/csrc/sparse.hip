@@ -15,14 +15,19 @@
 #include "apx_internal.h"
 #include "gemv_kernels.h"
 
+#include "small_dev.h"
+#include "solver_internal.h"
+
 namespace apx {
 
 // A group of G lanes per row; every group works on R rows at once (row, row + groups, ...): their pointer
 // pairs are loaded together, then the first U strides of all R rows (R*U independent index / value loads
 // per lane), then the R*U gathers; rows longer than U*G entries finish in a 4-way unrolled remainder loop.
 // The summation order per row is fixed (stride-major, then the width-G shuffle tree): bit-reproducible.
-// Measured (tools/sparse_bench.py, profiles/r01e_sparse_*): LIBSVM-sized matrices are cache-resident and the
-// iteration is launch-bound (~25 us); a 60 M-entry matrix with a 100 000-long gathered operand runs at
+// Measured (tools/sparse_bench.py, profiles/r01f_sparse_bench.jsonl): LIBSVM-sized matrices are cache-resident and
+// the iteration is launch-bound (26 - 35 us; the smallest ones run on a dense copy instead, small_dense_view below);
+// rows of thousands of entries take the chunked form (spmv_long); a 60 M-entry matrix with a 100 000-long gathered
+// operand runs at
 // 1.1 - 1.7 TB/s of value + index bytes whatever the loads in flight — every random 8-byte gather moves a
 // whole cache line from L2, which is what bounds it; an operand that fits LDS / a row-blocked layout is the
 // next step for that regime, not this kernel's schedule.
@@ -114,6 +119,56 @@ static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* 
 #undef APX_SPMV
 }
 
+// LONG rows (few rows, thousands of entries each: A' of a tall LIBSVM matrix — covtype is 581 012 x 54 — or A of a
+// wide one): a group of lanes per row leaves the chip idle (54 rows = 54 waves: 390 GB/s), so a row is cut into
+// chunks of kLongChunk entries, one block per (chunk, row), coalesced index / value loads, eight gathers in flight
+// per lane; the chunk totals are fp64 partials summed in a fixed order by the consumer (the row-finishing kernels
+// for A x, `sum_partials_rows` for A' r) — still no atomics, still bit-reproducible.
+constexpr int kLongU = 8;
+constexpr int kLongChunk = kBlock * kLongU;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spmv_long(const int64_t* __restrict__ ptr, const int32_t* __restrict__ ind,
+                                                    const T* __restrict__ val, const T* __restrict__ x,
+                                                    double* __restrict__ part, int64_t nrows, int64_t ld,
+                                                    const int* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  const int64_t row = blockIdx.y;
+  double s[1] = {0.0};
+  if (row < nrows) {                                    // (rows in [nrows, gridDim.y) get exact zeros)
+    const int64_t k0 = ptr[row] + (int64_t)blockIdx.x * kLongChunk, kend = ptr[row + 1];
+    if (k0 < kend) {
+      int32_t j[kLongU];
+      double v[kLongU], xv[kLongU];
+#pragma unroll
+      for (int u = 0; u < kLongU; ++u) {
+        const int64_t kk = k0 + threadIdx.x + (int64_t)u * kBlock;
+        const bool ok = kk < kend;
+        j[u] = ok ? ind[kk] : 0;
+        v[u] = ok ? (double)val[kk] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kLongU; ++u) xv[u] = (double)x[j[u]];
+#pragma unroll
+      for (int u = 0; u < kLongU; ++u) s[0] = fma(v[u], xv[u], s[0]);
+    }
+  }
+  block_sums_t0<1>(s);
+  if (threadIdx.x == 0) part[(int64_t)blockIdx.x * ld + row] = s[0];
+}
+
+// long-row form when the average row has more than 512 entries and the rows are few
+static bool long_rows(int64_t nnz, int64_t nrows, int64_t nrows_pad, int64_t maxlen, int* chunks) {
+  *chunks = (int)((maxlen + kLongChunk - 1) / kLongChunk);
+  return nrows > 0 && nnz / nrows > 512 && nrows_pad <= 8192 && *chunks >= 1 && *chunks <= 4096;
+}
+
+template <typename T>
+static void launch_long(apx_ctx* ctx, int chunks, const int64_t* ptr, const int32_t* ind, const void* val, const void* x,
+                        int64_t nrows, int64_t nrows_pad, const int* done) {
+  hipLaunchKernelGGL((spmv_long<T>), dim3((unsigned)chunks, (unsigned)nrows_pad), dim3(kBlock), 0, ctx->stream, ptr, ind,
+                     (const T*)val, (const T*)x, ctx->part, nrows, nrows_pad, done);
+}
+
 static int group_for(int64_t nnz, int64_t nrows) {
   const double avg = nrows > 0 ? (double)nnz / (double)nrows : 0.0;
   int g = 1;
@@ -122,6 +177,15 @@ static int group_for(int64_t nnz, int64_t nrows) {
 }
 
 int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
+  int chunks = 1;
+  if (long_rows(A->nnz, A->m, A->ld, A->r_maxlen, &chunks)) {      // every chunk is one fp64 split of A x
+    APX_TRY(ensure_part(ctx, (size_t)chunks * A->ld * sizeof(double)));
+    if (A->dtype == APX_F32) launch_long<float>(ctx, chunks, A->rptr, A->rind, A->rval, x, A->m, A->ld, done);
+    else launch_long<double>(ctx, chunks, A->rptr, A->rind, A->rval, x, A->m, A->ld, done);
+    APX_HIP(hipGetLastError());
+    *splits_out = chunks;
+    return APX_OK;
+  }
   APX_TRY(ensure_part(ctx, (size_t)A->ld * sizeof(double)));
   const int G = group_for(A->nnz, A->m);
   if (A->dtype == APX_F32)
@@ -134,6 +198,14 @@ int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
 }
 
 int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
+  int chunks = 1;
+  if (long_rows(A->nnz, A->n, A->n_pad, A->t_maxlen, &chunks)) {
+    APX_TRY(ensure_part(ctx, (size_t)chunks * A->n_pad * sizeof(double)));
+    if (A->dtype == APX_F32) launch_long<float>(ctx, chunks, A->tptr, A->tind, A->tval, r, A->n, A->n_pad, done);
+    else launch_long<double>(ctx, chunks, A->tptr, A->tind, A->tval, r, A->n, A->n_pad, done);
+    APX_HIP(hipGetLastError());
+    return launch_sum_partials_rows(ctx, A->dtype, chunks, A->n_pad, A->n_pad, out, done);
+  }
   const int G = group_for(A->nnz, A->n);
   if (A->dtype == APX_F32)
     launch_rows<float, float>(ctx, G, A->tptr, A->tind, A->tval, r, (float*)out, A->n, A->n_pad, done);
@@ -186,7 +258,52 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
   APX_TRY(up((void**)&A->tptr, p1, (size_t)(A->n + 1) * sizeof(int64_t)));
   APX_TRY(up((void**)&A->tind, i1, (size_t)nnz * sizeof(int32_t)));
   APX_TRY(up(&A->tval, v1, (size_t)nnz * sizeof(T)));
+  const int64_t* rp = (const int64_t*)p0;
+  const int64_t* tp = (const int64_t*)p1;
+  for (int64_t i = 0; i < A->m; ++i) A->r_maxlen = std::max(A->r_maxlen, rp[i + 1] - rp[i]);
+  for (int64_t j = 0; j < A->n; ++j) A->t_maxlen = std::max(A->t_maxlen, tp[j + 1] - tp[j]);
   APX_HIP(hipStreamSynchronize(ctx->stream));   // the host staging vectors die with this frame
+  return APX_OK;
+}
+
+// one thread per row of A: D[i, j] += v for the row's entries, in storage order (duplicates add up, as they do in
+// the products)
+template <typename T>
+__global__ __launch_bounds__(256) void k_densify(const int64_t* __restrict__ rptr, const int32_t* __restrict__ rind,
+                                                 const T* __restrict__ rval, int64_t m, T* __restrict__ D, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  for (int64_t k = rptr[i]; k < rptr[i + 1]; ++k) D[(int64_t)rind[k] * ld + i] += rval[k];
+}
+
+// The reference's LIBSVM datasets are tiny as dense matrices (mushrooms 8124 x 112, a5a 6414 x 123, phishing
+// 11 055 x 68: experiments/sparse_logreg/runme.jl:177-204): a problem built on such a sparse matrix runs on a
+// dense copy, where the small-size paths apply (2 launches per iteration instead of the SpMV path's 8).
+int32_t small_dense_view(const apx_matrix* A, const apx_matrix** out) {
+  *out = A;
+  if (A == nullptr || !A->sparse || !A->ctx->fused_small) return APX_OK;
+  const int64_t m = A->m, n = A->n;
+  const bool tall_skinny = n + 1 <= kSkinnyMaxN && m <= 256 * 1024;
+  if (!(tall_skinny || small_shape_ok(m, n + 1)) || m <= 0 || n <= 0) return APX_OK;
+  if ((double)m * (double)n * (double)dtype_size(A->dtype) > 256.0 * 1024 * 1024) return APX_OK;
+  if (A->dense_view == nullptr) {
+    apx_matrix* D = nullptr;
+    APX_TRY(apx_matrix_create(A->ctx, m, n, A->dtype, &D));     // zero-filled
+    const unsigned grid = (unsigned)((m + 255) / 256);
+    if (A->dtype == APX_F32)
+      hipLaunchKernelGGL((k_densify<float>), dim3(grid), dim3(256), 0, A->ctx->stream, A->rptr, A->rind, (const float*)A->rval, m,
+                         (float*)D->d, D->ld);
+    else
+      hipLaunchKernelGGL((k_densify<double>), dim3(grid), dim3(256), 0, A->ctx->stream, A->rptr, A->rind, (const double*)A->rval, m,
+                         (double*)D->d, D->ld);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      apx_matrix_free(D);
+      return fail(APX_ERR_HIP, std::string("small_dense_view: ") + hipGetErrorString(e));
+    }
+    A->dense_view = D;
+  }
+  *out = A->dense_view;
   return APX_OK;
 }
 

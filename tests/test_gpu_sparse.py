@@ -18,13 +18,21 @@ def apx():
     return apx
 
 
+@pytest.fixture(scope="module")
+def generic_ctx(apx):
+    ctx = apx.Context(0)
+    ctx.fused_small(False)
+    return ctx
+
+
 def _rel(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)))) / \
         max(float(np.max(np.abs(b))), 1e-300)
 
 
 @pytest.mark.parametrize("m,n,density", [(1, 1, 1.0), (7, 5, 0.5), (300, 1000, 0.01), (5000, 120, 0.15),
-                                         (2000, 3000, 0.002), (64, 64, 0.0), (800, 70, 0.9)])
+                                         (2000, 3000, 0.002), (64, 64, 0.0), (800, 70, 0.9),
+                                         (30000, 8, 0.6), (6, 40000, 0.4), (2049, 3, 1.0)])   # long rows of A' / of A
 @pytest.mark.parametrize("fmt", ["csr", "csc", "coo"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_sparse_products(apx, m, n, density, fmt, dtype):
@@ -43,10 +51,14 @@ def test_sparse_products(apx, m, n, density, fmt, dtype):
         dA.to_numpy()
 
 
-def test_sparse_logreg_matches_oracle(apx):
-    """experiments/sparse_logreg/runme.jl:41-63 with a sparse X, Float64 (as the reference runs it)."""
+@pytest.mark.parametrize("m,n,spmv", [(3000, 112, True), (3000, 112, False), (6414, 123, False), (1500, 400, False),
+                                      (20000, 12, True)])          # (long rows of X': the chunked SpMV)
+def test_sparse_logreg_matches_oracle(apx, generic_ctx, m, n, spmv):
+    """experiments/sparse_logreg/runme.jl:41-63 with a sparse X, Float64 (as the reference runs it): on the SpMV
+    kernels (spmv: a context without the small-size policy) and, by default, on the dense copy a small sparse
+    matrix is given (mushrooms- and a5a-like shapes: csrc/skinny_pg.hip ; 1500 x 400: csrc/small.hip)."""
     rng = np.random.default_rng(0)
-    m, n = 3000, 112                       # mushrooms-like shape (8124 x 112)
+    ctx = generic_ctx if spmv else apx.default_context()
     X = sp.random(m, n, density=0.19, format="csc", random_state=rng, data_rvs=lambda k: np.ones(k))
     w_true = rng.standard_normal(n) * (rng.uniform(size=n) < 0.2)
     y = (1 / (1 + np.exp(-(X @ w_true))) > rng.uniform(size=m)).astype(np.float64)
@@ -57,23 +69,28 @@ def test_sparse_logreg_matches_oracle(apx):
     orecs, drecs = [], []
     xo, _ = O.adaptive_proxgrad(np.zeros(n + 1), f=O.LogisticLoss(X.tocsr(), y), g=O.NormL1(0.01),
                                 rule=O.OurRule(gamma=gam), tol=0.0, maxit=K, record=orecs.append)
-    x, _ = apx.adaptive_proxgrad(np.zeros(n + 1), f=apx.LogisticLoss(X, y), g=apx.NormL1(0.01),
-                                 rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, record=drecs.append)
+    fX = apx.LogisticLoss(apx.DeviceMatrix.from_sparse(X, ctx), y, ctx=ctx)
+    x, _ = apx.adaptive_proxgrad(np.zeros(n + 1), f=fX, g=apx.NormL1(0.01),
+                                 rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, record=drecs.append, ctx=ctx)
     assert _rel(x, xo) <= 1e-10
     for ro, rd in zip(orecs, drecs):
+        if ro["norm_res"] <= 1e-4 * orecs[0]["norm_res"]:      # (the step size is a ratio of differences of iterates:
+            break                                              #  near convergence its digits are rounding)
         assert rd["gamma"] == pytest.approx(ro["gamma"], rel=1e-8)
         assert rd["objective"] == pytest.approx(ro["objective"], rel=1e-11)
     # backtracking and the PD loop run on the same storage
+    Kb = 25 if m < 10000 else 8            # (tall problems contract fast: `f_z > ub_z` soon compares rounding errors)
     zo, _ = O.backtracking_proxgrad(np.zeros(n + 1), f=O.LogisticLoss(X.tocsr(), y), g=O.NormL1(0.01), gamma0=gam,
-                                    xi=1.5, tol=0.0, maxit=25)
-    z, _ = apx.backtracking_proxgrad(np.zeros(n + 1), f=apx.LogisticLoss(X, y), g=apx.NormL1(0.01), gamma0=gam, xi=1.5,
-                                     tol=0.0, maxit=25)
+                                    xi=1.5, tol=0.0, maxit=Kb)
+    z, _ = apx.backtracking_proxgrad(np.zeros(n + 1), f=fX, g=apx.NormL1(0.01), gamma0=gam, xi=1.5,
+                                     tol=0.0, maxit=Kb, ctx=ctx)
     assert _rel(z, zo) <= 1e-10
 
 
-def test_sparse_lad_condat_vu(apx):
+@pytest.mark.parametrize("m,n,spmv", [(700, 90, True), (700, 90, False), (5000, 14, False)])
+def test_sparse_lad_condat_vu(apx, generic_ctx, m, n, spmv):
     rng = np.random.default_rng(5)
-    m, n = 700, 90
+    ctx = generic_ctx if spmv else apx.default_context()
     A = sp.hstack([sp.random(m, n - 1, density=0.1, random_state=rng), np.ones((m, 1))]).tocsr()
     yv = rng.standard_normal(m)
     nA = float(sp.linalg.norm(A))
@@ -81,7 +98,7 @@ def test_sparse_lad_condat_vu(apx):
     xo, yo, _ = O.condat_vu(np.zeros(n), np.zeros(m), f=O.Zero(), g=O.NormL1(2.0), h=O.Translate(O.NormL1(1.0), -yv),
                             A=A, **kw)
     x, y, _ = apx.condat_vu(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(2.0),
-                            h=apx.Translate(apx.NormL1(1.0), -yv), A=A, **kw)
+                            h=apx.Translate(apx.NormL1(1.0), -yv), A=apx.DeviceMatrix.from_sparse(A, ctx), ctx=ctx, **kw)
     assert _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-10
 
 

@@ -27,7 +27,7 @@ def timed(name, fn, K):
 
 
 def main():
-    K = 400
+    K = 2000
     prob = problems.device_lasso(500, 1000, pfactor=10, seed=0, power_iters=100)
     gam = 1 / prob.Lf
     f, g, x0 = apx.LinearLeastSquares(prob.A, prob.b), apx.NormL1(prob.lam), np.zeros(1000)

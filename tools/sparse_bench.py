@@ -25,7 +25,44 @@ def rand_csr(m, n, per_row, seed, dtype):
     return A
 
 
+def planted_labels(A, dtype):
+    """y_i = 1[sigmoid(<a_i, w>) > u_i] for a dense N(0, 1) w: coin-flip labels make x = 0 optimal at lam = 0.01 and
+    the loop converges (bit for bit) at its first iteration — then every timed iteration is a no-op."""
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal(A.shape[1])
+    return (1.0 / (1.0 + np.exp(-(A @ w))) > rng.uniform(size=A.shape[0])).astype(dtype)
+
+
+def dataset_shapes():
+    """The reference's three LIBSVM datasets (experiments/sparse_logreg/runme.jl:177-204) by shape and fill: with the
+    small-size policy a problem on such a matrix runs on its dense copy (csrc/skinny_pg.hip), without it on the SpMV
+    kernels."""
+    spmv = apx.Context(0)
+    spmv.fused_small(False)
+    for name, m, n, per_row in (("mushrooms", 8124, 112, 21), ("a5a", 6414, 123, 14), ("phishing", 11055, 68, 30)):
+        A = rand_csr(m, n, per_row, 0, np.float64)
+        y = planted_labels(A, np.float64)
+        gam = 4.0 * m / (A.multiply(A).sum() + m)
+        out = {"dataset_shape": name, "shape": [m, n], "nnz": int(A.nnz)}
+        for label, ctx in (("dense_copy_us_per_iteration", apx.default_context()), ("spmv_us_per_iteration", spmv)):
+            f = apx.LogisticLoss(apx.DeviceMatrix.from_sparse(A, ctx), y, ctx=ctx)
+            s = apx.Solver(np.zeros(n + 1), f=f, g=apx.NormL1(1e-4), rule=apx.OurRule(gamma=float(gam)), tol=0.0, ctx=ctx,
+                           poll_every=1 << 30)
+            s.step(50, sync=True)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                s.step(300, sync=True)
+                best = min(best, (time.perf_counter() - t0) / 300)
+            _, _, res = s.result()
+            s.close()
+            assert res.numit == 950 and not res.converged, (res.numit, res.converged)   # (every timed iteration was a real one)
+            out[label] = round(best * 1e6, 1)
+        print(json.dumps(out), flush=True)
+
+
 def main():
+    dataset_shapes()
     ctx = apx.default_context()
     for m, n, per_row, dtype in ((49749, 300, 12, np.float64),        # w8a-like
                                  (581012, 54, 12, np.float64),        # covtype-like
@@ -44,10 +81,10 @@ def main():
             for _ in range(5):
                 fn()
             per[name] = (time.perf_counter() - t0) / 5
-        lr_y = (np.random.default_rng(3).uniform(size=m) < 0.5).astype(dtype)
+        lr_y = planted_labels(A, dtype)
         f = apx.LogisticLoss(dA, lr_y, ctx=ctx)
         gam = 4.0 * m / (A.multiply(A).sum() + m)
-        s = apx.Solver(np.zeros(n + 1, dtype=dtype), f=f, g=apx.NormL1(0.01), rule=apx.OurRule(gamma=float(gam)), tol=0.0,
+        s = apx.Solver(np.zeros(n + 1, dtype=dtype), f=f, g=apx.NormL1(1e-4), rule=apx.OurRule(gamma=float(gam)), tol=0.0,
                        ctx=ctx, poll_every=1 << 30)
         s.step(20, sync=True)
         best = 1e9
@@ -55,7 +92,9 @@ def main():
             t0 = time.perf_counter()
             s.step(100, sync=True)
             best = min(best, (time.perf_counter() - t0) / 100)
+        _, _, res = s.result()
         s.close()
+        assert res.numit == 320 and not res.converged, (res.numit, res.converged)       # (every timed iteration was a real one)
         bytes_iter = 2.0 * A.nnz * (es + 4)
         print(json.dumps({"shape": [m, n], "nnz": int(A.nnz), "dtype": np.dtype(dtype).name,
                           "us_per_iteration": round(best * 1e6, 1),
