@@ -174,6 +174,8 @@ def main():
         x, _, res = solver.result()
         if not np.all(np.isfinite(x)):
             sys.exit("bench.py: non-finite iterate")
+        if int(res.numit) != args.warmup + args.steps or res.converged:
+            sys.exit("bench.py: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
         solver.close()
 
     if use_dist:
