@@ -96,6 +96,7 @@ int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0,
   APX_TRY(begin(p, maxit, false));
   APX_REQUIRE(x0 != nullptr && x_out != nullptr, "apx_backtracking_nesterov: NULL argument");
   // small dense problems: the linesearch stays on the device (csrc/small_bt.hip)
+  if (skinny_bt_eligible(p)) return skinny_bt_run(p, true, x0, gamma0, 1.0, shrink, tol, maxit, opts, x_out, res);
   if (small_bt_eligible(p)) return small_bt_run(p, true, x0, gamma0, 1.0, shrink, tol, maxit, opts, x_out, res);
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es;
@@ -178,7 +179,8 @@ int32_t apx_fixed_nesterov(apx_problem* p, const void* x0, double gamma, double 
   APX_REQUIRE(q < 1, "fixed_nesterov: assertion q < 1 failed");                         // :110
   if (theta < 0) theta = q > 0 ? 1.0 / std::sqrt(q) : 0.0;                              // :111-117
   APX_REQUIRE(theta >= 0 && theta <= 1.0 / std::sqrt(q), "fixed_nesterov: assertion 0 <= theta <= 1/sqrt(q) failed");
-  if (small_mom_eligible(p)) {      // small dense problems: the loop stays on the device (csrc/small_mom.hip)
+  const bool skinny = skinny_mom_eligible(p);
+  if (skinny || small_mom_eligible(p)) {      // the loop stays on the device (csrc/skinny_mom.hip, csrc/small_mom.hip)
     MomCtrl c0;
     memset(&c0, 0, sizeof(c0));
     c0.tol = tol;
@@ -188,7 +190,8 @@ int32_t apx_fixed_nesterov(apx_problem* p, const void* x0, double gamma, double 
     c0.mu = mu;
     c0.muf = muf;
     c0.mug = mug;
-    return small_mom_run(p, MOM_NESTEROV, c0, x0, x0, maxit, opts, x_out, res);
+    return skinny ? skinny_mom_run(p, MOM_NESTEROV, c0, x0, x0, maxit, opts, x_out, res)
+                  : small_mom_run(p, MOM_NESTEROV, c0, x0, x0, maxit, opts, x_out, res);
   }
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es;
@@ -246,7 +249,8 @@ int32_t apx_agraal(apx_problem* p, const void* x1, const void* x0, double gamma0
                    double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_TRY(begin(p, maxit, false));
   APX_REQUIRE(x1 != nullptr && x0 != nullptr && x_out != nullptr, "apx_agraal: NULL argument");
-  if (small_mom_eligible(p)) {      // small dense problems: the loop stays on the device (csrc/small_mom.hip)
+  const bool skinny = skinny_mom_eligible(p);
+  if (skinny || small_mom_eligible(p)) {      // the loop stays on the device (csrc/skinny_mom.hip, csrc/small_mom.hip)
     MomCtrl c0;
     memset(&c0, 0, sizeof(c0));
     c0.tol = tol;
@@ -256,7 +260,8 @@ int32_t apx_agraal(apx_problem* p, const void* x1, const void* x0, double gamma0
     c0.phi = phi;
     c0.rho = 1.0 / phi + 1.0 / (phi * phi);                  // :172
     c0.gamma_max = gamma_max;
-    return small_mom_run(p, MOM_AGRAAL, c0, x1, x0, maxit, opts, x_out, res);
+    return skinny ? skinny_mom_run(p, MOM_AGRAAL, c0, x1, x0, maxit, opts, x_out, res)
+                  : small_mom_run(p, MOM_AGRAAL, c0, x1, x0, maxit, opts, x_out, res);
   }
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es;

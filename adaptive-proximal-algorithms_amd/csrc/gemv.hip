@@ -247,8 +247,46 @@ __global__ __launch_bounds__(kBlock) void sum_partials_rows(const double* __rest
   }
 }
 
+// The same sum for a FEW rows and many splits (A = y' of the dual SVM is 1 x N: ~1000 column splits and one
+// output — a thread per row would walk them as a chain of dependent loads, 38 us): a block per row, the splits
+// dealt to its threads, then a fixed-order block sum.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_partials_few_rows(const double* __restrict__ part, int splits, int64_t ld,
+                                                                T* __restrict__ y, const int* __restrict__ done) {
+  __shared__ double sh[kBlock / 64];
+  if (done != nullptr && *done != 0) return;
+  const int64_t i = blockIdx.x;
+  double a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = (int)threadIdx.x + u * kBlock;
+    a[u] = k < splits ? part[(int64_t)k * ld + i] : 0.0;
+  }
+  double s = (a[0] + a[1]) + (a[2] + a[3]);
+  for (int k = (int)threadIdx.x + 4 * kBlock; k < splits; k += kBlock) s += part[(int64_t)k * ld + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sh[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) t += sh[w];
+    y[i] = (T)t;
+  }
+}
+
 int32_t launch_sum_partials_rows(apx_ctx* ctx, int32_t dtype, int splits, int64_t m, int64_t ld, void* y,
                                  const int* done) {
+  if (m <= 64 && splits > 16) {
+    if (dtype == APX_F32)
+      hipLaunchKernelGGL(sum_partials_few_rows<float>, dim3((unsigned)m), dim3(kBlock), 0, ctx->stream, ctx->part, splits, ld,
+                         (float*)y, done);
+    else
+      hipLaunchKernelGGL(sum_partials_few_rows<double>, dim3((unsigned)m), dim3(kBlock), 0, ctx->stream, ctx->part, splits, ld,
+                         (double*)y, done);
+    APX_HIP(hipGetLastError());
+    return APX_OK;
+  }
   const unsigned g = (unsigned)std::min<int64_t>(kMaxRedBlocks, (m + kBlock - 1) / kBlock);
   if (dtype == APX_F32)
     hipLaunchKernelGGL(sum_partials_rows<float>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->part, splits, ld, m,

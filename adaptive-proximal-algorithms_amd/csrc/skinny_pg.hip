@@ -21,93 +21,16 @@
 #include <cstdlib>
 #include <memory>
 
-#include "skinny_dev.h"
+#include "skinny_rows_dev.h"
 
 namespace apx {
 
-constexpr int kSpgMaxWaves = 8;       // column slices per block
-constexpr int kSpgCloseBlock = 1024;
-constexpr int kSpgMaxBlocks = 512;    // row blocks: what the closing block sums per column
-
-// (Every dependent trip to memory costs 1-2 us here — the partials and the control block were written by the previous
-//  launch, on other XCDs — so both kernels issue ALL their loads first, the done flag among them, and only then branch.)
-template <typename T, int FK, int CPW>
-__global__ __launch_bounds__(64 * kSpgMaxWaves) void k_spg_rows(SkinnyPgDev d) {
-  __shared__ double xs[kSkinnyMaxN + 8];
-  __shared__ double pd[2][kSpgMaxWaves][64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int W = blockDim.x >> 6;
-  const T* __restrict__ A = (const T*)d.A;
-  const T* __restrict__ bv = (const T*)d.b;
-  const int done = d.c->done;                  // written by an earlier launch: block-uniform
-  const T xv = tid < d.n ? ((const T*)d.X)[tid] : (T)0;
-  const int c0 = wv * CPW;
-  int64_t co[CPW];
-#pragma unroll
-  for (int u = 0; u < CPW; ++u) co[u] = (int64_t)min(c0 + u, d.ncols - 1) * d.ld;   // clamped: a valid address, weight 0
-  const int row0 = blockIdx.x * d.groups * 64 + lane;
-  T av[CPW], nv[CPW] = {};
-  T bi, nb = (T)0;
-  {
-    const int ic = min(row0, d.m - 1);
-#pragma unroll
-    for (int u = 0; u < CPW; ++u) av[u] = A[co[u] + ic];
-    bi = bv[ic];
-  }
-  if (done != 0) return;
-  if (tid < d.n) xs[tid] = (double)xv;
-  __syncthreads();
-  double xr[CPW], acc[CPW];
-#pragma unroll
-  for (int u = 0; u < CPW; ++u) {
-    xr[u] = c0 + u < d.ncols ? xs[c0 + u] : 0.0;
-    acc[u] = 0.0;
-  }
-  double ex[2] = {0.0, 0.0};
-  for (int g = 0; g < d.groups; ++g) {
-    const int i = row0 + g * 64;
-    if (g + 1 < d.groups) {                    // the next group's loads go out before this group's arithmetic
-      const int ic = min(i + 64, d.m - 1);
-#pragma unroll
-      for (int u = 0; u < CPW; ++u) nv[u] = A[co[u] + ic];
-      nb = bv[ic];
-    }
-    double part = 0.0;
-#pragma unroll
-    for (int u = 0; u < CPW; ++u) part = fma((double)av[u], xr[u], part);
-    pd[g & 1][wv][lane] = part;
-    __syncthreads();                           // (two buffers: one barrier per group is enough)
-    double a = pd[g & 1][0][lane];
-    for (int w = 1; w < W; ++w) a += pd[g & 1][w][lane];
-    a = (double)(T)a;                          // A_x rounded to T like every stored A x
-    double res = 0.0;
-    if (i < d.m) {
-      if constexpr (FK == APX_F_LEAST_SQUARES) {
-        res = (double)(T)(a - (double)bi);
-        ex[0] += res * res;
-      } else {
-        const double logit = a + xs[d.n - 1];
-        const double e = 1.0 + exp(-logit);
-        ex[0] += ((double)bi - 1.0) * logit - log(e);
-        res = (double)(T)(1.0 / e - (double)bi);
-        ex[1] += res;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < CPW; ++u) {
-      acc[u] = fma((double)av[u], res, acc[u]);
-      av[u] = nv[u];
-    }
-    bi = nb;
-  }
-  double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
-  wave_sum_multi<CPW>(acc);                    // lane l: the total of column c0 + l / (64 / CPW)
-  if (wv == 0) wave_sum_multi<2>(ex);          // (every wave holds the same two sums) lane l: ex[l / 32]
-  constexpr int kPer = 64 / CPW;
-  const int col = c0 + lane / kPer;
-  if (lane % kPer == 0 && col < d.ncols) out[col] = acc[0];
-  if (wv == 0 && (lane & 31) == 0) out[d.ncols + (lane >> 5)] = ex[0];
-}
+struct SkinnyPgState {
+  DBuf part;
+  SkinnyRowsPlan plan;
+  SkinnyPgDev dev{};
+};
+void skinny_pg_destroy(SkinnyPgState* st) { delete st; }
 
 // MODE 0: pre-loop (:328-332) grad f(x0) ; v = x0 - gamma grad ; x1 = prox(v)   MODE 1: close iteration k and step
 template <typename T, int FK, int MODE>
@@ -198,22 +121,13 @@ __global__ __launch_bounds__(kSpgCloseBlock) void k_spg_close(SkinnyPgDev d, int
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-bool skinny_pg_eligible(const apx_problem* p) {
-  if (!p->ctx->fused_small) return false;
-  if (p->A_lin != nullptr || p->allreduce != nullptr) return false;
-  if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
-  if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
-  const int64_t m = p->A_f->m;
-  // below ~2000 rows small.hip's redundant scheme is as fast (logistic 2000 x 120: 14.8 us)
-  return p->n <= kSkinnyMaxN && p->A_f->n > 0 && m >= 2048 && m <= 256 * 1024 && p->n * 4 <= m;
-}
+bool skinny_pg_eligible(const apx_problem* p) { return skinny_rows_eligible(p); }
 
 template <typename T, int FK, int MODE>
 static void spg_tick_t(const SkinnyPgState* st, hipStream_t q) {
   const SkinnyPgDev& d = st->dev;
-  if (st->cpw == 4) hipLaunchKernelGGL((k_spg_rows<T, FK, 4>), dim3(st->B), dim3(64 * st->waves), 0, q, d);
-  else hipLaunchKernelGGL((k_spg_rows<T, FK, 16>), dim3(st->B), dim3(64 * st->waves), 0, q, d);
-  hipLaunchKernelGGL((k_spg_close<T, FK, MODE>), dim3(1), dim3(kSpgCloseBlock), 0, q, d, st->B);
+  skinny_rows_launch<T, FK>(st->plan, d.X, &d.c->done, q);
+  hipLaunchKernelGGL((k_spg_close<T, FK, MODE>), dim3(1), dim3(kSpgCloseBlock), 0, q, d, st->plan.B);
 }
 template <int MODE>
 static void spg_tick(const SkinnyPgState* st, int32_t dtype, int fk, hipStream_t q) {
@@ -233,29 +147,19 @@ int32_t skinny_pg_setup(apx_solver* s) {
   apx_ctx* ctx = p->ctx;
   const apx_matrix* A = p->A_f;
   std::unique_ptr<SkinnyPgState> st(new SkinnyPgState());
-  // columns per wave: 4 up to 32 columns (more waves per row group), else 16 ; row groups per block so that at
-  // most kSpgMaxBlocks partial rows are left for the closing block
-  st->cpw = A->n <= 4 * kSpgMaxWaves ? 4 : 16;
-  st->waves = (int)((A->n + st->cpw - 1) / st->cpw);
-  const int64_t ngroups = (A->m + 63) / 64;
-  const int groups = (int)((ngroups + kSpgMaxBlocks - 1) / kSpgMaxBlocks);
-  st->B = (int)((ngroups + groups - 1) / groups);
+  skinny_rows_plan(A, p->n, p->b.p, &st->plan);
+  APX_TRY(st->part.alloc_zero((size_t)st->plan.B * st->plan.dev.ldpart * sizeof(double), ctx->stream));
+  st->plan.dev.part = (double*)st->part.p;
   SkinnyPgDev d{};
-  d.groups = groups;
-  d.A = A->d;
-  d.ld = A->ld;
-  d.m = (int32_t)A->m;
-  d.ncols = (int32_t)A->n;
-  d.n = (int32_t)p->n;
-  d.npow = skinny_npow(d.ncols);          // (>= ncols + 4 >= the ncols + 2 partial columns used here)
-  d.ldpart = round_up(d.ncols + kSkinnyExtra, 8);
-  APX_TRY(st->part.alloc_zero((size_t)st->B * d.ldpart * sizeof(double), ctx->stream));
-  d.b = p->b.p;
+  d.ncols = st->plan.dev.ncols;
+  d.n = st->plan.dev.n;
+  d.npow = st->plan.npow;
+  d.ldpart = st->plan.dev.ldpart;
   d.X = s->x.p;                 // the solver's own n-vectors: results and stepping work as in the generic path
   d.XP = s->xprev.p;
   d.GP = s->gprev.p;
   d.V = s->v.p;
-  d.part = (double*)st->part.p;
+  d.part = st->plan.dev.part;
   d.c = p->ctrl();
   d.g = p->gd;
   d.recs = (apx_record*)s->recs.p;

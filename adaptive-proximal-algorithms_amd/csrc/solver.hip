@@ -874,6 +874,7 @@ int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0,
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipSetDevice(ctx->device));
   // small dense problems (the reference's own lasso sizes): the linesearch as a device-resident state machine
+  if (skinny_bt_eligible(p)) return skinny_bt_run(p, false, x0, gamma0, xi, shrink, tol, maxit, opts, x_out, res);
   if (small_bt_eligible(p)) return small_bt_run(p, false, x0, gamma0, xi, shrink, tol, maxit, opts, x_out, res);
   const size_t es = p->es();
   const size_t nb = (size_t)p->n_pad * es;

@@ -126,26 +126,19 @@ struct SkinnyState {
 };
 
 // ---- skinny_pg.hip: proximal-gradient loop for tall, skinny dense A (LinearLeastSquares / LogisticLoss) --------
-struct SkinnyPgDev {
-  const void* A;          // m_pad x ncols, column-major
-  int64_t ld;
-  int32_t m, ncols, n, npow;
-  int32_t groups;         // groups of 64 rows per block
+struct SkinnyPgDev {       // what the closing kernel of skinny_pg.hip needs (the row kernel: skinny_rows_dev.h)
+  int32_t ncols, n, npow, _pad;
   int64_t ldpart;
-  const void* b;
   void *X, *XP, *GP, *V;  // the solver's n-vectors, written by k_spg_close only
-  double* part;           // [blocks][ldpart]: ncols partials of A' res, ||res||^2 or the loss sum, sum(res)
+  const double* part;     // [blocks][ldpart]: ncols partials of A' res, ||res||^2 or the loss sum, sum(res)
   Ctrl* c;
   ProxDev g;
   apx_record* recs;
   int64_t rec_cap;
 };
 
-struct SkinnyPgState {
-  DBuf part;
-  SkinnyPgDev dev{};
-  int B = 0, waves = 0, cpw = 0;
-};
+struct SkinnyPgState;      // (skinny_pg.hip: holds the row plan)
+void skinny_pg_destroy(SkinnyPgState* st);
 
 // ---- small_mom.hip: fixed Nesterov and aGRAAL as device-resident loops (small dense problems) ---------
 enum { MOM_AGRAAL = 0, MOM_NESTEROV = 1 };
@@ -161,7 +154,7 @@ struct MomCtrl {
   double norm_res, g_raw, f_new, objective;
   int64_t it;                       // finished iterations
   int32_t need_gamma0, stop_after, done, flags;
-  int32_t frozen, _pad;             // set in block B by a k_mom_a that found nothing left to do
+  int32_t frozen, phase;            // frozen: nothing left to do ; phase (skinny_mom.hip): what the point in XT is
 };
 
 }  // namespace apx
@@ -187,7 +180,7 @@ struct apx_solver {
     delete small;
     delete small_pd;
     delete skinny;
-    delete skinny_pg;
+    apx::skinny_pg_destroy(skinny_pg);
   }
 };
 
@@ -223,10 +216,16 @@ bool skinny_pd_eligible(const apx_problem* p);
 int32_t skinny_pd_setup(apx_solver* s, const void* x0, const void* y0);
 int32_t skinny_pd_enqueue(apx_solver* s);
 // small_mom.hip (the caller fills the method's parameters into c0)
+bool skinny_mom_eligible(const apx_problem* p);    // skinny_mom.hip: the same on tall, skinny A (n <= 124)
+int32_t skinny_mom_run(apx_problem* p, int method, const MomCtrl& c0, const void* x1, const void* x0, int64_t maxit,
+                       const apx_solve_opts* opts, void* x_out, apx_result* res);
 bool small_mom_eligible(const apx_problem* p);
 int32_t small_mom_run(apx_problem* p, int method, const MomCtrl& c0, const void* x1, const void* x0, int64_t maxit,
                       const apx_solve_opts* opts, void* x_out, apx_result* res);
 // small_bt.hip: backtracking_proxgrad with its linesearch as a device-side state machine (small dense problems)
+bool skinny_bt_eligible(const apx_problem* p);     // skinny_bt.hip: the same on tall, skinny A (n <= 124)
+int32_t skinny_bt_run(apx_problem* p, bool nesterov, const void* x0, double gamma0, double xi, double shrink, double tol,
+                      int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
 bool small_bt_eligible(const apx_problem* p);
 int32_t small_bt_run(apx_problem* p, bool nesterov, const void* x0, double gamma0, double xi, double shrink, double tol,
                      int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);

@@ -250,3 +250,120 @@ def test_backtracking_nesterov_small_shapes(apx, m, n, logistic):
         zo, _ = O.backtracking_nesterov(np.zeros(nx), f=mkf(O), g=O.NormL1(lam), gamma0=gam, tol=0.0, maxit=K2)
         z, it = apx.backtracking_nesterov(np.zeros(nx), f=mkf(apx), g=apx.NormL1(lam), gamma0=gam, tol=0.0, maxit=K2)
         assert it == K2 and np.max(np.abs(z - zo)) <= 1e-10 * max(1.0, np.max(np.abs(zo)))
+
+
+# ---------------------------------------------------------------------------------------
+# the backtracking methods on tall, skinny A (csrc/skinny_bt.hip: n <= 124, m >= 2048): the shapes of the
+# reference's logistic datasets (experiments/sparse_logreg/runme.jl:177-204)
+# ---------------------------------------------------------------------------------------
+def _tall_problem(M, m, n, logistic):
+    if logistic:
+        lr = P.random_logreg(m, n, seed=6, dtype=np.float64)
+        return (lambda: M.LogisticLoss(lr.X, lr.y)), lr.lam, lr.gamma0, n + 1
+    rng = np.random.default_rng(m + n)
+    A, b = rng.uniform(-1, 1, (m, n)) * np.logspace(0, -1, n), rng.standard_normal(m)
+    return (lambda: M.LinearLeastSquares(A, b)), 0.3, 1.0 / P.opnorm_sq_power(A, iters=30), n
+
+
+@pytest.mark.parametrize("m,n,logistic", [(8124, 112, True), (6414, 123, True), (11055, 68, True), (5000, 30, False),
+                                          (2048, 3, False)])
+def test_skinny_backtracking_methods(apx, m, n, logistic):
+    mko, lam, gam, nx = _tall_problem(O, m, n, logistic)
+    mkd = _tall_problem(apx, m, n, logistic)[0]
+    # (these problems contract fast; past ~15 iterations — 5 with three unknowns — `f_z > ub_z` compares rounding errors)
+    K = 12 if n >= 10 else 5
+    for xi in (1.0, 2.0):
+        of, og = O.Counting(mko()), O.Counting(O.NormL1(lam))
+        df, dg = apx.Counting(mkd()), apx.Counting(apx.NormL1(lam))
+        ro, rd = [], []
+        zo, ito = O.backtracking_proxgrad(np.zeros(nx), f=of, g=og, gamma0=4 * gam, xi=xi, tol=0.0, maxit=K, record=ro.append)
+        z, it = apx.backtracking_proxgrad(np.zeros(nx), f=df, g=dg, gamma0=4 * gam, xi=xi, tol=0.0, maxit=K, record=rd.append)
+        assert it == ito == K and _rel_inf(z, zo) <= 1e-10
+        _compare(ro, rd, ("gamma", "norm_res", "objective"), 1e-8)
+        assert (df.eval_count, df.grad_count, dg.prox_count) == (of.eval_count, of.grad_count, og.prox_count)
+    of, og = O.Counting(mko()), O.Counting(O.NormL1(lam))
+    df, dg = apx.Counting(mkd()), apx.Counting(apx.NormL1(lam))
+    ro, rd = [], []
+    zo, ito = O.backtracking_nesterov(np.zeros(nx), f=of, g=og, gamma0=8 * gam, tol=0.0, maxit=K, record=ro.append)
+    z, it = apx.backtracking_nesterov(np.zeros(nx), f=df, g=dg, gamma0=8 * gam, tol=0.0, maxit=K, record=rd.append)
+    assert it == ito == K and _rel_inf(z, zo) <= 1e-10
+    _compare(ro, rd, ("gamma", "norm_res", "objective"), 1e-8)
+    assert (df.eval_count, df.grad_count, dg.prox_count) == (of.eval_count, of.grad_count, og.prox_count)
+
+
+def test_skinny_backtracking_termination_maxit_fp32(apx):
+    mko, lam, gam, nx = _tall_problem(O, 4000, 40, True)
+    mkd = _tall_problem(apx, 4000, 40, True)[0]
+    for name, kw in (("backtracking_proxgrad", dict(gamma0=4 * gam, xi=1.5)), ("backtracking_nesterov", dict(gamma0=4 * gam))):
+        ro = []
+        getattr(O, name)(np.zeros(nx), f=mko(), g=O.NormL1(lam), tol=0.0, maxit=12, record=ro.append, **kw)
+        tol = ro[7]["norm_res"] * (1 + 1e-7)
+        kstar = 1 + next(k for k, r in enumerate(ro) if r["norm_res"] <= tol)
+        of, df = O.Counting(mko()), apx.Counting(mkd())
+        zo, ito = getattr(O, name)(np.zeros(nx), f=of, g=O.NormL1(lam), tol=tol, maxit=5000, **kw)
+        z, it = getattr(apx, name)(np.zeros(nx), f=df, g=apx.NormL1(lam), tol=tol, maxit=5000, **kw)
+        assert it == ito == kstar and _rel_inf(z, zo) <= 1e-10
+        assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
+        for K in (0, 1, 2, 9):
+            zo, ito = getattr(O, name)(np.zeros(nx), f=mko(), g=O.NormL1(lam), tol=0.0, maxit=K, **kw)
+            z, it = getattr(apx, name)(np.zeros(nx), f=mkd(), g=apx.NormL1(lam), tol=0.0, maxit=K, **kw)
+            assert it == ito == K and _rel_inf(z, zo) <= 1e-10
+    # fp32 storage: same loop, looser agreement
+    lr = P.random_logreg(4000, 40, seed=6, dtype=np.float32)
+    zo, _ = O.backtracking_proxgrad(np.zeros(41), f=O.LogisticLoss(lr.X.astype(np.float64), lr.y.astype(np.float64)),
+                                    g=O.NormL1(lr.lam), gamma0=4 * lr.gamma0, xi=1.5, tol=0.0, maxit=10)
+    z, _ = apx.backtracking_proxgrad(np.zeros(41, dtype=np.float32), f=apx.LogisticLoss(lr.X, lr.y), g=apx.NormL1(lr.lam),
+                                     gamma0=4 * lr.gamma0, xi=1.5, tol=0.0, maxit=10)
+    assert z.dtype == np.float32 and _rel_inf(z, zo) <= 5e-3
+
+
+@pytest.mark.parametrize("m,n,logistic", [(8124, 112, True), (6414, 123, True), (11055, 68, True), (5000, 30, False),
+                                          (2048, 3, False)])
+def test_skinny_mom_shapes(apx, m, n, logistic):
+    """fixed_nesterov and agraal on tall, skinny A (csrc/skinny_mom.hip)."""
+    mko, lam, gam, nx = _tall_problem(O, m, n, logistic)
+    mkd = _tall_problem(apx, m, n, logistic)[0]
+    K = 14 if n >= 10 else 6
+    for kw in (dict(gamma=gam), dict(gamma=gam, muf=0.05 / gam, mug=0.0)):
+        of, df = O.Counting(mko()), apx.Counting(mkd())
+        ro, rd = [], []
+        xo, ito = O.fixed_nesterov(np.zeros(nx), f=of, g=O.NormL1(lam), tol=0.0, maxit=K, record=ro.append, **kw)
+        x, it = apx.fixed_nesterov(np.zeros(nx), f=df, g=apx.NormL1(lam), tol=0.0, maxit=K, record=rd.append, **kw)
+        assert it == ito == K and _rel_inf(x, xo) <= 1e-10
+        _compare(ro, rd, ("gamma", "norm_res", "objective"), 1e-8)
+        assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count) == (K, K)
+        # without a record sink there is no objective pass: one tick per iteration, same iterate
+        x2, _ = apx.fixed_nesterov(np.zeros(nx), f=mkd(), g=apx.NormL1(lam), tol=0.0, maxit=K, **kw)
+        assert np.array_equal(x2, x)
+    x0 = 0.01 * np.cos(np.arange(nx))
+    for g0 in (gam, None):
+        of, df = O.Counting(mko()), apx.Counting(mkd())
+        ro, rd = [], []
+        xo, ito = O.agraal(np.zeros(nx), f=of, g=O.NormL1(lam), x0=x0, gamma0=g0, tol=0.0, maxit=K, record=ro.append)
+        x, it = apx.agraal(np.zeros(nx), f=df, g=apx.NormL1(lam), x0=x0, gamma0=g0, tol=0.0, maxit=K, record=rd.append)
+        assert it == ito == K and _rel_inf(x, xo) <= 1e-9
+        _compare(ro, rd, ("gamma", "norm_res", "objective"), 1e-7)
+        assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
+
+
+def test_skinny_mom_termination_and_maxit(apx):
+    mko, lam, gam, nx = _tall_problem(O, 4000, 40, True)
+    mkd = _tall_problem(apx, 4000, 40, True)[0]
+    x0 = 0.01 * np.cos(np.arange(nx))
+    for name, kw in (("fixed_nesterov", dict(gamma=gam)), ("agraal", dict(x0=x0, gamma0=gam))):
+        ro = []
+        getattr(O, name)(np.zeros(nx), f=mko(), g=O.NormL1(lam), tol=0.0, maxit=14, record=ro.append, **kw)
+        tol = min(r["norm_res"] for r in ro[:10]) * (1 + 1e-7)
+        for with_records in (False, True):
+            of, df = O.Counting(mko()), apx.Counting(mkd())
+            rd = []
+            xo, ito = getattr(O, name)(np.zeros(nx), f=of, g=O.NormL1(lam), tol=tol, maxit=5000, **kw)
+            x, it = getattr(apx, name)(np.zeros(nx), f=df, g=apx.NormL1(lam), tol=tol, maxit=5000,
+                                       record=rd.append if with_records else None, **kw)
+            assert it == ito <= 10 and _rel_inf(x, xo) <= 1e-10 and len(rd) == (it if with_records else 0)
+            assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
+        for K in (0, 1, 2, 9):
+            xo, _ = getattr(O, name)(np.zeros(nx), f=mko(), g=O.NormL1(lam), tol=0.0, maxit=K, **kw)
+            rd = []
+            x, it = getattr(apx, name)(np.zeros(nx), f=mkd(), g=apx.NormL1(lam), tol=0.0, maxit=K, record=rd.append, **kw)
+            assert it == K and len(rd) == K and _rel_inf(x, xo) <= 1e-10

@@ -64,6 +64,23 @@ def main():
                                                                                         maxit=k, **t2), K)
     timed("LAD 506x14  Malitsky-Pock", lambda k: apx.malitsky_pock(x0, y0, sigma=1.0 / nrm, maxit=k, **t), K)
 
+    # the logistic experiment's methods at mushrooms' shape (experiments/sparse_logreg/runme.jl:66-124), dense copy
+    m, n = 8124, 112
+    X = (rng.uniform(size=(m, n)) < 0.19).astype(np.float64)
+    w = rng.standard_normal(n) * (rng.uniform(size=n) < 0.3)
+    yl = (1 / (1 + np.exp(-(X @ w))) > rng.uniform(size=m)).astype(np.float64)
+    gam = 4.0 * m / (float(np.sum(X * X)) + m)
+    f, g, x0 = apx.LogisticLoss(X, yl), apx.NormL1(0.01), np.zeros(n + 1)
+    kw = dict(f=f, g=g, tol=0.0)
+    K = 60
+    timed("logreg 8124x112  AdaPGM (Ours)", lambda k: apx.adaptive_proxgrad(x0, rule=apx.OurRule(gamma=gam), maxit=k, **kw), K)
+    for xi in (1, 2):
+        timed(f"logreg 8124x112  PGM (backtracking, xi={xi})",
+              lambda k: apx.backtracking_proxgrad(x0, gamma0=gam, xi=xi, maxit=k, **kw), K)
+    timed("logreg 8124x112  Nesterov (backtracking)", lambda k: apx.backtracking_nesterov(x0, gamma0=gam, maxit=k, **kw), K)
+    timed("logreg 8124x112  Nesterov (fixed)", lambda k: apx.fixed_nesterov(x0, gamma=gam, maxit=k, **kw), K)
+    timed("logreg 8124x112  aGRAAL", lambda k: apx.agraal(x0, gamma0=gam, maxit=k, rng=np.random.default_rng(0), **kw), K)
+
 
 if __name__ == "__main__":
     main()

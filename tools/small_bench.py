@@ -95,14 +95,17 @@ def main():
                     pd=(A, h, m, apx.OurRule(t=1.0, norm_A=nrm)))
     # dual SVM (experiments/dual_svm/runme.jl:47-76): f = Quadratic(Q, q), g = IndBox, h = IndZero, A = y'
     rng = np.random.default_rng(0)
-    N = 1243                                             # svmguide3
-    X = rng.uniform(-1, 1, (N, 22))
-    yl = np.sign(X @ rng.standard_normal(22) + 0.1 * rng.standard_normal(N))
-    Q, q, Ay = (yl[:, None] * X) @ (yl[:, None] * X).T, -np.ones(N), yl[None, :].copy()
-    for name, ctx in (("small_pd.hip", fused), ("generic", generic)):
-        f = apx.Quadratic(apx.DeviceMatrix.from_numpy(Q, ctx), q, ctx=ctx)
-        run(f"dual SVM N={N} fp64 adaptive PD {name}", ctx, f, apx.IndBox(0.0, 0.1), N, None, False,
-            pd=(apx.DeviceMatrix.from_numpy(Ay, ctx), apx.IndZero(), 1, apx.OurRule(t=1.0, norm_A=float(np.sqrt(N)))))
+    for N, nf in ((270, 13), (1243, 22), (8124, 112)):   # heart_scale, svmguide3, mushrooms (Q is N x N: 528 MB there)
+        X = rng.uniform(-1, 1, (N, nf))
+        yl = np.sign(X @ rng.standard_normal(nf) + 0.1 * rng.standard_normal(N))
+        Q, q, Ay = (yl[:, None] * X) @ (yl[:, None] * X).T, -np.ones(N), yl[None, :].copy()
+        for name, ctx in (("small_pd.hip", fused), ("generic", generic)):
+            if N > 4096 and name != "generic":
+                continue
+            f = apx.Quadratic(apx.DeviceMatrix.from_numpy(Q, ctx), q, ctx=ctx)
+            run(f"dual SVM N={N} fp64 adaptive PD {name}", ctx, f, apx.IndBox(0.0, 0.1), N, None, False,
+                iters=2000 if N <= 4096 else 300,
+                pd=(apx.DeviceMatrix.from_numpy(Ay, ctx), apx.IndZero(), 1, apx.OurRule(t=1.0, norm_A=float(np.sqrt(N)))))
 
 
 if __name__ == "__main__":
