@@ -342,6 +342,7 @@ int32_t apx_malitsky_pock(apx_problem* p, const void* x0, const void* y0, double
   APX_REQUIRE(x0 != nullptr && y0 != nullptr && x_out != nullptr, "apx_malitsky_pock: NULL argument");
   // tall, skinny dense A with f = Zero (the reference's LAD / square-root-lasso data): device-resident linesearch
   if (skinny_mp_eligible(p)) return skinny_mp_run(p, x0, y0, sigma, t, tol, maxit, opts, x_out, y_out, res);
+  if (small_mpq_eligible(p)) return small_mpq_run(p, x0, y0, sigma, t, tol, maxit, opts, x_out, y_out, res);
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es, mb = (size_t)p->m_pad * es;
   DBuf bx, bxn, bv, bgp, baty, batyp, by, byn, bax, baxn;

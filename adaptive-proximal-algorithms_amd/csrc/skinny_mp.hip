@@ -151,7 +151,7 @@ __device__ __forceinline__ void mp_trial(const MpDev& d, MpCtrl& lc, double* ndx
     ((T*)d.V)[tid] = vi;
     ((T*)d.XT)[tid] = xi;
   }
-  block_sums_t0<1>(q);
+  block_sums_t0<1, kSkinnyCloseBlock>(q);
   if (tid == 0) {
     lc.gamma = gamma;
     *ndx2_out = q[0];

@@ -74,7 +74,9 @@ __device__ __forceinline__ void small_dots_w(int W, const T* __restrict__ M, int
   }
 }
 
-// block-wide sums of Q quantities, valid on thread 0 only
+// block-wide sums of Q quantities, valid on thread 0 only.  BS must be the block size of the calling kernel: the
+// staging rows and the (unrolled) final sum are sized by it; waves beyond BS / 64 are not stored, so a mismatch
+// cannot write outside the staging rows.
 template <int Q, int BS = kBlock>
 __device__ __forceinline__ void block_sums_t0(double (&v)[Q]) {
   __shared__ double sh[BS / 64][Q];
@@ -82,7 +84,7 @@ __device__ __forceinline__ void block_sums_t0(double (&v)[Q]) {
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const double s = wave_sum(v[q]);
-    if (lane == 0) sh[wv][q] = s;
+    if (lane == 0 && wv < BS / 64) sh[wv][q] = s;
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -230,6 +230,9 @@ bool small_bt_eligible(const apx_problem* p);
 int32_t small_bt_run(apx_problem* p, bool nesterov, const void* x0, double gamma0, double xi, double shrink, double tol,
                      int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
 // skinny_mp.hip: Malitsky-Pock with its linesearch as a device-side state machine
+bool small_mpq_eligible(const apx_problem* p);     // small_mpq.hip: Malitsky-Pock for f = Quadratic, few rows of A (dual SVM)
+int32_t small_mpq_run(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol, int64_t maxit,
+                      const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res);
 bool skinny_mp_eligible(const apx_problem* p);
 int32_t skinny_mp_run(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol, int64_t maxit,
                       const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res);

@@ -217,7 +217,8 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *   - the linesearch methods as state machines in device memory, no read-back per trial: backtracking_proxgrad,
  *     backtracking_nesterov (csrc/small_bt.hip), adaptive_linesearch_primal_dual, malitsky_pock on tall-skinny A
  *     (csrc/skinny_ls.hip, csrc/skinny_mp.hip); fixed_nesterov and agraal likewise (csrc/small_mom.hip); all four
- *     proximal-gradient comparison methods also on tall, skinny A (csrc/skinny_bt.hip, csrc/skinny_mom.hip).
+ *     proximal-gradient comparison methods also on tall, skinny A (csrc/skinny_bt.hip, csrc/skinny_mom.hip);
+ *     malitsky_pock with f = Quadratic and at most 64 rows of A — the dual SVM — in csrc/small_mpq.hip.
  *   - a problem built on a SPARSE matrix that is small as a dense one (m x n within the limits above, <= 256 MB:
  *     the three LIBSVM datasets of experiments/sparse_logreg/runme.jl:177-204) runs on a dense copy of it, which the
  *     matrix keeps (products through apx_gemv_n/t stay on the compressed storage).

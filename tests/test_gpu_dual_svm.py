@@ -61,3 +61,54 @@ def test_dual_svm_adaptive_primal_dual(apx, t):
         assert rd["objective"] == pytest.approx(ro["objective"], rel=1e-10, abs=1e-12)
     assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count)
     assert np.all(x >= 0) and np.all(x <= C)
+
+
+@pytest.mark.parametrize("N,t", [(400, 0.01), (400, 0.2), (400, 1.0), (400, 10.0), (270, 0.5), (1243, 2.0), (4096, 1.0)])
+def test_dual_svm_malitsky_pock_device_resident(apx, N, t):
+    """experiments/dual_svm/runme.jl:78-92: malitsky_pock(t, sigma = 1/norm_A) on the dual SVM — the device-resident
+    linesearch (csrc/small_mpq.hip) against the oracle and against the host-driven loop, incl. the evaluation counts."""
+    Q, q, A = _dual_svm(N=N, d=22)
+    norm_A = float(np.linalg.norm(A))
+    K = 40 if N <= 1243 else 15
+    kw = dict(sigma=1.0 / norm_A, t=t, tol=0.0, maxit=K)
+    orecs, drecs = [], []
+    of, df = O.Counting(O.Quadratic(Q, q)), apx.Counting(apx.Quadratic(Q, q))
+    oA, dA = O.Counting(A), apx.Counting(apx.DeviceMatrix.from_numpy(A))
+    xo, yo, ito = O.malitsky_pock(np.zeros(N), np.zeros(1), f=of, g=O.IndBox(0.0, 0.1), h=O.IndZero(), A=oA,
+                                  record=orecs.append, **kw)
+    x, y, it = apx.malitsky_pock(np.zeros(N), np.zeros(1), f=df, g=apx.IndBox(0.0, 0.1), h=apx.IndZero(), A=dA,
+                                 record=drecs.append, **kw)
+    assert it == ito == K and _rel_inf(x, xo) <= 1e-10 and _rel_inf(y, yo) <= 1e-9
+    assert len(drecs) == K
+    for ro, rd in zip(orecs, drecs):
+        assert list(rd) == list(ro)
+        for k in ("gamma", "sigma", "norm_res", "objective"):
+            assert rd[k] == pytest.approx(ro[k], rel=1e-8), k
+        for k in ro:
+            if k.endswith("_evals"):
+                assert rd[k] == ro[k], k
+    assert (df.eval_count, df.grad_count, dA.mul_count, dA.amul_count) == (of.eval_count, of.grad_count, oA.mul_count, oA.amul_count)
+    assert any(r["sigma"] < o["sigma"] * 2 ** 0.5 for r, o in zip(drecs[1:], drecs[:-1]))      # the linesearch did backtrack
+    # the host-driven loop (a context without the small-size policy) gives the same iterate
+    g = apx.Context(0)
+    g.fused_small(False)
+    xg, yg, _ = apx.malitsky_pock(np.zeros(N), np.zeros(1), f=apx.Quadratic(apx.DeviceMatrix.from_numpy(Q, g), q, ctx=g),
+                                  g=apx.IndBox(0.0, 0.1), h=apx.IndZero(), A=apx.DeviceMatrix.from_numpy(A, g), ctx=g, **kw)
+    assert _rel_inf(x, xg) <= 1e-10
+
+
+def test_dual_svm_malitsky_pock_termination_and_maxit(apx):
+    Q, q, A = _dual_svm(N=300, d=12)
+    N, norm_A = 300, float(np.linalg.norm(A))
+    kw = dict(sigma=1.0 / norm_A, t=1.0)
+    mk = lambda M: dict(f=M.Quadratic(Q, q), g=M.IndBox(0.0, 0.1), h=M.IndZero(), A=A)      # noqa: E731
+    ro = []
+    O.malitsky_pock(np.zeros(N), np.zeros(1), tol=0.0, maxit=60, record=ro.append, **mk(O), **kw)
+    tol = min(r["norm_res"] for r in ro[:40]) * (1 + 1e-7)
+    xo, yo, ito = O.malitsky_pock(np.zeros(N), np.zeros(1), tol=tol, maxit=5000, **mk(O), **kw)
+    x, y, it = apx.malitsky_pock(np.zeros(N), np.zeros(1), tol=tol, maxit=5000, **mk(apx), **kw)
+    assert it == ito <= 40 and _rel_inf(x, xo) <= 1e-10 and _rel_inf(y, yo) <= 1e-9
+    for K in (0, 1, 2, 70):
+        xo, yo, _ = O.malitsky_pock(np.zeros(N), np.zeros(1), tol=0.0, maxit=K, **mk(O), **kw)
+        x, y, it = apx.malitsky_pock(np.zeros(N), np.zeros(1), tol=0.0, maxit=K, **mk(apx), **kw)
+        assert it == K and _rel_inf(x, xo) <= 1e-10 if K else np.array_equal(x, np.zeros(N))

@@ -64,6 +64,17 @@ def main():
                                                                                         maxit=k, **t2), K)
     timed("LAD 506x14  Malitsky-Pock", lambda k: apx.malitsky_pock(x0, y0, sigma=1.0 / nrm, maxit=k, **t), K)
 
+    # the dual SVM's three methods (experiments/dual_svm/runme.jl:62-104) at svmguide3's size: Q is 1243 x 1243, A = y'
+    N, nf = 1243, 22
+    Xs = rng.uniform(-1, 1, (N, nf))
+    ys = np.sign(Xs @ rng.standard_normal(nf) + 0.1 * rng.standard_normal(N))
+    Q, qv, Ay = (ys[:, None] * Xs) @ (ys[:, None] * Xs).T, -np.ones(N), ys[None, :].copy()
+    ts = dict(f=apx.Quadratic(Q, qv), g=apx.IndBox(0.0, 0.1), h=apx.IndZero(), A=apx.DeviceMatrix.from_numpy(Ay), tol=0.0)
+    nA, xs0, ys0 = float(np.sqrt(N)), np.zeros(N), np.zeros(1)
+    timed("dual SVM N=1243  AdaPDM", lambda k: apx.adaptive_primal_dual(xs0, ys0, rule=apx.OurRule(t=1.0, norm_A=nA), maxit=k, **ts), 300)
+    timed("dual SVM N=1243  Malitsky-Pock", lambda k: apx.malitsky_pock(xs0, ys0, t=1.0, sigma=1 / nA, maxit=k, **ts), 300)
+    timed("dual SVM N=1243  Condat-Vu", lambda k: apx.condat_vu(xs0, ys0, Lf=float(np.linalg.norm(Q)), norm_A=nA, maxit=k, **ts), 300)
+
     # the logistic experiment's methods at mushrooms' shape (experiments/sparse_logreg/runme.jl:66-124), dense copy
     m, n = 8124, 112
     X = (rng.uniform(size=(m, n)) < 0.19).astype(np.float64)
