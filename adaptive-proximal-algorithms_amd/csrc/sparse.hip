@@ -288,7 +288,10 @@ int32_t small_dense_view(const apx_matrix* A, const apx_matrix** out) {
   if ((double)m * (double)n * (double)dtype_size(A->dtype) > 256.0 * 1024 * 1024) return APX_OK;
   if (A->dense_view == nullptr) {
     apx_matrix* D = nullptr;
-    APX_TRY(apx_matrix_create(A->ctx, m, n, A->dtype, &D));     // zero-filled
+    if (apx_matrix_create(A->ctx, m, n, A->dtype, &D) != APX_OK) {     // zero-filled ; no memory for it: stay sparse
+      (void)hipGetLastError();
+      return APX_OK;
+    }
     const unsigned grid = (unsigned)((m + 255) / 256);
     if (A->dtype == APX_F32)
       hipLaunchKernelGGL((k_densify<float>), dim3(grid), dim3(256), 0, A->ctx->stream, A->rptr, A->rind, (const float*)A->rval, m,
