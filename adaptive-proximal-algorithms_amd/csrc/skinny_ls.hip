@@ -1,5 +1,5 @@
 // skinny_ls.hip — AdaPDM+ (`adaptive_linesearch_primal_dual`, src/AdaProx.jl:463-550) as a DEVICE-RESIDENT
-// loop for tall, skinny dense A (n <= 120, f = Zero): the method the reference's least_absolute_deviation and
+// loop for tall, skinny dense A (n <= 124, f = Zero): the method the reference's least_absolute_deviation and
 // square_root_lasso experiments showcase (15 of their 31 runs each), on data of 8192 x 13, 4177 x 9, 506 x 14.
 // The generic implementation (solver.hip) drives the linesearch from the host — a scalar read-back per trial,
 // ~75 us per iteration at these sizes.  Here the linesearch is a small state machine in device memory:

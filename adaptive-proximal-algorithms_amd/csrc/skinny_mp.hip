@@ -1,5 +1,5 @@
 // skinny_mp.hip — Malitsky-Pock with linesearch (`malitsky_pock` + `backtrack_stepsize_MP`,
-// src/AdaProx.jl:555-629) as a DEVICE-RESIDENT loop for tall, skinny dense A (n <= 120, f = Zero): the
+// src/AdaProx.jl:555-629) as a DEVICE-RESIDENT loop for tall, skinny dense A (n <= 124, f = Zero): the
 // comparison method that takes 15 of the 31 runs of the reference's least_absolute_deviation and
 // square_root_lasso experiments.  Same construction as skinny_ls.hip — a thread per row, a one-block closing
 // kernel, the control flow as a state machine in device memory — with two kinds of tick:

@@ -1,5 +1,5 @@
 // skinny_pd.hip — the primal-dual iteration (src/AdaProx.jl:334-362, f = Zero) for TALL, SKINNY dense A:
-// n <= 120 columns, any reasonable number of rows — exactly the reference's own LAD / square-root-lasso
+// n <= 124 columns, any reasonable number of rows — exactly the reference's own LAD / square-root-lasso
 // data (experiments/least_absolute_deviation/runme.jl:128-160: cpusmall_scale 8192 x 13, abalone 4177 x 9,
 // housing_scale 506 x 14).  With so few columns x fits in a handful of LDS words, so nothing about the m
 // side has to be done redundantly (small_pd.hip's cost on these shapes) and A x needs no kernel of its own:
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_skinny_rows(SkinnyDev d) {
     //  them: each dependent round trip to memory costs 1-2 us here, and a private copy would live in scratch)
     const int done = d.c->done;                // written by an earlier launch: block-uniform
     if constexpr (PHASE == 1 || PHASE == 2) {
-      // ---- n side, redundantly per block (n <= 120 values): residual, rule ------------------------
+      // ---- n side, redundantly per block (n <= 124 values): residual, rule ------------------------
       const double gamma = d.c->gamma;
       const bool mine = tid < d.n;
       const T x_t = mine ? ((const T*)d.X)[tid] : (T)0, v_t = mine ? ((const T*)d.V)[tid] : (T)0,

@@ -1,5 +1,5 @@
 // skinny_pg.hip — the proximal-gradient iteration (`adaptive_proxgrad` / `fixed_proxgrad`, src/AdaProx.jl:418-421,
-// 457-459 over the loop :334-362) for TALL, SKINNY dense A: at most 120 unknowns, thousands of rows — the shape of the
+// 457-459 over the loop :334-362) for TALL, SKINNY dense A: at most 124 unknowns, thousands of rows — the shape of the
 // reference's logistic-regression data once densified (mushrooms 8124 x 112, phishing 11055 x 68,
 // experiments/sparse_logreg/runme.jl:177-204) and of any tall least-squares problem.  With so few columns the
 // gradient is n block-partial sums and the whole n side fits one workgroup:
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kSpgCloseBlock) void k_spg_close(SkinnyPgDev d, int
   }
   const double xj = (double)x_t;
   if constexpr (MODE == 1) {
-    if (tid < 128) {                                                // n <= 120: the first two waves hold it all
+    if (tid < 128) {                                                // n <= 124: the first two waves hold it all
       double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (mine) {
         const double pr = ((double)v_t - xj) / lc.gamma + gj;      // :338 (A'y == 0)
