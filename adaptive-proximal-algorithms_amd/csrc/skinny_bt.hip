@@ -146,7 +146,6 @@ __global__ __launch_bounds__(kSbtBlock) void k_sbt_close(SbtDev d, int B) {
   }
   __syncthreads();
   const int a = act;
-  const bool nes = lc.nesterov != 0;
   // ---- the n-vectors --------------------------------------------------------------------------------
   double bx = (double)x_t, bg = gx_t;                 // the point and gradient the next trial starts from
   if (a != 0) {                                       // XT was evaluated as (or accepted to be) the new base
@@ -194,7 +193,6 @@ __global__ __launch_bounds__(kSbtBlock) void k_sbt_close(SbtDev d, int B) {
     lc.halt = (lc.done != 0 || lc.it >= lc.maxit) ? 1 : 0;
     *d.c = lc;
   }
-  (void)nes;
 }
 
 // ---------------------------------------------------------------------------------------
