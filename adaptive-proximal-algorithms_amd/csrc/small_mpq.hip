@@ -2,7 +2,8 @@
 // as a DEVICE-RESIDENT loop for f = Quadratic(Q, q) with a FEW linear constraints: the dual SVM of the reference
 // (experiments/dual_svm/runme.jl:47-90: Q is N x N, A = y' is 1 x N, g = IndBox, h = IndZero), which runs this method
 // for twelve values of t per dataset.  The host-driven form reads the linesearch scalars back per trial
-// (142 us per iteration at N = 1243); here one linesearch trial is one TICK of two launches:
+// (142 us per iteration at N = 1243, 344 us at mushrooms' N = 8124); here one linesearch trial is one TICK of two
+// launches (29 / 230 us per iteration):
 //
 //   k_mpq_a (many blocks, each redoes the O(n) part): theta, gamma, A'ybar, v, the trial x+ = prox_{gamma g}(v)
 //           (:556-560) with ||x+ - x||^2 and <grad_x, x+ - x> ; then the two products as in-block dot products:
@@ -28,7 +29,8 @@ namespace apx {
 
 constexpr int kMpqMaxM = 64;          // rows of A: A'y is formed entry by entry in the one-block kernel
 constexpr int kMpqBlockB = 1024;
-constexpr int kMpqPerB = kSmallMax / kMpqBlockB;     // n-entries per thread of the one-block kernel
+constexpr int kMpqMaxN = 8192;        // (mushrooms' dual SVM is 8124 x 8124)
+constexpr int kMpqPerB = kMpqMaxN / kMpqBlockB;      // n-entries per thread of the one-block kernel
 
 struct MpqCtrl {
   double t, tol, theta_outer;
@@ -63,7 +65,7 @@ struct MpqDev {
 // MODE 1: a trial
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void k_mpq_a(MpqDev d) {
-  __shared__ double xs[kSmallMax];
+  extern __shared__ double xs[];                    // the point whose products are formed: n doubles (dynamic: up to 64 KB)
   const int tid = threadIdx.x;
   if constexpr (MODE == 0) {
     const T* __restrict__ X0 = (const T*)d.XT;
@@ -299,16 +301,19 @@ bool small_mpq_eligible(const apx_problem* p) {
   if (p->A_lin == nullptr || p->allreduce != nullptr || p->f_kind != APX_F_QUADRATIC) return false;
   if (p->A_f == nullptr || p->A_f->sparse || p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   if (p->hd.kind == APX_G_L2) return false;           // (its conjugate prox needs a norm over all rows first)
-  return p->n <= kSmallMax && p->n > 0 && p->A_lin->m > 0 && p->A_lin->m <= kMpqMaxM;
+  return p->n <= kMpqMaxN && p->n > 0 && p->A_lin->m > 0 && p->A_lin->m <= kMpqMaxM;
 }
 
 template <typename T>
 static void mpq_tick(const MpqDev& d, int mode, unsigned grid, hipStream_t q) {
+  const size_t lds = m_vector_lds_bytes(d.n);
   if (mode == 0) {
-    hipLaunchKernelGGL((k_mpq_a<T, 0>), dim3(grid), dim3(kBlock), 0, q, d);
+    allow_big_lds<k_mpq_a<T, 0>>();
+    hipLaunchKernelGGL((k_mpq_a<T, 0>), dim3(grid), dim3(kBlock), lds, q, d);
     hipLaunchKernelGGL((k_mpq_b<T, 0>), dim3(1), dim3(kMpqBlockB), 0, q, d);
   } else {
-    hipLaunchKernelGGL((k_mpq_a<T, 1>), dim3(grid), dim3(kBlock), 0, q, d);
+    allow_big_lds<k_mpq_a<T, 1>>();
+    hipLaunchKernelGGL((k_mpq_a<T, 1>), dim3(grid), dim3(kBlock), lds, q, d);
     hipLaunchKernelGGL((k_mpq_b<T, 1>), dim3(1), dim3(kMpqBlockB), 0, q, d);
   }
 }

@@ -63,13 +63,13 @@ def test_dual_svm_adaptive_primal_dual(apx, t):
     assert np.all(x >= 0) and np.all(x <= C)
 
 
-@pytest.mark.parametrize("N,t", [(400, 0.01), (400, 0.2), (400, 1.0), (400, 10.0), (270, 0.5), (1243, 2.0), (4096, 1.0)])
+@pytest.mark.parametrize("N,t", [(400, 0.01), (400, 0.2), (400, 1.0), (400, 10.0), (270, 0.5), (1243, 2.0), (4096, 1.0), (5200, 1.0)])
 def test_dual_svm_malitsky_pock_device_resident(apx, N, t):
     """experiments/dual_svm/runme.jl:78-92: malitsky_pock(t, sigma = 1/norm_A) on the dual SVM — the device-resident
     linesearch (csrc/small_mpq.hip) against the oracle and against the host-driven loop, incl. the evaluation counts."""
     Q, q, A = _dual_svm(N=N, d=22)
     norm_A = float(np.linalg.norm(A))
-    K = 40 if N <= 1243 else 15
+    K = 40 if N <= 1243 else (15 if N <= 4096 else 8)
     kw = dict(sigma=1.0 / norm_A, t=t, tol=0.0, maxit=K)
     orecs, drecs = [], []
     of, df = O.Counting(O.Quadratic(Q, q)), apx.Counting(apx.Quadratic(Q, q))
