@@ -285,3 +285,80 @@ def test_tall_skinny_methods_vs_generic_fuzz(m, n, logistic, f32, gk, method, k,
             assert a["it"] == b_["it"]
             if np.isfinite(b_["objective"]):
                 assert a["objective"] == pytest.approx(b_["objective"], rel=10 * tol, abs=10 * tol)
+
+
+@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(m=st.one_of(st.integers(1024, 6000), st.sampled_from([1024, 1025, 3071, 3072, 3073, 4096, 4097, 20000])),
+       n=st.one_of(st.integers(1, 30), st.sampled_from([7, 8, 9, 15, 16, 17, 64, 120, 124])),
+       hk=st.sampled_from(["tl1", "tl2", "l1"]), method=st.sampled_from(["adapdm", "adapdm+", "mp", "cv"]),
+       f32=st.booleans(), k=st.integers(0, 9), seed=st.integers(0, 2**31 - 1))
+def test_tall_skinny_primal_dual_methods_vs_generic_fuzz(m, n, hk, method, f32, k, seed):
+    """csrc/skinny_pd.hip, skinny_ls.hip, skinny_mp.hip (f = Zero, LAD / square-root-lasso terms) against the generic
+    kernels and the host-driven linesearch loops."""
+    apx, _ = _apx()
+    g_ctx = _generic_ctx()
+    if 4 * n > m:
+        m = 4 * n
+    if method in ("adapdm+", "mp") and hk == "l1":
+        hk = "tl1"          # (h without data: y stays 0 and AdaPDM+'s test is 0 / 0 for ever — the reference would spin)
+    dtype = np.float32 if f32 else np.float64
+    rng = np.random.default_rng(seed)
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, max(n - 1, 0))), np.ones((m, 1))]).astype(dtype))
+    yv = (A.astype(np.float64) @ rng.standard_normal(n) + rng.laplace(size=m)).astype(dtype)
+    nA = float(np.linalg.norm(A.astype(np.float64)))
+    x0, y0 = np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype)
+    out = []
+    for ctx in (apx.default_context(), g_ctx):
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        h = {"tl1": lambda: apx.Translate(apx.NormL1(1.0), -yv), "tl2": lambda: apx.Translate(apx.NormL2(1.0), -yv),
+             "l1": lambda: apx.NormL1(0.7)}[hk]()
+        kw = dict(f=apx.Zero(), g=apx.NormL1(0.05 if hk == "tl2" else 5.0), h=h, A=dA, tol=0.0, maxit=k, ctx=ctx)
+        if method == "adapdm":
+            x, y, it = apx.adaptive_primal_dual(x0, y0, rule=apx.OurRule(t=1.0, norm_A=nA), **kw)
+        elif method == "adapdm+":
+            x, y, it = apx.adaptive_linesearch_primal_dual(x0, y0, eta=nA, **kw)
+        elif method == "mp":
+            x, y, it = apx.malitsky_pock(x0, y0, sigma=1.0 / nA, **kw)
+        else:
+            x, y, it = apx.condat_vu(x0, y0, Lf=0.0, norm_A=nA, **kw)
+        out.append((x, y, it))
+        dA.free()
+    (xs, ys, its), (xg, yg, itg) = out
+    tol = 2e-3 if f32 else 1e-7
+    if its != itg:          # (an exact fixed point reached by one summation order and not the other)
+        assert max(its, itg) == k
+        return
+    assert np.all(np.isfinite(xs)) == np.all(np.isfinite(xg))
+    if np.all(np.isfinite(xg)) and np.all(np.isfinite(yg)):
+        assert np.max(np.abs(xs - xg)) <= tol * max(1.0, np.max(np.abs(xg)))
+        assert np.max(np.abs(ys - yg)) <= tol * max(1.0, np.max(np.abs(yg)))
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(N=st.one_of(st.integers(2, 600), st.sampled_from([255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097])),
+       rows=st.sampled_from([1, 2, 5, 64]), t=st.sampled_from([0.05, 1.0, 8.0]), f32=st.booleans(), k=st.integers(0, 9),
+       seed=st.integers(0, 2**31 - 1))
+def test_malitsky_pock_quadratic_vs_host_driven_fuzz(N, rows, t, f32, k, seed):
+    """csrc/small_mpq.hip (f = Quadratic, a few rows of A) against the host-driven loop."""
+    apx, _ = _apx()
+    g_ctx = _generic_ctx()
+    dtype = np.float32 if f32 else np.float64
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (N, 9))
+    yl = np.sign(X @ rng.standard_normal(9) + 0.1 * rng.standard_normal(N))
+    Q = np.asfortranarray(((yl[:, None] * X) @ (yl[:, None] * X).T).astype(dtype))
+    q = -np.ones(N, dtype=dtype)
+    A = np.asfortranarray(np.vstack([yl[None, :]] + [rng.uniform(-1, 1, (1, N)) for _ in range(rows - 1)]).astype(dtype))
+    nA = float(np.linalg.norm(A.astype(np.float64)))
+    out = []
+    for ctx in (apx.default_context(), g_ctx):
+        f = apx.Quadratic(apx.DeviceMatrix.from_numpy(Q, ctx), q, ctx=ctx)
+        x, y, it = apx.malitsky_pock(np.zeros(N, dtype=dtype), np.zeros(rows, dtype=dtype), f=f, g=apx.IndBox(0.0, 0.1),
+                                     h=apx.IndZero(), A=apx.DeviceMatrix.from_numpy(A, ctx), sigma=1.0 / nA, t=t, tol=0.0,
+                                     maxit=k, ctx=ctx)
+        out.append((x, y, it))
+    (xs, ys, its), (xg, yg, itg) = out
+    tol = 2e-3 if f32 else 1e-8
+    assert its == itg == k
+    assert np.max(np.abs(xs - xg)) <= tol * max(1.0, np.max(np.abs(xg)))
+    assert np.max(np.abs(ys - yg)) <= tol * max(1.0, np.max(np.abs(yg)))
