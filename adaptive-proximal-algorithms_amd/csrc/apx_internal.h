@@ -146,6 +146,9 @@ int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* ou
 int32_t launch_sum_partials_rows(apx_ctx* ctx, int32_t dtype, int splits, int64_t m, int64_t ld, void* y,
                                  const int* done);
 // sparse.hip: the same two products for compressed storage (same output conventions)
+// HIP events around one launch (apx_ctx_profile): kind = APX_KSTAT_*, bytes = its algorithmic bytes
+int32_t prof_begin(apx_ctx* ctx, int kind, double bytes);
+int32_t prof_end(apx_ctx* ctx);
 int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done);
 // A itself, or — for a sparse A small enough for the small-size paths — its dense copy (owned by A)
 int32_t small_dense_view(const apx_matrix* A, const apx_matrix** out);

@@ -83,7 +83,7 @@ int32_t ensure_part(apx_ctx* ctx, size_t bytes) {
 }
 
 // ---- HIP-event timing of single launches (bench.py roofline; off by default) ---------
-static int32_t prof_begin(apx_ctx* ctx, int kind, double bytes) {
+int32_t prof_begin(apx_ctx* ctx, int kind, double bytes) {
   if (!ctx->profile) return APX_OK;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (!ctx->ev_free.empty()) {
@@ -97,7 +97,7 @@ static int32_t prof_begin(apx_ctx* ctx, int kind, double bytes) {
   ctx->ev_pending.push_back({ev.first, ev.second, kind, bytes});
   return APX_OK;
 }
-static int32_t prof_end(apx_ctx* ctx) {
+int32_t prof_end(apx_ctx* ctx) {
   if (!ctx->profile) return APX_OK;
   APX_HIP(hipEventRecord(ctx->ev_pending.back().b, ctx->stream));
   return APX_OK;

@@ -1,5 +1,5 @@
 // skinny_bt.hip — `backtracking_proxgrad` (src/AdaProx.jl:34-64) and `backtracking_nesterov` (:66-84) as DEVICE-
-// RESIDENT loops for tall, skinny dense A (at most 124 unknowns, 2048 .. 262 144 rows): the shape of all three
+// RESIDENT loops for tall, skinny dense A (at most 124 unknowns, 2048 rows or more): the shape of all three
 // datasets of the reference's logistic experiment, which runs these methods five times per dataset
 // (experiments/sparse_logreg/runme.jl:66-124).  The host-driven forms read f_z back per linesearch trial (45 - 80 us
 // per iteration); here one trial is one TICK of the two launches of skinny_pg.hip:

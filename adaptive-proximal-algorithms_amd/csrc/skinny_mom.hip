@@ -1,5 +1,5 @@
 // skinny_mom.hip — `fixed_nesterov` (src/AdaProx.jl:91-142) and `agraal` (:150-192) as DEVICE-RESIDENT loops for
-// tall, skinny dense A (at most 124 unknowns, 2048 .. 262 144 rows): the shape of all three datasets of the
+// tall, skinny dense A (at most 124 unknowns, 2048 rows or more): the shape of all three datasets of the
 // reference's logistic experiment, which runs both methods on each (experiments/sparse_logreg/runme.jl:104-124).
 // The host-driven forms read scalars back every iteration (53 / 80 us per iteration at 8124 x 112); here an
 // iteration is one or two TICKS of the two launches of skinny_pg.hip:

@@ -139,7 +139,9 @@ inline bool skinny_rows_eligible(const apx_problem* p) {
   if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
   const int64_t m = p->A_f->m;
   // below ~2000 rows small.hip's redundant scheme is as fast (logistic 2000 x 120: 14.8 us)
-  return p->n <= kSkinnyMaxN && p->A_f->n > 0 && m >= 2048 && m <= 256 * 1024 && p->n * 4 <= m;
+  // (no upper limit that matters: a block walks as many groups of 64 rows as it takes to leave 512 partial rows, and
+  //  this ONE pass over A per iteration is half the traffic of the two GEMV passes whatever the size)
+  return p->n <= kSkinnyMaxN && p->A_f->n > 0 && m >= 2048 && m <= ((int64_t)1 << 24) && p->n * 4 <= m;
 }
 
 }  // namespace apx

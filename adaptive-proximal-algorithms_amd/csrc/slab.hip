@@ -1,0 +1,250 @@
+// slab.hip — f(x) and grad f(x) of LinearLeastSquares / LogisticLoss (experiments/lasso/runme.jl:21-25,
+// experiments/sparse_logreg/runme.jl:23-37) in ONE pass over A, for matrices whose rows are short enough to be held in
+// the registers of a workgroup (n <= 5120, fp32: 10 240).
+//
+// The reference's cost model — and the generic path here — is two streaming passes per iteration: res = A x - b (or
+// the logistic link), then grad = A' res (lasso/runme.jl:179-180).  The second pass needs every res[i] = <A[i,:], x>
+// complete, but only of the rows it touches: a block that owns a slab of ROWS and keeps R of them at a time in
+// registers (thread t holds the columns t, t + BS, ... of each, read from the transposed copy, where a row is
+// contiguous) can form their R dot products, the residuals, and add res[i] * A[i,:] to a private column accumulator
+// from the SAME registers.  A is read once; what is left are B partial n-vectors (20 MB at C3 against 4 GB of A),
+// summed in a fixed order by a second, small kernel that also finalises f and the logistic scaling.  No atomics:
+// bit-reproducible.  HBM traffic per iteration: m n sizeof(T) instead of 2 m n sizeof(T).
+//
+//   k_slab_rows  (one or two big blocks per CU, rows dealt in contiguous slabs): R rows per step ; per step two
+//                barriers (the R dots across the waves ; the R residuals back to every thread)
+//   k_slab_close (a thread per column): the B partials of its column, the loss sums (every block, redundantly),
+//                f -> Ctrl, grad (logistic: / N, the bias entry)
+//
+// Used by the generic loop (solver.hip) in place of gemv_n + k_finish_rows + k_f_reduce + gemv_t (+ k_logistic_grad)
+// when the matrix has its transposed copy (apx_matrix_build_transpose) and there is no all-reduce hook.
+#include <cstdlib>
+#include <memory>
+
+#include "skinny_dev.h"
+#include "solver_internal.h"
+#include "vecops_dev.h"
+
+namespace apx {
+
+constexpr int kSlabRows = 4;          // rows per step (fp64 with twenty columns per thread: 2)
+
+struct SlabDev {
+  const void* AT;         // A' column-major: row i of A at AT + i * ldT, contiguous
+  int64_t ldT;
+  int32_t m, ncols, n, rows_per_block;
+  const void* b;
+  double* part;           // [blocks][ldpart]: ncols column partials, then the loss sum(s)
+  int64_t ldpart;
+  Ctrl* c;
+};
+
+struct SlabState {
+  DBuf part;
+  SlabDev dev{};
+  int B = 0, cpt = 0, bs = 0;     // blocks ; columns per thread ; threads per block
+};
+void slab_destroy(SlabState* st) { delete st; }
+
+// BS threads, C columns per thread (BS * C >= n), R rows per step: R x C values of A, C of x and C doubles of acc must
+// fit the 128 VGPRs of a 1024-thread block, and R * n * sizeof(T) is what a CU has in flight per step.
+template <typename T, int FK, int C, int R, int BS>
+__global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
+  __shared__ double wsum[BS / 64][R];
+  __shared__ double res_s[R];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (d.c->done != 0) return;                    // written by an earlier launch: block-uniform
+  const T* __restrict__ AT = (const T*)d.AT;
+  const T* __restrict__ X = (const T*)xv;
+  const T* __restrict__ bv = (const T*)d.b;
+  T xr[C];                                       // (kept in T: the registers are what limits the row length)
+  double acc[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int j = tid + k * BS;
+    xr[k] = j < d.ncols ? X[j] : (T)0;           // columns beyond the last: weight 0 (their loads are clamped)
+    acc[k] = 0.0;
+  }
+  double bias = 0.0;
+  if constexpr (FK == APX_F_LOGISTIC) bias = (double)X[d.n - 1];
+  double e0 = 0.0, e1 = 0.0;                     // loss sums of the rows this thread finishes (tid < R)
+  const int row_begin = blockIdx.x * d.rows_per_block;
+  const int row_end = min(row_begin + d.rows_per_block, d.m);
+  for (int r0 = row_begin; r0 < row_end; r0 += R) {
+    T a[R][C];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const T* __restrict__ row = AT + (int64_t)min(r0 + r, d.m - 1) * d.ldT;
+#pragma unroll
+      for (int k = 0; k < C; ++k) a[r][k] = row[min(tid + k * BS, d.ncols - 1)];
+    }
+    double p[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      p[r] = 0.0;
+#pragma unroll
+      for (int k = 0; k < C; ++k) p[r] = fma((double)a[r][k], (double)xr[k], p[r]);
+    }
+    wave_sum_multi<R>(p);                        // lane l: the wave's sum for row l / (64 / R)
+    if (lane % (64 / R) == 0) wsum[wv][lane / (64 / R)] = p[0];
+    __syncthreads();
+    if (tid < R) {                               // thread r finishes row r0 + r
+      double dot = wsum[0][tid];
+#pragma unroll
+      for (int w = 1; w < BS / 64; ++w) dot += wsum[w][tid];
+      const int i = r0 + tid;
+      double res = 0.0;
+      if (i < row_end) {
+        const double bi = (double)bv[i];
+        const double ax = (double)(T)dot;        // A_x rounded to T like every stored A x
+        if constexpr (FK == APX_F_LEAST_SQUARES) {
+          res = (double)(T)(ax - bi);
+          e0 += res * res;
+        } else {
+          const double logit = ax + bias;
+          const double e = 1.0 + exp(-logit);
+          e0 += (bi - 1.0) * logit - log(e);
+          res = (double)(T)(1.0 / e - bi);
+          e1 += res;
+        }
+      }
+      res_s[tid] = res;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double rr = res_s[r];
+#pragma unroll
+      for (int k = 0; k < C; ++k) acc[k] = fma((double)a[r][k], rr, acc[k]);
+    }
+  }
+  double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int j = tid + k * BS;
+    if (j < d.ncols) out[j] = acc[k];
+  }
+  // the loss sums of this block: rows r0 + 0 .. R-1 were finished by threads 0 .. R-1 (one wave)
+  if (wv == 0) {
+    double ex[2] = {tid < R ? e0 : 0.0, tid < R ? e1 : 0.0};
+    wave_sum_multi<2>(ex);                       // lane l: ex[l / 32]
+    if ((lane & 31) == 0) out[d.ncols + (lane >> 5)] = ex[0];
+  }
+}
+
+template <typename T, int FK>
+__global__ __launch_bounds__(kBlock) void k_slab_close(SlabDev d, int B, T* __restrict__ grad) {
+  __shared__ double fs[2];
+  if (d.c->done != 0) return;
+  const int tid = threadIdx.x;
+  // the loss sums over the B blocks, by every block in the same fixed order (waves 0 and 1: one column each)
+  if (tid < 128) {
+    const int which = tid >> 6, lane = tid & 63;
+    double s = 0.0;
+    for (int b = lane; b < B; b += 64) s += d.part[(int64_t)b * d.ldpart + d.ncols + which];
+    s = wave_sum(s);
+    if (lane == 0) fs[which] = s;
+  }
+  const int j = blockIdx.x * kBlock + tid;
+  double g = 0.0;
+  if (j < d.ncols) g = skinny_strided_sum(d.part, d.ldpart, j, 0, 1, B);     // sixteen loads in flight, fixed order
+  __syncthreads();
+  const double N = d.c->n_mean;
+  if (j < d.ncols) {
+    const T gs = (T)g;                                                       // A' * res
+    grad[j] = FK == APX_F_LOGISTIC ? (T)((double)gs / N) : gs;
+  }
+  if (FK == APX_F_LOGISTIC && j == d.n - 1) grad[j] = (T)(fs[1] / N);        // grad[end] = mean(probs - y)
+  if (blockIdx.x == 0 && tid == 0) f_finalize(d.c, FK, fs);                  // f(x) (and the bias gradient) -> Ctrl
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct SlabShape {
+  int bs, cpt, rows;      // threads per block, columns per thread, rows per step (bs == 0: not eligible)
+};
+static SlabShape slab_shape(const apx_problem* p) {
+  const int64_t cols = p->A_f->n;
+  if (cols <= 2 * 1024) return {1024, 2, kSlabRows};
+  if (cols <= 5 * 1024) return {1024, 5, kSlabRows};
+  // ten fp32 columns per thread: two rows per step is what 128 VGPRs hold — half the bytes in flight per step, and
+  // only ~5 % ahead of the two passes at C3 (512 threads x 20 columns x 4 rows spilled and measured slower)
+  if (cols <= 10 * 1024 && p->dtype == APX_F32) return {1024, 10, kSlabRows / 2};
+  return {0, 0, 0};
+}
+
+bool slab_eligible(const apx_problem* p) {
+  if (!p->ctx->fused_small) return false;
+  if (p->A_lin != nullptr || p->allreduce != nullptr) return false;
+  if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
+  if (p->A_f == nullptr || p->A_f->sparse || p->A_f->dT == nullptr || p->ctx->skip_zero_cols) return false;
+  // bandwidth-bound sizes only: below, the small-size paths or the launch-bound generic kernels are the tools
+  if ((double)p->A_f->m * (double)p->A_f->n * (double)p->es() < 64.0 * 1024 * 1024) return false;
+  return p->A_f->m >= 4096 && p->A_f->m < ((int64_t)1 << 30) && slab_shape(p).bs != 0;
+}
+
+int32_t slab_setup(apx_solver* s) {
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  const apx_matrix* A = p->A_f;
+  std::unique_ptr<SlabState> st(new SlabState());
+  const SlabShape sh = slab_shape(p);
+  st->cpt = sh.cpt;
+  st->bs = sh.bs;
+  // one block per CU, two when the slabs stay long: rows in contiguous slabs, a multiple of the step
+  int64_t B = (int64_t)ctx->num_cu * (A->m >= 8 * kSlabRows * (int64_t)ctx->num_cu * 2 ? 2 : 1);
+  int64_t rpb = (A->m + B - 1) / B;
+  rpb = round_up(rpb, kSlabRows);          // (a multiple of every step size)
+  B = (A->m + rpb - 1) / rpb;
+  st->B = (int)B;
+  SlabDev d{};
+  d.AT = A->dT;
+  d.ldT = A->ldT;
+  d.m = (int32_t)A->m;
+  d.ncols = (int32_t)A->n;
+  d.n = (int32_t)p->n;
+  d.rows_per_block = (int32_t)rpb;
+  d.b = p->b.p;
+  d.ldpart = round_up(d.ncols + 2, 8);
+  APX_TRY(st->part.alloc_zero((size_t)B * d.ldpart * sizeof(double), ctx->stream));
+  d.part = (double*)st->part.p;
+  d.c = p->ctrl();
+  st->dev = d;
+  s->slab = st.release();
+  return APX_OK;
+}
+
+template <typename T, int FK>
+static void slab_launch_t(const SlabState* st, const void* x, void* grad, hipStream_t q) {
+  const SlabDev& d = st->dev;
+  const dim3 grid((unsigned)st->B);
+  if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
+  else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
+  else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_slab_rows<T, FK, 10, kSlabRows / 2, 1024>), grid, dim3(1024), 0, q, d, x);
+  hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kBlock - 1) / kBlock)), dim3(kBlock), 0, q, d, st->B,
+                     (T*)grad);
+}
+
+// f(x) -> Ctrl, grad f(x) -> p->grad for the device vector x: what eval_f + pullback_f leave behind
+int32_t slab_eval_pullback(apx_solver* s, const void* x) {
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  const SlabState* st = s->slab;
+  const bool ls = p->f_kind == APX_F_LEAST_SQUARES;
+  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)p->A_f->m * (double)p->A_f->n * (double)p->es()));
+  if (p->dtype == APX_F32) {
+    if (ls) slab_launch_t<float, APX_F_LEAST_SQUARES>(st, x, p->grad.p, ctx->stream);
+    else slab_launch_t<float, APX_F_LOGISTIC>(st, x, p->grad.p, ctx->stream);
+  } else {
+    if (ls) slab_launch_t<double, APX_F_LEAST_SQUARES>(st, x, p->grad.p, ctx->stream);
+    else slab_launch_t<double, APX_F_LOGISTIC>(st, x, p->grad.p, ctx->stream);
+  }
+  APX_TRY(prof_end(ctx));
+  APX_HIP(hipGetLastError());
+  p->have_eval = true;
+  p->fsc_reduced = true;
+  return APX_OK;
+}
+
+}  // namespace apx

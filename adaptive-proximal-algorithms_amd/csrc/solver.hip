@@ -470,8 +470,14 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
       APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, nullptr));
       APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, nullptr));
     }
-    APX_TRY(eval_f(p, s->x.p, false));                                           // :328
-    APX_TRY(pullback_f(p));
+    // rows short enough for a workgroup's registers: f and grad f in ONE pass over A (csrc/slab.hip)
+    if (slab_eligible(p)) APX_TRY(slab_setup(s.get()));
+    if (s->slab != nullptr) {
+      APX_TRY(slab_eval_pullback(s.get(), s->x.p));                              // :328
+    } else {
+      APX_TRY(eval_f(p, s->x.p, false));                                         // :328
+      APX_TRY(pullback_f(p));
+    }
     if (lin) {                                                                   // :329
       APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, nullptr));
       if (p->lin_sharded) APX_TRY(do_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));
@@ -499,8 +505,12 @@ static int32_t enqueue_iteration(apx_solver* s) {
     APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, p->done_ptr()));
     APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, p->done_ptr()));
   }
-  APX_TRY(eval_f(p, s->x.p, false));                                           // :336
-  APX_TRY(pullback_f(p));
+  if (s->slab != nullptr) {
+    APX_TRY(slab_eval_pullback(s, s->x.p));                                    // :336, one pass over A
+  } else {
+    APX_TRY(eval_f(p, s->x.p, false));                                         // :336
+    APX_TRY(pullback_f(p));
+  }
   APX_TRY(vo_reduce_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p,
                          lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
                          s->rec_cap));                                         // :338-342

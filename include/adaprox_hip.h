@@ -212,7 +212,7 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *     which each workgroup redundantly does the O(m + n) work (csrc/small.hip: proximal gradient with
  *     LinearLeastSquares / LogisticLoss ; csrc/small_pd.hip: primal-dual with f = Zero or Quadratic);
  *   - tall, skinny A (n <= 124, f = Zero): a thread per row and a one-block closing kernel (csrc/skinny_pd.hip);
- *   - tall, skinny A in the proximal-gradient loop (n <= 124, 2048 <= m <= 262144, LinearLeastSquares / LogisticLoss):
+ *   - tall, skinny A in the proximal-gradient loop (n <= 124, m >= 2048, LinearLeastSquares / LogisticLoss):
  *     a row kernel whose waves split the columns and a one-block closing kernel (csrc/skinny_pg.hip);
  *   - the linesearch methods as state machines in device memory, no read-back per trial: backtracking_proxgrad,
  *     backtracking_nesterov (csrc/small_bt.hip), adaptive_linesearch_primal_dual, malitsky_pock on tall-skinny A

@@ -221,7 +221,7 @@ def test_small_path_soak_long_run():
     assert np.max(np.abs(xa - xb)) < 1e-5 * max(1.0, np.max(np.abs(xb)))
 
 
-tall_rows = st.one_of(st.integers(2048, 9000), st.sampled_from([2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 30000, 70000]))
+tall_rows = st.one_of(st.integers(2048, 9000), st.sampled_from([2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 30000, 70000, 300007]))
 skinny_cols = st.one_of(st.integers(1, 40), st.sampled_from([3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 111, 122, 123]))
 
 

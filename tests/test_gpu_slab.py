@@ -1,0 +1,101 @@
+"""f and grad f in one pass over A (csrc/slab.hip: rows held in the registers of a workgroup, used by the generic loop
+when the matrix has its transposed copy) against the oracle and against the two GEMV passes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import adaprox_oracle as O
+
+
+@pytest.fixture(scope="module")
+def apx():
+    import adaprox_amd as apx
+    apx.load()
+    return apx
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)))) / \
+        max(float(np.max(np.abs(b))), 1e-300)
+
+
+# (64 MB of A is where the path starts: m * n * sizeof(T) >= 2^26)
+@pytest.mark.parametrize("m,n,logistic,dtype", [(8500, 1000, False, np.float64),      # 2 columns per thread
+                                                (4097, 2049, True, np.float64),       # 5 columns per thread, ragged rows
+                                                (4200, 5120, False, np.float64),      # the widest fp64 shape
+                                                (9000, 1900, True, np.float32),
+                                                (4099, 10239, True, np.float32),      # 10 columns per thread (fp32 only)
+                                                (4100, 10240, False, np.float32)])
+def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
+    rng = np.random.default_rng(m + n)
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
+    nx = n + 1 if logistic else n
+    if logistic:
+        w = rng.standard_normal(n) * (rng.uniform(size=n) < 0.05)
+        b = (1 / (1 + np.exp(-(A.astype(np.float64) @ w))) > rng.uniform(size=m)).astype(dtype)
+        gam, lam = 4.0 * m / (np.linalg.norm(A.astype(np.float64)) ** 2 + m), 0.01
+        mko = lambda: O.LogisticLoss(A.astype(np.float64), b.astype(np.float64))      # noqa: E731
+    else:
+        b = rng.standard_normal(m).astype(dtype)
+        gam, lam = 1.0 / (m * n / 3.0), 1.0
+        mko = lambda: O.LinearLeastSquares(A.astype(np.float64), b.astype(np.float64))      # noqa: E731
+    K = 12
+    x0 = (0.01 * rng.standard_normal(nx)).astype(dtype)
+    ro = []
+    xo, _ = O.adaptive_proxgrad(x0.astype(np.float64), f=mko(), g=O.NormL1(lam), rule=O.OurRule(gamma=gam), tol=0.0, maxit=K,
+                                record=ro.append)
+    out = []
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        f = apx.Counting(apx.LogisticLoss(dA, b, ctx=ctx) if logistic else apx.LinearLeastSquares(dA, b, ctx=ctx))
+        recs = []
+        x, it = apx.adaptive_proxgrad(x0, f=f, g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, ctx=ctx,
+                                      record=recs.append)
+        assert it == K and (f.eval_count, f.grad_count) == (K + 1, K + 1)
+        out.append((x, recs))
+        dA.free()
+    (x1, r1), (x2, r2) = out
+    tol = 1e-10 if dtype == np.float64 else 2e-3
+    assert _rel(x1, xo) <= tol and _rel(x1, x2) <= tol
+    for a, b_, c in zip(r1, ro, r2):
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10 if dtype == np.float64 else 1e-4)
+        assert a["gamma"] == pytest.approx(c["gamma"], rel=1e-7 if dtype == np.float64 else 5e-2)
+
+
+def test_one_pass_every_rule_termination_and_stepping(apx):
+    rng = np.random.default_rng(3)
+    m, n = 9000, 1200
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    b = rng.standard_normal(m)
+    gam = 1.0 / (m * n / 3.0)
+    ctx = apx.Context(0)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+    f, g = apx.LinearLeastSquares(dA, b, ctx=ctx), apx.NormL1(1.0)
+    fo, go = O.LinearLeastSquares(A, b), O.NormL1(1.0)
+    for mk in (lambda M: M.FixedStepsize(gam, 1.0), lambda M: M.MalitskyMishchenkoRule(gamma=gam), lambda M: M.OurRulePlus(gamma=gam)):
+        xo, _ = O.adaptive_proxgrad(np.zeros(n), f=fo, g=go, rule=mk(O), tol=0.0, maxit=15)
+        x, _ = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=mk(apx), tol=0.0, maxit=15, ctx=ctx)
+        assert _rel(x, xo) <= 1e-10
+    rule = apx.OurRule(gamma=gam)
+    x1, _ = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, maxit=30, ctx=ctx)
+    x2, _ = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, maxit=30, ctx=ctx, use_graph=True)
+    assert np.array_equal(x1, x2)
+    s = apx.Solver(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, ctx=ctx)
+    for k in (1, 9, 20):
+        s.step(k)
+        s.result()
+    xs, _, res = s.result()
+    s.close()
+    assert res.numit == 30 and np.array_equal(xs, x1)
+    recs = []
+    apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, maxit=30, ctx=ctx, record=recs.append)
+    tol = recs[19]["norm_res"] * (1 + 1e-9)
+    kstar = 1 + next(k for k, r in enumerate(recs) if r["norm_res"] <= tol)
+    xo, ito = O.adaptive_proxgrad(np.zeros(n), f=fo, g=go, rule=O.OurRule(gamma=gam), tol=tol, maxit=1000)
+    for poll in (1, 64):
+        x, it = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=tol, maxit=1000, ctx=ctx, poll_every=poll)
+        assert it == kstar == ito and _rel(x, xo) <= 1e-10
+    dA.free()

@@ -469,7 +469,7 @@ def test_backtracking_small_termination_maxit_fp32(apx):
 @pytest.mark.parametrize("m,n,logistic,dtype", [(8124, 112, True, np.float64), (11055, 68, True, np.float64),
                                                 (2048, 119, True, np.float64), (6000, 40, False, np.float64),
                                                 (100000, 7, False, np.float64), (2049, 2, False, np.float64),
-                                                (262144, 4, False, np.float64), (3000, 1, False, np.float64),
+                                                (262144, 4, False, np.float64), (3000, 1, False, np.float64), (700001, 20, False, np.float64),
                                                 (2048, 123, True, np.float64),
                                                 (8124, 112, True, np.float32)])
 def test_skinny_pg_shapes(apx, generic_ctx, m, n, logistic, dtype):

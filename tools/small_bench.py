@@ -77,7 +77,7 @@ def main():
             f = apx.LogisticLoss(apx.DeviceMatrix.from_numpy(X_h, ctx), y_h, ctx=ctx)
             for graph in (False, True):
                 run(f"logreg {lm}x{ln} fp32 {name}", ctx, f, apx.NormL1(0.01), ln + 1, gam0, graph, dtype=np.float32)
-    for m, n in ((8124, 112), (100000, 20)):
+    for m, n in ((8124, 112), (100000, 20), (1000000, 32)):
         A_h, b_h, gam = lasso(m, n)
         for name, ctx in (("skinny_pg.hip", fused), ("generic", generic)):
             f = apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A_h, ctx), b_h, ctx=ctx)
