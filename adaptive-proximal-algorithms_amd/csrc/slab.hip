@@ -59,10 +59,12 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
   const T* __restrict__ bv = (const T*)d.b;
   T xr[C];                                       // (kept in T: the registers are what limits the row length)
   double acc[C];
-#pragma unroll
+  unsigned off[C];                               // 32-bit column offsets: with a uniform row pointer every load of the
+#pragma unroll                                   // step is "scalar base + vector offset", no 64-bit address per load
   for (int k = 0; k < C; ++k) {
     const int j = tid + k * BS;
-    xr[k] = j < d.ncols ? X[j] : (T)0;           // columns beyond the last: weight 0 (their loads are clamped)
+    off[k] = (unsigned)min(j, d.ncols - 1);      // clamped: a valid address, weight 0
+    xr[k] = j < d.ncols ? X[j] : (T)0;
     acc[k] = 0.0;
   }
   double bias = 0.0;
@@ -74,9 +76,10 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
     T a[R][C];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const T* __restrict__ row = AT + (int64_t)min(r0 + r, d.m - 1) * d.ldT;
+      const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, d.m - 1));       // (uniform: keep it scalar)
+      const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
-      for (int k = 0; k < C; ++k) a[r][k] = row[min(tid + k * BS, d.ncols - 1)];
+      for (int k = 0; k < C; ++k) a[r][k] = row[off[k]];
     }
     double p[R];
 #pragma unroll
@@ -102,9 +105,16 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
           e0 += res * res;
         } else {
           const double logit = ax + bias;
-          const double e = 1.0 + exp(-logit);
-          e0 += (bi - 1.0) * logit - log(e);
-          res = (double)(T)(1.0 / e - bi);
+          if constexpr (sizeof(T) == 4) {        // Float32 data: the link in Float32, as Julia would on Float32 arrays
+            const float lf = (float)logit;       // (and the fp64 exp / log need ~50 more registers than this kernel has)
+            const float ef = 1.0f + expf(-lf);
+            e0 += (double)(((float)bi - 1.0f) * lf - logf(ef));
+            res = (double)(1.0f / ef - (float)bi);
+          } else {
+            const double e = 1.0 + exp(-logit);
+            e0 += (bi - 1.0) * logit - log(e);
+            res = (double)(T)(1.0 / e - bi);
+          }
           e1 += res;
         }
       }
@@ -115,7 +125,11 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
     for (int r = 0; r < R; ++r) {
       const double rr = res_s[r];
 #pragma unroll
-      for (int k = 0; k < C; ++k) acc[k] = fma((double)a[r][k], rr, acc[k]);
+      for (int k = 0; k < C; ++k) {
+        T av = a[r][k];
+        if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(av));    // convert again here: keeping the doubles of the dot
+        acc[k] = fma((double)av, rr, acc[k]);                         // phase alive would double the registers of A
+      }
     }
   }
   double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
@@ -132,11 +146,19 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
   }
 }
 
+// 64 columns per block (a wave reads 512 contiguous bytes of a partial row), the B partials of a column dealt to 4
+// threads (b = s, s + 4, ...: sixteen loads in flight each), then the 4 sub-sums added in order.
+constexpr int kSlabCloseCols = 64;
 template <typename T, int FK>
 __global__ __launch_bounds__(kBlock) void k_slab_close(SlabDev d, int B, T* __restrict__ grad) {
+  constexpr int S = kBlock / kSlabCloseCols;
   __shared__ double fs[2];
+  __shared__ double sub[S][kSlabCloseCols];
   if (d.c->done != 0) return;
   const int tid = threadIdx.x;
+  const int c = tid % kSlabCloseCols, sl = tid / kSlabCloseCols;
+  const int j = blockIdx.x * kSlabCloseCols + c;
+  const double part_sum = j < d.ncols ? skinny_strided_sum(d.part, d.ldpart, j, sl, S, B) : 0.0;
   // the loss sums over the B blocks, by every block in the same fixed order (waves 0 and 1: one column each)
   if (tid < 128) {
     const int which = tid >> 6, lane = tid & 63;
@@ -145,16 +167,17 @@ __global__ __launch_bounds__(kBlock) void k_slab_close(SlabDev d, int B, T* __re
     s = wave_sum(s);
     if (lane == 0) fs[which] = s;
   }
-  const int j = blockIdx.x * kBlock + tid;
-  double g = 0.0;
-  if (j < d.ncols) g = skinny_strided_sum(d.part, d.ldpart, j, 0, 1, B);     // sixteen loads in flight, fixed order
+  sub[sl][c] = part_sum;
   __syncthreads();
   const double N = d.c->n_mean;
-  if (j < d.ncols) {
+  if (sl == 0 && j < d.ncols) {
+    double g = sub[0][c];
+#pragma unroll
+    for (int k = 1; k < S; ++k) g += sub[k][c];
     const T gs = (T)g;                                                       // A' * res
     grad[j] = FK == APX_F_LOGISTIC ? (T)((double)gs / N) : gs;
   }
-  if (FK == APX_F_LOGISTIC && j == d.n - 1) grad[j] = (T)(fs[1] / N);        // grad[end] = mean(probs - y)
+  if (FK == APX_F_LOGISTIC && blockIdx.x == 0 && tid == 0) grad[d.n - 1] = (T)(fs[1] / N);      // grad[end] = mean(probs - y)
   if (blockIdx.x == 0 && tid == 0) f_finalize(d.c, FK, fs);                  // f(x) (and the bias gradient) -> Ctrl
 }
 
@@ -170,7 +193,7 @@ static SlabShape slab_shape(const apx_problem* p) {
   if (cols <= 5 * 1024) return {1024, 5, kSlabRows};
   // ten fp32 columns per thread: two rows per step is what 128 VGPRs hold — half the bytes in flight per step, and
   // only ~5 % ahead of the two passes at C3 (512 threads x 20 columns x 4 rows spilled and measured slower)
-  if (cols <= 10 * 1024 && p->dtype == APX_F32) return {1024, 10, kSlabRows / 2};
+  if (cols <= 14 * 768 && p->dtype == APX_F32) return {768, 14, kSlabRows};
   return {0, 0, 0};
 }
 
@@ -192,8 +215,9 @@ int32_t slab_setup(apx_solver* s) {
   const SlabShape sh = slab_shape(p);
   st->cpt = sh.cpt;
   st->bs = sh.bs;
-  // one block per CU, two when the slabs stay long: rows in contiguous slabs, a multiple of the step
-  int64_t B = (int64_t)ctx->num_cu * (A->m >= 8 * kSlabRows * (int64_t)ctx->num_cu * 2 ? 2 : 1);
+  // as many blocks as fit the chip at once — one per CU, two of the two-columns-per-thread kind (~58 VGPRs): rows in
+  // contiguous slabs, a multiple of the step ; fewer blocks = fewer partial vectors for the closing kernel
+  int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
   int64_t rpb = (A->m + B - 1) / B;
   rpb = round_up(rpb, kSlabRows);          // (a multiple of every step size)
   B = (A->m + rpb - 1) / rpb;
@@ -221,9 +245,9 @@ static void slab_launch_t(const SlabState* st, const void* x, void* grad, hipStr
   const dim3 grid((unsigned)st->B);
   if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
   else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
-  else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_slab_rows<T, FK, 10, kSlabRows / 2, 1024>), grid, dim3(1024), 0, q, d, x);
-  hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kBlock - 1) / kBlock)), dim3(kBlock), 0, q, d, st->B,
-                     (T*)grad);
+  else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_slab_rows<T, FK, 14, kSlabRows, 768>), grid, dim3(768), 0, q, d, x);
+  hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kBlock), 0, q, d,
+                     st->B, (T*)grad);
 }
 
 // f(x) -> Ctrl, grad f(x) -> p->grad for the device vector x: what eval_f + pullback_f leave behind

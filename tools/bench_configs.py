@@ -23,8 +23,13 @@ def timed(solver, steps, warm, bytes_per_iter):
     k = {n: dict(avg_ms=v["total_ms"] / v["launches"], GBps=v["bytes"] / v["total_ms"] / 1e6) for n, v in st.items() if v["launches"]}
     x, y, res = solver.result()
     assert np.all(np.isfinite(x))
-    return dict(iters_per_s=steps / dt, ms_per_iter=dt / steps * 1e3, frac_of_8TBs=bytes_per_iter * steps / dt / 8e12, kernels=k,
-                objective=res.objective, norm_res=res.norm_res)
+    r = dict(iters_per_s=steps / dt, ms_per_iter=dt / steps * 1e3, frac_of_8TBs=bytes_per_iter * steps / dt / 8e12, kernels=k,
+             objective=res.objective, norm_res=res.norm_res)
+    if "gemv_t" not in k and "gemv_n" in k:      # csrc/slab.hip: f and grad f in ONE pass over A (booked under gemv_n)
+        r["note"] = ("one pass over A per iteration: frac_of_8TBs is of the TWO-pass algorithmic bytes (SURVEY 8d) and can "
+                     "exceed 1; the bytes actually read per iteration are half, at kernels.gemv_n.GBps")
+        r["frac_of_8TBs_bytes_read"] = k["gemv_n"]["GBps"] / 8e3
+    return r
 
 which = sys.argv[1:] or ["c3", "c5", "c2bt", "c1"]
 if "c3" in which:
