@@ -17,7 +17,8 @@
 //                f -> Ctrl, grad (logistic: / N, the bias entry)
 //
 // Used by the generic loop (solver.hip) in place of gemv_n + k_finish_rows + k_f_reduce + gemv_t (+ k_logistic_grad)
-// when the matrix has its transposed copy (apx_matrix_build_transpose) and there is no all-reduce hook.
+// when there is no all-reduce hook; it reads the transposed copy of A (apx_matrix_build_transpose), which a matrix of up to
+// 16 GB is given on the spot.
 #include <cstdlib>
 #include <memory>
 
@@ -197,14 +198,25 @@ static SlabShape slab_shape(const apx_problem* p) {
   return {0, 0, 0};
 }
 
-bool slab_eligible(const apx_problem* p) {
+static bool slab_shape_ok(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin != nullptr || p->allreduce != nullptr) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
-  if (p->A_f == nullptr || p->A_f->sparse || p->A_f->dT == nullptr || p->ctx->skip_zero_cols) return false;
+  if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
   // bandwidth-bound sizes only: below, the small-size paths or the launch-bound generic kernels are the tools
   if ((double)p->A_f->m * (double)p->A_f->n * (double)p->es() < 64.0 * 1024 * 1024) return false;
   return p->A_f->m >= 4096 && p->A_f->m < ((int64_t)1 << 30) && slab_shape(p).bs != 0;
+}
+
+// The kernel reads only the transposed copy.  A matrix of up to 16 GB that has none gets one here (the same second
+// copy as apx_matrix_build_transpose; twice the memory, one transpose): every iteration then moves half the bytes.
+// Failing to allocate it is not an error — the two passes remain.
+bool slab_eligible(const apx_problem* p) {
+  if (!slab_shape_ok(p)) return false;
+  if (p->A_f->dT == nullptr && (double)p->A_f->ld * (double)p->A_f->n_pad * (double)p->es() <= 16.0 * 1024 * 1024 * 1024) {
+    if (apx_matrix_build_transpose(const_cast<apx_matrix*>(p->A_f)) != APX_OK) (void)hipGetLastError();
+  }
+  return p->A_f->dT != nullptr;
 }
 
 int32_t slab_setup(apx_solver* s) {
@@ -240,8 +252,7 @@ int32_t slab_setup(apx_solver* s) {
 }
 
 template <typename T, int FK>
-static void slab_launch_t(const SlabState* st, const void* x, void* grad, hipStream_t q) {
-  const SlabDev& d = st->dev;
+static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
   else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
@@ -255,14 +266,21 @@ int32_t slab_eval_pullback(apx_solver* s, const void* x) {
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   const SlabState* st = s->slab;
+  if (p->A_f->dT == nullptr) {                   // the transposed copy was dropped (A edited in place): the two passes
+    APX_TRY(eval_f(p, x, false));
+    return pullback_f(p);
+  }
+  SlabDev d = st->dev;
+  d.AT = p->A_f->dT;                             // (rebuilt copies may live elsewhere)
+  d.ldT = p->A_f->ldT;
   const bool ls = p->f_kind == APX_F_LEAST_SQUARES;
   APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)p->A_f->m * (double)p->A_f->n * (double)p->es()));
   if (p->dtype == APX_F32) {
-    if (ls) slab_launch_t<float, APX_F_LEAST_SQUARES>(st, x, p->grad.p, ctx->stream);
-    else slab_launch_t<float, APX_F_LOGISTIC>(st, x, p->grad.p, ctx->stream);
+    if (ls) slab_launch_t<float, APX_F_LEAST_SQUARES>(st, d, x, p->grad.p, ctx->stream);
+    else slab_launch_t<float, APX_F_LOGISTIC>(st, d, x, p->grad.p, ctx->stream);
   } else {
-    if (ls) slab_launch_t<double, APX_F_LEAST_SQUARES>(st, x, p->grad.p, ctx->stream);
-    else slab_launch_t<double, APX_F_LOGISTIC>(st, x, p->grad.p, ctx->stream);
+    if (ls) slab_launch_t<double, APX_F_LEAST_SQUARES>(st, d, x, p->grad.p, ctx->stream);
+    else slab_launch_t<double, APX_F_LOGISTIC>(st, d, x, p->grad.p, ctx->stream);
   }
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());

@@ -65,6 +65,31 @@ def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
         assert a["gamma"] == pytest.approx(c["gamma"], rel=1e-7 if dtype == np.float64 else 5e-2)
 
 
+def test_one_pass_builds_its_transposed_copy_and_survives_losing_it(apx):
+    """A matrix without the transposed copy is given one when a solver is created on it; editing the matrix in place
+    drops the copy, and a solver that is alive then falls back to the two passes."""
+    rng = np.random.default_rng(5)
+    m, n = 9000, 1000
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    b = rng.standard_normal(m)
+    gam = 1.0 / (m * n / 3.0)
+    xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(A, b), g=O.NormL1(1.0), rule=O.OurRule(gamma=gam), tol=0.0,
+                                maxit=12)
+    ctx = apx.Context(0)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)                       # no build_transpose()
+    f = apx.LinearLeastSquares(dA, b, ctx=ctx)
+    x, _ = apx.adaptive_proxgrad(np.zeros(n), f=f, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=12, ctx=ctx)
+    assert _rel(x, xo) <= 1e-10
+    s = apx.Solver(np.zeros(n), f=f, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=gam), tol=0.0, ctx=ctx)
+    s.step(5)
+    dA.scale_columns(np.ones(n))                                   # an in-place edit (by 1.0): the copy is gone
+    s.step(7)
+    xs, _, res = s.result()
+    s.close()
+    assert res.numit == 12 and _rel(xs, xo) <= 1e-10
+    dA.free()
+
+
 def test_one_pass_every_rule_termination_and_stepping(apx):
     rng = np.random.default_rng(3)
     m, n = 9000, 1200

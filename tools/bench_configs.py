@@ -1,6 +1,8 @@
 """Times the non-headline BASELINE configs at full size on one MI355X (C3 logreg fp32,
 C5 LAD via Condat-Vu, C2 backtracking, C1 small lasso).  Same protocol as bench.py: data
-resident, warm-up, K timed iterations, HIP-event kernel times from the library."""
+resident, warm-up, K timed iterations, HIP-event kernel times from the library.
+(C3 runs f and grad f in one pass over A, csrc/slab.hip, booked under gemv_n; APX_SINGLE_LAYOUT=1 no longer gives a
+single-layout C3: the one-pass kernel builds the transposed copy it reads.)"""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
