@@ -1,0 +1,247 @@
+// wide_probe.hip — feasibility probe for ONE pass over A per iteration at the headline's row length (C2: 50 000 x
+// 100 000 fp64, rows of 800 KB): csrc/slab.hip keeps whole rows in one workgroup's registers, which stops at ~5000 fp64
+// columns.  Here the COLUMNS are split over the CUs: block p keeps its ~392-column slice of a batch of R rows in
+// registers, publishes R partial dot products, waits until all blocks have published theirs (release fence + counter ;
+// bounded spin ; acquire fence), sums the P partials per row in a fixed order, forms the residuals and accumulates
+// res[i] * A[i, slice] from the same registers.  Every block owns its columns over ALL rows, so the gradient needs no
+// partial vectors.  Not wired into the library: this measures what the device-wide hand-off per batch costs.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o wide_probe tools/wide_probe.hip && ./wide_probe [m] [n] [iters]
+// prints ms per pass, the implied GB/s of A, and the max |grad - reference| of a two-pass check on a few columns.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                         \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));          \
+      exit(1);                                                                           \
+    }                                                                                    \
+  } while (0)
+
+constexpr int kThreads = 512;
+constexpr int kR = 32;                 // rows per batch
+constexpr int kSlots = 4;              // batches whose partials may be alive at once
+constexpr long long kSpinLimit = 4000000;
+
+__device__ __forceinline__ double elem(long long i, long long j) {     // A[i, j], a cheap hash in (-1, 1)
+  unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + (unsigned long long)j * 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 31;
+  z *= 0x94D049BB133111EBull;
+  z ^= z >> 29;
+  return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+__global__ void fill_at(double* AT, long long ldT, long long m, long long n) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = blockIdx.y;
+  if (j < n && i < m) AT[i * ldT + j] = elem(i, j);
+}
+
+struct Args {
+  const double* AT;
+  long long ldT;
+  int m, n, width;          // columns per block
+  const double* x;
+  const double* b;
+  double* part;             // [kSlots][kR][P]
+  int* cnt;                 // [batches]
+  double* grad;
+  double* fsum;             // [P]: sum res^2 of block 0's view (every block forms the same residuals)
+  int* err;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(kThreads) void wide_rows(Args a) {
+  __shared__ double wpart[kThreads / 64][kR];
+  __shared__ double seg_s[16][kR];
+  __shared__ double res_s[kR];
+  __shared__ int bad;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int P = gridDim.x;
+  const int c0 = blockIdx.x * a.width;
+  const int col = c0 + tid;
+  const bool mine = tid < a.width && col < a.n;
+  const int cc = mine ? col : c0;                         // clamped: a valid address, weight 0
+  const double xt = mine ? a.x[col] : 0.0;
+  double acc = 0.0, f2 = 0.0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  const int batches = (a.m + kR - 1) / kR;
+  for (int bt = 0; bt < batches; ++bt) {
+    const int row0 = bt * kR;
+    double av[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const int i = min(row0 + r, a.m - 1);
+      av[r] = a.AT[(long long)i * a.ldT + cc];
+    }
+    // ---- partial dot products of this block's slice ---------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const double s = wave_sum(mine ? av[r] * xt : 0.0);
+      if (lane == 0) wpart[wv][r] = s;
+    }
+    __syncthreads();
+    double* slot = a.part + (long long)(bt % kSlots) * kR * P;
+    if (tid < kR) {
+      double s = wpart[0][tid];
+#pragma unroll
+      for (int w = 1; w < kThreads / 64; ++w) s += wpart[w][tid];
+      __hip_atomic_store(&slot[(long long)tid * P + blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // ---- hand-off: publish, wait for everyone (bounded), acquire -------------------------------------------
+    if (tid == 0) {
+      // (the partials above are agent-scope atomic stores, the reads below agent-scope atomic loads: they meet in
+      //  memory, not in a per-XCD L2, so no cache write-back / invalidate is needed around the counter)
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_fetch_add(&a.cnt[bt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long spins = 0;
+      while (__hip_atomic_load(&a.cnt[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kSpinLimit) {
+          bad = 1;
+          atomicExch(a.err, 1);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (bad != 0) return;                                 // (block-uniform: every wave leaves)
+    // ---- the P partials of every row, summed in a fixed order: thread (r, seg) takes P / 16 of them ----------
+    {
+      const int r = tid % kR, seg = tid / kR;             // 32 rows x 16 segments
+      const int per = (P + 15) / 16;
+      double s = 0.0;
+      const double* src = slot + (long long)r * P;
+      for (int k = seg * per; k < min(P, (seg + 1) * per); ++k) s += __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seg_s[seg][r] = s;
+    }
+    __syncthreads();
+    if (tid < kR) {
+      double d = 0.0;
+#pragma unroll
+      for (int sg = 0; sg < 16; ++sg) d += seg_s[sg][tid];
+      const int i = row0 + tid;
+      const double rs = i < a.m ? d - a.b[i] : 0.0;
+      res_s[tid] = rs;
+      f2 += rs * rs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kR; ++r) acc = fma(av[r], res_s[r], acc);
+  }
+  if (mine) a.grad[col] = acc;
+  if (tid < kR) {
+    double t = f2;                                        // rows finished by threads 0..31 (one wave)
+    for (int off = 16; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (tid == 0) a.fsum[blockIdx.x] = t;
+  }
+}
+
+int main(int argc, char** argv) {
+  const long long m = argc > 1 ? atoll(argv[1]) : 50000;
+  const long long n = argc > 2 ? atoll(argv[2]) : 100000;
+  const int iters = argc > 3 ? atoi(argv[3]) : 5;
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int P = prop.multiProcessorCount;                 // one block per CU: all resident
+  const int width = (int)(((n + P - 1) / P + 7) / 8 * 8);
+  if (width > kThreads) {
+    fprintf(stderr, "n too large for %d threads per block\n", kThreads);
+    return 1;
+  }
+  const long long ldT = (n + 31) / 32 * 32;
+  const int batches = (int)((m + kR - 1) / kR);
+  double *AT, *x, *b, *part, *grad, *fsum;
+  int *cnt, *err;
+  CHECK(hipMalloc(&AT, (size_t)ldT * m * sizeof(double)));
+  CHECK(hipMalloc(&x, n * sizeof(double)));
+  CHECK(hipMalloc(&b, m * sizeof(double)));
+  CHECK(hipMalloc(&part, (size_t)kSlots * kR * P * sizeof(double)));
+  CHECK(hipMalloc(&grad, n * sizeof(double)));
+  CHECK(hipMalloc(&fsum, P * sizeof(double)));
+  CHECK(hipMalloc(&cnt, batches * sizeof(int)));
+  CHECK(hipMalloc(&err, sizeof(int)));
+  CHECK(hipMemset(err, 0, sizeof(int)));
+  hipLaunchKernelGGL(fill_at, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, 0, AT, ldT, m, n);
+  std::vector<double> hx(n), hb(m);
+  for (long long j = 0; j < n; ++j) hx[j] = std::sin(0.001 * (double)j) / (double)n;
+  for (long long i = 0; i < m; ++i) hb[i] = std::cos(0.002 * (double)i);
+  CHECK(hipMemcpy(x, hx.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(b, hb.data(), m * sizeof(double), hipMemcpyHostToDevice));
+  CHECK(hipDeviceSynchronize());
+  int blocks_per_cu = 0;
+  CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, wide_rows, kThreads, 0));
+  printf("m %lld n %lld  P %d blocks x %d threads, %d columns each, %d batches of %d rows ; occupancy %d block(s) per CU\n", m, n, P,
+         kThreads, width, batches, kR, blocks_per_cu);
+  if (blocks_per_cu < 1) return 1;
+  Args a{AT, ldT, (int)m, (int)n, width, x, b, part, cnt, grad, fsum, err};
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int it = 0; it < iters; ++it) {
+    CHECK(hipMemsetAsync(cnt, 0, batches * sizeof(int), 0));
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(wide_rows, dim3(P), dim3(kThreads), 0, 0, a);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    int herr = 0;
+    CHECK(hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr) {
+      printf("iteration %d: a block gave up waiting (bounded spin) after %.1f ms\n", it, ms);
+      return 2;
+    }
+    if (ms < best) best = ms;
+    printf("pass %d: %.3f ms\n", it, ms);
+  }
+  const double bytes = (double)m * (double)n * 8.0;
+  printf("best %.3f ms per ONE-pass iteration = %.0f GB/s of A read once (two GEMV passes at 7.1 TB/s: %.3f ms)\n", best,
+         bytes / best / 1e6, 2.0 * bytes / 7.1e12 * 1e3);
+  // check a few gradient entries against a host two-pass evaluation on a row sample is too slow at full size: check
+  // the identity sum_j grad[j] * x[j] == <A x - b, A x> instead, with A x recomputed on the host for 64 sampled rows only
+  std::vector<double> hg(n), hf(P);
+  CHECK(hipMemcpy(hg.data(), grad, n * sizeof(double), hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(hf.data(), fsum, P * sizeof(double), hipMemcpyDeviceToHost));
+  // exact check on small problems
+  if (m * n <= 4000000) {
+    std::vector<double> res(m);
+    auto el = [](long long i, long long j) {
+      unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + (unsigned long long)j * 0xBF58476D1CE4E5B9ull;
+      z ^= z >> 31;
+      z *= 0x94D049BB133111EBull;
+      z ^= z >> 29;
+      return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    };
+    double f2 = 0;
+    for (long long i = 0; i < m; ++i) {
+      double s = 0;
+      for (long long j = 0; j < n; ++j) s += el(i, j) * hx[j];
+      res[i] = s - hb[i];
+      f2 += res[i] * res[i];
+    }
+    double maxerr = 0, maxg = 0;
+    for (long long j = 0; j < n; ++j) {
+      double g = 0;
+      for (long long i = 0; i < m; ++i) g += el(i, j) * res[i];
+      maxerr = std::fmax(maxerr, std::fabs(g - hg[j]));
+      maxg = std::fmax(maxg, std::fabs(g));
+    }
+    printf("check: max |grad - ref| = %.3e (max |grad| %.3e) ; sum res^2 %.12e vs %.12e\n", maxerr, maxg, hf[0], f2);
+  }
+  return 0;
+}
