@@ -100,7 +100,8 @@ __global__ __launch_bounds__(BS) void k_small_b(SmallDev d, int dot_blocks) {
     f_finalize(&lt, FK, q);
     *d.ca = lt;
   }
-  small_dots_w<T, BS>(d.w_t, (const T*)d.A, d.ld, d.ncols, d.m, rs, d.grp, live);       // A' r: columns of A
+  // (only the first dot_blocks blocks of this grid form dot products: the rotation blocks behind them have left)
+  small_dots_w<T, BS>(d.w_t, (const T*)d.A, d.ld, d.ncols, d.m, rs, d.grp, live, dot_blocks);       // A' r: columns of A
 }
 
 // MODE 0: only A x for the staged x (start of the pre-loop, :327-328)

@@ -18,15 +18,19 @@ constexpr int kSmallPer = kSmallMax / kBlock;
 // is finished inside its block — no split partials, no second stage.
 constexpr int kDotUnroll = 16;   // loads in flight per lane: a 1024-element dot product is one round trip
 
+// `nblk`: the blocks [0, nblk) of the launch share the dot products (0: all of them).  A kernel whose grid carries
+// other blocks behind them must say so: striding by gridDim.x would skip outputs as soon as a second pass is needed.
 template <typename T, int W, int BS = kBlock>
 __device__ __forceinline__ void small_dots(const T* __restrict__ M, int64_t ld, int n_out, int len,
-                                           const double* __restrict__ vec, double* __restrict__ out, bool live) {
+                                           const double* __restrict__ vec, double* __restrict__ out, bool live,
+                                           int nblk = 0) {
   constexpr int DPB = (BS / 64) / W;
   __shared__ double wsum[BS / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int part = wv % W;
   constexpr int step = W * 64;
-  for (int d0 = blockIdx.x * DPB; d0 < n_out; d0 += gridDim.x * DPB) {
+  const int nb = nblk > 0 ? nblk : (int)gridDim.x;
+  for (int d0 = blockIdx.x * DPB; d0 < n_out; d0 += nb * DPB) {
     const int dot = d0 + wv / W;
     double acc = 0.0;
     if (dot < n_out) {
@@ -64,13 +68,14 @@ __device__ __forceinline__ void small_dots(const T* __restrict__ M, int64_t ld, 
 
 template <typename T, int BS = kBlock>
 __device__ __forceinline__ void small_dots_w(int W, const T* __restrict__ M, int64_t ld, int n_out, int len,
-                                             const double* __restrict__ vec, double* __restrict__ out, bool live) {
-  if (W == 1) small_dots<T, 1, BS>(M, ld, n_out, len, vec, out, live);
-  else if (W == 2) small_dots<T, 2, BS>(M, ld, n_out, len, vec, out, live);
-  else if (W == 4 || BS / 64 <= 4) small_dots<T, 4, BS>(M, ld, n_out, len, vec, out, live);
+                                             const double* __restrict__ vec, double* __restrict__ out, bool live,
+                                             int nblk = 0) {
+  if (W == 1) small_dots<T, 1, BS>(M, ld, n_out, len, vec, out, live, nblk);
+  else if (W == 2) small_dots<T, 2, BS>(M, ld, n_out, len, vec, out, live, nblk);
+  else if (W == 4 || BS / 64 <= 4) small_dots<T, 4, BS>(M, ld, n_out, len, vec, out, live, nblk);
   else if constexpr (BS / 64 >= 16) {         // 1024-thread blocks (tall matrices): up to 16 waves per dot
-    if (W == 8) small_dots<T, 8, BS>(M, ld, n_out, len, vec, out, live);
-    else small_dots<T, 16, BS>(M, ld, n_out, len, vec, out, live);
+    if (W == 8) small_dots<T, 8, BS>(M, ld, n_out, len, vec, out, live, nblk);
+    else small_dots<T, 16, BS>(M, ld, n_out, len, vec, out, live, nblk);
   }
 }
 

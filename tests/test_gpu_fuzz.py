@@ -362,3 +362,48 @@ def test_malitsky_pock_quadratic_vs_host_driven_fuzz(N, rows, t, f32, k, seed):
     assert its == itg == k
     assert np.max(np.abs(xs - xg)) <= tol * max(1.0, np.max(np.abs(xg)))
     assert np.max(np.abs(ys - yg)) <= tol * max(1.0, np.max(np.abs(yg)))
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(n=st.sampled_from([125, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5119, 5120, 5121, 7679, 10751, 10752]),
+       extra_rows=st.integers(0, 9), logistic=st.booleans(), f32=st.booleans(), rule=st.sampled_from(["ours", "fixed", "mm"]),
+       k=st.integers(0, 6), seed=st.integers(0, 2**31 - 1))
+def test_one_pass_vs_two_passes_fuzz(n, extra_rows, logistic, f32, rule, k, seed):
+    """csrc/slab.hip (f and grad f in one pass over A) against the two GEMV passes: column counts around the 2 / 5 / 14
+    columns-per-thread shapes, row counts that are not multiples of the step or of the slab."""
+    apx, _ = _apx()
+    dtype = np.float32 if f32 else np.float64
+    es = 4 if f32 else 8
+    m = max(4096, -(-(64 * 1024 * 1024) // (n * es))) + extra_rows            # just past the 64 MB where the path starts
+    if m * n * es > 400 * 1024 * 1024:
+        return
+    rng = np.random.default_rng(seed)
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
+    nx = n + 1 if logistic else n
+    if logistic:
+        w = rng.standard_normal(n) * (rng.uniform(size=n) < 0.05)
+        b = (1 / (1 + np.exp(-(A.astype(np.float64) @ w))) > rng.uniform(size=m)).astype(dtype)
+        gam = 4.0 * m / (float(np.sum(A.astype(np.float64) ** 2)) + m)
+    else:
+        b = rng.standard_normal(m).astype(dtype)
+        gam = 1.0 / (m * n / 3.0)
+    mk = {"ours": lambda: apx.OurRule(gamma=gam), "fixed": lambda: apx.FixedStepsize(gam),
+          "mm": lambda: apx.MalitskyMishchenkoRule(gam)}[rule]
+    x0 = (0.01 * rng.standard_normal(nx)).astype(dtype)
+    out = []
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        f = apx.LogisticLoss(dA, b, ctx=ctx) if logistic else apx.LinearLeastSquares(dA, b, ctx=ctx)
+        recs = []
+        x, it = apx.adaptive_proxgrad(x0, f=f, g=apx.NormL1(0.01 if logistic else 1.0), rule=mk(), tol=0.0, maxit=k, ctx=ctx,
+                                      record=recs.append)
+        out.append((x, it, recs))
+        dA.free()
+    (x1, it1, r1), (x2, it2, r2) = out
+    tol = 2e-3 if f32 else 1e-9
+    assert it1 == it2 == k
+    assert np.max(np.abs(x1 - x2)) <= tol * max(1.0, np.max(np.abs(x2)))
+    for a, b_ in zip(r1, r2):
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-4 if f32 else 1e-10)

@@ -539,3 +539,42 @@ def test_skinny_pg_rules_graph_stepping_termination(apx):
         ff = apx.Counting(f)
         xf, itf = apx.adaptive_proxgrad(np.zeros(61), f=ff, g=g, rule=rule, tol=tol, maxit=1000, poll_every=poll)
         assert itf == kstar == ito and _rel(xf, xo) <= RTOL and (ff.eval_count, ff.grad_count) == (itf + 1, itf + 1)
+
+
+# ---------------------------------------------------------------------------------------
+# both dimensions large at once: the in-block dot products need several passes per block (more than 1024 outputs
+# with four waves per dot).  small.hip skipped outputs there while its grid carried the rotation blocks behind the
+# dot blocks — found by the one-pass fuzz test, which compares shapes of exactly 64 MB
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(3000, 3000), (2049, 2048), (4096, 4096), (4096, 1100), (2500, 4000)])
+def test_small_paths_with_several_passes_per_block(apx, generic_ctx, m, n):
+    rng = np.random.default_rng(m + n)
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    b = rng.standard_normal(m)
+    x0 = 0.01 * rng.standard_normal(n)
+    gam = 1.0 / (m * n / 3.0)
+    K = 6
+    fo, go = O.LinearLeastSquares(A, b), O.NormL1(1.0)
+    f, g = apx.LinearLeastSquares(A, b), apx.NormL1(1.0)
+    for k in (0, K):
+        xo, _ = O.adaptive_proxgrad(x0, f=fo, g=go, rule=O.OurRule(gamma=gam), tol=0.0, maxit=k)
+        x, _ = apx.adaptive_proxgrad(x0, f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, maxit=k)
+        assert _rel(x, xo) <= RTOL
+    # the other device-resident proximal-gradient loops on the same scheme (m, n <= 4096)
+    zo, _ = O.backtracking_proxgrad(x0, f=fo, g=go, gamma0=4 * gam, xi=1.5, tol=0.0, maxit=K)
+    z, _ = apx.backtracking_proxgrad(x0, f=f, g=g, gamma0=4 * gam, xi=1.5, tol=0.0, maxit=K)
+    assert _rel(z, zo) <= RTOL
+    zo, _ = O.fixed_nesterov(x0, f=fo, g=go, gamma=gam, tol=0.0, maxit=K)
+    z, _ = apx.fixed_nesterov(x0, f=f, g=g, gamma=gam, tol=0.0, maxit=K)
+    assert _rel(z, zo) <= RTOL
+    zo, _ = O.agraal(x0, f=fo, g=go, x0=x0 + 0.01, gamma0=gam, tol=0.0, maxit=K)
+    z, _ = apx.agraal(x0, f=f, g=g, x0=x0 + 0.01, gamma0=gam, tol=0.0, maxit=K)
+    assert _rel(z, zo) <= 1e-9
+    # the primal-dual loop (csrc/small_pd.hip) with the same matrix as the linear operator
+    yv = rng.standard_normal(m)
+    nA = float(np.linalg.norm(A))
+    kw = dict(Lf=0.0, norm_A=nA, tol=0.0, maxit=K)
+    xo, yo, _ = O.condat_vu(np.zeros(n), np.zeros(m), f=O.Zero(), g=O.NormL1(2.0), h=O.Translate(O.NormL1(1.0), -yv), A=A, **kw)
+    x, y, _ = apx.condat_vu(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(2.0), h=apx.Translate(apx.NormL1(1.0), -yv), A=A,
+                            **kw)
+    assert _rel(x, xo) <= RTOL and _rel(y, yo) <= 1e-9
