@@ -112,3 +112,22 @@ def test_dual_svm_malitsky_pock_termination_and_maxit(apx):
         xo, yo, _ = O.malitsky_pock(np.zeros(N), np.zeros(1), tol=0.0, maxit=K, **mk(O), **kw)
         x, y, it = apx.malitsky_pock(np.zeros(N), np.zeros(1), tol=0.0, maxit=K, **mk(apx), **kw)
         assert it == K and _rel_inf(x, xo) <= 1e-10 if K else np.array_equal(x, np.zeros(N))
+
+
+@pytest.mark.parametrize("N", [1243, 3000, 4096])
+def test_dual_svm_adaptive_primal_dual_larger_sizes(apx, N):
+    """The two-kernel primal-dual path (csrc/small_pd.hip) where its in-block dot products need several passes per
+    block: Q is N x N with N > 1024."""
+    Q, q, A = _dual_svm(N=N, d=22)
+    norm_A = float(np.linalg.norm(A))
+    K = 25
+    xo, yo, _ = O.adaptive_primal_dual(np.zeros(N), np.zeros(1), f=O.Quadratic(Q, q), g=O.IndBox(0.0, 0.1), h=O.IndZero(), A=A,
+                                       rule=O.OurRule(t=1.0, norm_A=norm_A), maxit=K, tol=0.0)
+    x, y, it = apx.adaptive_primal_dual(np.zeros(N), np.zeros(1), f=apx.Quadratic(Q, q), g=apx.IndBox(0.0, 0.1), h=apx.IndZero(),
+                                        A=A, rule=apx.OurRule(t=1.0, norm_A=norm_A), maxit=K, tol=0.0)
+    assert it == K and _rel_inf(x, xo) <= 1e-10 and _rel_inf(y, yo) <= 1e-9
+    xo, yo, _ = O.condat_vu(np.zeros(N), np.zeros(1), f=O.Quadratic(Q, q), g=O.IndBox(0.0, 0.1), h=O.IndZero(), A=A,
+                            Lf=float(np.linalg.norm(Q)), norm_A=norm_A, maxit=K, tol=0.0)
+    x, y, it = apx.condat_vu(np.zeros(N), np.zeros(1), f=apx.Quadratic(Q, q), g=apx.IndBox(0.0, 0.1), h=apx.IndZero(), A=A,
+                             Lf=float(np.linalg.norm(Q)), norm_A=norm_A, maxit=K, tol=0.0)
+    assert it == K and _rel_inf(x, xo) <= 1e-10 and _rel_inf(y, yo) <= 1e-9
