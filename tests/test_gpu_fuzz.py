@@ -102,8 +102,8 @@ def _g_term(apx, kind, n, rng):
 def test_small_proxgrad_vs_generic_fuzz(m, n, logistic, f32, gk, rule, k, seed):
     apx, _ = _apx()
     g_ctx = _generic_ctx()
-    if m * n > 3_000_000:
-        m = max(1, 3_000_000 // n)
+    if m * n > 17_000_000:
+        m = max(1, 17_000_000 // n)
     dtype = np.float32 if f32 else np.float64
     rng = np.random.default_rng(seed)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
@@ -146,8 +146,8 @@ def test_small_primal_dual_vs_generic_fuzz(m, n, quad, hk, gk, rule, k, seed):
     g_ctx = _generic_ctx()
     if quad:
         n = min(n, 1500)
-    if m * n > 3_000_000:
-        m = max(1, 3_000_000 // n)
+    if m * n > 17_000_000:
+        m = max(1, 17_000_000 // n)
     rng = np.random.default_rng(seed)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
     nrm = float(np.linalg.norm(A))
