@@ -1,6 +1,6 @@
 // slab.hip — f(x) and grad f(x) of LinearLeastSquares / LogisticLoss (experiments/lasso/runme.jl:21-25,
 // experiments/sparse_logreg/runme.jl:23-37) in ONE pass over A, for matrices whose rows are short enough to be held in
-// the registers of a workgroup (n <= 5120, fp32: 10 240).
+// the registers of a workgroup (n <= 10 752).
 //
 // The reference's cost model — and the generic path here — is two streaming passes per iteration: res = A x - b (or
 // the logistic link), then grad = A' res (lasso/runme.jl:179-180).  The second pass needs every res[i] = <A[i,:], x>
@@ -194,7 +194,7 @@ static SlabShape slab_shape(const apx_problem* p) {
   if (cols <= 5 * 1024) return {1024, 5, kSlabRows};
   // ten fp32 columns per thread: two rows per step is what 128 VGPRs hold — half the bytes in flight per step, and
   // only ~5 % ahead of the two passes at C3 (512 threads x 20 columns x 4 rows spilled and measured slower)
-  if (cols <= 14 * 768 && p->dtype == APX_F32) return {768, 14, kSlabRows};
+  if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};      // (160 KB per step either way)
   return {0, 0, 0};
 }
 
@@ -256,7 +256,7 @@ static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, 
   const dim3 grid((unsigned)st->B);
   if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
   else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
-  else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_slab_rows<T, FK, 14, kSlabRows, 768>), grid, dim3(768), 0, q, d, x);
+  else hipLaunchKernelGGL((k_slab_rows<T, FK, 14, (sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2)), 768>), grid, dim3(768), 0, q, d, x);
   hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kBlock), 0, q, d,
                      st->B, (T*)grad);
 }

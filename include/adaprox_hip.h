@@ -222,7 +222,7 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *   - a problem built on a SPARSE matrix that is small as a dense one (m x n within the limits above, <= 256 MB:
  *     the three LIBSVM datasets of experiments/sparse_logreg/runme.jl:177-204) runs on a dense copy of it, which the
  *     matrix keeps (products through apx_gemv_n/t stay on the compressed storage).
- *   - dense LinearLeastSquares / LogisticLoss with rows of at most 5120 entries (fp32: 10752) and >= 64 MB of A: f and
+ *   - dense LinearLeastSquares / LogisticLoss with rows of at most 10752 entries and >= 64 MB of A: f and
  *     grad f in ONE pass over A per iteration instead of two (csrc/slab.hip); it reads the transposed copy of A, which
  *     a matrix of up to 16 GB is given when a solver is created on it (as by apx_matrix_build_transpose).
  * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and

@@ -23,7 +23,9 @@ def _rel(a, b):
 # (64 MB of A is where the path starts: m * n * sizeof(T) >= 2^26)
 @pytest.mark.parametrize("m,n,logistic,dtype", [(8500, 1000, False, np.float64),      # 2 columns per thread
                                                 (4097, 2049, True, np.float64),       # 5 columns per thread, ragged rows
-                                                (4200, 5120, False, np.float64),      # the widest fp64 shape
+                                                (4200, 5120, False, np.float64),
+                                                (4098, 10000, False, np.float64),     # 14 columns per thread, two rows per step
+                                                (4101, 8000, True, np.float64),       # ... logistic fp64: one row per step
                                                 (9000, 1900, True, np.float32),
                                                 (4099, 10239, True, np.float32),      # 10 columns per thread (fp32 only)
                                                 (4100, 10240, False, np.float32)])

@@ -46,6 +46,8 @@ def run(label, m, n, dtype, logistic, one_pass, iters=60):
 def main():
     for label, m, n, dt, lg in (("C3 logistic 100000x10000 fp32", 100_000, 10_000, np.float32, True),
                                 ("lasso 200000x5000 fp64", 200_000, 5000, np.float64, False),
+                                ("lasso 50000x10000 fp64", 50_000, 10_000, np.float64, False),
+                                ("logistic 60000x8000 fp64", 60_000, 8000, np.float64, True),
                                 ("lasso 400000x2000 fp32", 400_000, 2000, np.float32, False),
                                 ("logistic 50000x4000 fp64", 50_000, 4000, np.float64, True)):
         for one_pass in (True, False):
