@@ -13,7 +13,7 @@
 //
 //   k_slab_rows  (one or two big blocks per CU, rows dealt in contiguous slabs): R rows per step ; per step two
 //                barriers (the R dots across the waves ; the R residuals back to every thread)
-//   k_slab_close (a thread per column): the B partials of its column, the loss sums (every block, redundantly),
+//   k_slab_close (64 columns per block): the B partials of every column, the loss sums (every block, redundantly),
 //                f -> Ctrl, grad (logistic: / N, the bias entry)
 //
 // Used by the generic loop (solver.hip) in place of gemv_n + k_finish_rows + k_f_reduce + gemv_t (+ k_logistic_grad)
@@ -192,9 +192,10 @@ static SlabShape slab_shape(const apx_problem* p) {
   const int64_t cols = p->A_f->n;
   if (cols <= 2 * 1024) return {1024, 2, kSlabRows};
   if (cols <= 5 * 1024) return {1024, 5, kSlabRows};
-  // ten fp32 columns per thread: two rows per step is what 128 VGPRs hold — half the bytes in flight per step, and
-  // only ~5 % ahead of the two passes at C3 (512 threads x 20 columns x 4 rows spilled and measured slower)
-  if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};      // (160 KB per step either way)
+  // longer rows: 768 threads x 14 columns in the ~170 VGPRs that twelve waves per CU leave; fp64 takes two rows per
+  // step (the same 160 KB) and one with the logistic link (see slab_launch_t).  Measured and dropped: 1024 x 10 x 2
+  // (half the bytes in flight: +5 % over the two passes at C3), 512 x 20 x 4 and 1024 x 10 x 4 (spills).
+  if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};
   return {0, 0, 0};
 }
 
