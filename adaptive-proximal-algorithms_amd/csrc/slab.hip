@@ -82,6 +82,7 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
 #pragma unroll
       for (int k = 0; k < C; ++k) a[r][k] = row[off[k]];
     }
+    const double b_in = tid < R ? (double)bv[min(r0 + tid, d.m - 1)] : 0.0;     // (goes out with the loads of A)
     double p[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
       const int i = r0 + tid;
       double res = 0.0;
       if (i < row_end) {
-        const double bi = (double)bv[i];
+        const double bi = b_in;
         const double ax = (double)(T)dot;        // A_x rounded to T like every stored A x
         if constexpr (FK == APX_F_LEAST_SQUARES) {
           res = (double)(T)(ax - bi);

@@ -1,0 +1,273 @@
+// slab_pd.hip — the linear-operator half of the primal-dual iteration (src/AdaProx.jl:335, :344-347, :358) in ONE pass
+// over A: A_x = A x ; w = y + sigma ((1 + rho) A_x - rho A_x_prev) ; y = prox_{sigma h*}(w) ; dual_res = (w - y) / sigma
+// - A_x ; At_y = A' y — for a separable h (the least-absolute-deviation clamp, experiments/least_absolute_deviation/
+// runme.jl:39-41) with rows of at most 10 752 entries.  The generic path streams A twice per iteration (A x, then
+// A' y); but y[i] depends on row i of A only, so a block that owns a slab of rows and keeps R of them at a time in
+// registers (csrc/slab.hip's scheme: thread t holds the columns t, t + BS, ..., read from the transposed copy) can
+// form A_x[i], update y[i] and add y[i] * A[i,:] to a private column accumulator from the SAME registers.  The B
+// partial n-vectors and the dual-residual sums are closed by a second small kernel, which also runs the end of the
+// iteration (norm_res, record, termination: :348-354).  No atomics: bit-reproducible.
+#include <cstdlib>
+#include <memory>
+
+#include "skinny_dev.h"
+#include "solver_internal.h"
+#include "vecops_dev.h"
+
+namespace apx {
+
+struct SlabPdDev {
+  const void* AT;         // A' column-major: row i of A at AT + i * ldT, contiguous
+  int64_t ldT;
+  int32_t m, n, rows_per_block, _pad;
+  void* Y;                // y (T), updated in place
+  void* AXP;              // A_x_prev (T), updated in place (:360)
+  double* part;           // [blocks][ldpart]: n column partials of A' y, then sum dual_res^2, raw h(A_x)
+  int64_t ldpart;
+  Ctrl* c;
+  ProxDev h;
+};
+
+struct SlabPdState {
+  DBuf part;
+  SlabPdDev dev{};
+  int B = 0, cpt = 0, bs = 0, rows = 0;
+};
+void slab_pd_destroy(SlabPdState* st) { delete st; }
+
+template <typename T, int C, int R, int BS>
+__global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv) {
+  constexpr int RP = R < 2 ? 2 : R;                // (the multi-value wave sum wants a power of two >= 2... and R is one)
+  __shared__ double wsum[BS / 64][RP];
+  __shared__ double y_s[RP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (d.c->done != 0) return;                      // written by an earlier launch: block-uniform
+  const double sigma = d.c->sigma, rho = d.c->rho; // this iteration's, set by the rule kernel before this launch
+  const T* __restrict__ AT = (const T*)d.AT;
+  const T* __restrict__ X = (const T*)xv;
+  T* __restrict__ Y = (T*)d.Y;
+  T* __restrict__ AXP = (T*)d.AXP;
+  T xr[C];
+  double acc[C];
+  unsigned off[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int j = tid + k * BS;
+    off[k] = (unsigned)min(j, d.n - 1);            // clamped: a valid address, weight 0
+    xr[k] = j < d.n ? X[j] : (T)0;
+    acc[k] = 0.0;
+  }
+  double e0 = 0.0, e1 = 0.0;                       // sum dual_res^2, raw h(A_x) of the rows this thread finishes
+  const int row_begin = blockIdx.x * d.rows_per_block;
+  const int row_end = min(row_begin + d.rows_per_block, d.m);
+  for (int r0 = row_begin; r0 < row_end; r0 += R) {
+    T a[R][C];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, d.m - 1));
+      const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
+#pragma unroll
+      for (int k = 0; k < C; ++k) a[r][k] = row[off[k]];
+    }
+    // the per-row state of the rows this thread will finish goes out with the loads of A (not behind the dot products)
+    double y_in = 0.0, axp_in = 0.0, b_in = 0.0;
+    if (tid < R) {
+      const int ic = min(r0 + tid, d.m - 1);
+      y_in = (double)Y[ic];
+      axp_in = (double)AXP[ic];
+      b_in = shift_at<T>(d.h, ic);
+    }
+    double p[RP];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+      p[r] = 0.0;
+      if (r < R) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) p[r] = fma((double)a[r < R ? r : 0][k], (double)xr[k], p[r]);
+      }
+    }
+    wave_sum_multi<RP>(p);                         // lane l: the wave's sum for row l / (64 / RP)
+    if (lane % (64 / RP) == 0) wsum[wv][lane / (64 / RP)] = p[0];
+    __syncthreads();
+    if (tid < R) {                                 // thread r finishes row r0 + r
+      double dot = wsum[0][tid];
+#pragma unroll
+      for (int w = 1; w < BS / 64; ++w) dot += wsum[w][tid];
+      const int i = r0 + tid;
+      double yn = 0.0;
+      if (i < row_end) {
+        const double ax = (double)(T)dot;                                                   // :335, rounded to T like every stored A x
+        const double b = b_in;
+        const double w = y_in + sigma * ((1.0 + rho) * ax - rho * axp_in);                  // :344
+        const T ynt = (T)prox_conj_elem_s<T>(d.h, w, sigma, i, 0.0, b);                     // :345
+        yn = (double)ynt;
+        const double dr = (w - yn) / sigma - ax;                                            // :347
+        e0 += dr * dr;
+        e1 += gval_elem_s<T>(d.h, ax, i, b);
+        Y[i] = ynt;
+        AXP[i] = (T)ax;                                                                     // :360
+      }
+      y_s[tid] = yn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double yy = y_s[r];
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        T av = a[r][k];
+        if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(av));    // (convert again: see csrc/slab.hip)
+        acc[k] = fma((double)av, yy, acc[k]);
+      }
+    }
+  }
+  double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int j = tid + k * BS;
+    if (j < d.n) out[j] = acc[k];
+  }
+  if (wv == 0) {                                   // the rows were finished by threads 0 .. R-1 (one wave)
+    double ex[2] = {tid < R ? e0 : 0.0, tid < R ? e1 : 0.0};
+    wave_sum_multi<2>(ex);                         // lane l: ex[l / 32]
+    if ((lane & 31) == 0) out[d.n + (lane >> 5)] = ex[0];
+  }
+}
+
+// A'y from the block partials (64 columns per block, sixteen loads in flight, fixed order) ; the dual residual and the
+// end of the iteration (:347-354) by block 0
+constexpr int kSlabPdCloseCols = 64;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_slabpd_close(SlabPdDev d, int B, T* __restrict__ aty, apx_record* recs, int64_t rec_cap) {
+  constexpr int S = kBlock / kSlabPdCloseCols;
+  __shared__ double fs[2];
+  __shared__ double sub[S][kSlabPdCloseCols];
+  if (d.c->done != 0) return;
+  const int tid = threadIdx.x;
+  const int c = tid % kSlabPdCloseCols, sl = tid / kSlabPdCloseCols;
+  const int j = blockIdx.x * kSlabPdCloseCols + c;
+  const double part_sum = j < d.n ? skinny_strided_sum(d.part, d.ldpart, j, sl, S, B) : 0.0;
+  if (blockIdx.x == 0 && tid < 128) {
+    const int which = tid >> 6, lane = tid & 63;
+    double s = 0.0;
+    for (int b = lane; b < B; b += 64) s += d.part[(int64_t)b * d.ldpart + d.n + which];
+    s = wave_sum(s);
+    if (lane == 0) fs[which] = s;
+  }
+  sub[sl][c] = part_sum;
+  __syncthreads();
+  if (sl == 0 && j < d.n) {
+    double g = sub[0][c];
+#pragma unroll
+    for (int k = 1; k < S; ++k) g += sub[k][c];
+    aty[j] = (T)g;                                                                         // :358  At_y = A' * y
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    const double ndr = sqrt(fs[0]);
+    d.c->ndr2 = ndr * ndr;
+    d.c->h_Ax = gval_final(d.h, fs[1]);
+    finish_iteration(d.c, recs, rec_cap);                                                  // :348-354
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct SlabPdShape {
+  int bs, cpt, rows;
+};
+static SlabPdShape slab_pd_shape(const apx_problem* p) {
+  const int64_t cols = p->A_lin->n;
+  const bool f32 = p->dtype == APX_F32;
+  if (cols <= 2 * 1024) return {1024, 2, 4};
+  if (cols <= 5 * 1024) return {1024, 5, 4};
+  if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
+  // (C5's row length, 20 000 fp64, is out of reach: x, the accumulator and one row are 480 KB of a CU's 512 KB of
+  //  VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two passes)
+  return {0, 0, 0};
+}
+
+static bool slab_pd_shape_ok(const apx_problem* p) {
+  if (!p->ctx->fused_small) return false;
+  if (p->A_lin == nullptr || p->allreduce != nullptr) return false;
+  if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
+  if (p->hd.kind == APX_G_L2) return false;        // (its conjugate prox needs a norm over all rows first)
+  if ((double)p->A_lin->m * (double)p->A_lin->n * (double)p->es() < 64.0 * 1024 * 1024) return false;
+  return p->A_lin->m >= 4096 && p->A_lin->m < ((int64_t)1 << 30) && slab_pd_shape(p).bs != 0;
+}
+
+// (reads only the transposed copy, which a matrix of up to 16 GB is given here: see slab_eligible)
+bool slab_pd_eligible(const apx_problem* p) {
+  if (!slab_pd_shape_ok(p)) return false;
+  const apx_matrix* A = p->A_lin;
+  if (A->dT == nullptr && (double)A->ld * (double)A->n_pad * (double)p->es() <= 16.0 * 1024 * 1024 * 1024) {
+    if (apx_matrix_build_transpose(const_cast<apx_matrix*>(A)) != APX_OK) (void)hipGetLastError();
+  }
+  return A->dT != nullptr;
+}
+
+int32_t slab_pd_setup(apx_solver* s) {
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  const apx_matrix* A = p->A_lin;
+  std::unique_ptr<SlabPdState> st(new SlabPdState());
+  const SlabPdShape sh = slab_pd_shape(p);
+  st->cpt = sh.cpt;
+  st->bs = sh.bs;
+  st->rows = sh.rows;
+  int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
+  int64_t rpb = (A->m + B - 1) / B;
+  rpb = round_up(rpb, 4);                          // (a multiple of every step size)
+  B = (A->m + rpb - 1) / rpb;
+  st->B = (int)B;
+  SlabPdDev d{};
+  d.AT = A->dT;
+  d.ldT = A->ldT;
+  d.m = (int32_t)A->m;
+  d.n = (int32_t)p->n;
+  d.rows_per_block = (int32_t)rpb;
+  d.Y = s->y.p;
+  d.AXP = s->axprev.p;
+  d.ldpart = round_up(d.n + 2, 8);
+  APX_TRY(st->part.alloc_zero((size_t)B * d.ldpart * sizeof(double), ctx->stream));
+  d.part = (double*)st->part.p;
+  d.c = p->ctrl();
+  d.h = p->hd;
+  st->dev = d;
+  s->slab_pd = st.release();
+  return APX_OK;
+}
+
+template <typename T>
+static void slab_pd_launch_t(const SlabPdState* st, const SlabPdDev& d, const void* x, void* aty, apx_record* recs, int64_t rec_cap,
+                             hipStream_t q) {
+  const dim3 grid((unsigned)st->B);
+  constexpr bool f32 = sizeof(T) == 4;
+  if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 4, 1024>), grid, dim3(1024), 0, q, d, x);
+  else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024>), grid, dim3(1024), 0, q, d, x);
+  else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768>), grid, dim3(768), 0, q, d, x);
+  hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kBlock), 0, q, d,
+                     st->B, (T*)aty, recs, rec_cap);
+}
+
+// what gemv_n(A, x) + the dual step + gemv_t(A, y) leave behind: y, A_x_prev updated, At_y in s->aty, the iteration closed.
+// false in *done_here: the transposed copy is gone (A edited in place) — the caller runs the generic kernels
+int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  const SlabPdState* st = s->slab_pd;
+  *done_here = false;
+  if (p->A_lin->dT == nullptr) return APX_OK;
+  SlabPdDev d = st->dev;
+  d.AT = p->A_lin->dT;
+  d.ldT = p->A_lin->ldT;
+  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)p->A_lin->m * (double)p->A_lin->n * (double)p->es()));
+  if (p->dtype == APX_F32) slab_pd_launch_t<float>(st, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
+  else slab_pd_launch_t<double>(st, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
+  APX_TRY(prof_end(ctx));
+  APX_HIP(hipGetLastError());
+  *done_here = true;
+  return APX_OK;
+}
+
+}  // namespace apx

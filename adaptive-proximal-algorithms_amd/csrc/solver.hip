@@ -486,6 +486,7 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
                     p->gd, p->ctrl()));                                          // :330-332
     if (lin)                                                                     // :331  A_x_prev = A_x
       APX_HIP(hipMemcpyAsync(s->axprev.p, s->ax.p, (size_t)p->m_pad * es, hipMemcpyDeviceToDevice, ctx->stream));
+    if (lin && slab_pd_eligible(p)) APX_TRY(slab_pd_setup(s.get()));
   }
   p->active = s.get();
   *out = s.release();
@@ -500,7 +501,9 @@ static int32_t enqueue_iteration(apx_solver* s) {
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   const bool lin = p->A_lin != nullptr;
-  if (lin) {                                                                   // :335
+  // the linear operator's half in ONE pass over A (csrc/slab_pd.hip) while its transposed copy is there
+  const bool lin_one_pass = lin && s->slab_pd != nullptr && p->A_lin->dT != nullptr;
+  if (lin && !lin_one_pass) {                                                  // :335
     int splits = 0;
     APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, p->done_ptr()));
     APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, p->done_ptr()));
@@ -514,7 +517,11 @@ static int32_t enqueue_iteration(apx_solver* s) {
   APX_TRY(vo_reduce_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p,
                          lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
                          s->rec_cap));                                         // :338-342
-  if (lin) {
+  if (lin_one_pass) {
+    bool done_here = false;
+    APX_TRY(slab_pd_iteration(s, &done_here));                                 // :335, :344-358
+    APX_REQUIRE(done_here, "internal: the one-pass primal-dual kernel lost its matrix copy inside an iteration");
+  } else if (lin) {
     if (p->lin_sharded) {   // y, A_x, dual_res are row shards: their norms / values are all-reduced
       APX_TRY(vo_dual_sharded(ctx, p->dtype, s->y.p, s->ax.p, s->axprev.p, p->m, p->hd, p->ctrl(),
                               (apx_record*)s->recs.p, s->rec_cap,

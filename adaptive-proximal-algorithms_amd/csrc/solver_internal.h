@@ -141,6 +141,8 @@ struct SkinnyPgState;      // (skinny_pg.hip: holds the row plan)
 void skinny_pg_destroy(SkinnyPgState* st);
 struct SlabState;          // (slab.hip: f and grad f in one pass over A)
 void slab_destroy(SlabState* st);
+struct SlabPdState;        // (slab_pd.hip: A x, the dual step and A' y in one pass over A)
+void slab_pd_destroy(SlabPdState* st);
 
 // ---- small_mom.hip: fixed Nesterov and aGRAAL as device-resident loops (small dense problems) ---------
 enum { MOM_AGRAAL = 0, MOM_NESTEROV = 1 };
@@ -179,12 +181,14 @@ struct apx_solver {
   apx::SkinnyState* skinny = nullptr;      // non-null: ... as skinny_pd.hip's row + closing kernels
   apx::SkinnyPgState* skinny_pg = nullptr; // non-null: ... as skinny_pg.hip's row + closing kernels
   apx::SlabState* slab = nullptr;          // non-null: the generic loop takes f, grad f from slab.hip (one pass over A)
+  apx::SlabPdState* slab_pd = nullptr;     // non-null: ... and A x, the dual step, A' y from slab_pd.hip
   ~apx_solver() {
     delete small;
     delete small_pd;
     delete skinny;
     apx::skinny_pg_destroy(skinny_pg);
     apx::slab_destroy(slab);
+    apx::slab_pd_destroy(slab_pd);
   }
 };
 
@@ -212,6 +216,9 @@ int32_t small_pd_setup(apx_solver* s, const void* x0, const void* y0);
 int32_t small_pd_enqueue(apx_solver* s);
 const void* small_pd_ctrl(const apx_solver* s);
 // skinny_pg.hip
+bool slab_pd_eligible(const apx_problem* p);
+int32_t slab_pd_setup(apx_solver* s);
+int32_t slab_pd_iteration(apx_solver* s, bool* done_here);
 bool slab_eligible(const apx_problem* p);
 int32_t slab_setup(apx_solver* s);
 int32_t slab_eval_pullback(apx_solver* s, const void* x_dev);

@@ -225,6 +225,7 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *   - dense LinearLeastSquares / LogisticLoss with rows of at most 10752 entries and >= 64 MB of A: f and
  *     grad f in ONE pass over A per iteration instead of two (csrc/slab.hip); it reads the transposed copy of A, which
  *     a matrix of up to 16 GB is given when a solver is created on it (as by apx_matrix_build_transpose).
+ *     The primal-dual loop likewise for a separable h (A x, the dual step and A' y in one pass: csrc/slab_pd.hip).
  * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and
  * the host-driven loops. */
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);

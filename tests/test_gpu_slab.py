@@ -126,3 +126,75 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
         x, it = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=tol, maxit=1000, ctx=ctx, poll_every=poll)
         assert it == kstar == ito and _rel(x, xo) <= 1e-10
     dA.free()
+
+
+# ---------------------------------------------------------------------------------------
+# the primal-dual loop: A x, the dual step and A' y in one pass over A (csrc/slab_pd.hip)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,hkind,dtype", [(9000, 1000, "tl1", np.float64),      # 2 columns per thread
+                                             (4099, 2100, "tbox", np.float64),     # 5
+                                             (4097, 9000, "tl1", np.float64),      # 14, two rows per step
+                                             (4100, 10752, "tl1", np.float32),     # 14, four rows per step
+                                             (9001, 1900, "tbox", np.float32)])
+def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dtype):
+    rng = np.random.default_rng(m + n)
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))
+    yv = (A.astype(np.float64) @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)).astype(dtype)
+    nA = float(np.linalg.norm(A.astype(np.float64)))
+    mk_h = {"tl1": lambda M: M.Translate(M.NormL1(1.0), -yv.astype(np.float64) if M is O else -yv),
+            "tbox": lambda M: M.Translate(M.IndBox(-0.5, 0.8), -yv.astype(np.float64) if M is O else -yv)}[hkind]
+    K = 10
+    x0, y0 = np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype)
+    ro = []
+    xo, yo, _ = O.adaptive_primal_dual(x0.astype(np.float64), y0.astype(np.float64), f=O.Zero(), g=O.NormL1(5.0), h=mk_h(O),
+                                       A=A.astype(np.float64), rule=O.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, record=ro.append)
+    out = []
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        recs = []
+        x, y, it = apx.adaptive_primal_dual(x0, y0, f=apx.Zero(), g=apx.NormL1(5.0), h=mk_h(apx), A=dA,
+                                            rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx, record=recs.append)
+        assert it == K and len(recs) == K
+        out.append((x, y, recs))
+        dA.free()
+    (x1, y1, r1), (x2, y2, r2) = out
+    tol = 1e-10 if dtype == np.float64 else 2e-3
+    assert _rel(x1, xo) <= tol and _rel(y1, yo) <= 10 * tol and _rel(x1, x2) <= tol and _rel(y1, y2) <= 10 * tol
+    for a, b_ in zip(r1, ro):
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7 if dtype == np.float64 else 1e-2)
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-9 if dtype == np.float64 else 1e-3)
+
+
+def test_one_pass_primal_dual_condat_vu_termination_and_stepping(apx):
+    rng = np.random.default_rng(11)
+    m, n = 9000, 1000
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+    yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+    nA = float(np.linalg.norm(A))
+    ctx = apx.Context(0)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    t = dict(f=apx.Zero(), g=apx.NormL1(5.0), h=apx.Translate(apx.NormL1(1.0), -yv), A=dA, ctx=ctx)
+    to = dict(f=O.Zero(), g=O.NormL1(5.0), h=O.Translate(O.NormL1(1.0), -yv), A=A)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    recs = []
+    xo, yo, _ = O.condat_vu(x0, y0, Lf=0.0, norm_A=nA, tol=0.0, maxit=30, **to)
+    x, y, it = apx.condat_vu(x0, y0, Lf=0.0, norm_A=nA, tol=0.0, maxit=30, record=recs.append, **t)
+    assert it == 30 and _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-9
+    tol = recs[19]["norm_res"] * (1 + 1e-9)
+    kstar = 1 + next(k for k, r in enumerate(recs) if r["norm_res"] <= tol)
+    xo, yo, ito = O.condat_vu(x0, y0, Lf=0.0, norm_A=nA, tol=tol, maxit=1000, **to)
+    for poll in (1, 64):
+        x, y, it = apx.condat_vu(x0, y0, Lf=0.0, norm_A=nA, tol=tol, maxit=1000, poll_every=poll, **t)
+        assert it == kstar == ito and _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-9
+    rule = apx.OurRule(t=1.0, norm_A=nA)
+    x1, y1, _ = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=0.0, maxit=20, **t)
+    s = apx.Solver(x0, y0, rule=rule, tol=0.0, **t)
+    for k in (1, 9, 10):
+        s.step(k)
+        s.result()
+    xs, ys, res = s.result()
+    s.close()
+    assert res.numit == 20 and np.array_equal(xs, x1) and np.array_equal(ys, y1)
+    dA.free()
