@@ -407,3 +407,38 @@ def test_one_pass_vs_two_passes_fuzz(n, extra_rows, logistic, f32, rule, k, seed
     assert np.max(np.abs(x1 - x2)) <= tol * max(1.0, np.max(np.abs(x2)))
     for a, b_ in zip(r1, r2):
         assert a["objective"] == pytest.approx(b_["objective"], rel=1e-4 if f32 else 1e-10)
+
+
+@settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(n=st.sampled_from([125, 1024, 2048, 2049, 5120, 5121, 10752]), extra_rows=st.integers(0, 9),
+       hk=st.sampled_from(["tl1", "tbox"]), f32=st.booleans(), fixed=st.booleans(), k=st.integers(0, 5),
+       seed=st.integers(0, 2**31 - 1))
+def test_one_pass_primal_dual_vs_two_passes_fuzz(n, extra_rows, hk, f32, fixed, k, seed):
+    """csrc/slab_pd.hip (A x, the dual step, A' y in one pass over A) against the generic kernels."""
+    apx, _ = _apx()
+    dtype = np.float32 if f32 else np.float64
+    es = 4 if f32 else 8
+    m = max(4096, -(-(64 * 1024 * 1024) // (n * es))) + extra_rows
+    if m * n * es > 400 * 1024 * 1024:
+        return
+    rng = np.random.default_rng(seed)
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))
+    yv = (rng.laplace(size=m) + 0.3).astype(dtype)
+    nA = float(np.sqrt(m * (n - 1) / 3.0 + m))
+    x0, y0 = (0.01 * rng.standard_normal(n)).astype(dtype), (0.1 * rng.standard_normal(m)).astype(dtype)
+    out = []
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        h = apx.Translate(apx.NormL1(1.0) if hk == "tl1" else apx.IndBox(-0.5, 0.8), -yv)
+        rule = apx.FixedStepsize(1.0 / nA, 0.99) if fixed else apx.OurRule(t=1.0, norm_A=nA)
+        x, y, it = apx.adaptive_primal_dual(x0, y0, f=apx.Zero(), g=apx.NormL1(3.0), h=h, A=dA, rule=rule, tol=0.0, maxit=k,
+                                            ctx=ctx)
+        out.append((x, y, it))
+        dA.free()
+    (x1, y1, it1), (x2, y2, it2) = out
+    tol = 2e-3 if f32 else 1e-9
+    assert it1 == it2 == k
+    assert np.max(np.abs(x1 - x2)) <= tol * max(1.0, np.max(np.abs(x2)))
+    assert np.max(np.abs(y1 - y2)) <= tol * max(1.0, np.max(np.abs(y2)))
