@@ -16,8 +16,9 @@
 //   k_slab_close (64 columns per block): the B partials of every column, the loss sums (every block, redundantly),
 //                f -> Ctrl, grad (logistic: / N, the bias entry)
 //
-// Used by the generic loop (solver.hip) in place of gemv_n + k_finish_rows + k_f_reduce + gemv_t (+ k_logistic_grad)
-// when there is no all-reduce hook; it reads the transposed copy of A (apx_matrix_build_transpose), which a matrix of up to
+// Used by every evaluation of such an f (eval_f in solver.hip: the adaptive loops, the linesearch and momentum
+// methods, apx_eval) in place of gemv_n + k_finish_rows + k_f_reduce and of the gemv_t (+ k_logistic_grad) of the
+// pullback, when there is no all-reduce hook; it reads the transposed copy of A (apx_matrix_build_transpose), which a matrix of up to
 // 16 GB is given on the spot.
 #include <cstdlib>
 #include <memory>
@@ -45,7 +46,7 @@ struct SlabState {
   SlabDev dev{};
   int B = 0, cpt = 0, bs = 0;     // blocks ; columns per thread ; threads per block
 };
-void slab_destroy(SlabState* st) { delete st; }
+void slab_destroy(SlabState* st) { delete st; }      // (null is fine)
 
 // BS threads, C columns per thread (BS * C >= n), R rows per step: R x C values of A, C of x and C doubles of acc must
 // fit the 128 VGPRs of a 1024-thread block, and R * n * sizeof(T) is what a CU has in flight per step.
@@ -213,7 +214,7 @@ static bool slab_shape_ok(const apx_problem* p) {
 // The kernel reads only the transposed copy.  A matrix of up to 16 GB that has none gets one here (the same second
 // copy as apx_matrix_build_transpose; twice the memory, one transpose): every iteration then moves half the bytes.
 // Failing to allocate it is not an error — the two passes remain.
-bool slab_eligible(const apx_problem* p) {
+static bool slab_eligible(const apx_problem* p) {
   if (!slab_shape_ok(p)) return false;
   if (p->A_f->dT == nullptr && (double)p->A_f->ld * (double)p->A_f->n_pad * (double)p->es() <= 16.0 * 1024 * 1024 * 1024) {
     if (apx_matrix_build_transpose(const_cast<apx_matrix*>(p->A_f)) != APX_OK) (void)hipGetLastError();
@@ -221,8 +222,7 @@ bool slab_eligible(const apx_problem* p) {
   return p->A_f->dT != nullptr;
 }
 
-int32_t slab_setup(apx_solver* s) {
-  apx_problem* p = s->p;
+static int32_t slab_setup(apx_problem* p) {
   apx_ctx* ctx = p->ctx;
   const apx_matrix* A = p->A_f;
   std::unique_ptr<SlabState> st(new SlabState());
@@ -249,7 +249,7 @@ int32_t slab_setup(apx_solver* s) {
   d.part = (double*)st->part.p;
   d.c = p->ctrl();
   st->dev = d;
-  s->slab = st.release();
+  p->slab = st.release();
   return APX_OK;
 }
 
@@ -263,15 +263,19 @@ static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, 
                      st->B, (T*)grad);
 }
 
-// f(x) -> Ctrl, grad f(x) -> p->grad for the device vector x: what eval_f + pullback_f leave behind
-int32_t slab_eval_pullback(apx_solver* s, const void* x) {
-  apx_problem* p = s->p;
-  apx_ctx* ctx = p->ctx;
-  const SlabState* st = s->slab;
-  if (p->A_f->dT == nullptr) {                   // the transposed copy was dropped (A edited in place): the two passes
-    APX_TRY(eval_f(p, x, false));
-    return pullback_f(p);
+// f(x) -> Ctrl, grad f(x) -> p->grad for the device vector x: what eval_f + pullback_f leave behind.  Called by eval_f
+// (solver.hip) for every least-squares / logistic evaluation: *done_here stays false when the problem is not eligible (or
+// its transposed copy is gone), and the two passes run.  An evaluation whose gradient is never asked for (a rejected
+// linesearch trial) costs the same one pass as before.
+int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) {
+  *done_here = false;
+  if (!p->slab_checked) {
+    p->slab_checked = true;
+    if (slab_eligible(p)) APX_TRY(slab_setup(p));
   }
+  const SlabState* st = p->slab;
+  if (st == nullptr || p->A_f->dT == nullptr) return APX_OK;      // (dropped copy: A edited in place)
+  apx_ctx* ctx = p->ctx;
   SlabDev d = st->dev;
   d.AT = p->A_f->dT;                             // (rebuilt copies may live elsewhere)
   d.ldT = p->A_f->ldT;
@@ -286,8 +290,7 @@ int32_t slab_eval_pullback(apx_solver* s, const void* x) {
   }
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
-  p->have_eval = true;
-  p->fsc_reduced = true;
+  *done_here = true;
   return APX_OK;
 }
 

@@ -78,11 +78,21 @@ static int32_t do_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dt
 int32_t eval_f(apx_problem* p, const void* x_dev, bool need_f) {
   apx_ctx* ctx = p->ctx;
   p->fsc_reduced = false;
+  p->grad_ready = false;
   switch (p->f_kind) {
     case APX_F_ZERO:
       break;
     case APX_F_LEAST_SQUARES:
     case APX_F_LOGISTIC: {
+      // rows short enough for a workgroup's registers: f AND grad f in one pass over A (csrc/slab.hip); the pullback
+      // then has nothing left to do
+      bool one_pass = false;
+      APX_TRY(slab_eval_with_gradient(p, x_dev, &one_pass));
+      if (one_pass) {
+        p->grad_ready = true;
+        p->fsc_reduced = true;
+        break;
+      }
       int splits = 0;
       APX_TRY(launch_gemv_n(ctx, p->A_f, x_dev, &splits, p->done_ptr()));
       const bool local_final = !p->f_sharded;
@@ -131,6 +141,7 @@ int32_t pullback_f(apx_problem* p) {
       break;
     case APX_F_LEAST_SQUARES:
     case APX_F_LOGISTIC: {
+      if (p->grad_ready) break;                    // (formed together with f by csrc/slab.hip)
       APX_TRY(launch_gemv_t(ctx, p->A_f, p->res.p, p->grad.p, p->done_ptr()));
       if (p->f_sharded) {
         // [A_k' r_k] summed over the row shards (K12).  In fp64 the two partial f scalars sit
@@ -470,14 +481,8 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
       APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, nullptr));
       APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, nullptr));
     }
-    // rows short enough for a workgroup's registers: f and grad f in ONE pass over A (csrc/slab.hip)
-    if (slab_eligible(p)) APX_TRY(slab_setup(s.get()));
-    if (s->slab != nullptr) {
-      APX_TRY(slab_eval_pullback(s.get(), s->x.p));                              // :328
-    } else {
-      APX_TRY(eval_f(p, s->x.p, false));                                         // :328
-      APX_TRY(pullback_f(p));
-    }
+    APX_TRY(eval_f(p, s->x.p, false));                                           // :328
+    APX_TRY(pullback_f(p));
     if (lin) {                                                                   // :329
       APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, nullptr));
       if (p->lin_sharded) APX_TRY(do_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));
@@ -508,12 +513,8 @@ static int32_t enqueue_iteration(apx_solver* s) {
     APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, p->done_ptr()));
     APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, p->done_ptr()));
   }
-  if (s->slab != nullptr) {
-    APX_TRY(slab_eval_pullback(s, s->x.p));                                    // :336, one pass over A
-  } else {
-    APX_TRY(eval_f(p, s->x.p, false));                                         // :336
-    APX_TRY(pullback_f(p));
-  }
+  APX_TRY(eval_f(p, s->x.p, false));                                           // :336 (one pass over A where csrc/slab.hip applies)
+  APX_TRY(pullback_f(p));
   APX_TRY(vo_reduce_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p,
                          lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
                          s->rec_cap));                                         // :338-342

@@ -7,6 +7,11 @@
 #include "apx_internal.h"
 #include "vecops.h"
 
+namespace apx {
+struct SlabState;          // (slab.hip: f and grad f in one pass over A)
+void slab_destroy(SlabState* st);
+}
+
 struct apx_problem {
   apx_ctx* ctx = nullptr;
   int32_t f_kind = APX_F_ZERO, dtype = APX_F64;
@@ -27,6 +32,11 @@ struct apx_problem {
   bool have_eval = false;
   bool fsc_reduced = false;
   apx_solver* active = nullptr;
+  // f and grad f in one pass over A (slab.hip): set up on the first evaluation of an eligible problem ; grad_ready: the
+  // evaluation at hand already left the gradient in `grad`, the pullback has nothing to do
+  apx::SlabState* slab = nullptr;
+  bool slab_checked = false, grad_ready = false;
+  ~apx_problem() { apx::slab_destroy(slab); }
 
   apx::Ctrl* ctrl() const { return (apx::Ctrl*)ctrl_buf.p; }
   const int* done_ptr() const { return (const int*)((const char*)ctrl_buf.p + offsetof(apx::Ctrl, done)); }
@@ -139,8 +149,6 @@ struct SkinnyPgDev {       // what the closing kernel of skinny_pg.hip needs (th
 
 struct SkinnyPgState;      // (skinny_pg.hip: holds the row plan)
 void skinny_pg_destroy(SkinnyPgState* st);
-struct SlabState;          // (slab.hip: f and grad f in one pass over A)
-void slab_destroy(SlabState* st);
 struct SlabPdState;        // (slab_pd.hip: A x, the dual step and A' y in one pass over A)
 void slab_pd_destroy(SlabPdState* st);
 
@@ -180,14 +188,12 @@ struct apx_solver {
   apx::SmallPdState* small_pd = nullptr;   // non-null: ... as small_pd.hip's two kernels
   apx::SkinnyState* skinny = nullptr;      // non-null: ... as skinny_pd.hip's row + closing kernels
   apx::SkinnyPgState* skinny_pg = nullptr; // non-null: ... as skinny_pg.hip's row + closing kernels
-  apx::SlabState* slab = nullptr;          // non-null: the generic loop takes f, grad f from slab.hip (one pass over A)
   apx::SlabPdState* slab_pd = nullptr;     // non-null: ... and A x, the dual step, A' y from slab_pd.hip
   ~apx_solver() {
     delete small;
     delete small_pd;
     delete skinny;
     apx::skinny_pg_destroy(skinny_pg);
-    apx::slab_destroy(slab);
     apx::slab_pd_destroy(slab_pd);
   }
 };
@@ -219,9 +225,8 @@ const void* small_pd_ctrl(const apx_solver* s);
 bool slab_pd_eligible(const apx_problem* p);
 int32_t slab_pd_setup(apx_solver* s);
 int32_t slab_pd_iteration(apx_solver* s, bool* done_here);
-bool slab_eligible(const apx_problem* p);
-int32_t slab_setup(apx_solver* s);
-int32_t slab_eval_pullback(apx_solver* s, const void* x_dev);
+// slab.hip: true when f and grad f at x_dev were formed in one pass over A (f -> Ctrl, grad -> p->grad)
+int32_t slab_eval_with_gradient(apx_problem* p, const void* x_dev, bool* done_here);
 bool skinny_pg_eligible(const apx_problem* p);
 int32_t skinny_pg_setup(apx_solver* s);
 int32_t skinny_pg_enqueue(apx_solver* s);

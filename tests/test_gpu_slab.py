@@ -198,3 +198,30 @@ def test_one_pass_primal_dual_condat_vu_termination_and_stepping(apx):
     s.close()
     assert res.numit == 20 and np.array_equal(xs, x1) and np.array_equal(ys, y1)
     dA.free()
+
+
+def test_one_pass_serves_every_loop_and_the_operator_calls(apx):
+    """eval_f uses the one-pass kernel for any evaluation of an eligible f: the linesearch and momentum methods (host-driven
+    at this size) and eval_with_pullback get f and the gradient from the same pass; counts stay those of the oracle."""
+    rng = np.random.default_rng(21)
+    m, n = 9000, 1100
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    w = rng.standard_normal(n) * (rng.uniform(size=n) < 0.05)
+    b = (1 / (1 + np.exp(-(A @ w))) > rng.uniform(size=m)).astype(np.float64)
+    gam = 4.0 * m / (float(np.sum(A * A)) + m)
+    ctx = apx.Context(0)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    mk = lambda M: (M.Counting(M.LogisticLoss(dA, b, ctx=ctx)) if M is apx else M.Counting(M.LogisticLoss(A, b)))      # noqa: E731
+    x0 = 0.01 * rng.standard_normal(n + 1)
+    fx_o, pb_o = O.LogisticLoss(A, b).eval_with_pullback(x0)
+    fx, pb = apx.eval_with_pullback(apx.LogisticLoss(dA, b, ctx=ctx), x0)
+    assert fx == pytest.approx(fx_o, rel=1e-12) and _rel(pb(), pb_o()) <= 1e-11
+    K = 8
+    for name, kw in (("backtracking_proxgrad", dict(gamma0=4 * gam, xi=1.5)), ("backtracking_nesterov", dict(gamma0=4 * gam)),
+                     ("fixed_nesterov", dict(gamma=gam)), ("agraal", dict(x0=x0 + 0.01, gamma0=gam))):
+        of, df = mk(O), mk(apx)
+        zo, ito = getattr(O, name)(x0, f=of, g=O.NormL1(0.01), tol=0.0, maxit=K, **kw)
+        z, it = getattr(apx, name)(x0, f=df, g=apx.NormL1(0.01), tol=0.0, maxit=K, ctx=ctx, **kw)
+        assert it == ito == K and _rel(z, zo) <= 1e-10, name
+        assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count), name
+    dA.free()
