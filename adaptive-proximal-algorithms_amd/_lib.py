@@ -90,6 +90,7 @@ PROTOTYPES = {
     "apx_ctx_set_gemv_config": (c_int32, [c_void_p, c_int32, c_int32, c_int64, c_int64]),
     "apx_ctx_exploit_sparsity": (c_int32, [c_void_p, c_int32]),
     "apx_ctx_fused_small": (c_int32, [c_void_p, c_int32]),
+    "apx_ctx_one_pass_threshold": (c_int32, [c_void_p, c_int64]),
     "apx_gemv_variant_count": (c_int32, [c_int32]),
     "apx_gemv_variant_name": (C.c_char_p, [c_int32, c_int32]),
     "apx_matrix_create": (c_int32, [c_void_p, c_int64, c_int64, c_int32, _P(c_void_p)]),

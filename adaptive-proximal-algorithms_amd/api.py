@@ -90,6 +90,12 @@ class Context:
     def set_gemv_config(self, n_variant: int = -1, t_variant: int = -1, n_blocks: int = 0, t_blocks: int = 0):
         L.check(self._lib.apx_ctx_set_gemv_config(self._h, n_variant, t_variant, n_blocks, t_blocks))
 
+    def one_pass_threshold(self, min_bytes: int):
+        """Matrix size from which f and grad f (and the linear operator's half of the primal-dual loop) are formed in one
+        pass over A (csrc/slab.hip, csrc/slab_pd.hip); default 192 MB."""
+        L.check(self._lib.apx_ctx_one_pass_threshold(self._h, int(min_bytes)))
+        return self
+
     def fused_small(self, enable: bool = True):
         """Default on: small dense proximal-gradient problems run as two kernels per iteration (csrc/small.hip)."""
         L.check(self._lib.apx_ctx_fused_small(self._h, 1 if enable else 0))

@@ -94,6 +94,7 @@ struct apx_ctx {
   double* h_scal = nullptr;      // pinned host scalars (64 doubles): read-backs of scal / Ctrl fields
   // opt-in: A*x streams only the columns with x_j != 0 (apx_ctx_exploit_sparsity)
   bool fused_small = true;       // small dense proximal-gradient problems run as two kernels per iteration (small.hip)
+  int64_t one_pass_min_bytes = 192ll << 20;   // slab.hip / slab_pd.hip take matrices from this size on (apx_ctx_one_pass_threshold)
   bool skip_zero_cols = false;
   int32_t* nz_idx = nullptr;     // compacted column indices + [nz_cap] = count
   int64_t nz_cap = 0;

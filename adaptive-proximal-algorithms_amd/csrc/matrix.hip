@@ -257,6 +257,12 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable) {
   return APX_OK;
 }
 
+int32_t apx_ctx_one_pass_threshold(apx_ctx* ctx, int64_t min_bytes) {
+  APX_REQUIRE(ctx != nullptr && min_bytes >= 0, "apx_ctx_one_pass_threshold: bad argument");
+  ctx->one_pass_min_bytes = min_bytes;
+  return APX_OK;
+}
+
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable) {
   APX_REQUIRE(ctx != nullptr, "apx_ctx_fused_small: ctx is NULL");
   ctx->fused_small = enable != 0;

@@ -206,8 +206,11 @@ static bool slab_shape_ok(const apx_problem* p) {
   if (p->A_lin != nullptr || p->allreduce != nullptr) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
   if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
-  // bandwidth-bound sizes only: below, the small-size paths or the launch-bound generic kernels are the tools
-  if ((double)p->A_f->m * (double)p->A_f->n * (double)p->es() < 64.0 * 1024 * 1024) return false;
+  // large matrices only: every block walks its slab in steps of R rows with two barriers each, and below ~200 MB
+  // (a few dozen steps per block) that latency costs more than the second pass saves — measured fp64, one pass / two
+  // passes: 8300 x 1024 (65 MB) 59 / 49 us, 16 384 x 1024 (128 MB) 77 / 72, 32 768 x 1024 (256 MB) 105 / 118,
+  // 8300 x 4096 (259 MB) 77 / 107, 16 384 x 8192 (1 GB) 239 / 343
+  if ((double)p->A_f->m * (double)p->A_f->n * (double)p->es() < (double)p->ctx->one_pass_min_bytes) return false;
   return p->A_f->m >= 4096 && p->A_f->m < ((int64_t)1 << 30) && slab_shape(p).bs != 0;
 }
 

@@ -192,7 +192,7 @@ static bool slab_pd_shape_ok(const apx_problem* p) {
   if (p->A_lin == nullptr || p->allreduce != nullptr) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   if (p->hd.kind == APX_G_L2) return false;        // (its conjugate prox needs a norm over all rows first)
-  if ((double)p->A_lin->m * (double)p->A_lin->n * (double)p->es() < 64.0 * 1024 * 1024) return false;
+  if ((double)p->A_lin->m * (double)p->A_lin->n * (double)p->es() < (double)p->ctx->one_pass_min_bytes) return false;   // (see slab.hip)
   return p->A_lin->m >= 4096 && p->A_lin->m < ((int64_t)1 << 30) && slab_pd_shape(p).bs != 0;
 }
 

@@ -222,13 +222,17 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *   - a problem built on a SPARSE matrix that is small as a dense one (m x n within the limits above, <= 256 MB:
  *     the three LIBSVM datasets of experiments/sparse_logreg/runme.jl:177-204) runs on a dense copy of it, which the
  *     matrix keeps (products through apx_gemv_n/t stay on the compressed storage).
- *   - dense LinearLeastSquares / LogisticLoss with rows of at most 10752 entries and >= 64 MB of A: f and
+ *   - dense LinearLeastSquares / LogisticLoss with rows of at most 10752 entries and >= 192 MB of A: f and
  *     grad f in ONE pass over A per iteration instead of two (csrc/slab.hip); it reads the transposed copy of A, which
  *     a matrix of up to 16 GB is given when a solver is created on it (as by apx_matrix_build_transpose).
  *     The primal-dual loop likewise for a separable h (A x, the dual step and A' y in one pass: csrc/slab_pd.hip).
  * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and
  * the host-driven loops. */
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
+/* Tuning hook: the matrix size in bytes from which the one-pass kernels (csrc/slab.hip, csrc/slab_pd.hip) replace the two
+ * GEMV passes.  Default 192 MB — the measured break-even on MI355X; the parity tests lower it to reach the kernels
+ * with small matrices. */
+int32_t apx_ctx_one_pass_threshold(apx_ctx* ctx, int64_t min_bytes);
 int32_t apx_gemv_variant_count(int32_t transposed);
 const char* apx_gemv_variant_name(int32_t transposed, int32_t i);
 

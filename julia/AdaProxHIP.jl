@@ -95,6 +95,7 @@ end
 
 "Execution policy: the two-kernel iteration for small dense problems (default on) and the opt-in sparse-iterate product."
 fused_small!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_fused_small, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
+one_pass_threshold!(c::Context, min_bytes::Integer) = check(ccall((:apx_ctx_one_pass_threshold, LIB), Int32, (Ptr{Cvoid}, Int64), c.h, min_bytes))
 exploit_sparsity!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_exploit_sparsity, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
 
 dtype_code(::Type{Float64}) = APX_F64

@@ -394,6 +394,7 @@ def test_one_pass_vs_two_passes_fuzz(n, extra_rows, logistic, f32, rule, k, seed
     for one_pass in (True, False):
         ctx = apx.Context(0)
         ctx.fused_small(one_pass)
+        ctx.one_pass_threshold(16 << 20)
         dA = apx.DeviceMatrix.from_numpy(A, ctx)
         f = apx.LogisticLoss(dA, b, ctx=ctx) if logistic else apx.LinearLeastSquares(dA, b, ctx=ctx)
         recs = []
@@ -430,6 +431,7 @@ def test_one_pass_primal_dual_vs_two_passes_fuzz(n, extra_rows, hk, f32, fixed, 
     for one_pass in (True, False):
         ctx = apx.Context(0)
         ctx.fused_small(one_pass)
+        ctx.one_pass_threshold(16 << 20)
         dA = apx.DeviceMatrix.from_numpy(A, ctx)
         h = apx.Translate(apx.NormL1(1.0) if hk == "tl1" else apx.IndBox(-0.5, 0.8), -yv)
         rule = apx.FixedStepsize(1.0 / nA, 0.99) if fixed else apx.OurRule(t=1.0, norm_A=nA)
