@@ -29,7 +29,7 @@
 
 namespace apx {
 
-constexpr int kSlabRows = 4;          // rows per step (fp64 with twenty columns per thread: 2)
+constexpr int kSlabRows = 4;          // rows per step (two columns per thread: 16 ; fourteen fp64 columns: 2, or 1 with the logistic link)
 
 struct SlabDev {
   const void* AT;         // A' column-major: row i of A at AT + i * ldT, contiguous
@@ -236,7 +236,7 @@ static int32_t slab_setup(apx_problem* p) {
   // contiguous slabs, a multiple of the step ; fewer blocks = fewer partial vectors for the closing kernel
   int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
   int64_t rpb = (A->m + B - 1) / B;
-  rpb = round_up(rpb, kSlabRows);          // (a multiple of every step size)
+  rpb = round_up(rpb, 16);                 // (a multiple of every step size)
   B = (A->m + rpb - 1) / rpb;
   st->B = (int)B;
   SlabDev d{};
@@ -259,7 +259,7 @@ static int32_t slab_setup(apx_problem* p) {
 template <typename T, int FK>
 static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
-  if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
+  if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, 16, 1024>), grid, dim3(1024), 0, q, d, x);
   else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
   else hipLaunchKernelGGL((k_slab_rows<T, FK, 14, (sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2)), 768>), grid, dim3(768), 0, q, d, x);
   hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kBlock), 0, q, d,

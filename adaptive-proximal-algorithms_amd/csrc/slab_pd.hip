@@ -217,7 +217,7 @@ int32_t slab_pd_setup(apx_solver* s) {
   st->rows = sh.rows;
   int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
   int64_t rpb = (A->m + B - 1) / B;
-  rpb = round_up(rpb, 4);                          // (a multiple of every step size)
+  rpb = round_up(rpb, 16);                         // (a multiple of every step size)
   B = (A->m + rpb - 1) / rpb;
   st->B = (int)B;
   SlabPdDev d{};
@@ -243,7 +243,7 @@ static void slab_pd_launch_t(const SlabPdState* st, const SlabPdDev& d, const vo
                              hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   constexpr bool f32 = sizeof(T) == 4;
-  if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 4, 1024>), grid, dim3(1024), 0, q, d, x);
+  if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024>), grid, dim3(1024), 0, q, d, x);
   else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024>), grid, dim3(1024), 0, q, d, x);
   else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768>), grid, dim3(768), 0, q, d, x);
   hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kBlock), 0, q, d,
