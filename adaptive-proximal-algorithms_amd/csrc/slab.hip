@@ -11,8 +11,9 @@
 // summed in a fixed order by a second, small kernel that also finalises f and the logistic scaling.  No atomics:
 // bit-reproducible.  HBM traffic per iteration: m n sizeof(T) instead of 2 m n sizeof(T).
 //
-//   k_slab_rows  (one or two big blocks per CU, rows dealt in contiguous slabs): R rows per step ; per step two
-//                barriers (the R dots across the waves ; the R residuals back to every thread)
+//   k_slab_rows  (one or two big blocks per CU, rows dealt in contiguous slabs): R rows in registers, as one group or as
+//                two that alternate (one computes while the other's non-temporal loads arrive) ; per group two
+//                barriers (the dots across the waves ; the residuals back to every thread)
 //   k_slab_close (64 columns per block): the B partials of every column, the loss sums (every block, redundantly),
 //                f -> Ctrl, grad (logistic: / N, the bias entry)
 //
@@ -48,17 +49,106 @@ struct SlabState {
 };
 void slab_destroy(SlabState* st) { delete st; }      // (null is fine)
 
-// BS threads, C columns per thread (BS * C >= n), R rows per step: R x C values of A, C of x and C doubles of acc must
-// fit the 128 VGPRs of a 1024-thread block, and R * n * sizeof(T) is what a CU has in flight per step.
-template <typename T, int FK, int C, int R, int BS>
+// H rows of A (from the transposed copy) into registers: thread t gets the columns t, t + BS, ... of each ; the rows past
+// the slab are clamped to its last one (a valid address that is in the cache already ; their residual is 0)
+template <typename T, int C, int H>
+__device__ __forceinline__ void slab_load(T (&a)[H][C], T& b_in, const SlabDev& d, const unsigned (&off)[C], int r0,
+                                          int row_end, int tid) {
+  const T* __restrict__ AT = (const T*)d.AT;
+  const T* __restrict__ bv = (const T*)d.b;
+#pragma unroll
+  for (int r = 0; r < H; ++r) {
+    const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, row_end - 1));   // (uniform: keep it scalar)
+    const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
+#pragma unroll
+    for (int k = 0; k < C; ++k) a[r][k] = __builtin_nontemporal_load(&row[off[k]]);   // (read once: past the caches)
+  }
+  b_in = bv[min(r0 + min(tid, H - 1), row_end - 1)];      // (goes out with the loads of A ; every thread, unconverted: a
+                                                          //  branch or a conversion here would wait for all of them)
+}
+
+// the H rows r0 .. r0 + H - 1 held in a: their dots with x, the residuals (thread r finishes row r0 + r), and
+// res[i] * A[i,:] into the column accumulator ; two barriers
+template <typename T, int FK, int C, int H, int BS, bool TIGHT>
+__device__ __forceinline__ void slab_group(const T (&a)[H][C], T b_in, const T (&xr)[C], double (&acc)[C], double bias,
+                                           double& e0, double& e1, int r0, int row_end, double (*wsum)[H], double* res_s,
+                                           int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  double p[H];
+#pragma unroll
+  for (int r = 0; r < H; ++r) p[r] = 0.0;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    T xv = xr[k];
+    if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(xv));        // (x stays in T: its doubles hoisted out of the row
+    const double xd = (double)xv;                                     //  loop would be C more register pairs)
+#pragma unroll
+    for (int r = 0; r < H; ++r) p[r] = fma((double)a[r][k], xd, p[r]);
+    if constexpr (TIGHT && sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);   // (no batch of conversions ahead of their use:
+  }                                                                             //  the other group's rows hold the registers)
+  wave_sum_multi<H>(p);                          // lane l: the wave's sum for row l / (64 / H)
+  if (lane % (64 / H) == 0) wsum[wv][lane / (64 / H)] = p[0];
+  __syncthreads();
+  if (tid < H) {
+    double dot = wsum[0][tid];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w) dot += wsum[w][tid];
+    const int i = r0 + tid;
+    double res = 0.0;
+    if (i < row_end) {
+      const double bi = (double)b_in;
+      const double ax = (double)(T)dot;          // A_x rounded to T like every stored A x
+      if constexpr (FK == APX_F_LEAST_SQUARES) {
+        res = (double)(T)(ax - bi);
+        e0 += res * res;
+      } else {
+        const double logit = ax + bias;
+        if constexpr (sizeof(T) == 4) {          // Float32 data: the link in Float32, as Julia would on Float32 arrays
+          const float lf = (float)logit;         // (and the fp64 exp / log need ~50 more registers than this kernel has)
+          const float ef = 1.0f + expf(-lf);
+          e0 += (double)(((float)bi - 1.0f) * lf - logf(ef));
+          res = (double)(1.0f / ef - (float)bi);
+        } else {
+          const double e = 1.0 + exp(-logit);
+          e0 += (bi - 1.0) * logit - log(e);
+          res = (double)(T)(1.0 / e - bi);
+        }
+        e1 += res;
+      }
+    }
+    res_s[tid] = res;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < H; ++r) {
+    const double rr = res_s[r];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      T av = a[r][k];
+      if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(av));      // convert again here: keeping the doubles of the dot
+      acc[k] = fma((double)av, rr, acc[k]);                           // phase alive would double the registers of A
+    }
+    if constexpr (TIGHT && sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (TIGHT) {                         // the sums are complete HERE: left to itself the compiler sinks these FMAs
+#pragma unroll                                   // towards their next use, past the loads that re-fill a — which then need
+    for (int k = 0; k < C; ++k) asm volatile("" : "+v"(acc[k]));      // registers of their own
+  }
+}
+
+// BS threads, C columns per thread (BS * C >= n), R rows in registers: R x C values of A, C of x and C doubles of acc
+// must fit the 128 VGPRs of a 1024-thread block.  PIPE: the R rows are two groups of R / 2 ; the loads of a group go
+// out as soon as its registers are free and have the other group's dots, barriers and accumulation to arrive in
+// (everything in the loop is unconditional: a branch around a load would make the compiler wait for ALL loads at the join).
+template <typename T, int FK, int C, int R, int BS, bool PIPE>
 __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
-  __shared__ double wsum[BS / 64][R];
-  __shared__ double res_s[R];
+  constexpr int H = PIPE ? R / 2 : R;
+  static_assert(!PIPE || R % 2 == 0, "two groups");
+  __shared__ double wsum[BS / 64][H];
+  __shared__ double res_s[H];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (d.c->done != 0) return;                    // written by an earlier launch: block-uniform
-  const T* __restrict__ AT = (const T*)d.AT;
   const T* __restrict__ X = (const T*)xv;
-  const T* __restrict__ bv = (const T*)d.b;
   T xr[C];                                       // (kept in T: the registers are what limits the row length)
   double acc[C];
   unsigned off[C];                               // 32-bit column offsets: with a uniform row pointer every load of the
@@ -71,68 +161,34 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
   }
   double bias = 0.0;
   if constexpr (FK == APX_F_LOGISTIC) bias = (double)X[d.n - 1];
-  double e0 = 0.0, e1 = 0.0;                     // loss sums of the rows this thread finishes (tid < R)
+  double e0 = 0.0, e1 = 0.0;                     // loss sums of the rows this thread finishes (tid < H)
   const int row_begin = blockIdx.x * d.rows_per_block;
   const int row_end = min(row_begin + d.rows_per_block, d.m);
-  for (int r0 = row_begin; r0 < row_end; r0 += R) {
-    T a[R][C];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, d.m - 1));       // (uniform: keep it scalar)
-      const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
-#pragma unroll
-      for (int k = 0; k < C; ++k) a[r][k] = row[off[k]];
+  if constexpr (!PIPE) {
+    for (int r0 = row_begin; r0 < row_end; r0 += R) {
+      T a[H][C];
+      T b_in;
+      slab_load<T, C, H>(a, b_in, d, off, r0, row_end, tid);
+      slab_group<T, FK, C, H, BS, false>(a, b_in, xr, acc, bias, e0, e1, r0, row_end, wsum, res_s, tid);
     }
-    const double b_in = tid < R ? (double)bv[min(r0 + tid, d.m - 1)] : 0.0;     // (goes out with the loads of A)
-    double p[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      p[r] = 0.0;
-#pragma unroll
-      for (int k = 0; k < C; ++k) p[r] = fma((double)a[r][k], (double)xr[k], p[r]);
-    }
-    wave_sum_multi<R>(p);                        // lane l: the wave's sum for row l / (64 / R)
-    if (lane % (64 / R) == 0) wsum[wv][lane / (64 / R)] = p[0];
-    __syncthreads();
-    if (tid < R) {                               // thread r finishes row r0 + r
-      double dot = wsum[0][tid];
-#pragma unroll
-      for (int w = 1; w < BS / 64; ++w) dot += wsum[w][tid];
-      const int i = r0 + tid;
-      double res = 0.0;
-      if (i < row_end) {
-        const double bi = b_in;
-        const double ax = (double)(T)dot;        // A_x rounded to T like every stored A x
-        if constexpr (FK == APX_F_LEAST_SQUARES) {
-          res = (double)(T)(ax - bi);
-          e0 += res * res;
-        } else {
-          const double logit = ax + bias;
-          if constexpr (sizeof(T) == 4) {        // Float32 data: the link in Float32, as Julia would on Float32 arrays
-            const float lf = (float)logit;       // (and the fp64 exp / log need ~50 more registers than this kernel has)
-            const float ef = 1.0f + expf(-lf);
-            e0 += (double)(((float)bi - 1.0f) * lf - logf(ef));
-            res = (double)(1.0f / ef - (float)bi);
-          } else {
-            const double e = 1.0 + exp(-logit);
-            e0 += (bi - 1.0) * logit - log(e);
-            res = (double)(T)(1.0 / e - bi);
-          }
-          e1 += res;
-        }
-      }
-      res_s[tid] = res;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const double rr = res_s[r];
-#pragma unroll
-      for (int k = 0; k < C; ++k) {
-        T av = a[r][k];
-        if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(av));    // convert again here: keeping the doubles of the dot
-        acc[k] = fma((double)av, rr, acc[k]);                         // phase alive would double the registers of A
-      }
+  } else {
+    T a0[H][C], a1[H][C];
+    T b0, b1;
+    __builtin_amdgcn_sched_barrier(0);
+    slab_load<T, C, H>(a0, b0, d, off, row_begin, row_end, tid);
+    __builtin_amdgcn_sched_barrier(0);           // (in this order: the waits of the loop count the loads issued after a group's)
+    slab_load<T, C, H>(a1, b1, d, off, row_begin + H, row_end, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int r0 = row_begin; r0 < row_end; r0 += R) {
+      slab_group<T, FK, C, H, BS, true>(a0, b0, xr, acc, bias, e0, e1, r0, row_end, wsum, res_s, tid);
+      __builtin_amdgcn_sched_barrier(0);         // (the loads AFTER the accumulation that frees their registers, and
+      slab_load<T, C, H>(a0, b0, d, off, r0 + R, row_end, tid);
+      __builtin_amdgcn_sched_barrier(0);         //  before the other group's dots: hoisted or sunk they cost registers or overlap)
+      slab_group<T, FK, C, H, BS, true>(a1, b1, xr, acc, bias, e0, e1, r0 + H, row_end, wsum, res_s, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      slab_load<T, C, H>(a1, b1, d, off, r0 + R + H, row_end, tid);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
@@ -141,9 +197,9 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
     const int j = tid + k * BS;
     if (j < d.ncols) out[j] = acc[k];
   }
-  // the loss sums of this block: rows r0 + 0 .. R-1 were finished by threads 0 .. R-1 (one wave)
+  // the loss sums of this block: the rows of every group were finished by threads 0 .. H-1 (one wave)
   if (wv == 0) {
-    double ex[2] = {tid < R ? e0 : 0.0, tid < R ? e1 : 0.0};
+    double ex[2] = {tid < H ? e0 : 0.0, tid < H ? e1 : 0.0};
     wave_sum_multi<2>(ex);                       // lane l: ex[l / 32]
     if ((lane & 31) == 0) out[d.ncols + (lane >> 5)] = ex[0];
   }
@@ -259,9 +315,14 @@ static int32_t slab_setup(apx_problem* p) {
 template <typename T, int FK>
 static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
-  if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, 16, 1024>), grid, dim3(1024), 0, q, d, x);
-  else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024>), grid, dim3(1024), 0, q, d, x);
-  else hipLaunchKernelGGL((k_slab_rows<T, FK, 14, (sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2)), 768>), grid, dim3(768), 0, q, d, x);
+  // two groups in flight (PIPE) wherever they fit the registers: every Float32 shape, the Float64 least-squares shapes of
+  // up to 5 columns per thread (measured, one group / two: C3 0.639 / 0.619 ms, 400 000 x 2000 fp32 0.562 / 0.524,
+  // 200 000 x 5000 fp64 1.277 / 1.263 ; with scratch — fp64 at 14 columns, the fp64 logistic link — 0.690 / 0.732, 0.363 / 0.421)
+  constexpr int R14 = sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2);
+  constexpr bool kPipe = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;
+  if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, 16, 1024, kPipe>), grid, dim3(1024), 0, q, d, x);
+  else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024, kPipe>), grid, dim3(1024), 0, q, d, x);
+  else hipLaunchKernelGGL((k_slab_rows<T, FK, 14, R14, 768, (sizeof(T) == 4)>), grid, dim3(768), 0, q, d, x);
   hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kBlock), 0, q, d,
                      st->B, (T*)grad);
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
       const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, d.m - 1));
       const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
-      for (int k = 0; k < C; ++k) a[r][k] = row[off[k]];
+      for (int k = 0; k < C; ++k) a[r][k] = __builtin_nontemporal_load(&row[off[k]]);   // (read once: past the caches)
     }
     // the per-row state of the rows this thread will finish goes out with the loads of A (not behind the dot products)
     double y_in = 0.0, axp_in = 0.0, b_in = 0.0;
