@@ -35,18 +35,100 @@ struct SlabPdState {
 };
 void slab_pd_destroy(SlabPdState* st) { delete st; }
 
-template <typename T, int C, int R, int BS>
+// H rows of A into registers (csrc/slab.hip's slab_load) together with the per-row state of the rows this thread may
+// finish: y, A_x_prev and the shift of h — every thread, unconverted, so that nothing waits for the loads here
+template <typename T, int C, int H>
+__device__ __forceinline__ void slabpd_load(T (&a)[H][C], T& y_in, T& axp_in, T& b_in, const SlabPdDev& d,
+                                            const unsigned (&off)[C], int r0, int row_end, int tid) {
+  const T* __restrict__ AT = (const T*)d.AT;
+#pragma unroll
+  for (int r = 0; r < H; ++r) {
+    const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, row_end - 1));
+    const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
+#pragma unroll
+    for (int k = 0; k < C; ++k) a[r][k] = __builtin_nontemporal_load(&row[off[k]]);   // (read once: past the caches)
+  }
+  const int ic = min(r0 + min(tid, H - 1), row_end - 1);
+  y_in = ((const T*)d.Y)[ic];
+  axp_in = ((const T*)d.AXP)[ic];
+  b_in = d.h.has_shift ? ((const T*)d.h.shift)[ic] : (T)0;
+}
+
+// the H rows r0 .. r0 + H - 1 held in a: A_x, the dual step of each (thread r finishes row r0 + r: :344-347, :360) and
+// y[i] * A[i,:] into the column accumulator ; two barriers
+template <typename T, int C, int H, int BS, bool TIGHT>
+__device__ __forceinline__ void slabpd_group(const T (&a)[H][C], T y_in, T axp_in, T b_in, const T (&xr)[C], double (&acc)[C],
+                                             const SlabPdDev& d, double sigma, double rho, double& e0, double& e1, int r0,
+                                             int row_end, double (*wsum)[(H < 2 ? 2 : H)], double* y_s, int tid) {
+  constexpr int RP = H < 2 ? 2 : H;                // (the multi-value wave sum wants at least two)
+  const int lane = tid & 63, wv = tid >> 6;
+  T* __restrict__ Y = (T*)d.Y;
+  T* __restrict__ AXP = (T*)d.AXP;
+  double p[RP];
+#pragma unroll
+  for (int r = 0; r < RP; ++r) p[r] = 0.0;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    T xv = xr[k];
+    if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(xv));        // (x stays in T: see csrc/slab.hip)
+    const double xd = (double)xv;
+#pragma unroll
+    for (int r = 0; r < H; ++r) p[r] = fma((double)a[r][k], xd, p[r]);
+    if constexpr (TIGHT && sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_sum_multi<RP>(p);                           // lane l: the wave's sum for row l / (64 / RP)
+  if (lane % (64 / RP) == 0) wsum[wv][lane / (64 / RP)] = p[0];
+  __syncthreads();
+  if (tid < H) {                                   // thread r finishes row r0 + r
+    double dot = wsum[0][tid];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w) dot += wsum[w][tid];
+    const int i = r0 + tid;
+    double yn = 0.0;
+    if (i < row_end) {
+      const double ax = (double)(T)dot;                                                   // :335, rounded to T like every stored A x
+      const double b = (double)b_in;
+      const double w = (double)y_in + sigma * ((1.0 + rho) * ax - rho * (double)axp_in);  // :344
+      const T ynt = (T)prox_conj_elem_s<T>(d.h, w, sigma, i, 0.0, b);                     // :345
+      yn = (double)ynt;
+      const double dr = (w - yn) / sigma - ax;                                            // :347
+      e0 += dr * dr;
+      e1 += gval_elem_s<T>(d.h, ax, i, b);
+      Y[i] = ynt;
+      AXP[i] = (T)ax;                                                                     // :360
+    }
+    y_s[tid] = yn;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < H; ++r) {
+    const double yy = y_s[r];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      T av = a[r][k];
+      if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(av));      // (convert again: see csrc/slab.hip)
+      acc[k] = fma((double)av, yy, acc[k]);
+    }
+    if constexpr (TIGHT && sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (TIGHT) {                           // (the sums complete HERE, not sunk past the next loads: csrc/slab.hip)
+#pragma unroll
+    for (int k = 0; k < C; ++k) asm volatile("" : "+v"(acc[k]));
+  }
+}
+
+// PIPE: the R rows as two groups of R / 2 that alternate, one computing while the other's loads arrive (csrc/slab.hip)
+template <typename T, int C, int R, int BS, bool PIPE>
 __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv) {
-  constexpr int RP = R < 2 ? 2 : R;                // (the multi-value wave sum wants a power of two >= 2... and R is one)
+  constexpr int H = PIPE ? R / 2 : R;
+  static_assert(!PIPE || R % 2 == 0, "two groups");
+  constexpr int RP = H < 2 ? 2 : H;
   __shared__ double wsum[BS / 64][RP];
   __shared__ double y_s[RP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (d.c->done != 0) return;                      // written by an earlier launch: block-uniform
   const double sigma = d.c->sigma, rho = d.c->rho; // this iteration's, set by the rule kernel before this launch
-  const T* __restrict__ AT = (const T*)d.AT;
   const T* __restrict__ X = (const T*)xv;
-  T* __restrict__ Y = (T*)d.Y;
-  T* __restrict__ AXP = (T*)d.AXP;
   T xr[C];
   double acc[C];
   unsigned off[C];
@@ -60,65 +142,31 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
   double e0 = 0.0, e1 = 0.0;                       // sum dual_res^2, raw h(A_x) of the rows this thread finishes
   const int row_begin = blockIdx.x * d.rows_per_block;
   const int row_end = min(row_begin + d.rows_per_block, d.m);
-  for (int r0 = row_begin; r0 < row_end; r0 += R) {
-    T a[R][C];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, d.m - 1));
-      const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
-#pragma unroll
-      for (int k = 0; k < C; ++k) a[r][k] = __builtin_nontemporal_load(&row[off[k]]);   // (read once: past the caches)
+  if constexpr (!PIPE) {
+    for (int r0 = row_begin; r0 < row_end; r0 += R) {
+      T a[H][C];
+      T y_in, axp_in, b_in;
+      slabpd_load<T, C, H>(a, y_in, axp_in, b_in, d, off, r0, row_end, tid);
+      slabpd_group<T, C, H, BS, false>(a, y_in, axp_in, b_in, xr, acc, d, sigma, rho, e0, e1, r0, row_end, wsum, y_s, tid);
     }
-    // the per-row state of the rows this thread will finish goes out with the loads of A (not behind the dot products)
-    double y_in = 0.0, axp_in = 0.0, b_in = 0.0;
-    if (tid < R) {
-      const int ic = min(r0 + tid, d.m - 1);
-      y_in = (double)Y[ic];
-      axp_in = (double)AXP[ic];
-      b_in = shift_at<T>(d.h, ic);
-    }
-    double p[RP];
-#pragma unroll
-    for (int r = 0; r < RP; ++r) {
-      p[r] = 0.0;
-      if (r < R) {
-#pragma unroll
-        for (int k = 0; k < C; ++k) p[r] = fma((double)a[r < R ? r : 0][k], (double)xr[k], p[r]);
-      }
-    }
-    wave_sum_multi<RP>(p);                         // lane l: the wave's sum for row l / (64 / RP)
-    if (lane % (64 / RP) == 0) wsum[wv][lane / (64 / RP)] = p[0];
-    __syncthreads();
-    if (tid < R) {                                 // thread r finishes row r0 + r
-      double dot = wsum[0][tid];
-#pragma unroll
-      for (int w = 1; w < BS / 64; ++w) dot += wsum[w][tid];
-      const int i = r0 + tid;
-      double yn = 0.0;
-      if (i < row_end) {
-        const double ax = (double)(T)dot;                                                   // :335, rounded to T like every stored A x
-        const double b = b_in;
-        const double w = y_in + sigma * ((1.0 + rho) * ax - rho * axp_in);                  // :344
-        const T ynt = (T)prox_conj_elem_s<T>(d.h, w, sigma, i, 0.0, b);                     // :345
-        yn = (double)ynt;
-        const double dr = (w - yn) / sigma - ax;                                            // :347
-        e0 += dr * dr;
-        e1 += gval_elem_s<T>(d.h, ax, i, b);
-        Y[i] = ynt;
-        AXP[i] = (T)ax;                                                                     // :360
-      }
-      y_s[tid] = yn;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const double yy = y_s[r];
-#pragma unroll
-      for (int k = 0; k < C; ++k) {
-        T av = a[r][k];
-        if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(av));    // (convert again: see csrc/slab.hip)
-        acc[k] = fma((double)av, yy, acc[k]);
-      }
+  } else {
+    T a0[H][C], a1[H][C];
+    T y0, y1, p0, p1, b0, b1;
+    __builtin_amdgcn_sched_barrier(0);
+    slabpd_load<T, C, H>(a0, y0, p0, b0, d, off, row_begin, row_end, tid);
+    __builtin_amdgcn_sched_barrier(0);             // (in this order: the waits of the loop count the loads issued after a group's)
+    slabpd_load<T, C, H>(a1, y1, p1, b1, d, off, row_begin + H, row_end, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int r0 = row_begin; r0 < row_end; r0 += R) {
+      slabpd_group<T, C, H, BS, true>(a0, y0, p0, b0, xr, acc, d, sigma, rho, e0, e1, r0, row_end, wsum, y_s, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      slabpd_load<T, C, H>(a0, y0, p0, b0, d, off, r0 + R, row_end, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      slabpd_group<T, C, H, BS, true>(a1, y1, p1, b1, xr, acc, d, sigma, rho, e0, e1, r0 + H, row_end, wsum, y_s, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      slabpd_load<T, C, H>(a1, y1, p1, b1, d, off, r0 + R + H, row_end, tid);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
@@ -127,8 +175,8 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
     const int j = tid + k * BS;
     if (j < d.n) out[j] = acc[k];
   }
-  if (wv == 0) {                                   // the rows were finished by threads 0 .. R-1 (one wave)
-    double ex[2] = {tid < R ? e0 : 0.0, tid < R ? e1 : 0.0};
+  if (wv == 0) {                                   // the rows were finished by threads 0 .. H-1 (one wave)
+    double ex[2] = {tid < H ? e0 : 0.0, tid < H ? e1 : 0.0};
     wave_sum_multi<2>(ex);                         // lane l: ex[l / 32]
     if ((lane & 31) == 0) out[d.n + (lane >> 5)] = ex[0];
   }
@@ -243,9 +291,12 @@ static void slab_pd_launch_t(const SlabPdState* st, const SlabPdDev& d, const vo
                              hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   constexpr bool f32 = sizeof(T) == 4;
-  if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024>), grid, dim3(1024), 0, q, d, x);
-  else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024>), grid, dim3(1024), 0, q, d, x);
-  else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768>), grid, dim3(768), 0, q, d, x);
+  // two row groups in flight only where it measured faster here — Float32 at two columns per thread (400 000 x 2000: 0.572 ->
+  // 0.552 ms) ; with the per-row state of y and A_x_prev on top of the rows, the other shapes lose (200 000 x 5000 fp64
+  // 1.31 -> 1.38, 100 000 x 10 000 fp32 0.68 -> 0.71)
+  if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32>), grid, dim3(1024), 0, q, d, x);
+  else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false>), grid, dim3(1024), 0, q, d, x);
+  else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false>), grid, dim3(768), 0, q, d, x);
   hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kBlock), 0, q, d,
                      st->B, (T*)aty, recs, rec_cap);
 }
