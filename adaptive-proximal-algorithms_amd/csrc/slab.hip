@@ -61,7 +61,8 @@ __device__ __forceinline__ void slab_load(T (&a)[H][C], T& b_in, const SlabDev& 
     const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, row_end - 1));   // (uniform: keep it scalar)
     const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
-    for (int k = 0; k < C; ++k) a[r][k] = __builtin_nontemporal_load(&row[off[k]]);   // (read once: past the caches)
+    for (int k = 0; k < C; ++k)                  // scalar row base + 32-bit BYTE offset: one address register per load
+      a[r][k] = __builtin_nontemporal_load((const T*)((const char*)row + off[k]));    // (read once: past the caches)
   }
   b_in = bv[min(r0 + min(tid, H - 1), row_end - 1)];      // (goes out with the loads of A ; every thread, unconverted: a
                                                           //  branch or a conversion here would wait for all of them)
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
 #pragma unroll                                   // step is "scalar base + vector offset", no 64-bit address per load
   for (int k = 0; k < C; ++k) {
     const int j = tid + k * BS;
-    off[k] = (unsigned)min(j, d.ncols - 1);      // clamped: a valid address, weight 0
+    off[k] = (unsigned)min(j, d.ncols - 1) * (unsigned)sizeof(T);     // in bytes ; clamped: a valid address, weight 0
     xr[k] = j < d.ncols ? X[j] : (T)0;
     acc[k] = 0.0;
   }

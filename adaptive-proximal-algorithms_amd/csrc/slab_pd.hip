@@ -46,7 +46,8 @@ __device__ __forceinline__ void slabpd_load(T (&a)[H][C], T& y_in, T& axp_in, T&
     const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, row_end - 1));
     const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
-    for (int k = 0; k < C; ++k) a[r][k] = __builtin_nontemporal_load(&row[off[k]]);   // (read once: past the caches)
+    for (int k = 0; k < C; ++k)                  // scalar row base + 32-bit BYTE offset: one address register per load
+      a[r][k] = __builtin_nontemporal_load((const T*)((const char*)row + off[k]));    // (read once: past the caches)
   }
   const int ic = min(r0 + min(tid, H - 1), row_end - 1);
   y_in = ((const T*)d.Y)[ic];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const int j = tid + k * BS;
-    off[k] = (unsigned)min(j, d.n - 1);            // clamped: a valid address, weight 0
+    off[k] = (unsigned)min(j, d.n - 1) * (unsigned)sizeof(T);         // in bytes ; clamped: a valid address, weight 0
     xr[k] = j < d.n ? X[j] : (T)0;
     acc[k] = 0.0;
   }
