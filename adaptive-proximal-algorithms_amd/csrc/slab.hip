@@ -46,12 +46,13 @@ struct SlabState {
   DBuf part;
   SlabDev dev{};
   int B = 0, cpt = 0, bs = 0;     // blocks ; columns per thread ; threads per block
+  bool pipe = true, nt = true;    // two row groups in flight ; non-temporal loads of A
 };
 void slab_destroy(SlabState* st) { delete st; }      // (null is fine)
 
 // H rows of A (from the transposed copy) into registers: thread t gets the columns t, t + BS, ... of each ; the rows past
 // the slab are clamped to its last one (a valid address that is in the cache already ; their residual is 0)
-template <typename T, int C, int H>
+template <typename T, int C, int H, bool NT>
 __device__ __forceinline__ void slab_load(T (&a)[H][C], T& b_in, const SlabDev& d, const unsigned (&off)[C], int r0,
                                           int row_end, int tid) {
   const T* __restrict__ AT = (const T*)d.AT;
@@ -62,7 +63,8 @@ __device__ __forceinline__ void slab_load(T (&a)[H][C], T& b_in, const SlabDev& 
     const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
     for (int k = 0; k < C; ++k)                  // scalar row base + 32-bit BYTE offset: one address register per load
-      a[r][k] = __builtin_nontemporal_load((const T*)((const char*)row + off[k]));    // (read once: past the caches)
+      a[r][k] = NT ? __builtin_nontemporal_load((const T*)((const char*)row + off[k]))   // (read once: past the caches,
+                   : *(const T*)((const char*)row + off[k]);                             //  unless A fits the Infinity Cache)
   }
   b_in = bv[min(r0 + min(tid, H - 1), row_end - 1)];      // (goes out with the loads of A ; every thread, unconverted: a
                                                           //  branch or a conversion here would wait for all of them)
@@ -141,7 +143,7 @@ __device__ __forceinline__ void slab_group(const T (&a)[H][C], T b_in, const T (
 // must fit the 128 VGPRs of a 1024-thread block.  PIPE: the R rows are two groups of R / 2 ; the loads of a group go
 // out as soon as its registers are free and have the other group's dots, barriers and accumulation to arrive in
 // (everything in the loop is unconditional: a branch around a load would make the compiler wait for ALL loads at the join).
-template <typename T, int FK, int C, int R, int BS, bool PIPE>
+template <typename T, int FK, int C, int R, int BS, bool PIPE, bool NT>
 __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
   constexpr int H = PIPE ? R / 2 : R;
   static_assert(!PIPE || R % 2 == 0, "two groups");
@@ -169,26 +171,26 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
     for (int r0 = row_begin; r0 < row_end; r0 += R) {
       T a[H][C];
       T b_in;
-      slab_load<T, C, H>(a, b_in, d, off, r0, row_end, tid);
+      slab_load<T, C, H, NT>(a, b_in, d, off, r0, row_end, tid);
       slab_group<T, FK, C, H, BS, false>(a, b_in, xr, acc, bias, e0, e1, r0, row_end, wsum, res_s, tid);
     }
   } else {
     T a0[H][C], a1[H][C];
     T b0, b1;
     __builtin_amdgcn_sched_barrier(0);
-    slab_load<T, C, H>(a0, b0, d, off, row_begin, row_end, tid);
+    slab_load<T, C, H, NT>(a0, b0, d, off, row_begin, row_end, tid);
     __builtin_amdgcn_sched_barrier(0);           // (in this order: the waits of the loop count the loads issued after a group's)
-    slab_load<T, C, H>(a1, b1, d, off, row_begin + H, row_end, tid);
+    slab_load<T, C, H, NT>(a1, b1, d, off, row_begin + H, row_end, tid);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int r0 = row_begin; r0 < row_end; r0 += R) {
       slab_group<T, FK, C, H, BS, true>(a0, b0, xr, acc, bias, e0, e1, r0, row_end, wsum, res_s, tid);
       __builtin_amdgcn_sched_barrier(0);         // (the loads AFTER the accumulation that frees their registers, and
-      slab_load<T, C, H>(a0, b0, d, off, r0 + R, row_end, tid);
+      slab_load<T, C, H, NT>(a0, b0, d, off, r0 + R, row_end, tid);
       __builtin_amdgcn_sched_barrier(0);         //  before the other group's dots: hoisted or sunk they cost registers or overlap)
       slab_group<T, FK, C, H, BS, true>(a1, b1, xr, acc, bias, e0, e1, r0 + H, row_end, wsum, res_s, tid);
       __builtin_amdgcn_sched_barrier(0);
-      slab_load<T, C, H>(a1, b1, d, off, r0 + R + H, row_end, tid);
+      slab_load<T, C, H, NT>(a1, b1, d, off, r0 + R + H, row_end, tid);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -308,22 +310,40 @@ static int32_t slab_setup(apx_problem* p) {
   APX_TRY(st->part.alloc_zero((size_t)B * d.ldpart * sizeof(double), ctx->stream));
   d.part = (double*)st->part.p;
   d.c = p->ctrl();
+  // measured (tools/slab_bench.py threshold, profiles/r01g_one_pass_variants.md): a matrix of up to 256 MB is partly
+  // served by the Infinity Cache from one iteration to the next, and non-temporal loads forgo that (256 MB fp32: 81 vs
+  // 87 us ; from 512 MB on they win, 121 vs 130) ; two row groups in flight pay from ~16 steps per block on (their
+  // prologue and the doubled barrier count cost more than the overlap gains on a short slab)
+  st->nt = (int64_t)A->m * A->n * (int64_t)dtype_size(p->dtype) >= ((int64_t)384 << 20);
+  const int rows_per_step = st->cpt == 2 ? 16 : kSlabRows;
+  st->pipe = rpb / rows_per_step >= 16;
   st->dev = d;
   p->slab = st.release();
   return APX_OK;
 }
 
+// the variant of the row kernel for this matrix (SlabState::pipe, ::nt, chosen at setup)
+template <typename T, int FK, int C, int R, int BS, bool PIPE_OK>
+static void slab_rows_launch(const SlabState* st, dim3 grid, hipStream_t q, const SlabDev& d, const void* x) {
+  if constexpr (PIPE_OK) {
+    if (st->pipe) {
+      if (st->nt) hipLaunchKernelGGL((k_slab_rows<T, FK, C, R, BS, true, true>), grid, dim3(BS), 0, q, d, x);
+      else hipLaunchKernelGGL((k_slab_rows<T, FK, C, R, BS, true, false>), grid, dim3(BS), 0, q, d, x);
+      return;
+    }
+  }
+  if (st->nt) hipLaunchKernelGGL((k_slab_rows<T, FK, C, R, BS, false, true>), grid, dim3(BS), 0, q, d, x);
+  else hipLaunchKernelGGL((k_slab_rows<T, FK, C, R, BS, false, false>), grid, dim3(BS), 0, q, d, x);
+}
+
 template <typename T, int FK>
 static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
-  // two groups in flight (PIPE) wherever they fit the registers: every Float32 shape, the Float64 least-squares shapes of
-  // up to 5 columns per thread (measured, one group / two: C3 0.639 / 0.619 ms, 400 000 x 2000 fp32 0.562 / 0.524,
-  // 200 000 x 5000 fp64 1.277 / 1.263 ; with scratch — fp64 at 14 columns, the fp64 logistic link — 0.690 / 0.732, 0.363 / 0.421)
   constexpr int R14 = sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2);
-  constexpr bool kPipe = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;
-  if (st->cpt == 2) hipLaunchKernelGGL((k_slab_rows<T, FK, 2, 16, 1024, kPipe>), grid, dim3(1024), 0, q, d, x);
-  else if (st->cpt == 5) hipLaunchKernelGGL((k_slab_rows<T, FK, 5, kSlabRows, 1024, kPipe>), grid, dim3(1024), 0, q, d, x);
-  else hipLaunchKernelGGL((k_slab_rows<T, FK, 14, R14, 768, (sizeof(T) == 4)>), grid, dim3(768), 0, q, d, x);
+  constexpr bool kPipeOk = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;       // (the others spill as two groups)
+  if (st->cpt == 2) slab_rows_launch<T, FK, 2, 16, 1024, kPipeOk>(st, grid, q, d, x);
+  else if (st->cpt == 5) slab_rows_launch<T, FK, 5, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
+  else slab_rows_launch<T, FK, 14, R14, 768, (sizeof(T) == 4)>(st, grid, q, d, x);
   hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kBlock), 0, q, d,
                      st->B, (T*)grad);
 }

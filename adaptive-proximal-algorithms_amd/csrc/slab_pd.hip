@@ -32,12 +32,13 @@ struct SlabPdState {
   DBuf part;
   SlabPdDev dev{};
   int B = 0, cpt = 0, bs = 0, rows = 0;
+  bool nt = true;         // non-temporal loads of A (a matrix beyond the Infinity Cache)
 };
 void slab_pd_destroy(SlabPdState* st) { delete st; }
 
 // H rows of A into registers (csrc/slab.hip's slab_load) together with the per-row state of the rows this thread may
 // finish: y, A_x_prev and the shift of h — every thread, unconverted, so that nothing waits for the loads here
-template <typename T, int C, int H>
+template <typename T, int C, int H, bool NT>
 __device__ __forceinline__ void slabpd_load(T (&a)[H][C], T& y_in, T& axp_in, T& b_in, const SlabPdDev& d,
                                             const unsigned (&off)[C], int r0, int row_end, int tid) {
   const T* __restrict__ AT = (const T*)d.AT;
@@ -47,7 +48,8 @@ __device__ __forceinline__ void slabpd_load(T (&a)[H][C], T& y_in, T& axp_in, T&
     const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
     for (int k = 0; k < C; ++k)                  // scalar row base + 32-bit BYTE offset: one address register per load
-      a[r][k] = __builtin_nontemporal_load((const T*)((const char*)row + off[k]));    // (read once: past the caches)
+      a[r][k] = NT ? __builtin_nontemporal_load((const T*)((const char*)row + off[k]))   // (read once: past the caches,
+                   : *(const T*)((const char*)row + off[k]);                             //  unless A fits the Infinity Cache)
   }
   const int ic = min(r0 + min(tid, H - 1), row_end - 1);
   y_in = ((const T*)d.Y)[ic];
@@ -119,7 +121,7 @@ __device__ __forceinline__ void slabpd_group(const T (&a)[H][C], T y_in, T axp_i
 }
 
 // PIPE: the R rows as two groups of R / 2 that alternate, one computing while the other's loads arrive (csrc/slab.hip)
-template <typename T, int C, int R, int BS, bool PIPE>
+template <typename T, int C, int R, int BS, bool PIPE, bool NT>
 __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv) {
   constexpr int H = PIPE ? R / 2 : R;
   static_assert(!PIPE || R % 2 == 0, "two groups");
@@ -147,26 +149,26 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
     for (int r0 = row_begin; r0 < row_end; r0 += R) {
       T a[H][C];
       T y_in, axp_in, b_in;
-      slabpd_load<T, C, H>(a, y_in, axp_in, b_in, d, off, r0, row_end, tid);
+      slabpd_load<T, C, H, NT>(a, y_in, axp_in, b_in, d, off, r0, row_end, tid);
       slabpd_group<T, C, H, BS, false>(a, y_in, axp_in, b_in, xr, acc, d, sigma, rho, e0, e1, r0, row_end, wsum, y_s, tid);
     }
   } else {
     T a0[H][C], a1[H][C];
     T y0, y1, p0, p1, b0, b1;
     __builtin_amdgcn_sched_barrier(0);
-    slabpd_load<T, C, H>(a0, y0, p0, b0, d, off, row_begin, row_end, tid);
+    slabpd_load<T, C, H, NT>(a0, y0, p0, b0, d, off, row_begin, row_end, tid);
     __builtin_amdgcn_sched_barrier(0);             // (in this order: the waits of the loop count the loads issued after a group's)
-    slabpd_load<T, C, H>(a1, y1, p1, b1, d, off, row_begin + H, row_end, tid);
+    slabpd_load<T, C, H, NT>(a1, y1, p1, b1, d, off, row_begin + H, row_end, tid);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int r0 = row_begin; r0 < row_end; r0 += R) {
       slabpd_group<T, C, H, BS, true>(a0, y0, p0, b0, xr, acc, d, sigma, rho, e0, e1, r0, row_end, wsum, y_s, tid);
       __builtin_amdgcn_sched_barrier(0);
-      slabpd_load<T, C, H>(a0, y0, p0, b0, d, off, r0 + R, row_end, tid);
+      slabpd_load<T, C, H, NT>(a0, y0, p0, b0, d, off, r0 + R, row_end, tid);
       __builtin_amdgcn_sched_barrier(0);
       slabpd_group<T, C, H, BS, true>(a1, y1, p1, b1, xr, acc, d, sigma, rho, e0, e1, r0 + H, row_end, wsum, y_s, tid);
       __builtin_amdgcn_sched_barrier(0);
-      slabpd_load<T, C, H>(a1, y1, p1, b1, d, off, r0 + R + H, row_end, tid);
+      slabpd_load<T, C, H, NT>(a1, y1, p1, b1, d, off, r0 + R + H, row_end, tid);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -282,6 +284,7 @@ int32_t slab_pd_setup(apx_solver* s) {
   d.part = (double*)st->part.p;
   d.c = p->ctrl();
   d.h = p->hd;
+  st->nt = (int64_t)A->m * A->n * (int64_t)dtype_size(p->dtype) >= ((int64_t)384 << 20);     // (csrc/slab.hip: measured)
   st->dev = d;
   s->slab_pd = st.release();
   return APX_OK;
@@ -295,9 +298,19 @@ static void slab_pd_launch_t(const SlabPdState* st, const SlabPdDev& d, const vo
   // two row groups in flight only where it measured faster here — Float32 at two columns per thread (400 000 x 2000: 0.572 ->
   // 0.552 ms) ; with the per-row state of y and A_x_prev on top of the rows, the other shapes lose (200 000 x 5000 fp64
   // 1.31 -> 1.38, 100 000 x 10 000 fp32 0.68 -> 0.71)
-  if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32>), grid, dim3(1024), 0, q, d, x);
-  else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false>), grid, dim3(1024), 0, q, d, x);
-  else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false>), grid, dim3(768), 0, q, d, x);
+  // (from ~16 steps per block on, as in csrc/slab.hip ; non-temporal loads for a matrix beyond the Infinity Cache: st->nt)
+  const bool pipe = f32 && d.rows_per_block / 16 >= 16;
+  if (st->nt) {
+    if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, true>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
+    else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, true>), grid, dim3(768), 0, q, d, x);
+  } else {
+    if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, false>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
+    else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, false>), grid, dim3(768), 0, q, d, x);
+  }
   hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kBlock), 0, q, d,
                      st->B, (T*)aty, recs, rec_cap);
 }

@@ -28,7 +28,12 @@ def _rel(a, b):
                                                 (4101, 8000, True, np.float64),       # ... logistic fp64: one row per step
                                                 (9000, 1900, True, np.float32),
                                                 (4099, 10239, True, np.float32),      # 10 columns per thread (fp32 only)
-                                                (4100, 10240, False, np.float32)])
+                                                (4100, 10240, False, np.float32),
+                                                # long slabs (>= 16 steps per block): two row groups in flight
+                                                (140000, 200, False, np.float32),
+                                                (140000, 300, False, np.float64),
+                                                (20000, 2500, True, np.float32),
+                                                (17000, 6000, False, np.float32)])    # ... and > 384 MB: non-temporal loads
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
@@ -138,7 +143,9 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              (4099, 2100, "tbox", np.float64),     # 5
                                              (4097, 9000, "tl1", np.float64),      # 14, two rows per step
                                              (4100, 10752, "tl1", np.float32),     # 14, four rows per step
-                                             (9001, 1900, "tbox", np.float32)])
+                                             (9001, 1900, "tbox", np.float32),
+                                             (140000, 200, "tl1", np.float32),     # long slabs: two row groups in flight
+                                             (17000, 6000, "tl1", np.float32)])    # > 384 MB: non-temporal loads
 def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))

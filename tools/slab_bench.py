@@ -12,8 +12,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import adaprox_amd as apx  # noqa: E402
 
 
-def run(label, m, n, dtype, logistic, one_pass, iters=60):
+def run(label, m, n, dtype, logistic, one_pass, iters=60, threshold=None):
     ctx = apx.Context(0)
+    if threshold is not None:
+        ctx.one_pass_threshold(threshold)
     ctx.fused_small(one_pass)                 # the one-pass kernel belongs to the same execution policy
     A = apx.DeviceMatrix.uniform(m, n, seed=1, dtype=dtype, ctx=ctx)
     A.build_transpose()
@@ -43,7 +45,18 @@ def run(label, m, n, dtype, logistic, one_pass, iters=60):
     A.free()
 
 
+def threshold_sweep():
+    """`python tools/slab_bench.py threshold`: where one pass starts to pay (apx_ctx_one_pass_threshold's default)."""
+    for m, n in ((8300, 1024), (16384, 1024), (24576, 1024), (32768, 1024), (8300, 4096), (16384, 4096), (16384, 8192)):
+        for dt in (np.float64, np.float32):
+            label = "lasso %dx%d %s (%d MB)" % (m, n, np.dtype(dt).name, m * n * np.dtype(dt).itemsize >> 20)
+            for one_pass in (True, False):
+                run(label, m, n, dt, False, one_pass, iters=200, threshold=1 << 20)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "threshold":
+        return threshold_sweep()
     for label, m, n, dt, lg in (("C3 logistic 100000x10000 fp32", 100_000, 10_000, np.float32, True),
                                 ("lasso 200000x5000 fp64", 200_000, 5000, np.float64, False),
                                 ("lasso 50000x10000 fp64", 50_000, 10_000, np.float64, False),
