@@ -15,7 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadaprox_hip.so")
 
 # ---- enums (include/adaprox_hip.h) ---------------------------------------------------
-APX_OK, APX_ERR_INVALID, APX_ERR_HIP, APX_ERR_UNSUPPORTED, APX_ERR_DOMAIN, APX_ERR_CALLBACK = range(6)
+APX_OK, APX_ERR_INVALID, APX_ERR_HIP, APX_ERR_UNSUPPORTED, APX_ERR_DOMAIN, APX_ERR_CALLBACK, APX_ERR_COMM = range(7)
+APX_ABI_VERSION = 2
+APX_COMM_ID_BYTES = 128
 APX_FLAG_TINY_GAMMA, APX_FLAG_NAN_GAMMA, APX_FLAG_DOMAIN = 1, 2, 4
 APX_F64, APX_F32 = 0, 1
 APX_F_ZERO, APX_F_LEAST_SQUARES, APX_F_LOGISTIC, APX_F_CALLBACK, APX_F_QUADRATIC = range(5)
@@ -41,7 +43,8 @@ class ProblemDesc(C.Structure):
                 ("A_f", c_void_p), ("b", c_void_p), ("n_total_rows", c_int64),
                 ("eval_cb", EVAL_FN), ("pullback_cb", PULLBACK_FN), ("cb_user", c_void_p),
                 ("g", ProxDesc), ("h", ProxDesc), ("A_lin", c_void_p),
-                ("allreduce", ALLREDUCE_FN), ("allreduce_user", c_void_p), ("shard_mask", c_int32), ("_pad2", c_int32)]
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", c_void_p), ("shard_mask", c_int32), ("_pad2", c_int32),
+                ("comm", c_void_p)]
 
 
 class Rule(C.Structure):
@@ -91,6 +94,16 @@ PROTOTYPES = {
     "apx_ctx_exploit_sparsity": (c_int32, [c_void_p, c_int32]),
     "apx_ctx_fused_small": (c_int32, [c_void_p, c_int32]),
     "apx_ctx_one_pass_threshold": (c_int32, [c_void_p, c_int64]),
+    "apx_ctx_auto_transpose": (c_int32, [c_void_p, c_int32]),
+    "apx_comm_unique_id": (c_int32, [c_void_p]),
+    "apx_comm_init_rank": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, _P(c_void_p)]),
+    "apx_comm_init_all": (c_int32, [_P(c_void_p), c_int32, _P(c_void_p)]),
+    "apx_comm_info": (c_int32, [c_void_p, _P(c_int32), _P(c_int32)]),
+    "apx_comm_allreduce_host": (c_int32, [c_void_p, _P(c_double), c_int64]),
+    "apx_comm_destroy": (c_int32, [c_void_p]),
+    "apx_comm_library": (C.c_char_p, []),
+    "apx_adaptive_primal_dual_group": (c_int32, [c_int32, _P(c_void_p), _P(Rule), c_void_p, _P(c_void_p), c_double,
+                                                 c_int64, _P(SolveOpts), c_void_p, _P(c_void_p), _P(Result)]),
     "apx_gemv_variant_count": (c_int32, [c_int32]),
     "apx_gemv_variant_name": (C.c_char_p, [c_int32, c_int32]),
     "apx_matrix_create": (c_int32, [c_void_p, c_int64, c_int64, c_int32, _P(c_void_p)]),
@@ -98,6 +111,7 @@ PROTOTYPES = {
     "apx_matrix_upload_sparse": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                            c_int32, _P(c_void_p)]),
     "apx_matrix_build_transpose": (c_int32, [c_void_p]),
+    "apx_matrix_drop_transpose": (c_int32, [c_void_p]),
     "apx_matrix_download": (c_int32, [c_void_p, c_void_p, c_int64]),
     "apx_matrix_free": (c_int32, [c_void_p]),
     "apx_matrix_shape": (c_int32, [c_void_p, _P(c_int64), _P(c_int64), _P(c_int32)]),
@@ -169,6 +183,9 @@ def _share_hip_runtime_with_torch() -> None:
         return
     if spec is None or not spec.submodule_search_locations:
         return
+    # (librccl is NOT mapped here: mapped before torch maps its own, it aborts the process at exit — `double free or
+    # corruption` from the exit handlers; the library binds RCCL at its first apx_comm_* call, csrc/comm.hip, and
+    # sharded.Comm imports torch first when it is installed so that the pair in the process is torch's own)
     cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
     if os.path.exists(cand):
         try:
@@ -193,7 +210,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.apx_abi_version() != 1:
+    if lib.apx_abi_version() != APX_ABI_VERSION:
         raise ImportError("libadaprox_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -96,6 +96,12 @@ class Context:
         L.check(self._lib.apx_ctx_one_pass_threshold(self._h, int(min_bytes)))
         return self
 
+    def auto_transpose(self, enable: bool = True):
+        """Default on: a one-pass-eligible problem gives its matrix (up to 16 GB) the transposed copy by itself;
+        off: only where the caller built it (DeviceMatrix.build_transpose)."""
+        L.check(self._lib.apx_ctx_auto_transpose(self._h, 1 if enable else 0))
+        return self
+
     def fused_small(self, enable: bool = True):
         """Default on: small dense proximal-gradient problems run as two kernels per iteration (csrc/small.hip)."""
         L.check(self._lib.apx_ctx_fused_small(self._h, 1 if enable else 0))
@@ -213,6 +219,11 @@ class DeviceMatrix:
     def build_transpose(self):
         """Optional dual layout: a transposed copy in HBM so that `A*x` streams contiguously too."""
         L.check(self._lib.apx_matrix_build_transpose(self._h))
+        return self
+
+    def drop_transpose(self):
+        """Releases the transposed copy (problems on this matrix go back to the two GEMV passes)."""
+        L.check(self._lib.apx_matrix_drop_transpose(self._h))
         return self
 
     def to_numpy(self) -> np.ndarray:
@@ -726,8 +737,7 @@ class _Problem:
         d = L.ProblemDesc()
         d.dtype = _code(dtype)
         if lin_allreduce is not None:        # rows of A (hence y, A_x) are sharded over ranks
-            self._ar = L.ALLREDUCE_FN(self._wrap_allreduce(lin_allreduce))
-            d.allreduce = self._ar
+            self._set_collective(d, lin_allreduce)
             d.shard_mask = 2
         self._cb_exc: Optional[BaseException] = None
         if isinstance(fu, (LinearLeastSquares, LogisticLoss, Quadratic)):
@@ -743,8 +753,7 @@ class _Problem:
             self.keep += [fu.A, fu.b]
             if fu.allreduce is not None:
                 if lin_allreduce is None:
-                    self._ar = L.ALLREDUCE_FN(self._wrap_allreduce(fu.allreduce))
-                    d.allreduce = self._ar
+                    self._set_collective(d, fu.allreduce)
                 d.shard_mask |= 1            # rows of the matrix of f are sharded (one hook serves both)
         elif isinstance(fu, Zero):
             d.f_kind = L.APX_F_ZERO
@@ -817,6 +826,17 @@ class _Problem:
         except BaseException as e:
             self._cb_exc = e
             return 1
+
+    def _set_collective(self, d, how):
+        """``how``: a sharded.Comm (RCCL inside the library: the loop enqueues ncclAllReduce itself) or a
+        callable ``(buf, count, dtype, stream)`` — the callback transport of the CPU / shared-GPU tests."""
+        from .sharded import Comm
+        if isinstance(how, Comm):
+            d.comm = how._h
+            self.keep.append(how)
+        else:
+            self._ar = L.ALLREDUCE_FN(self._wrap_allreduce(how))
+            d.allreduce = self._ar
 
     def _wrap_allreduce(self, fn):
         def cb(user, buf, count, dtype, stream):
@@ -994,8 +1014,9 @@ def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=
 
 def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=1.0, delta=1e-8, Theta=1.2, r=2,
                                     R=0.95, tol=1e-5, maxit=10_000, name="AdaPDM+", record: Record = None,
-                                    ctx: Optional[Context] = None, max_linesearch: int = 0):
-    """src/AdaProx.jl:463-550 ("AdaPDM+").  Returns (x, y, it)."""
+                                    ctx: Optional[Context] = None, max_linesearch: int = 0, A_allreduce=None):
+    """src/AdaProx.jl:463-550 ("AdaPDM+").  Returns (x, y, it).  (``A_allreduce``: a row-sharded A is refused by the
+    library — only the generic loop has the all-reduces for it.)"""
     maxit = int(math.floor(maxit))
     # the @assert's of :481-488 (AssertionError in Julia)
     assert eta > 0, "eta must be positive"
@@ -1004,7 +1025,7 @@ def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=
         assert gamma <= 1 / (2 * Theta * t * eta), "gamma is too large"
     dtype = _problem_dtype(x, f, A)
     x = _as_vec(x, dtype)
-    prob = _Problem(f, g, h, A, dtype, ctx).finalize(x.size)
+    prob = _Problem(f, g, h, A, dtype, ctx, lin_allreduce=A_allreduce).finalize(x.size)
     try:
         yv = _as_vec(y, dtype)
         if yv.size != prob._d.m:

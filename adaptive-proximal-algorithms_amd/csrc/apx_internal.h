@@ -95,6 +95,7 @@ struct apx_ctx {
   // opt-in: A*x streams only the columns with x_j != 0 (apx_ctx_exploit_sparsity)
   bool fused_small = true;       // small dense proximal-gradient problems run as two kernels per iteration (small.hip)
   int64_t one_pass_min_bytes = 192ll << 20;   // slab.hip / slab_pd.hip take matrices from this size on (apx_ctx_one_pass_threshold)
+  bool auto_transpose = true;    // a one-pass-eligible problem may give its matrix the transposed copy (apx_ctx_auto_transpose)
   bool skip_zero_cols = false;
   int32_t* nz_idx = nullptr;     // compacted column indices + [nz_cap] = count
   int64_t nz_cap = 0;
@@ -136,6 +137,12 @@ namespace apx {
 
 void ctx_retain(apx_ctx* ctx);
 void ctx_release(apx_ctx* ctx);
+// true once exit() has begun to run this library's exit handlers: the destroy entry points then leave everything to the
+// dying process (the HIP runtime may be torn down already — matrix.hip)
+bool process_exiting();
+// comm.hip: in-place sum over the ranks of `count` elements at the device pointer buf, on the context's stream
+int32_t comm_allreduce(apx_comm* c, void* buf, int64_t count, int32_t dtype);
+apx_ctx* comm_ctx(const apx_comm* c);
 
 // ---- launchers implemented in gemv.hip -------------------------------------------
 int32_t ensure_part(apx_ctx* ctx, size_t bytes);

@@ -41,8 +41,13 @@ int32_t begin(apx_problem* p, int64_t maxit, bool need_lin) {
   APX_REQUIRE(p != nullptr, "problem is NULL");
   APX_REQUIRE(p->active == nullptr, "a solver is active on this problem");
   APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
-  if (need_lin) APX_REQUIRE(p->A_lin != nullptr, "this method needs a linear operator A");
-  else APX_REQUIRE(p->A_lin == nullptr, "this method takes no linear operator (A = 0)");
+  if (need_lin) {
+    APX_REQUIRE(p->A_lin != nullptr, "this method needs a linear operator A");
+    // (only the generic loop all-reduces A'y, the dual residual and h(Ax) over row shards of A_lin: solver.hip enqueue_iteration)
+    if (p->lin_sharded)
+      return fail(APX_ERR_UNSUPPORTED, "malitsky_pock does not take a row-sharded linear operator (shard_mask bit 1): "
+                                       "use adaptive_primal_dual / condat_vu");
+  } else APX_REQUIRE(p->A_lin == nullptr, "this method takes no linear operator (A = 0)");
   APX_HIP(hipSetDevice(p->ctx->device));
   apx_rule r{};
   r.kind = APX_RULE_FIXED;
@@ -100,8 +105,10 @@ int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0,
   if (small_bt_eligible(p)) return small_bt_run(p, true, x0, gamma0, 1.0, shrink, tol, maxit, opts, x_out, res);
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es;
-  DBuf bx, bz0, bz1, bz2;
-  for (DBuf* b : {&bx, &bz0, &bz1, &bz2}) APX_TRY(b->alloc_zero(nb, ctx->stream));
+  // bgx: grad_x of :69 / :81, private to the loop (an evaluation at a trial point may leave ITS gradient in p->grad:
+  // csrc/slab.hip forms f and grad f in one pass; the shrink trials of :38-46 still need grad f(x))
+  DBuf bx, bz0, bz1, bz2, bgx;
+  for (DBuf* b : {&bx, &bz0, &bz1, &bz2, &bgx}) APX_TRY(b->alloc_zero(nb, ctx->stream));
   void *x = bx.p, *z = bz0.p, *zprev = bz1.p, *znew = bz2.p;
   APX_TRY(h2d(ctx, x, x0, (size_t)p->n * es));
   APX_HIP(hipMemcpyAsync(z, x, nb, hipMemcpyDeviceToDevice, ctx->stream));             // :67  x, z = x0, x0
@@ -115,6 +122,7 @@ int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0,
   double f_x = sc.f();
   APX_TRY(pullback_f(p));
   grad_evals++;
+  APX_HIP(hipMemcpyAsync(bgx.p, p->grad.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
   int64_t it_done = maxit;
   bool conv = false;
   double norm_res = kNaN, objective = kNaN;
@@ -126,7 +134,7 @@ int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0,
         gamma *= shrink;                                                                // :39
         if (gamma < 1e-12) flags |= APX_FLAG_TINY_GAMMA;                                // :40-42
       }
-      APX_TRY(vo_bt_trial(ctx, p->dtype, x, p->grad.p, znew, p->n, p->gd, gamma, ctx->scal));
+      APX_TRY(vo_bt_trial(ctx, p->dtype, x, bgx.p, znew, p->n, p->gd, gamma, ctx->scal));
       prox_evals++;
       APX_TRY(eval_f(p, znew, true));
       f_evals++;
@@ -159,6 +167,7 @@ int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0,
     f_x = sc.f();
     APX_TRY(pullback_f(p));
     grad_evals++;
+    APX_HIP(hipMemcpyAsync(bgx.p, p->grad.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
   }
   if (maxit == 0) z = x;
   APX_TRY(d2h(ctx, x_out, z, (size_t)p->n * es));

@@ -6,6 +6,7 @@
 // 256-B boundary (fp64), so every 16-B lane access of the GEMV kernels is aligned and
 // whole-wave loads are 1 KiB contiguous.  A 50 000 x 100 000 fp64 matrix is 40.0 GB of the
 // 288 GB; nothing is tiled or duplicated.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,19 @@ int32_t fail(int32_t code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+
+// Process exit.  Finalizers of a host language may call the destroy entry points while the process is going down
+// (Julia runs every registered finalizer at exit; Python `__del__`s run during interpreter teardown), possibly after the
+// HIP runtime's own exit handlers: a HIP call then throws from inside the runtime (seen in round 1 as
+// `terminate called after throwing 'std::bad_variant_access'` at the end of a sweep — DESIGN.md §9).  This object is
+// constructed when the library is loaded, i.e. after libamdhip64 it depends on, so its destructor runs BEFORE the HIP
+// runtime's teardown: from then on every destroy is a no-op — the dying process gives the memory back anyway.
+static std::atomic<bool> g_exiting{false};
+struct ExitMark {
+  ~ExitMark() { g_exiting.store(true); }
+};
+static ExitMark g_exit_mark;
+bool process_exiting() { return g_exiting.load(); }
 
 void ctx_retain(apx_ctx* ctx) { ctx->children += 1; }
 void ctx_release(apx_ctx* ctx) {
@@ -193,12 +207,15 @@ int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
 static void ctx_free(apx_ctx* ctx);
 
 int32_t apx_ctx_destroy(apx_ctx* ctx) {
-  if (ctx == nullptr) return APX_OK;
+  if (ctx == nullptr || process_exiting()) return APX_OK;
   if (ctx->children > 0) {   // matrices / problems still alive: defer
     ctx->zombie = true;
     return APX_OK;
   }
-  ctx_free(ctx);
+  try {
+    ctx_free(ctx);
+  } catch (...) {            // (nothing throws across the boundary, whatever state the runtime is in)
+  }
   return APX_OK;
 }
 
@@ -260,6 +277,12 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable) {
 int32_t apx_ctx_one_pass_threshold(apx_ctx* ctx, int64_t min_bytes) {
   APX_REQUIRE(ctx != nullptr && min_bytes >= 0, "apx_ctx_one_pass_threshold: bad argument");
   ctx->one_pass_min_bytes = min_bytes;
+  return APX_OK;
+}
+
+int32_t apx_ctx_auto_transpose(apx_ctx* ctx, int32_t enable) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_auto_transpose: ctx is NULL");
+  ctx->auto_transpose = enable != 0;
   return APX_OK;
 }
 
@@ -363,17 +386,20 @@ int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda) {
 }
 
 int32_t apx_matrix_free(apx_matrix* A) {
-  if (A == nullptr) return APX_OK;
-  (void)hipSetDevice(A->ctx->device);
-  (void)hipStreamSynchronize(A->ctx->stream);
-  if (A->dense_view) apx_matrix_free(A->dense_view);
-  if (A->d) (void)hipFree(A->d);
-  if (A->dT) (void)hipFree(A->dT);
-  for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval})
-    if (q) (void)hipFree(q);
-  apx_ctx* ctx = A->ctx;
-  delete A;
-  ctx_release(ctx);
+  if (A == nullptr || process_exiting()) return APX_OK;
+  try {
+    (void)hipSetDevice(A->ctx->device);
+    (void)hipStreamSynchronize(A->ctx->stream);
+    if (A->dense_view) apx_matrix_free(A->dense_view);
+    if (A->d) (void)hipFree(A->d);
+    if (A->dT) (void)hipFree(A->dT);
+    for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval})
+      if (q) (void)hipFree(q);
+    apx_ctx* ctx = A->ctx;
+    delete A;
+    ctx_release(ctx);
+  } catch (...) {
+  }
   return APX_OK;
 }
 
@@ -437,6 +463,13 @@ int32_t apx_matrix_build_transpose(apx_matrix* A) {
   APX_HIP(hipStreamSynchronize(ctx->stream));
   A->dT = dT;
   A->ldT = ldT;
+  return APX_OK;
+}
+
+int32_t apx_matrix_drop_transpose(apx_matrix* A) {
+  APX_REQUIRE(A != nullptr, "apx_matrix_drop_transpose: A is NULL");
+  APX_HIP(hipSetDevice(A->ctx->device));
+  drop_transpose(A);
   return APX_OK;
 }
 

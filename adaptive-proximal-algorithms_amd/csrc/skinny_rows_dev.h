@@ -134,7 +134,7 @@ inline void skinny_rows_launch(const SkinnyRowsPlan& pl, const void* X, const in
 // shapes the family takes: dense LinearLeastSquares / LogisticLoss, no linear operator, no all-reduce hook
 inline bool skinny_rows_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
-  if (p->A_lin != nullptr || p->allreduce != nullptr) return false;
+  if (p->A_lin != nullptr || p->sharded()) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
   if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
   const int64_t m = p->A_f->m;

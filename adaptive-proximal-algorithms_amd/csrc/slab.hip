@@ -262,7 +262,7 @@ static SlabShape slab_shape(const apx_problem* p) {
 
 static bool slab_shape_ok(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
-  if (p->A_lin != nullptr || p->allreduce != nullptr) return false;
+  if (p->A_lin != nullptr || p->sharded()) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
   if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
   // large matrices only: every block walks its slab in steps of R rows with two barriers each, and below ~200 MB
@@ -275,10 +275,11 @@ static bool slab_shape_ok(const apx_problem* p) {
 
 // The kernel reads only the transposed copy.  A matrix of up to 16 GB that has none gets one here (the same second
 // copy as apx_matrix_build_transpose; twice the memory, one transpose): every iteration then moves half the bytes.
-// Failing to allocate it is not an error — the two passes remain.
+// Failing to allocate it is not an error — the two passes remain.  apx_ctx_auto_transpose(ctx, 0) turns this off: the
+// copy is then the caller's to build (apx_matrix_build_transpose) and to drop (apx_matrix_drop_transpose).
 static bool slab_eligible(const apx_problem* p) {
   if (!slab_shape_ok(p)) return false;
-  if (p->A_f->dT == nullptr && (double)p->A_f->ld * (double)p->A_f->n_pad * (double)p->es() <= 16.0 * 1024 * 1024 * 1024) {
+  if (p->A_f->dT == nullptr && p->ctx->auto_transpose && (double)p->A_f->ld * (double)p->A_f->n_pad * (double)p->es() <= 16.0 * 1024 * 1024 * 1024) {
     if (apx_matrix_build_transpose(const_cast<apx_matrix*>(p->A_f)) != APX_OK) (void)hipGetLastError();
   }
   return p->A_f->dT != nullptr;

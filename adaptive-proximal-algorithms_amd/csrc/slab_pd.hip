@@ -240,7 +240,7 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
 
 static bool slab_pd_shape_ok(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
-  if (p->A_lin == nullptr || p->allreduce != nullptr) return false;
+  if (p->A_lin == nullptr || p->sharded()) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   if (p->hd.kind == APX_G_L2) return false;        // (its conjugate prox needs a norm over all rows first)
   if ((double)p->A_lin->m * (double)p->A_lin->n * (double)p->es() < (double)p->ctx->one_pass_min_bytes) return false;   // (see slab.hip)
@@ -251,7 +251,7 @@ static bool slab_pd_shape_ok(const apx_problem* p) {
 bool slab_pd_eligible(const apx_problem* p) {
   if (!slab_pd_shape_ok(p)) return false;
   const apx_matrix* A = p->A_lin;
-  if (A->dT == nullptr && (double)A->ld * (double)A->n_pad * (double)p->es() <= 16.0 * 1024 * 1024 * 1024) {
+  if (A->dT == nullptr && p->ctx->auto_transpose && (double)A->ld * (double)A->n_pad * (double)p->es() <= 16.0 * 1024 * 1024 * 1024) {
     if (apx_matrix_build_transpose(const_cast<apx_matrix*>(A)) != APX_OK) (void)hipGetLastError();
   }
   return A->dT != nullptr;

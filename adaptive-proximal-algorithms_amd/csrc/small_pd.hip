@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_small_pd_a(PdDev d) {
 // ---------------------------------------------------------------------------------------
 bool small_pd_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
-  if (p->A_lin == nullptr || p->allreduce != nullptr) return false;
+  if (p->A_lin == nullptr || p->sharded()) return false;
   if (p->f_kind != APX_F_ZERO && p->f_kind != APX_F_QUADRATIC) return false;
   if (p->f_kind == APX_F_QUADRATIC && (p->A_f == nullptr || p->A_f->sparse)) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;

@@ -67,6 +67,7 @@ static int32_t make_prox_dev(apx_ctx* ctx, const apx_prox_desc& d, int32_t dtype
 }
 
 static int32_t do_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dtype) {
+  if (p->comm != nullptr) return comm_allreduce(p->comm, buf, count, dtype);   // ncclAllReduce on the loop's stream (comm.hip)
   const int32_t rc = p->allreduce(p->ar_user, buf, count, dtype, (void*)p->ctx->stream);
   if (rc != 0) return fail(APX_ERR_CALLBACK, "all-reduce callback failed");
   return APX_OK;
@@ -257,15 +258,20 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   p->n_pad = round_up(d->n, kPad) + kPad;   // room for a logistic X with n-1 == k*32 columns
   p->A_f = d->A_f;
   p->A_lin = d->A_lin;
-  if (d->allreduce == nullptr) {        // small sparse matrices: the problem runs on their dense copies
+  APX_REQUIRE(d->comm == nullptr || d->allreduce == nullptr,
+              "apx_problem_create: give a communicator (comm) or an all-reduce callback, not both");
+  APX_REQUIRE(d->comm == nullptr || comm_ctx(d->comm) == ctx, "apx_problem_create: comm belongs to another context");
+  const bool shards = d->allreduce != nullptr || d->comm != nullptr;
+  if (!shards) {                        // small sparse matrices: the problem runs on their dense copies
     APX_TRY(small_dense_view(d->A_f, &p->A_f));
     APX_TRY(small_dense_view(d->A_lin, &p->A_lin));
   }
   p->allreduce = d->allreduce;
   p->ar_user = d->allreduce_user;
-  // shard_mask: bit 0 = rows of A_f sharded, bit 1 = rows of A_lin sharded; 0 with a hook = bit 0 (the original ABI)
-  p->f_sharded = d->allreduce != nullptr && (d->shard_mask == 0 || (d->shard_mask & 1) != 0);
-  p->lin_sharded = d->allreduce != nullptr && (d->shard_mask & 2) != 0;
+  p->comm = d->comm;
+  // shard_mask: bit 0 = rows of A_f sharded, bit 1 = rows of A_lin sharded; 0 with a hook / comm = bit 0
+  p->f_sharded = shards && (d->shard_mask == 0 || (d->shard_mask & 1) != 0);
+  p->lin_sharded = shards && (d->shard_mask & 2) != 0;
   const size_t es = dtype_size(d->dtype);
 
   switch (d->f_kind) {
@@ -343,12 +349,15 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
 }
 
 int32_t apx_problem_destroy(apx_problem* p) {
-  if (p == nullptr) return APX_OK;
-  (void)hipSetDevice(p->ctx->device);
-  (void)hipStreamSynchronize(p->ctx->stream);
-  apx_ctx* ctx = p->ctx;
-  delete p;
-  ctx_release(ctx);
+  if (p == nullptr || process_exiting()) return APX_OK;      // (exit: matrix.hip ExitMark)
+  try {
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    apx_ctx* ctx = p->ctx;
+    delete p;
+    ctx_release(ctx);
+  } catch (...) {
+  }
   return APX_OK;
 }
 
@@ -434,9 +443,9 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
   const bool want_graph = opts != nullptr && opts->use_graph == 1;
   const bool skinny = skinny_pd_eligible(p);                   // tall, skinny A: row kernel + closing kernel
   const bool small_pd = !skinny && !want_graph && small_pd_eligible(p);   // (its buffer roles rotate on the host: no replay)
-  if (want_graph && (p->f_kind == APX_F_CALLBACK || p->allreduce != nullptr))
+  if (want_graph && (p->f_kind == APX_F_CALLBACK || p->sharded()))
     return fail(APX_ERR_UNSUPPORTED,
-                "hipGraph replay needs a device-only iteration: not with a host-callback f or an all-reduce hook");
+                "hipGraph replay needs a device-only iteration: not with a host-callback f, an all-reduce hook or a communicator");
   const bool lin = p->A_lin != nullptr;
   APX_REQUIRE(!lin || y0 != nullptr, "adaptive_primal_dual needs y0");
   std::unique_ptr<apx_solver> s(new apx_solver());
@@ -651,13 +660,16 @@ int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* r
 }
 
 int32_t apx_solver_destroy(apx_solver* s) {
-  if (s == nullptr) return APX_OK;
-  (void)hipSetDevice(s->p->ctx->device);
-  (void)hipStreamSynchronize(s->p->ctx->stream);
-  if (s->p->active == s) s->p->active = nullptr;
-  if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-  if (s->graph) (void)hipGraphDestroy(s->graph);
-  delete s;
+  if (s == nullptr || process_exiting()) return APX_OK;
+  try {
+    (void)hipSetDevice(s->p->ctx->device);
+    (void)hipStreamSynchronize(s->p->ctx->stream);
+    if (s->p->active == s) s->p->active = nullptr;
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    delete s;
+  } catch (...) {
+  }
   return APX_OK;
 }
 
@@ -721,6 +733,11 @@ int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch
   APX_REQUIRE(p != nullptr && prm != nullptr && x0 != nullptr && y0 != nullptr && x_out != nullptr,
               "apx_adaptive_linesearch_primal_dual: NULL argument");
   APX_REQUIRE(p->A_lin != nullptr, "adaptive_linesearch_primal_dual needs a linear operator");
+  // (its linesearch compares ||A'y+ - A'y|| with ||y+ - y||: with row shards of A_lin both would need all-reduces per
+  // trial, which only the generic loop has — enqueue_iteration)
+  if (p->lin_sharded)
+    return fail(APX_ERR_UNSUPPORTED, "adaptive_linesearch_primal_dual does not take a row-sharded linear operator "
+                                     "(shard_mask bit 1): use adaptive_primal_dual / condat_vu");
   APX_REQUIRE(p->active == nullptr, "a solver is active on this problem");
   APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
   double eta = prm->eta;
@@ -896,9 +913,13 @@ int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0,
   if (small_bt_eligible(p)) return small_bt_run(p, false, x0, gamma0, xi, shrink, tol, maxit, opts, x_out, res);
   const size_t es = p->es();
   const size_t nb = (size_t)p->n_pad * es;
-  DBuf bx, bz;
+  // bgx: grad_x of :52 / :61, private to the loop — every trial evaluates f at z, and where one pass over A forms
+  // the gradient along with f (csrc/slab.hip) that evaluation leaves grad f(z) in p->grad; the next shrink trial of the
+  // same iteration still needs grad f(x) (:43-45)
+  DBuf bx, bz, bgx;
   APX_TRY(bx.alloc_zero(nb, ctx->stream));
   APX_TRY(bz.alloc_zero(nb, ctx->stream));
+  APX_TRY(bgx.alloc_zero(nb, ctx->stream));
   void* x = bx.p;
   void* z = bz.p;
   apx_rule r{};
@@ -929,6 +950,7 @@ int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0,
   double f_x = sc[3];
   APX_TRY(pullback_f(p));
   grad_evals++;
+  APX_HIP(hipMemcpyAsync(bgx.p, p->grad.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
 
   void* last_z = x;
   int64_t it_done = maxit;
@@ -938,7 +960,7 @@ int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0,
     gamma = xi * gamma;                                                   // :54  backtrack_stepsize(xi * gamma, ...)
     double f_z = 0, ub_z = 0, nrm = 0, g_z = 0;
     auto trial = [&]() -> int32_t {
-      APX_TRY(vo_bt_trial(ctx, p->dtype, x, p->grad.p, z, p->n, p->gd, gamma, ctx->scal));   // :35 / :43
+      APX_TRY(vo_bt_trial(ctx, p->dtype, x, bgx.p, z, p->n, p->gd, gamma, ctx->scal));       // :35 / :43
       prox_evals++;
       APX_TRY(eval_f(p, z, true));                                        // :37 / :45
       f_evals++;
@@ -979,6 +1001,7 @@ int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0,
     f_x = f_z;
     APX_TRY(pullback_f(p));                                               // :61  grad_x = pb()
     grad_evals++;
+    APX_HIP(hipMemcpyAsync(bgx.p, p->grad.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
     last_z = x;
   }
   APX_TRY(d2h(ctx, x_out, last_z, (size_t)p->n * es));

@@ -21,8 +21,10 @@ struct apx_problem {
   apx_eval_fn eval_cb = nullptr;
   apx_pullback_fn pb_cb = nullptr;
   void* cb_user = nullptr;
-  apx_allreduce_fn allreduce = nullptr;
+  apx_allreduce_fn allreduce = nullptr;   // the collective of a row-sharded problem: a host callback (tests), or
   void* ar_user = nullptr;
+  apx_comm* comm = nullptr;               // an RCCL communicator the loop enqueues ncclAllReduce on (comm.hip)
+  bool sharded() const { return allreduce != nullptr || comm != nullptr; }
   bool f_sharded = false, lin_sharded = false;   // which operand's rows the all-reduce hook sums over
   double n_mean = 0.0;
   apx::DBuf b, res, grad, fsc_buf, xtmp, ctrl_buf;

@@ -9,13 +9,20 @@ recurrences on identical all-reduced inputs, so all ranks take identical decisio
 convergence poll happens at fixed iteration numbers, never on a timer).
 
 There is no reference counterpart (the reference is single-process Julia).  The collective
-is torch.distributed — backend "nccl" is RCCL over xGMI on ROCm; CPU tests use "gloo".
+of the product path is RCCL INSIDE the library (`Comm`: apx_comm_* in include/adaprox_hip.h,
+csrc/comm.hip — the native loop enqueues ncclAllReduce on its own stream; a launcher such as
+torch.distributed.run only starts the ranks and carries the 128-byte id).  The callback
+transport below (`device_allreduce` over torch.distributed) is what the CPU tests ("gloo")
+and the two-ranks-on-one-GPU rehearsal use, where RCCL cannot run.
 """
 from __future__ import annotations
 
 from typing import Callable, Tuple
 
 import numpy as np
+
+import ctypes as C
+import sys
 
 from . import _lib as L
 
@@ -28,7 +35,97 @@ def shard_rows(m_total: int, rank: int, world: int) -> Tuple[int, int]:
     return r0, base + (1 if rank < extra else 0)
 
 
-# ---- collectives -----------------------------------------------------------------------
+# ---- RCCL inside the library -----------------------------------------------------------
+class Comm:
+    """An RCCL communicator bound to one Context (apx_comm_*).  Pass it where a row-sharded
+    term takes its collective: ``LinearLeastSquares(A_k, b_k, allreduce=comm)``,
+    ``adaptive_primal_dual(..., A_allreduce=comm)``; ``comm(v)`` sums a host fp64 vector over
+    the ranks (set-up code)."""
+
+    def __init__(self, handle, ctx):
+        self._h, self.ctx, self._lib = handle, ctx, ctx._lib
+
+    @staticmethod
+    def _plumbing():
+        """The library binds librccl at its first apx_comm_* call and takes the copy already in the process.  Where
+        PyTorch-ROCm is installed its HIP runtime is the one in use (_lib._share_hip_runtime_with_torch), so its RCCL
+        must be too: importing torch first lets torch map its own pair in its own order (a librccl mapped before torch
+        maps its copy aborts the process at exit)."""
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+
+    @staticmethod
+    def library() -> str:
+        """Path of the librccl in use ("" before the first communicator call failed to find one)."""
+        Comm._plumbing()
+        return L.load().apx_comm_library().decode()
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """ncclGetUniqueId (rank 0); hand the bytes to every rank (store, MPI, file)."""
+        Comm._plumbing()
+        buf = C.create_string_buffer(L.APX_COMM_ID_BYTES)
+        L.check(L.load().apx_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, ctx, nranks: int, rank: int, uid: bytes) -> "Comm":
+        """One process per GPU: ncclCommInitRank on the context's device."""
+        if len(uid) != L.APX_COMM_ID_BYTES:
+            raise ValueError("Comm.init_rank: the id must be APX_COMM_ID_BYTES long")
+        cls._plumbing()
+        h = C.c_void_p()
+        L.check(ctx._lib.apx_comm_init_rank(ctx._h, int(nranks), int(rank), C.c_char_p(uid), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def init_all(cls, ctxs) -> list:
+        """One process, one Context per device: ncclCommInitAll."""
+        cls._plumbing()
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c._h for c in ctxs])
+        out = (C.c_void_p * n)()
+        L.check(ctxs[0]._lib.apx_comm_init_all(hs, n, out))
+        return [cls(C.c_void_p(out[i]), ctxs[i]) for i in range(n)]
+
+    def info(self):
+        """(nranks, rank) as RCCL reports them (ncclCommCount, ncclCommUserRank)."""
+        n, r = C.c_int32(), C.c_int32()
+        L.check(self._lib.apx_comm_info(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    @property
+    def nranks(self) -> int:
+        return self.info()[0]
+
+    @property
+    def rank(self) -> int:
+        return self.info()[1]
+
+    def __call__(self, v: np.ndarray) -> np.ndarray:
+        out = np.ascontiguousarray(v, dtype=np.float64).copy()
+        if out.size:
+            L.check(self._lib.apx_comm_allreduce_host(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
+        return out.reshape(np.shape(v))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.apx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- collectives through torch.distributed (test transport) ----------------------------
 def host_allreduce(dist, local_rank=None) -> Callable[[np.ndarray], np.ndarray]:
     """Sum of a (small) numpy vector over the ranks — used by the O(n) set-up code."""
     import torch

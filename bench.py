@@ -9,8 +9,14 @@ A "step" = ONE iteration of src/AdaProx.jl:334-362 = GEMV-N (A x - b, ||r||^2) +
 (A' r) + the fused residual / step-size / soft-threshold kernels, on data already resident
 in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every
 rank holds a 50 000-row shard of the (50 000 N) x 100 000 matrix (BASELINE config C4 at
-N = 8) and the partial gradient A_k' r_k is all-reduced with RCCL over xGMI each iteration.
+N = 8) and the partial gradient A_k' r_k is all-reduced with RCCL over xGMI each iteration: ONE
+ncclAllReduce(n + 2 fp64) per iteration, enqueued by the native loop itself on its stream through the communicator
+the library owns (apx_comm_init_rank, csrc/comm.hip).  torch.distributed is the launcher only: a gloo group carries
+the 128-byte RCCL id from rank 0, the barriers of the timing protocol and the max over ranks of the elapsed time.
 `value` = shard-iterations per second summed over the ranks (= iterations/sec at N = 1).
+
+At N = 1 the same JSON line also carries `other_configs`: BASELINE configs C3 (sparse_logreg 100 000 x 10 000 fp32)
+and C5 (LAD 50 000 x 20 000 fp64, Condat-Vu) timed with the same protocol after the headline has released its memory.
 
 Prints ONE JSON line on rank 0.
 """
@@ -52,44 +58,166 @@ def parse():
                     help="do not keep the transposed copy of A (40 GB instead of 80 GB; A*x ~5 %% slower)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --rows is the GLOBAL row count, split over the ranks (default: weak, rows per GPU)")
-    # CPU baseline sample: 4000 x 100000 fp64 (3.2 GB), 50 iterations ~ 10 s of dgemv on the box's host cores
-    ap.add_argument("--cpu-rows", type=int, default=4000, help="rows of the CPU-baseline sample")
-    ap.add_argument("--cpu-iters", type=int, default=50)
+    # CPU baseline sample: 10 000 x 100 000 fp64 (8 GB) when the host has >= 32 GB of RAM, else 4000 rows
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0: 10000, or 4000 on a small host)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="time budget of each CPU-baseline leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 legs of the N = 1 run")
     return ap.parse_args()
 
 
-def cpu_baseline(n: int, m_full: int, rows: int, iters: int, seed: int) -> dict:
-    """The oracle (numpy -> OpenBLAS dgemv, the BLAS family Julia's `A*x` reaches) timed on the
-    host cores on a bounded row-sample of the same workload, scaled per byte to the full
-    matrix.  A reported baseline, not the target."""
+def host_ram_gb() -> float:
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2**30
+    except (ValueError, OSError):
+        return 0.0
+
+
+def cpu_baseline(n: int, m_full: int, rows: int, seconds: float, seed: int) -> dict:
+    """The CPU restatement of the reference iteration timed on the host cores on a bounded row sample of the same
+    workload (same generator), scaled per byte to the full matrix.  Two legs: C + OpenMP on every host thread
+    (oracle/lasso_omp.c — the figure reported as `value`) and the numpy oracle (-> OpenBLAS dgemv, the BLAS family
+    Julia's `A*x` reaches; its dgemv barely threads).  A reported baseline, not the target."""
+    import tempfile
     from oracle import adaprox_oracle as O
-    from oracle import problems as P
+    from oracle import lasso_omp
+    if rows <= 0:
+        rows = 10_000 if host_ram_gb() >= 32.0 else 4_000
+    # rebuilt HERE with -march=native: this leg is about this host's cores
+    lib = lasso_omp.load(lasso_omp.build(native=True, out=os.path.join(tempfile.mkdtemp(prefix="apx_omp_"), "liblasso_omp.so")))
+    threads = int(lib.apx_oracle_omp_threads())
+    t0 = time.perf_counter()
+    prob = lasso_omp.random_lasso(rows, n, pfactor=10, seed=seed, lib=lib)
+    t_gen = time.perf_counter() - t0
+    sample_bytes = float(rows) * n * 8
+    # Lf by power iteration on A'A (reference: opnorm(A)^2, experiments/lasso/runme.jl:81)
+    v = np.ones(n) / np.sqrt(n)
+    for _ in range(5):
+        w = lasso_omp.gemv_t(prob.A, lasso_omp.gemv_n(prob.A, v, lib), lib)
+        Lf = float(np.linalg.norm(w))
+        v = w / Lf
+    gam = 1.0 / Lf
+
+    def leg(run) -> tuple:
+        run(2)                                             # warm-up (page faults, thread pool)
+        t0 = time.perf_counter()
+        run(3)
+        per_it = (time.perf_counter() - t0) / 4            # 3 loop passes + the pre-loop gradient
+        iters = max(3, min(200, int(seconds / per_it)))
+        t0 = time.perf_counter()
+        run(iters)
+        dt = time.perf_counter() - t0
+        return iters, dt, (iters + 1) / dt                 # iterations/s on the sample
+
+    it_c, dt_c, ips_c = leg(lambda k: lasso_omp.adaptive_proxgrad_lasso(prob.A, prob.b, prob.lam, gam, k, lib=lib))
+    f, g = O.LinearLeastSquares(prob.A, prob.b), O.NormL1(prob.lam)
+    it_p, dt_p, ips_p = leg(lambda k: O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=k))
     try:
         from threadpoolctl import threadpool_info
-        threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+        blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count() or 1
-    prob = P.random_lasso(rows, n, pfactor=10, seed=seed)
-    gam = 1.0 / P.opnorm_sq_power(prob.A, iters=5)
-    f, g = O.LinearLeastSquares(prob.A, prob.b), O.NormL1(prob.lam)
-    O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=2)       # warm-up
-    t0 = time.perf_counter()
-    O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=iters)
-    dt = time.perf_counter() - t0
-    its_sample = (iters + 1) / dt                       # iters loop passes + the pre-loop gradient
+        blas_threads = os.cpu_count() or 1
+    scale = rows / m_full
     return {
-        "value": its_sample * rows / m_full, "unit": "iters/sec", "cores": threads, "kind": "port",
-        "sample": f"oracle (numpy/OpenBLAS dgemv, {threads} threads) on a {rows}x{n} fp64 lasso of the same "
-                  f"generator, {iters} iterations in {dt:.2f} s = {its_sample:.2f} it/s on the sample, scaled by "
-                  f"bytes ({rows}/{m_full}) to the {m_full}x{n} matrix; Julia runtime absent on this image",
+        "value": ips_c * scale, "unit": "iters/sec", "cores": threads, "kind": "port",
+        "host_GBps": 2 * sample_bytes * ips_c / 1e9,
+        "sample": f"C + OpenMP restatement of the reference iteration (oracle/lasso_omp.c, {threads} threads) on a {rows}x{n} "
+                  f"fp64 lasso of the same generator ({sample_bytes / 1e9:.1f} GB, built in {t_gen:.1f} s): {it_c} iterations "
+                  f"in {dt_c:.2f} s = {ips_c:.2f} it/s on the sample = {2 * sample_bytes * ips_c / 1e9:.0f} GB/s of A streamed, "
+                  f"scaled by bytes ({rows}/{m_full}) to the {m_full}x{n} matrix; Julia runtime absent on this image",
+        "numpy_openblas": {"value": ips_p * scale, "cores": blas_threads, "host_GBps": 2 * sample_bytes * ips_p / 1e9,
+                           "sample": f"numpy oracle (OpenBLAS dgemv, {blas_threads} threads) on the same sample: {it_p} "
+                                     f"iterations in {dt_p:.2f} s"},
     }
+
+
+def kernel_table(stats: dict) -> dict:
+    out = {}
+    for k, st in stats.items():
+        if st["launches"]:
+            avg_ms = st["total_ms"] / st["launches"]
+            out[k] = {"launches": st["launches"], "avg_ms": avg_ms,
+                      "GBps": st["bytes"] / st["launches"] / (avg_ms * 1e-3) / 1e9}
+    return out
+
+
+def timed_steps(ctx, solver, steps: int, warmup: int, barrier) -> tuple:
+    """W untimed steps, then exactly K steps between two barrier + device-synchronise brackets, with HIP events
+    around every pass over A on the launch stream (apx_ctx_profile)."""
+    solver.step(warmup, sync=True)
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    solver.step(steps, sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    return dt, ctx.kernel_stats(reset=True)
+
+
+def other_configs(apx, problems, ctx, barrier) -> dict:
+    """BASELINE configs C3 and C5 at full size, same protocol as the headline (data resident, warm-up, K timed
+    iterations, HIP-event durations of the passes over A).  Each reports the fraction of the HBM peak twice: of the
+    bytes the dominant kernel actually READS per launch, and of the two-pass algorithmic bytes SURVEY 8d defines
+    (2 m n sizeof(T) per iteration: above 1 where one pass over A serves both products)."""
+    out = {}
+
+    def report(m, n, es, steps, dt, stats, res, one_pass_note):
+        k = kernel_table(stats)
+        dom = max(k, key=lambda q: k[q]["avg_ms"] * k[q]["launches"])
+        its = steps / dt
+        passes = sum(v["launches"] for v in k.values()) / steps       # passes over A per iteration, as launched
+        r = {"iters_per_s": its, "ms_per_iter": dt / steps * 1e3, "steps": steps,
+             "passes_over_A_per_iter": passes, "kernels": k,
+             "roofline": {"bound": "hbm", "kernel": dom, "achieved": k[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": k[dom]["GBps"] / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": float(m) * n * es,
+                          "two_pass_equivalent_frac": 2.0 * m * n * es * its / 1e9 / HBM_PEAK_GBS,
+                          "bytes_read_iteration_frac": passes * m * n * es * its / 1e9 / HBM_PEAK_GBS},
+             "objective": res.objective, "norm_res": res.norm_res}
+        if passes < 1.5:
+            r["note"] = one_pass_note
+        return r
+
+    # C3: sparse_logreg, dense synthetic X 100 000 x 10 000 fp32, logistic gradient + NormL1 prox
+    m, n = 100_000, 10_000
+    p = problems.device_logreg(m, n, seed=0, lam=0.01, dtype=np.float32, ctx=ctx)
+    p.X.build_transpose()
+    s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(p.X, p.y), g=apx.NormL1(p.lam),
+                   rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    dt, st = timed_steps(ctx, s, 400, 20, barrier)
+    x, _, res = s.result()
+    if not np.all(np.isfinite(x)) or int(res.numit) != 420 or res.converged:
+        sys.exit("bench.py: C3 leg: the timed steps were not all real")
+    out["C3"] = report(m, n, 4, 400, dt, st, res,
+                       "f and grad f in ONE pass over X per iteration (csrc/slab.hip, booked under gemv_n): "
+                       "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read")
+    out["C3"]["workload"] = "sparse_logreg, dense synthetic A 100000x10000 fp32, logistic grad + NormL1 prox, adaptive_proxgrad (OurRule)"
+    s.close()
+    p.X.free()
+
+    # C5: least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50 000 x 20 000 fp64
+    m, n = 50_000, 20_000
+    p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx)
+    p.A.build_transpose()
+    gamma = 1.0 / (0.0 / 2 + p.norm_A / 1.0)                    # condat_vu with Lf = 0 (src/AdaProx.jl:405-411)
+    sigma = 0.99 / (p.norm_A * 1.0)
+    s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y),
+                   A=p.A, rule=apx.FixedStepsize(gamma, np.sqrt(sigma / gamma)), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    dt, st = timed_steps(ctx, s, 200, 10, barrier)
+    x, _, res = s.result()
+    if not np.all(np.isfinite(x)) or int(res.numit) != 210 or res.converged:
+        sys.exit("bench.py: C5 leg: the timed steps were not all real")
+    out["C5"] = report(m, n, 8, 200, dt, st, res,
+                       "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip)")
+    out["C5"]["workload"] = "least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50000x20000 fp64 (Ax / A'y pair + conj-prox)"
+    s.close()
+    p.A.free()
+    return out
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -97,34 +225,46 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # ---- the transport of the row-sharded run: decided from the environment alone, BEFORE anything touches the GPU ----
+    #   "rccl"   (default with more than one rank; APX_BENCH_FORCE_DIST=1 runs it with a single rank — the 1-GPU box
+    #             rehearsal): the library's own communicator, ncclAllReduce enqueued by the native loop (csrc/comm.hip);
+    #             torch.distributed (gloo, CPU) only launches, carries the id and synchronises the clocks
+    #   "gloo"   (APX_BENCH_SHARE_GPU=1): every rank on device 0, the all-reduce CALLBACK over gloo — rehearsal of the
+    #             N-rank logic on a one-GPU box (RCCL refuses two ranks on one device); its timings mean nothing
+    #   "torch-nccl" (APX_BENCH_TRANSPORT=torch-nccl): the round-1 path, the callback over torch's nccl backend
+    share_gpu = os.environ.get("APX_BENCH_SHARE_GPU") == "1"
+    use_dist = world > 1 or os.environ.get("APX_BENCH_FORCE_DIST") == "1"
+    transport = "none"
+    if use_dist:
+        transport = "gloo" if share_gpu else os.environ.get("APX_BENCH_TRANSPORT", "rccl")
+        if transport not in ("rccl", "gloo", "torch-nccl"):
+            sys.exit(f"bench.py: unknown APX_BENCH_TRANSPORT {transport!r}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: RCCL between processes needs it here)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # APX_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a ONE-GPU box — every rank uses
-    # device 0 and the collectives go through gloo (RCCL refuses two ranks on one device).  Checks
-    # the sharding / all-reduce logic with real ranks; its timings mean nothing.
-    share_gpu = os.environ.get("APX_BENCH_SHARE_GPU") == "1"
     dev = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev)
-    # APX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (the 1-GPU box
-    # rehearsal of what the driver launches with N ranks)
-    use_dist = world > 1 or os.environ.get("APX_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if share_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
+        if transport == "torch-nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend="gloo")
 
-    if not os.path.exists(os.path.join(ROOT, "adaptive-proximal-algorithms_amd", "csrc", "libadaprox_hip.so")):
-        if local_rank == 0:
-            import __graft_entry__
-            __graft_entry__.build()          # in-tree hipcc build (the .so is git-ignored)
-        if use_dist:
-            dist.barrier()
+    # a library built from other sources than the ones in the tree is rebuilt (content hash), never benchmarked
+    import __graft_entry__
+    if local_rank == 0 and __graft_entry__.is_stale():
+        __graft_entry__.build()              # in-tree hipcc build (the .so is git-ignored)
+    if use_dist:
+        dist.barrier()
+    if __graft_entry__.is_stale():
+        sys.exit("bench.py: libadaprox_hip.so does not match the sources in the tree")
     import adaprox_amd as apx
     from importlib import import_module
     problems = import_module("adaptive-proximal-algorithms_amd.problems")
@@ -135,11 +275,24 @@ def main():
     if args.strong:
         row0, args.m = sharded.shard_rows(m_global, rank, world)   # this rank's first row and row count
     stream = torch.cuda.Stream(device=dev)
+    rccl_ranks = None
+    other = None
     with torch.cuda.stream(stream):
         ctx = apx.Context(device=dev, stream=stream.cuda_stream)
         apx.set_default_context(ctx)
-        ar_host = sharded.host_allreduce(dist, dev) if use_dist else None
-        ar_dev = sharded.device_allreduce(dist, dev) if use_dist else None
+        comm = None
+        ar_host = ar_dev = None
+        if transport == "rccl":
+            uid = [sharded.Comm.unique_id() if rank == 0 else None]      # ncclGetUniqueId on rank 0 ...
+            dist.broadcast_object_list(uid, src=0)                       # ... carried to every rank by the launcher's group
+            comm = sharded.Comm.init_rank(ctx, world, rank, uid[0])      # ncclCommInitRank on this rank's device
+            rccl_ranks = comm.nranks                                     # (ncclCommCount of the live communicator)
+            if rccl_ranks != world:
+                sys.exit(f"bench.py: the communicator has {rccl_ranks} ranks, the job {world}")
+            ar_host = ar_dev = comm
+        elif use_dist:
+            ar_host = sharded.host_allreduce(dist, dev)
+            ar_dev = sharded.device_allreduce(dist, dev)
 
         t_setup = time.perf_counter()
         prob = problems.device_lasso(args.m, args.n, pfactor=10, seed=args.seed, rank=rank, world=world,
@@ -156,20 +309,12 @@ def main():
                             ctx=ctx, poll_every=1 << 30)
 
         def barrier():
+            torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        solver.step(args.warmup, sync=True)
-        ctx.kernel_stats(reset=True)
-        ctx.profile(True)                       # HIP events around every GEMV launch, on the launch stream
-        barrier()
-        t0 = time.perf_counter()
-        solver.step(args.steps, sync=False)
-        barrier()
-        dt = time.perf_counter() - t0
-        ctx.profile(False)
-        stats = ctx.kernel_stats(reset=True)
+        dt, stats = timed_steps(ctx, solver, args.steps, args.warmup, barrier)
 
         x, _, res = solver.result()
         if not np.all(np.isfinite(x)):
@@ -177,33 +322,36 @@ def main():
         if int(res.numit) != args.warmup + args.steps or res.converged:
             sys.exit("bench.py: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
         solver.close()
+        dual_layout = prob.dual_layout
+        final_objective, optimum = res.objective, prob.optimum
+        if world == 1 and not use_dist and not args.no_other_configs and (args.m, args.n) == (50_000, 100_000):
+            prob.A.free()                                  # give the 80 GB back before the other configs
+            other = other_configs(apx, problems, ctx, barrier)
 
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else f"cuda:{dev}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}" if transport == "torch-nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     if rank == 0:
         es = 8
-        per_kernel = {}
-        for k, st in stats.items():
-            if st["launches"]:
-                avg_ms = st["total_ms"] / st["launches"]
-                per_kernel[k] = {"launches": st["launches"], "avg_ms": avg_ms,
-                                 "GBps": st["bytes"] / st["launches"] / (avg_ms * 1e-3) / 1e9}
+        per_kernel = kernel_table(stats)
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
         algo_bytes = float(args.m) * args.n * es                 # one streaming read of A per launch
         achieved = per_kernel[dom]["GBps"]
         iters_per_s = args.steps / dt
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        # PMC traffic was collected (separate rocprofv3 --pmc passes, profiles/README.md) for the
-        # default per-GPU shape only
+        # HBM bytes per launch from the PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS
+        # command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; profiles/README.md): a counter
+        # run cannot be nested inside the timed run, so the line quotes the committed passes and says which
         if os.path.exists(tpath) and (args.m, args.n) == (50_000, 100_000) and not share_gpu:
             try:
                 # with the dual layout both passes run the column-streaming kernel (the "gemv_t" entry)
-                tkey = "gemv_t" if prob.dual_layout else dom
-                traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("gemv_t" if dual_layout else dom, {}).get("hbm_bytes_per_launch")
+                traffic_source = tj.get("source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes of round 1, r01c; "
+                                                  "the GEMV kernels are unchanged since)")
             except Exception:
                 traffic = None
         out = {
@@ -215,26 +363,38 @@ def main():
                                    f"{world} MI355X (GEMV + soft-threshold + stepsize reductions)"
                                    + ("" if world == 1 else f"; row-sharded {m_global}x{args.n}, RCCL all-reduce of A'r"),
                        "rows_per_gpu": args.m, "cols": args.n, "rule": "OurRule(gamma=1/Lf)",
-                       "layout": ("single: A column-major, 40 GB" if not prob.dual_layout else
+                       "layout": ("single: A column-major, 40 GB" if not dual_layout else
                                   "dual: A and its transposed copy resident (2 x 40 GB of the 288 GB), "
                                   "each pass still reads 40 GB"),
                        "parallelism": "single" if world == 1 else f"row-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
                          "frac_of_measured_read_ceiling": achieved / HBM_READ_GBS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": algo_bytes, "per_kernel": per_kernel,
                          "iteration_frac": 2 * algo_bytes * iters_per_s / 1e9 / HBM_PEAK_GBS},
-            "setup_s": t_setup, "final_objective": res.objective, "lasso_optimum": prob.optimum,
+            "setup_s": t_setup, "final_objective": final_objective, "lasso_optimum": optimum,
+            "lib_srchash": __graft_entry__.source_hash()[:16],
         }
+        if use_dist:
+            out["collective"] = {
+                "transport": transport, "rccl_ranks": rccl_ranks,
+                "what": ("ncclAllReduce(sum, %d fp64) per iteration, enqueued by the native loop on its stream "
+                         "(apx_comm_init_rank, csrc/comm.hip)" % (args.n + 2)) if transport == "rccl" else
+                        "all-reduce callback of the test transport (not RCCL inside the library)"}
+            out["rccl_ranks"] = rccl_ranks
         if args.exploit_sparsity:
             out["note"] = ("x-sparsity exploited (A*x skips columns with x_j == 0; nnz(x) = %d of %d at the end): this "
                            "is NOT the BASELINE dense metric; roofline figures assume the dense byte count"
                            % (int(np.count_nonzero(x)), args.n))
+        if other is not None:
+            out["other_configs"] = other
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.n, args.m, args.cpu_rows, args.cpu_iters, args.seed)
+            out["cpu_baseline"] = cpu_baseline(args.n, args.m, args.cpu_rows, args.cpu_seconds, args.seed)
         print(json.dumps(out), flush=True)
 
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -18,7 +18,11 @@
  *    call only.  Device memory lives behind the opaque handles.
  *  - matrices are column-major (Julia layout).  dtype selects fp64 / fp32 storage.
  *  - a context is bound to one device and one HIP stream and is NOT thread-safe
- *    (the reference is single-threaded too: src/counting.jl:4-14).
+ *    (the reference is single-threaded too: src/counting.jl:4-14); different contexts may be
+ *    driven from different threads.
+ *  - the destroy / free entry points are safe to call from finalizers that run while the process
+ *    exits (Julia runs them at exit): once exit() has reached this library's handlers they return
+ *    APX_OK without touching the HIP runtime, which may be gone by then.
  */
 #ifndef ADAPROX_HIP_H
 #define ADAPROX_HIP_H
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APX_ABI_VERSION 1
+#define APX_ABI_VERSION 2   /* 2: apx_problem_desc.comm, apx_comm_*, APX_ERR_COMM */
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -38,7 +42,8 @@ enum {
   APX_ERR_HIP = 2,          /* HIP runtime failure (no device, OOM, launch failure)   */
   APX_ERR_UNSUPPORTED = 3,  /* combination not built (e.g. callback f + hipGraph)     */
   APX_ERR_DOMAIN = 4,       /* Julia would have thrown DomainError (sqrt of negative) */
-  APX_ERR_CALLBACK = 5      /* a user callback returned non-zero                      */
+  APX_ERR_CALLBACK = 5,     /* a user callback returned non-zero                      */
+  APX_ERR_COMM = 6          /* RCCL reported an error (apx_comm_*, or a collective of the loop) */
 };
 
 /* warning bits reported in apx_result.flags (the loop keeps going, like the reference) */
@@ -81,6 +86,7 @@ typedef struct apx_ctx apx_ctx;
 typedef struct apx_matrix apx_matrix;
 typedef struct apx_problem apx_problem;
 typedef struct apx_solver apx_solver;
+typedef struct apx_comm apx_comm;       /* an RCCL communicator bound to one context (row-sharded multi-GPU path) */
 
 /* A proximable term: kind + parameters.  `shift` (length = vector length, host,
  * may be NULL) wraps the term in Translate(., shift): x -> g(x + shift)
@@ -105,8 +111,9 @@ typedef int32_t (*apx_pullback_fn)(void* user, void* grad, int64_t n);
 
 /* all-reduce hook for the row-sharded multi-GPU path: sums `count` elements of
  * dtype `dtype` at DEVICE pointer `buf` across ranks, enqueued on `stream`
- * (hipStream_t).  bench.py / the Python host wire this to torch.distributed
- * (backend "nccl" = RCCL over xGMI).  NULL = single device. */
+ * (hipStream_t).  The product path is apx_problem_desc.comm (RCCL inside the library, below);
+ * this callback is the TEST transport (gloo on CPU / two ranks sharing one GPU, where RCCL refuses).
+ * NULL = single device or comm. */
 typedef int32_t (*apx_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, void* stream);
 
 typedef struct {
@@ -129,6 +136,9 @@ typedef struct {
                               (y, A_x and the dual residual become shards; A'y and ||dual_res||^2 are all-reduced);
                               0 means bit 0                                                                       */
   int32_t _pad2;
+  apx_comm* comm;          /* row-sharded problem: the communicator whose ranks hold the other row blocks; the loop
+                              enqueues ncclAllReduce on the context's stream where the callback above would be called
+                              (shard_mask as above).  Must outlive the problem.  NULL = single device / callback.       */
 } apx_problem_desc;
 
 typedef struct {
@@ -233,8 +243,47 @@ int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
  * GEMV passes.  Default 192 MB — the measured break-even on MI355X; the parity tests lower it to reach the kernels
  * with small matrices. */
 int32_t apx_ctx_one_pass_threshold(apx_ctx* ctx, int64_t min_bytes);
+/* Default ON: a dense matrix of up to 16 GB that a one-pass-eligible problem is evaluated on is given its transposed
+ * copy on the spot (as by apx_matrix_build_transpose: twice the memory of A, held until apx_matrix_free /
+ * apx_matrix_drop_transpose / an in-place edit).  0: the library never allocates it by itself — the one-pass kernels
+ * then run only where the caller built the copy. */
+int32_t apx_ctx_auto_transpose(apx_ctx* ctx, int32_t enable);
 int32_t apx_gemv_variant_count(int32_t transposed);
 const char* apx_gemv_variant_name(int32_t transposed, int32_t i);
+
+/* ---- RCCL communicators: the row-sharded multi-GPU path ---------------------------------
+ * No reference counterpart (the reference is one Julia process on CPU).  A = [A_1; ...; A_P] by rows, rank k holds
+ * A_k and b_k; x, the prox and the step-size state are replicated; what crosses ranks is the gradient the pullback
+ * returns — `A' * res` of experiments/lasso/runme.jl:23, consumed at src/AdaProx.jl:336 — plus the two partial f
+ * scalars in the same message: ONE ncclAllReduce(sum, n + 2 elements) per gradient, enqueued by the native loop on
+ * its own stream (with a sharded A_lin also A'y and the dual residual, src/AdaProx.jl:344-358).  The caller of
+ * experiments/lasso/runme.jl:141-149 only swaps its matrix for a row block and passes the communicator.
+ *
+ *  - one process per GPU: rank 0 obtains an id (ncclGetUniqueId), the launcher (torch.distributed.run, MPI, a shared
+ *    file) hands its APX_COMM_ID_BYTES bytes to every rank, each rank calls apx_comm_init_rank (ncclCommInitRank) on
+ *    its own context;
+ *  - one process, several GPUs (a Julia session): one context per device, apx_comm_init_all (ncclCommInitAll), then
+ *    apx_adaptive_primal_dual_group, which runs every device's loop on its own host thread inside the call. */
+#define APX_COMM_ID_BYTES 128
+int32_t apx_comm_unique_id(void* id_out /* [APX_COMM_ID_BYTES] */);
+int32_t apx_comm_init_rank(apx_ctx* ctx, int32_t nranks, int32_t rank, const void* id, apx_comm** out);
+int32_t apx_comm_init_all(apx_ctx* const* ctxs, int32_t ndev, apx_comm** comms_out /* [ndev] */);
+/* ncclCommCount / ncclCommUserRank of the live communicator */
+int32_t apx_comm_info(const apx_comm* comm, int32_t* nranks, int32_t* rank);
+/* sum of a host fp64 vector over the ranks, in place (set-up code: power iteration for Lf, norms; not per iteration) */
+int32_t apx_comm_allreduce_host(apx_comm* comm, double* buf, int64_t count);
+int32_t apx_comm_destroy(apx_comm* comm);
+/* path of the librccl the communicators run on — bound at the first apx_comm_* call, not when this library is loaded:
+ * the copy already in the process if there is one, else the one next to the libamdhip64 in use (csrc/comm.hip);
+ * "" when it could not be loaded (every apx_comm_* call then fails with APX_ERR_COMM) */
+const char* apx_comm_library(void);
+/* adaptive_primal_dual (src/AdaProx.jl:312-364) on ndev row shards held by ONE process: ps[i] lives on device i's context
+ * and carries comm i of apx_comm_init_all; x0 is replicated, y0s[i] / y_outs[i] are shard i of y (NULL arrays when there
+ * is no linear operator); x_out, res and opts->records are rank 0's (all ranks take identical steps).  With ndev = 1 and
+ * no communicator it is apx_adaptive_primal_dual. */
+int32_t apx_adaptive_primal_dual_group(int32_t ndev, apx_problem* const* ps, const apx_rule* rule, const void* x0,
+                                       const void* const* y0s, double tol, int64_t maxit, const apx_solve_opts* opts,
+                                       void* x_out, void* const* y_outs, apx_result* res);
 
 /* ---- dense matrices (the `A` / `X` the experiments build) ------------------ */
 int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx_matrix** out); /* zero-filled */
@@ -254,6 +303,8 @@ int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda);
  * the A*x pass for 2x the matrix memory: 80 GB of the 288 GB at 50 000 x 100 000 fp64).  Any later
  * in-place edit of A (fill / scale) drops the copy. */
 int32_t apx_matrix_build_transpose(apx_matrix* A);
+/* releases that second copy (A itself is untouched); problems on A fall back to the two GEMV passes */
+int32_t apx_matrix_drop_transpose(apx_matrix* A);
 int32_t apx_matrix_free(apx_matrix* A);
 int32_t apx_matrix_shape(const apx_matrix* A, int64_t* m, int64_t* n, int32_t* dtype);
 /* element (i,j) = lo + (hi-lo)*u(seed, j*m_total + row_offset + i); counter-based, so a

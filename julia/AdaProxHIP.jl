@@ -49,6 +49,7 @@ struct ProblemDesc         # apx_problem_desc
     A_lin::Ptr{Cvoid}
     allreduce::Ptr{Cvoid}; allreduce_user::Ptr{Cvoid}
     shard_mask::Int32; _pad2::Int32
+    comm::Ptr{Cvoid}
 end
 
 struct Rule                # apx_rule
@@ -98,6 +99,54 @@ fused_small!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_fused_small, L
 one_pass_threshold!(c::Context, min_bytes::Integer) = check(ccall((:apx_ctx_one_pass_threshold, LIB), Int32, (Ptr{Cvoid}, Int64), c.h, min_bytes))
 exploit_sparsity!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_exploit_sparsity, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
 
+auto_transpose!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_auto_transpose, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
+
+# ---- RCCL communicators: the row-sharded multi-GPU path (include/adaprox_hip.h, apx_comm_*) --------------
+# A = [A_1; ...; A_P] by rows.  One Julia process drives all GPUs of the node:
+#
+#     ctxs  = [AdaProxHIP.Context(d) for d in 0:P-1]
+#     comms = AdaProxHIP.init_all(ctxs)                                   # ncclCommInitAll
+#     fs    = [AdaProxHIP.HipLeastSquares(AdaProxHIP.HipMatrix(ctxs[k], A[rows[k], :]), b[rows[k]]; comm = comms[k]) for k in 1:P]
+#     sol, numit = AdaProxHIP.adaptive_proxgrad_sharded(zeros(n); f = fs, g = NormL1(lam), rule = AdaProx.OurRule(gamma = gam), tol, maxit)
+#
+# (keyword arguments do not dispatch in Julia, hence the separate name; it calls apx_adaptive_primal_dual_group: every device's loop on its own host thread
+# inside the call, ONE ncclAllReduce of [A_k' r_k ; partial f] per gradient on each loop's stream).  With one process per
+# GPU (MPI.jl, Distributed): rank 0 calls `unique_id()`, broadcasts the 128 bytes, every rank `Comm(ctx, nranks, rank, id)`.
+const COMM_ID_BYTES = 128
+mutable struct Comm
+    h::Ptr{Cvoid}
+    ctx::Context
+    function Comm(h::Ptr{Cvoid}, ctx::Context)
+        c = new(h, ctx)
+        finalizer(c -> ccall((:apx_comm_destroy, LIB), Int32, (Ptr{Cvoid},), c.h), c)
+        return c
+    end
+end
+function unique_id()
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    check(ccall((:apx_comm_unique_id, LIB), Int32, (Ptr{Cvoid},), id)); id
+end
+function Comm(ctx::Context, nranks::Integer, rank::Integer, id::Vector{UInt8})
+    @assert length(id) == COMM_ID_BYTES
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:apx_comm_init_rank, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx.h, nranks, rank, id, out))
+    Comm(out[], ctx)
+end
+function init_all(ctxs::Vector{Context})
+    hs = Ptr{Cvoid}[c.h for c in ctxs]
+    out = fill(C_NULL, length(ctxs))
+    check(ccall((:apx_comm_init_all, LIB), Int32, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Ptr{Cvoid}}), hs, length(ctxs), out))
+    [Comm(out[k], ctxs[k]) for k in eachindex(ctxs)]
+end
+function comm_info(c::Comm)
+    n = Ref{Int32}(0); r = Ref{Int32}(0)
+    check(ccall((:apx_comm_info, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), c.h, n, r)); (Int(n[]), Int(r[]))
+end
+"sum of a Float64 vector over the ranks (set-up code: Lf by power iteration over the shards)"
+function allreduce!(c::Comm, v::Vector{Float64})
+    check(ccall((:apx_comm_allreduce_host, LIB), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Int64), c.h, v, length(v))); v
+end
+
 dtype_code(::Type{Float64}) = APX_F64
 dtype_code(::Type{Float32}) = APX_F32
 
@@ -138,9 +187,11 @@ end
 
 # ---- smooth terms --------------------------------------------------------------------------
 "LinearLeastSquares of experiments/lasso/runme.jl:16-27 with A resident on the GPU."
-struct HipLeastSquares{T}; A::HipMatrix{T}; b::Vector{T}; end
-"LogisticLoss of experiments/sparse_logreg/runme.jl:18-39 (bias = last coordinate)."
-struct HipLogistic{T}; X::HipMatrix{T}; y::Vector{T}; end
+struct HipLeastSquares{T}; A::HipMatrix{T}; b::Vector{T}; comm::Union{Nothing,Comm}; end
+HipLeastSquares(A::HipMatrix{T}, b::Vector{T}; comm = nothing) where {T} = HipLeastSquares{T}(A, b, comm)
+"LogisticLoss of experiments/sparse_logreg/runme.jl:18-39 (bias = last coordinate).  Row-sharded: n_total_rows = the N of the mean."
+struct HipLogistic{T}; X::HipMatrix{T}; y::Vector{T}; comm::Union{Nothing,Comm}; n_total_rows::Int; end
+HipLogistic(X::HipMatrix{T}, y::Vector{T}; comm = nothing, n_total_rows = 0) where {T} = HipLogistic{T}(X, y, comm, n_total_rows)
 
 f_fields(f::HipLeastSquares) = (F_LS, f.A, f.b, f.A.n)
 f_fields(f::HipLogistic) = (F_LOGISTIC, f.X, f.y, f.X.n + 1)
@@ -177,6 +228,8 @@ cnt(_, ::Symbol, _) = nothing
 function with_problem(body, f, g, h, A, ::Type{T}) where {T}
     fu, gu, hu, Au = unwrap(f), unwrap(g), unwrap(h), unwrap(A)
     keep = Any[]
+    cm = fu isa Union{HipLeastSquares,HipLogistic} ? fu.comm : nothing
+    ntot = fu isa HipLogistic ? fu.n_total_rows : 0
     A_lin = Au isa HipMatrix ? Au.h : C_NULL
     m = Au isa HipMatrix ? Au.m : 0
     if fu isa Zero                       # experiments/least_absolute_deviation/runme.jl:18-21
@@ -185,10 +238,11 @@ function with_problem(body, f, g, h, A, ::Type{T}) where {T}
         fk, Af, b, n = f_fields(fu)
         Af_h, ctx = Af.h, Af.ctx
     end
-    desc = ProblemDesc(fk, dtype_code(T), n, m, Af_h, isempty(b) ? C_NULL : pointer(b), 0, C_NULL, C_NULL, C_NULL,
-                       proxdesc(gu, T, keep), proxdesc(hu, T, keep), A_lin, C_NULL, C_NULL, 0, 0)
+    desc = ProblemDesc(fk, dtype_code(T), n, m, Af_h, isempty(b) ? C_NULL : pointer(b), ntot, C_NULL, C_NULL, C_NULL,
+                       proxdesc(gu, T, keep), proxdesc(hu, T, keep), A_lin, C_NULL, C_NULL, cm === nothing ? 0 : 1, 0,
+                       cm === nothing ? C_NULL : cm.h)
     out = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve b keep begin
+    GC.@preserve b keep cm begin
         check(ccall((:apx_problem_create, LIB), Int32, (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), ctx.h, Ref(desc), out))
         try
             return body(out[])
@@ -222,6 +276,30 @@ function adaptive_primal_dual(x::Vector{T}, y::Vector{T}; f, g, h, A, rule, tol 
         end
         bump!(f, g, h, A, res)
         return x_out, (lin ? y_out : zero(x_out)), Int(res.numit)
+    end
+end
+
+# several problems at once (one per device), innermost first: body receives the vector of handles
+with_problems(body, fs, g, ::Type{T}, acc = Ptr{Cvoid}[]) where {T} =
+    length(acc) == length(fs) ? body(acc) :
+    with_problem(p -> with_problems(body, fs, g, T, vcat(acc, p)), fs[length(acc) + 1], g, Zero(), 0, T)
+
+"adaptive_proxgrad on row shards held by ONE process: `f` is a vector of HipLeastSquares / HipLogistic, one per device, each with its `comm`"
+function adaptive_proxgrad_sharded(x::Vector{T}; f::AbstractVector, g, rule, tol = 1e-5, maxit = 100_000, name = "AdaPGM") where {T}
+    maxit = floor(Int, maxit)
+    with_problems(f, g, T) do probs
+        recs = Vector{Record}(undef, max(maxit, 1))
+        opts = SolveOpts(pointer(recs), maxit, 0, 0)
+        res = Result(); x_out = similar(x)
+        GC.@preserve recs probs check(ccall((:apx_adaptive_primal_dual_group, LIB), Int32,
+            (Int32, Ptr{Ptr{Cvoid}}, Ref{Rule}, Ptr{T}, Ptr{Ptr{Cvoid}}, Cdouble, Int64, Ref{SolveOpts}, Ptr{T}, Ptr{Ptr{Cvoid}}, Ref{Result}),
+            length(probs), probs, Ref(ruledesc(rule)), x, C_NULL, tol, maxit, Ref(opts), x_out, C_NULL, res))
+        for i in 1:res.n_records                      # replay `@logmsg Record` (:351)
+            r = recs[i]
+            @logmsg AdaProx.Record "" method=name it=r.it gamma=r.gamma sigma=r.sigma norm_res=r.norm_res objective=r.objective grad_f_evals=nothing prox_g_evals=cnt(g, :prox_count, r.it) prox_h_evals=nothing A_evals=nothing At_evals=nothing f_evals=nothing
+        end
+        g isa AdaProx.Counting && (g.prox_count += res.prox_g_evals)
+        return x_out, Int(res.numit)
     end
 end
 

@@ -41,23 +41,35 @@ def test_products_with_transposed_copy(apx, m, n, dtype):
 
 
 def test_solvers_with_dual_layout(apx):
+    """The GENERIC loop on a matrix with a transposed copy (`A*x` as the column-streaming kernel over the copy): a context
+    with the small-size policy off — with it on, 500 x 1000 and 600 x 240 would run small.hip / small_pd.hip on private
+    copies and never reach the dual-layout products this test is about."""
+    ctx = apx.Context(0)
+    ctx.fused_small(False)
     prob = P.random_lasso(500, 1000, pfactor=10, seed=0)
     gam = 1.0 / P.opnorm_sq_power(prob.A, iters=50)
-    dA = apx.DeviceMatrix.from_numpy(prob.A).build_transpose()
+    dA = apx.DeviceMatrix.from_numpy(prob.A, ctx).build_transpose()
     f, g = apx.LinearLeastSquares(dA, prob.b), apx.NormL1(1.0)
     K = 200
     xo, _ = O.adaptive_proxgrad(np.zeros(1000), f=O.LinearLeastSquares(prob.A, prob.b), g=O.NormL1(1.0),
                                 rule=O.OurRule(gamma=gam), tol=0.0, maxit=K)
-    x, _ = apx.adaptive_proxgrad(np.zeros(1000), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K)
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    x, _ = apx.adaptive_proxgrad(np.zeros(1000), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, ctx=ctx)
+    st = ctx.kernel_stats(reset=True)
+    ctx.profile(False)
+    # both products of every iteration were GEMV launches (the small paths book none)
+    assert st["gemv_n"]["launches"] == K + 1 and st["gemv_t"]["launches"] == K + 1
     assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
-    xg, _ = apx.adaptive_proxgrad(np.zeros(1000), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, use_graph=True)
+    xg, _ = apx.adaptive_proxgrad(np.zeros(1000), f=f, g=g, rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, use_graph=True,
+                                  ctx=ctx)
     assert np.array_equal(xg, x)
     lad = P.random_lad(600, 240, seed=1, lam=10.0)
-    dL = apx.DeviceMatrix.from_numpy(lad.A).build_transpose()
+    dL = apx.DeviceMatrix.from_numpy(lad.A, ctx).build_transpose()
     kw = dict(Lf=0.0, norm_A=lad.norm_A, tol=0.0, maxit=150)
     xo, yo, _ = O.condat_vu(np.zeros(240), np.zeros(600), f=O.Zero(), g=O.NormL1(10.0),
                             h=O.Translate(O.NormL1(1.0), -lad.y), A=lad.A, **kw)
     x, y, _ = apx.condat_vu(np.zeros(240), np.zeros(600), f=apx.Zero(), g=apx.NormL1(10.0),
-                            h=apx.Translate(apx.NormL1(1.0), -lad.y), A=dL, **kw)
+                            h=apx.Translate(apx.NormL1(1.0), -lad.y), A=dL, ctx=ctx, **kw)
     assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
     assert np.max(np.abs(y - yo)) <= 1e-10 * np.max(np.abs(yo))

@@ -118,6 +118,104 @@ def test_lasso_c2_solver_at_full_size(apx):
     prob.A.free()
 
 
+def test_logreg_c3_solver_at_full_size(apx):
+    """BASELINE config C3 on its own product path: 100 000 x 10 000 fp32, logistic, f and grad f in one pass over X
+    (k_slab_rows<float, LOGISTIC, 14 columns, 4 rows, 768 threads, two groups, non-temporal loads> — csrc/slab.hip).
+    f and grad f at a point against CPU arithmetic (experiments/sparse_logreg/runme.jl:23-37) on logits whose spot rows
+    are regenerated on the CPU; then the solver: reproducible bit for bit, the first step of the rule exact, progress,
+    and agreement with the two GEMV passes."""
+    problems = importlib.import_module("adaptive-proximal-algorithms_amd.problems")
+    m, n, seed = 100_000, 10_000, 0
+    ctx = apx.Context(0)
+    p = problems.device_logreg(m, n, seed=seed, lam=0.01, dtype=np.float32, ctx=ctx)
+    p.X.build_transpose()
+    f = apx.LogisticLoss(p.X, p.y, ctx=ctx)
+    rng = np.random.default_rng(1)
+    w = (0.05 * rng.standard_normal(n + 1) * (rng.uniform(size=n + 1) < 0.3)).astype(np.float32)
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    fx, pb = apx.eval_with_pullback(f, w)
+    grad = pb()
+    st = ctx.kernel_stats(reset=True)
+    ctx.profile(False)
+    assert st["gemv_n"]["launches"] == 1 and st["gemv_t"]["launches"] == 0        # ONE pass over X gave both
+    # logits: the GEMV path (itself checked on spot rows here), the rest on the CPU in fp64
+    Xw = (p.X @ w[:-1]).astype(np.float64)
+    rows = [0, 1, 767, 768, m // 2, m - 2, m - 1]
+    ref = _cpu_rows(seed, rows, m, n, np.float32) @ w[:-1].astype(np.float64)
+    assert np.max(np.abs(Xw[rows] - ref)) <= 3e-5 * max(np.max(np.abs(ref)), 1.0)
+    logits = Xw + float(w[-1])                                                      # :24
+    u = 1.0 + np.exp(-logits)                                                       # :25
+    y64 = p.y.astype(np.float64)
+    f_ref = -np.mean((y64 - 1.0) * logits - np.log(u))                              # :36
+    assert fx == pytest.approx(f_ref, rel=2e-5)
+    r = 1.0 / u - y64                                                               # :28-30
+    cols = [0, 1, 767, 768, 769, n // 2, n - 2, n - 1]
+    g_ref = _cpu_cols(seed, cols, m, m, np.float32).T @ r / m                       # :31
+    assert np.max(np.abs(grad[cols] - g_ref)) <= 2e-4 * np.max(np.abs(grad[:-1]))
+    assert grad[-1] == pytest.approx(np.mean(r), rel=2e-4, abs=1e-7)                # :32 bias = last coordinate
+    # the solver on this path
+    kw = dict(g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0), tol=0.0, maxit=12)
+    runs = []
+    for _ in range(2):
+        recs = []
+        x, it = apx.adaptive_proxgrad(np.zeros(n + 1, dtype=np.float32), f=f, record=recs.append, ctx=ctx, **kw)
+        runs.append((x, [r_["objective"] for r_ in recs], [r_["gamma"] for r_ in recs]))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]      # no atomics: bit-reproducible
+    obj = runs[0][1]
+    assert all(np.isfinite(obj)) and obj[-1] < obj[0]
+    assert runs[0][2][0] == pytest.approx(np.sqrt(2) * p.gamma0, rel=1e-12)         # src/AdaProx.jl:264, gamma_1 = gamma_0
+    # the two GEMV passes on the same data (policy off): same iterates to fp32 rounding
+    ctx2 = apx.Context(0)
+    ctx2.fused_small(False)
+    # (same device matrix; a problem created on ctx2 needs a matrix of ctx2: regenerate — counter-based, identical bits)
+    X2 = apx.DeviceMatrix.uniform(m, n, seed=seed, lo=-1.0, hi=1.0, dtype=np.float32, ctx=ctx2)
+    x2, _ = apx.adaptive_proxgrad(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(X2, p.y, ctx=ctx2), ctx=ctx2, **kw)
+    assert np.max(np.abs(x2 - runs[0][0])) <= 2e-3 * max(np.max(np.abs(x2)), 1e-30)
+    X2.free()
+    p.X.free()
+
+
+def test_lad_c5_solver_at_full_size(apx):
+    """BASELINE config C5: least absolute deviation 50 000 x 20 000 fp64 through condat_vu (src/AdaProx.jl:367-416 on the
+    loop of :324-363).  The first iteration from (0, 0) has a closed form — y1 = clamp(sigma * b, -1, 1) (the conjugate
+    prox of Translate(NormL1, -b)), x2 = soft-threshold(-gamma * A' y1, gamma * lam) — checked on spot
+    columns regenerated on the CPU; then reproducibility, the fixed step sizes and the residual bookkeeping."""
+    problems = importlib.import_module("adaptive-proximal-algorithms_amd.problems")
+    m, n, seed, lam = 50_000, 20_000, 0, 10.0
+    ctx = apx.Context(0)
+    p = problems.device_lad(m, n, seed=seed, lam=lam, ctx=ctx)
+    p.A.build_transpose()
+    norm_A = p.norm_A
+    gamma = 1.0 / (0.0 / 2 + norm_A / 1.0)                      # :405-411 with Lf = 0
+    sigma = 0.99 / (norm_A * 1.0)
+    t = dict(f=apx.Zero(), g=apx.NormL1(lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=p.A, ctx=ctx)
+    recs = []
+    x2, y1, it = apx.condat_vu(np.zeros(n), np.zeros(m), Lf=0.0, norm_A=norm_A, tol=0.0, maxit=1, record=recs.append, **t)
+    assert it == 1
+    sig_eff = gamma * np.sqrt(sigma / gamma) ** 2               # FixedStepsize recomputes sigma = gamma * t^2 (Appendix A.4)
+    y_ref = np.clip(0.0 - sig_eff * p.y, -1.0, 1.0)             # w = 0 ; h = ||. - b||_1: prox of sigma h* is clamp(w - sigma b, -1, 1)
+    assert np.max(np.abs(y1 - y_ref)) <= 1e-13
+    assert recs[0]["gamma"] == gamma and recs[0]["sigma"] == pytest.approx(sigma, rel=1e-15)
+    assert recs[0]["norm_res"] == pytest.approx(np.linalg.norm(y_ref) / sig_eff, rel=1e-12)      # dual_res = -y1 / sigma
+    cols = [0, 1, 31, 32, n // 2, n - 3, n - 2]
+    Aty = _cpu_cols(seed, cols, m, m).T @ y_ref
+    v = -gamma * Aty
+    x_ref = np.sign(v) * np.maximum(np.abs(v) - gamma * lam, 0.0)
+    assert np.max(np.abs(x2[cols] - x_ref)) <= 1e-11 * max(np.max(np.abs(v)), 1e-300)
+    v_last = -gamma * float(np.sum(y_ref))                      # the column of ones (runme.jl:42)
+    assert x2[n - 1] == pytest.approx(np.sign(v_last) * max(abs(v_last) - gamma * lam, 0.0), rel=1e-10, abs=1e-18)
+    runs = []
+    for _ in range(2):
+        recs = []
+        x, y, it = apx.condat_vu(np.zeros(n), np.zeros(m), Lf=0.0, norm_A=norm_A, tol=0.0, maxit=10, record=recs.append, **t)
+        runs.append((x, y, [r_["norm_res"] for r_ in recs], [r_["objective"] for r_ in recs]))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+    assert all(np.isfinite(runs[0][2])) and all(np.isfinite(runs[0][3]))
+    assert np.max(np.abs(runs[0][1])) <= 1.0                    # y stays in the dual ball of the l1 norm
+    p.A.free()
+
+
 def test_native_allreduce_hook_world_size_one(apx):
     """The RCCL hook of the row-sharded path with a single rank: all-reduce over one rank is the
     identity, so the run must equal the un-hooked one bit for bit."""

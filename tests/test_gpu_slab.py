@@ -33,7 +33,10 @@ def _rel(a, b):
                                                 (140000, 200, False, np.float32),
                                                 (140000, 300, False, np.float64),
                                                 (20000, 2500, True, np.float32),
-                                                (17000, 6000, False, np.float32)])    # ... and > 384 MB: non-temporal loads
+                                                (17000, 6000, False, np.float32),     # ... and > 384 MB: non-temporal loads
+                                                # BASELINE config C3's own kernel: fp32 logistic, 14 columns per thread, four rows
+                                                # per step in two groups, >= 384 MB (non-temporal loads) — 9800 x 10000 x 4 B = 392 MB
+                                                (9800, 10000, True, np.float32)])
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
@@ -237,4 +240,66 @@ def test_one_pass_serves_every_loop_and_the_operator_calls(apx):
         z, it = getattr(apx, name)(x0, f=df, g=apx.NormL1(0.01), tol=0.0, maxit=K, ctx=ctx, **kw)
         assert it == ito == K and _rel(z, zo) <= 1e-10, name
         assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count), name
+    dA.free()
+
+
+def test_linesearch_trials_rejected_on_the_one_pass_path(apx):
+    """backtracking_proxgrad / backtracking_nesterov where EVERY iteration rejects trials (gamma0 = 1000 / L): each trial
+    evaluates f at z, and on this path that evaluation also forms grad f(z); the next shrink trial must still be built
+    from grad f(x) (src/AdaProx.jl:43-45).  Iterates, step sizes and evaluation counts against the oracle."""
+    rng = np.random.default_rng(33)
+    m, n = 9000, 1100
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    b = rng.standard_normal(m)
+    L = float(np.linalg.norm(A, 2) ** 2)
+    K = 10
+    x0 = 0.01 * rng.standard_normal(n)
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        ctx.one_pass_threshold(16 << 20)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        for name, kw in (("backtracking_proxgrad", dict(gamma0=1e3 / L, xi=2.0)), ("backtracking_proxgrad", dict(gamma0=1e3 / L, xi=1.0)),
+                         ("backtracking_nesterov", dict(gamma0=1e3 / L))):
+            of, df = O.Counting(O.LinearLeastSquares(A, b)), apx.Counting(apx.LinearLeastSquares(dA, b, ctx=ctx))
+            ro, rd = [], []
+            zo, ito = getattr(O, name)(x0, f=of, g=O.NormL1(1.0), tol=0.0, maxit=K, record=ro.append, **kw)
+            z, it = getattr(apx, name)(x0, f=df, g=apx.NormL1(1.0), tol=0.0, maxit=K, ctx=ctx, record=rd.append, **kw)
+            assert it == ito == K
+            assert of.eval_count > K + 1 + (K if name.endswith("nesterov") else 0), "no trial was rejected: the test tests nothing"
+            assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count), (name, kw, one_pass)
+            assert _rel(z, zo) <= 1e-10, (name, kw, one_pass)
+            assert [r["gamma"] for r in rd] == pytest.approx([r["gamma"] for r in ro], rel=1e-12)
+            assert [r["objective"] for r in rd] == pytest.approx([r["objective"] for r in ro], rel=1e-10)
+        dA.free()
+
+
+def test_transposed_copy_is_opt_out(apx):
+    """apx_ctx_auto_transpose(0): the library never allocates the second copy by itself; the one-pass kernels
+    then run only where the caller built it, and apx_matrix_drop_transpose gives the memory back."""
+    rng = np.random.default_rng(8)
+    m, n = 9000, 1000
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    b = rng.standard_normal(m)
+    gam = 1.0 / (m * n / 3.0)
+    xo, _ = O.adaptive_proxgrad(np.zeros(n), f=O.LinearLeastSquares(A, b), g=O.NormL1(1.0), rule=O.OurRule(gamma=gam), tol=0.0, maxit=10)
+    ctx = apx.Context(0)
+    ctx.one_pass_threshold(16 << 20)
+    ctx.auto_transpose(False)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    kw = dict(g=apx.NormL1(1.0), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=10, ctx=ctx)
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    x, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(dA, b, ctx=ctx), **kw)
+    st = ctx.kernel_stats(reset=True)
+    assert st["gemv_t"]["launches"] == 11 and _rel(x, xo) <= 1e-10          # two passes: no copy was made
+    dA.build_transpose()
+    x, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(dA, b, ctx=ctx), **kw)
+    st = ctx.kernel_stats(reset=True)
+    assert st["gemv_t"]["launches"] == 0 and st["gemv_n"]["launches"] == 11 and _rel(x, xo) <= 1e-10      # one pass
+    dA.drop_transpose()
+    x, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(dA, b, ctx=ctx), **kw)
+    st = ctx.kernel_stats(reset=True)
+    assert st["gemv_t"]["launches"] == 11 and _rel(x, xo) <= 1e-10
+    ctx.profile(False)
     dA.free()

@@ -57,6 +57,10 @@ def test_lasso_reference_sizes_vs_oracle_and_generic(apx, generic_ctx, m, n, K):
     else:
         assert itf == itg == len(ro) == K and len(rf) == len(rg) == K
     assert _rel(xf, xo) <= RTOL and _rel(xf, xg) <= RTOL
+    assert _rel(xg, xo) <= RTOL                             # the generic kernels against the oracle directly, not via xf
+    for a, b_ in zip(rg, [] if min(m, n) == 1 else ro):
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-8)
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10)
     for a, b_ in zip(rf, [] if min(m, n) == 1 else ro):     # (n = 1: the rule's ratios turn into 0/0 noise)
         assert a["it"] == b_["it"]
         assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-8)
