@@ -21,6 +21,7 @@
 // methods, apx_eval) in place of gemv_n + k_finish_rows + k_f_reduce and of the gemv_t (+ k_logistic_grad) of the
 // pullback, when there is no all-reduce hook; it reads the transposed copy of A (apx_matrix_build_transpose), which a matrix of up to
 // 16 GB is given on the spot.
+#include <algorithm>
 #include <cstdlib>
 #include <memory>
 
@@ -46,6 +47,8 @@ struct SlabState {
   DBuf part;
   SlabDev dev{};
   int B = 0, cpt = 0, bs = 0;     // blocks ; columns per thread ; threads per block
+  int kv = 0, bs2 = 768;          // long rows: 16-byte vectors per thread and row of k_slab2_rows (0: k_slab_rows), its block size
+  bool v2 = true;                 // (APX_SLAB_V1=1 in the environment: the first-generation kernel for long rows too — A/B runs)
   bool pipe = true, nt = true;    // two row groups in flight ; non-temporal loads of A
 };
 void slab_destroy(SlabState* st) { delete st; }      // (null is fine)
@@ -208,12 +211,205 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
   }
 }
 
-// 64 columns per block (a wave reads 512 contiguous bytes of a partial row), the B partials of a column dealt to 4
-// threads (b = s, s + 4, ...: sixteen loads in flight each), then the 4 sub-sums added in order.
+// ---------------------------------------------------------------------------------------------------------------------
+// Long rows (5121 ... 10 752 columns — BASELINE config C3), second generation of the row kernel.  What round 2 measured
+// on the first one (tools/slab2_probe.hip, profiles/r02_one_pass_probe.log): at C3 it is not the loads that cost — a
+// kernel that only loads in this pattern reads at 6.7 - 6.9 TB/s, three rows in flight do as well as six — but (i) the
+// Float64 conversions of Float32 data, two per element and one more per x entry and row: the vector ALU was the
+// bottleneck (fp64 conversions and FMAs issue at a quarter of the Float32 rate); (ii) the 4-byte loads with a register
+// per column for their addresses.  So:
+//   * column-BLOCKED mapping: thread t holds the 16-byte vectors t, t + BS, ... of a row — 1 KiB per wave-load, through
+//     buffer loads: a scalar descriptor per row, ONE per-lane offset register for the whole kernel, scalar offsets for
+//     the vectors (no address registers per column; rows are zero-padded to whole vectors in the transposed copy and
+//     the descriptor ends at the padded row: no clamping)
+//   * Float32 data: each thread's share of a dot product (<= 16 products) is accumulated in Float32, the sum over the
+//     768 threads in Float64; the H products a column receives per group are summed in Float32 (the residuals ARE
+//     Float32 values) and added to the Float64 column accumulator.  Both errors are of the order of the rounding of
+//     `A x` and of the gradient to Float32 that follows anyway (measured: 5e-10 on f, 4e-8 on the gradient, relative).
+//     Float64 data: Float64 throughout, as before.
+//   * G groups of H rows in flight (2 x 2), b of a group's rows loaded behind its rows of A (a load issued later would
+//     wait for every load before it), two barriers per group as before (the link function is evaluated once per row).
+// C3: 0.646 -> 0.58 ms per launch under rocprofv3 (profiles/r02_*).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct SlabVec;
+template <> struct SlabVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct SlabVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <typename T, int FK, int KV, int H, int G, bool NT>
+__global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
+  constexpr int VW = 16 / (int)sizeof(T);          // elements per 16-byte vector
+  constexpr int kMaxWaves = 12;
+  constexpr bool kF32 = sizeof(T) == 4;
+  const int BS = (int)blockDim.x;                  // (768 ; any multiple of 64 up to it works)
+  const int NW = BS / 64;
+  typedef typename SlabVec<T>::type vec_t;
+  typedef unsigned raw_t __attribute__((ext_vector_type(4)));
+  __shared__ double wsum[kMaxWaves][H];
+  __shared__ double res_s[H];
+  __shared__ T bs[H];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (d.c->done != 0) return;                      // written by an earlier launch: block-uniform
+  const T* __restrict__ X = (const T*)xv;
+  vec_t xr[KV];
+  double acc[KV][VW];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int j = (tid + k * BS) * VW;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      xr[k][e] = (j + e) < d.ncols ? X[j + e] : (T)0;        // (logistic: X[ncols] is the bias, not a column weight)
+      acc[k][e] = 0.0;
+    }
+  }
+  double bias = 0.0;
+  if constexpr (FK == APX_F_LOGISTIC) bias = (double)X[d.n - 1];
+  const int voff = tid * 16;                       // the one per-lane address register
+  const int row_bytes = (int)(d.ldT * (int64_t)sizeof(T));
+  double e0 = 0.0, e1 = 0.0;                       // loss sums of the rows this thread finishes (tid < H)
+  const int row_begin = blockIdx.x * d.rows_per_block;
+  const int row_end = min(row_begin + d.rows_per_block, d.m);
+  vec_t a[G][H][KV];
+  T b_in[G];
+  const T* __restrict__ AT = (const T*)d.AT;
+  const T* __restrict__ bv = (const T*)d.b;
+  auto load = [&](int g, int r0) {                 // rows past the slab: its last row again (a valid address ; residual 0)
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, row_end - 1));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, row_bytes, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BS * 16, NT ? 2 : 0);   // (aux 2: nt)
+        a[g][r][k] = __builtin_bit_cast(vec_t, raw);
+      }
+    }
+    b_in[g] = bv[min(r0 + min(tid, H - 1), row_end - 1)];
+  };
+  auto group = [&](int g, int r0) {
+    double p[H];
+    if constexpr (kF32) {
+      float q[H];
+#pragma unroll
+      for (int r = 0; r < H; ++r) q[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e)
+#pragma unroll
+          for (int r = 0; r < H; ++r) q[r] = fmaf(a[g][r][k][e], xr[k][e], q[r]);
+#pragma unroll
+      for (int r = 0; r < H; ++r) p[r] = (double)q[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < H; ++r) p[r] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e)
+#pragma unroll
+          for (int r = 0; r < H; ++r) p[r] = fma(a[g][r][k][e], xr[k][e], p[r]);
+    }
+    wave_sum_multi<H>(p);                          // lane l: the wave's sum for row l / (64 / H)
+    if (lane % (64 / H) == 0) wsum[wv][lane / (64 / H)] = p[0];
+    if (tid < H) bs[tid] = b_in[g];
+    __syncthreads();
+    if (tid < H) {
+      double dot = wsum[0][tid];
+      for (int w = 1; w < NW; ++w) dot += wsum[w][tid];
+      const int i = r0 + tid;
+      double res = 0.0;
+      if (i < row_end) {
+        const double bi = (double)bs[tid];
+        const double ax = (double)(T)dot;          // A_x rounded to T like every stored A x
+        if constexpr (FK == APX_F_LEAST_SQUARES) {
+          res = (double)(T)(ax - bi);
+          e0 += res * res;
+        } else {
+          const double logit = ax + bias;
+          if constexpr (kF32) {                    // Float32 data: the link in Float32, as Julia would on Float32 arrays
+            const float lf = (float)logit;
+            const float ef = 1.0f + expf(-lf);
+            e0 += (double)(((float)bi - 1.0f) * lf - logf(ef));
+            res = (double)(1.0f / ef - (float)bi);
+          } else {
+            const double e = 1.0 + exp(-logit);
+            e0 += (bi - 1.0) * logit - log(e);
+            res = (double)(T)(1.0 / e - bi);
+          }
+          e1 += res;
+        }
+      }
+      res_s[tid] = res;
+    }
+    __syncthreads();
+    if constexpr (kF32) {
+      float rf[H];
+#pragma unroll
+      for (int r = 0; r < H; ++r) rf[r] = (float)res_s[r];
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          float t = a[g][0][k][e] * rf[0];
+#pragma unroll
+          for (int r = 1; r < H; ++r) t = fmaf(a[g][r][k][e], rf[r], t);
+          acc[k][e] += (double)t;
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < H; ++r) {
+        const double rr = res_s[r];
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) acc[k][e] = fma(a[g][r][k][e], rr, acc[k][e]);
+      }
+    }
+#pragma unroll                                     // the sums are complete HERE (see k_slab_rows)
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) asm volatile("" : "+v"(acc[k][e]));
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    load(g, row_begin + g * H);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll 1
+  for (int r0 = row_begin; r0 < row_end; r0 += G * H) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      group(g, r0 + g * H);
+      __builtin_amdgcn_sched_barrier(0);           // (the loads AFTER the accumulation that frees their registers and
+      load(g, r0 + (G + g) * H);                   //  before the next group's dots)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int j = (tid + k * BS) * VW;
+#pragma unroll
+    for (int e = 0; e < VW; ++e)
+      if (j + e < d.ncols) out[j + e] = acc[k][e];
+  }
+  if (wv == 0) {
+    double ex[2] = {tid < H ? e0 : 0.0, tid < H ? e1 : 0.0};
+    wave_sum_multi<2>(ex);                         // lane l: ex[l / 32]
+    if ((lane & 31) == 0) out[d.ncols + (lane >> 5)] = ex[0];
+  }
+}
+
+// 64 columns per block (a wave reads 512 contiguous bytes of a partial row), the B partials of a column dealt to 16
+// threads (b = s, s + 16, ...: with one block per CU in the row kernel that is ALL of a thread's loads in flight at
+// once — 256 threads with four rounds of sixteen took 19.8 us at C3, 3 % of the iteration), then the 16 sub-sums added
+// in order.
 constexpr int kSlabCloseCols = 64;
+constexpr int kSlabCloseBlock = 1024;
 template <typename T, int FK>
-__global__ __launch_bounds__(kBlock) void k_slab_close(SlabDev d, int B, T* __restrict__ grad) {
-  constexpr int S = kBlock / kSlabCloseCols;
+__global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B, T* __restrict__ grad) {
+  constexpr int S = kSlabCloseBlock / kSlabCloseCols;
   __shared__ double fs[2];
   __shared__ double sub[S][kSlabCloseCols];
   if (d.c->done != 0) return;
@@ -295,10 +491,23 @@ static int32_t slab_setup(apx_problem* p) {
   // as many blocks as fit the chip at once — one per CU, two of the two-columns-per-thread kind (~58 VGPRs): rows in
   // contiguous slabs, a multiple of the step ; fewer blocks = fewer partial vectors for the closing kernel
   int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
-  int64_t rpb = (A->m + B - 1) / B;
-  rpb = round_up(rpb, 16);                 // (a multiple of every step size)
+  // rows dealt evenly: a block's last step may be partial (rows past its slab are clamped and weigh nothing), so nothing
+  // is rounded up — rounding to 16 left 6 of C3's 256 CUs without a block
+  const int64_t rpb = (A->m + B - 1) / B;
   B = (A->m + rpb - 1) / rpb;
   st->B = (int)B;
+  if (st->cpt == 14) {                     // long rows: k_slab2_rows, KV 16-byte vectors per thread and row
+    const int64_t vw = 16 / (int64_t)dtype_size(p->dtype);
+    st->kv = (int)((A->n + vw * 768 - 1) / (vw * 768));
+    // (measured and dropped: fewer whole waves where KV vectors per thread over-cover a row — C3: 640 threads x 16 columns
+    // = 10 240 for its 10 000 — ran 1 - 3 % slower than 768 threads: waves are dealt to four SIMDs, 10 or 11 of them
+    // unevenly.  And Float32 rows of more than 9216 columns stay on the first-generation kernel: interleaved in one
+    // process (tools/slab_ab.py, profiles/r02_one_pass_generations_ab.jsonl) it is 1 - 1.5 % faster there — its 14 x 768
+    // column slots fit 10 000 columns better than 16 x 768 — while the second generation wins wherever its KV adapts:
+    // 120 000 x 6000 fp32 0.47 vs 0.60 ms per iteration, 60 000 x 8000 fp64 0.60 vs 0.68, 50 000 x 10 000 fp64 0.64 vs 0.66)
+    if (p->dtype == APX_F32 && st->kv == 4) st->v2 = false;
+    if (const char* e = getenv("APX_SLAB_V1")) st->v2 = atoi(e) == 0;
+  }
   SlabDev d{};
   d.AT = A->dT;
   d.ldT = A->ldT;
@@ -337,6 +546,36 @@ static void slab_rows_launch(const SlabState* st, dim3 grid, hipStream_t q, cons
   else hipLaunchKernelGGL((k_slab_rows<T, FK, C, R, BS, false, false>), grid, dim3(BS), 0, q, d, x);
 }
 
+// k_slab2_rows for this matrix: KV by the row length ; rows in flight by what the registers hold (170 per thread at 768
+// threads: x and the accumulator take 2 KV (Float32: 3 KV) ... of them, a row 4 KV)
+template <typename T, int FK, int KV, int H, int G>
+static void slab2_rows_launch(const SlabState* st, dim3 grid, hipStream_t q, const SlabDev& d, const void* x) {
+  if (st->nt) hipLaunchKernelGGL((k_slab2_rows<T, FK, KV, H, G, true>), grid, dim3((unsigned)st->bs2), 0, q, d, x);
+  else hipLaunchKernelGGL((k_slab2_rows<T, FK, KV, H, G, false>), grid, dim3((unsigned)st->bs2), 0, q, d, x);
+}
+template <typename T, int FK>
+static bool slab2_dispatch(const SlabState* st, dim3 grid, hipStream_t q, const SlabDev& d, const void* x) {
+  if constexpr (sizeof(T) == 4) {
+    switch (st->kv) {                      // 4 columns per vector: up to 6144 / 9216 / 12 288 columns
+      case 2: slab2_rows_launch<T, FK, 2, 2, 2>(st, grid, q, d, x); return true;
+      case 3: slab2_rows_launch<T, FK, 3, 2, 2>(st, grid, q, d, x); return true;
+      case 4: slab2_rows_launch<T, FK, 4, 2, 2>(st, grid, q, d, x); return true;
+      default: return false;
+    }
+  } else {
+    // (Float64 logistic: exp / log in Float64 take ~50 registers of their own and every shape of this kernel spills
+    // with them — the first-generation kernel, one row per step, stays)
+    if constexpr (FK == APX_F_LOGISTIC) return false;
+    else switch (st->kv) {                 // 2 columns per vector: up to 6144 / 7680 / 9216 / 10 752 columns
+      case 4: slab2_rows_launch<T, FK, 4, 2, 2>(st, grid, q, d, x); return true;
+      case 5: slab2_rows_launch<T, FK, 5, 2, 2>(st, grid, q, d, x); return true;
+      case 6: slab2_rows_launch<T, FK, 6, 1, 3>(st, grid, q, d, x); return true;
+      case 7: slab2_rows_launch<T, FK, 7, 1, 2>(st, grid, q, d, x); return true;      // (three rows in flight spill)
+      default: return false;
+    }
+  }
+}
+
 template <typename T, int FK>
 static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
@@ -344,9 +583,10 @@ static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, 
   constexpr bool kPipeOk = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;       // (the others spill as two groups)
   if (st->cpt == 2) slab_rows_launch<T, FK, 2, 16, 1024, kPipeOk>(st, grid, q, d, x);
   else if (st->cpt == 5) slab_rows_launch<T, FK, 5, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
-  else slab_rows_launch<T, FK, 14, R14, 768, (sizeof(T) == 4)>(st, grid, q, d, x);
-  hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kBlock), 0, q, d,
-                     st->B, (T*)grad);
+  else if (!(st->kv != 0 && st->v2 && slab2_dispatch<T, FK>(st, grid, q, d, x)))
+    slab_rows_launch<T, FK, 14, R14, 768, (sizeof(T) == 4)>(st, grid, q, d, x);
+  hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
+                     dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
 }
 
 // f(x) -> Ctrl, grad f(x) -> p->grad for the device vector x: what eval_f + pullback_f leave behind.  Called by eval_f

@@ -185,11 +185,13 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     p.X.build_transpose()
     s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(p.X, p.y), g=apx.NormL1(p.lam),
                    rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
-    dt, st = timed_steps(ctx, s, 400, 20, barrier)
+    # (200 timed iterations: in fp32 this run reaches a bit-for-bit fixed point a few hundred iterations in, after which
+    # the frozen loop's launches are no-ops — the check below refuses such a run)
+    dt, st = timed_steps(ctx, s, 200, 20, barrier)
     x, _, res = s.result()
-    if not np.all(np.isfinite(x)) or int(res.numit) != 420 or res.converged:
-        sys.exit("bench.py: C3 leg: the timed steps were not all real")
-    out["C3"] = report(m, n, 4, 400, dt, st, res,
+    if not np.all(np.isfinite(x)) or int(res.numit) != 220 or res.converged:
+        sys.exit("bench.py: C3 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
+    out["C3"] = report(m, n, 4, 200, dt, st, res,
                        "f and grad f in ONE pass over X per iteration (csrc/slab.hip, booked under gemv_n): "
                        "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read")
     out["C3"]["workload"] = "sparse_logreg, dense synthetic A 100000x10000 fp32, logistic grad + NormL1 prox, adaptive_proxgrad (OurRule)"
@@ -207,7 +209,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     dt, st = timed_steps(ctx, s, 200, 10, barrier)
     x, _, res = s.result()
     if not np.all(np.isfinite(x)) or int(res.numit) != 210 or res.converged:
-        sys.exit("bench.py: C5 leg: the timed steps were not all real")
+        sys.exit("bench.py: C5 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
     out["C5"] = report(m, n, 8, 200, dt, st, res,
                        "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip)")
     out["C5"]["workload"] = "least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50000x20000 fp64 (Ax / A'y pair + conj-prox)"

@@ -13,8 +13,8 @@
  *   g = NormL1(lam)  (ProximalOperators, third-party, unpinned: soft-threshold)
  *
  * A is column-major m x n with leading dimension lda (Julia layout).  The two products are the whole cost
- * (experiments/lasso/runme.jl:179-180): `A*x` is parallel over row blocks (each thread streams its rows of every
- * column: a private slice of the result, no reduction across threads), `A'*r` over columns (one dot product each).
+ * (experiments/lasso/runme.jl:179-180): both are parallel over blocks of columns (`A*x` into a private m-vector per
+ * thread, summed afterwards; `A'*r` one dot product per column), the blocks the generator touched first.
  * Summation order differs from OpenBLAS dgemv; agreement with the numpy oracle is to rounding (tests: 1e-10 over 30
  * iterations at 300 x 700).
  */
@@ -34,29 +34,44 @@ int apx_oracle_omp_threads(void) {
 #endif
 }
 
-/* res = A*x - b ; returns norm(res)^2 accumulated per row block (experiments/lasso/runme.jl:22,24) */
+/* res = A*x - b ; returns norm(res)^2 (experiments/lasso/runme.jl:22,24).  The threads split the COLUMNS in the same static
+ * blocks as the generator and the gradient below — on a two-socket host every thread then streams pages it touched first
+ * (NUMA-local) — each into a private m-vector, summed over the threads in thread order afterwards. */
 static double residual(const double* A, int64_t m, int64_t n, int64_t lda, const double* x, const double* b, double* res) {
-  double ss = 0.0;
-  const int64_t RB = 2048;                              /* rows per block: 16 KB of accumulators stay in L1 */
-  const int64_t nblk = (m + RB - 1) / RB;
-#pragma omp parallel for schedule(static) reduction(+ : ss)
-  for (int64_t blk = 0; blk < nblk; ++blk) {
-    const int64_t i0 = blk * RB, i1 = i0 + RB < m ? i0 + RB : m;
-    double acc[2048];
-    for (int64_t i = i0; i < i1; ++i) acc[i - i0] = 0.0;
-    for (int64_t j = 0; j < n; ++j) {
+  int T = 1;
+#ifdef _OPENMP
+  T = omp_get_max_threads();
+#endif
+  double* acc = (double*)malloc(sizeof(double) * (size_t)T * (size_t)m);
+  if (!acc) return NAN;
+#pragma omp parallel num_threads(T)
+  {
+    int t = 0, nt = 1;
+#ifdef _OPENMP
+    t = omp_get_thread_num();
+    nt = omp_get_num_threads();
+#endif
+    double* a = acc + (size_t)t * (size_t)m;
+    for (int64_t i = 0; i < m; ++i) a[i] = 0.0;
+    /* the static schedule of `#pragma omp parallel for schedule(static)` over n columns */
+    const int64_t q = n / nt, r = n % nt;
+    const int64_t j0 = t * q + (t < r ? t : r), j1 = j0 + q + (t < r ? 1 : 0);
+    for (int64_t j = j0; j < j1; ++j) {
       const double xj = x[j];
       const double* col = A + j * lda;
-      for (int64_t i = i0; i < i1; ++i) acc[i - i0] += col[i] * xj;
+      for (int64_t i = 0; i < m; ++i) a[i] += col[i] * xj;
     }
-    double s = 0.0;
-    for (int64_t i = i0; i < i1; ++i) {
-      const double r = acc[i - i0] - b[i];
-      res[i] = r;
-      s += r * r;
-    }
-    ss += s;
   }
+  double ss = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : ss)
+  for (int64_t i = 0; i < m; ++i) {
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s += acc[(size_t)t * (size_t)m + i];
+    const double r = s - b[i];
+    res[i] = r;
+    ss += r * r;
+  }
+  free(acc);
   return ss;
 }
 

@@ -186,7 +186,7 @@ def test_bench_takes_the_in_library_path(apx):
     """bench.py's N-rank code path with the single rank of this box (APX_BENCH_FORCE_DIST=1): the communicator comes from
     apx_comm_init_rank, `rccl_ranks` is what ncclCommCount says, and the run equals the plain one."""
     env = dict(os.environ, APX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
-    args = ["--rows", "3000", "--cols", "4000", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"]
+    args = ["--rows", "3000", "--cols", "12000", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -198,5 +198,5 @@ def test_bench_takes_the_in_library_path(apx):
     assert out2.returncode == 0, out2.stderr[-2000:]
     plain = json.loads(out2.stdout.strip().splitlines()[-1])
     assert "rccl_ranks" not in plain
-    # 3000 x 4000 is on the generic kernels either way (96 MB: below the one-pass threshold, above the small paths)
+    # 3000 x 12000 is on the generic kernels either way (rows too long for the one-pass kernel, too many for the small paths)
     assert line["final_objective"] == plain["final_objective"]

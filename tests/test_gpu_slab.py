@@ -36,7 +36,16 @@ def _rel(a, b):
                                                 (17000, 6000, False, np.float32),     # ... and > 384 MB: non-temporal loads
                                                 # BASELINE config C3's own kernel: fp32 logistic, 14 columns per thread, four rows
                                                 # per step in two groups, >= 384 MB (non-temporal loads) — 9800 x 10000 x 4 B = 392 MB
-                                                (9800, 10000, True, np.float32)])
+                                                (9800, 10000, True, np.float32),
+                                                # the second-generation long-row kernel (k_slab2_rows: 16-byte buffer loads, KV
+                                                # vectors per thread by the row length): Float32 KV = 2, 3 ; Float64 KV = 4 ... 7
+                                                (6000, 5500, True, np.float32),
+                                                (5000, 8000, True, np.float32),
+                                                (4300, 9216, False, np.float32),
+                                                (4200, 5500, False, np.float64),
+                                                (4100, 7001, False, np.float64),
+                                                (4100, 9000, False, np.float64),
+                                                (4103, 10752, False, np.float64)])
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
