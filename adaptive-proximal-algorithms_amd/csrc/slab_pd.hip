@@ -28,11 +28,31 @@ struct SlabPdDev {
   ProxDev h;
 };
 
+// hand-off state of the two-CU teams (k_teampd_rows below)
+struct TeamRec {          // one partial dot product: the value and value ^ sequence
+  unsigned long long v, chk;
+};
+constexpr int kTeamSlots = 8;      // ring of published rows per member (>= 4 suffices: a partner is at most 2 rows ahead)
+struct TeamDev {
+  TeamRec* ring;          // [teams][kTeamSlots][2]
+  unsigned* tickets;      // [8] one counter per XCD, monotonic over the launches
+  int* err;               // != 0: a wait timed out (1) / an XCD received more than 32 workgroups of a launch (2)
+  unsigned long long seq0;   // sequence base of this launch (the ring is never reset)
+  unsigned launch;        // launches so far: the ticket base is launch * 32
+  int32_t rows_per_team;
+};
+
 struct SlabPdState {
   DBuf part;
   SlabPdDev dev{};
   int B = 0, cpt = 0, bs = 0, rows = 0;
   bool nt = true;         // non-temporal loads of A (a matrix beyond the Infinity Cache)
+  // rows of 10 753 ... 21 504 Float64 entries: teams of two workgroups (k_teampd_rows)
+  int team_kv = 0;        // 16-byte vectors per thread and row of a member's half (0: not this scheme)
+  DBuf team_buf;          // ring, tickets, err
+  TeamDev team{};
+  int32_t* h_err = nullptr;  // pinned copy of err
+  ~SlabPdState() { if (h_err) (void)hipHostFree(h_err); }
 };
 void slab_pd_destroy(SlabPdState* st) { delete st; }
 
@@ -185,12 +205,215 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Rows too long for one workgroup's registers (10 753 ... 21 504 Float64 entries — BASELINE config C5: 20 000, a row is
+// 160 KB): TEAMS of two workgroups, one per CU, share a slab of rows.  Member s keeps columns [s n/2, (s+1) n/2) of x and
+// of the column accumulator in registers and streams that half of every row (16-byte buffer loads, csrc/slab.hip's
+// second-generation mapping).  Per row a member forms its partial dot product, PUBLISHES it, goes on to the dots of the
+// next row, and only then takes the partner's partial of the first — the hand-off (1 - 3 us, MI355X_MICROARCH.md) is off
+// the critical path.  Both members add the two partials in member order: the same `A x`, the same y+, no atomics on data.
+//
+// What the hand-off must not do is touch the vector-memory counter.  Loads return in order per wave, so a release
+// fence, or a polling vector load, waits for every load of A the wave has in flight and the pipeline drains at every
+// row: that is the 23 - 28 us per hand-off of round 1's probe.  Hence:
+//   * a record is two words {value, value ^ sequence} stored by one lane, fire and forget — no fence; the check word
+//     validates the pair, whatever order the words become visible in;
+//   * every WAVE takes the partner's record itself with a scalar load (`s_load_dwordx4 ... glc`: its own counter, past
+//     the scalar cache) requested before the dots of the next row and validated after them — no broadcast through LDS,
+//     ONE barrier per row (the partial dots of the waves; each wave sums them itself);
+//   * scalar loads see the L2 of the XCD, so teams are formed INSIDE an XCD at run time (XCC_ID + a ticket per XCD),
+//     whatever order the dispatcher deals workgroups in;
+//   * every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
+// Rows past the slab are dummy rows (clamped loads, weight 0) that both members run alike, so the loop body has no
+// branch between a request and its use.  tools/split_probe.hip: 8.0 GB of C5 in 1.28 ms = 6.3 TB/s, against 2 x 1.13 ms
+// for the two GEMV passes.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KV, int G, bool NT, bool XLDS>
+__global__ __launch_bounds__(768) void k_teampd_rows(SlabPdDev d, TeamDev t, const void* xv) {
+  extern __shared__ double team_xs[];              // XLDS: the member's half of x in LDS (KV * 768 * 2 doubles: 84 KB at KV = 7),
+  constexpr int BS = 768, NW = BS / 64;            //       where x in registers would make the row state spill
+  typedef double vec_t __attribute__((ext_vector_type(2)));
+  typedef unsigned raw_t __attribute__((ext_vector_type(4)));
+  typedef unsigned long long rec_t __attribute__((ext_vector_type(2)));
+  __shared__ double wsum[2][NW];
+  __shared__ int ident[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // (provably wave-uniform: scalar branches, SGPR values)
+  if (d.c->done != 0) return;                      // written by an earlier launch: uniform over the grid
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
+    const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
+    ident[0] = k < 32u ? (int)(xcc * 16 + k / 2) : -1;
+    ident[1] = (int)(k % 2);
+    if (k >= 32u) atomicExch(t.err, 2);
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0) return;
+  const double sigma = d.c->sigma, rho = d.c->rho; // this iteration's, set by the rule kernel before this launch
+  const double* __restrict__ X = (const double*)xv;
+  const int nvs = ((d.n + 1) / 2 + 1) / 2;         // 16-byte vectors per member
+  const int v0 = s * nvs;
+  vec_t xr[KV];
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BS;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      xr[k][e] = (lv < nvs && j + e < d.n) ? X[j + e] : 0.0;
+      acc[k][e] = 0.0;
+      if constexpr (XLDS) team_xs[lv * 2 + e] = xr[k][e];      // (each thread reads back only what it wrote: no barrier)
+    }
+  }
+  const int voff = tid * 16;
+  const int64_t cbase = (int64_t)v0 * 16;
+  const int slice_bytes = (int)min((int64_t)nvs * 16, d.ldT * 8 - cbase);      // (rows are zero-padded to whole vectors)
+  const int row_begin = team * t.rows_per_team;
+  const int row_end = min(row_begin + t.rows_per_team, d.m);
+  const int nrows = max(row_end - row_begin, 0);
+  double e0 = 0.0, e1 = 0.0;
+  vec_t a[G][KV];
+  double y_in[G], axp_in[G], b_in[G];              // the row's state rides behind its loads of A (every thread: one address)
+  const double* __restrict__ AT = (const double*)d.AT;
+  double* __restrict__ Y = (double*)d.Y;
+  double* __restrict__ AXP = (double*)d.AXP;
+  auto load = [&](int g, int row) {
+    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BS * 16, NT ? 2 : 0);
+      a[g][k] = __builtin_bit_cast(vec_t, raw);
+    }
+    y_in[g] = Y[ri];
+    axp_in[g] = AXP[ri];
+    b_in[g] = d.h.has_shift ? ((const double*)d.h.shift)[ri] : 0.0;
+  };
+  TeamRec* ring = t.ring + (int64_t)team * kTeamSlots * 2;
+  // the workgroup's partial dot of row `seq` of the slab (slot g): every thread returns it ; thread 0 publishes it
+  auto dots = [&](int g, long long seq) -> double {
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) p = fma(a[g][k][e], XLDS ? team_xs[(tid + k * BS) * 2 + e] : xr[k][e], p);
+    p = wave_sum(p);
+    if (lane == 0) wsum[seq & 1][wv] = p;          // (double-buffered by row parity: one barrier per row)
+    __syncthreads();
+    double own = wsum[seq & 1][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) own += wsum[seq & 1][w];
+    if (tid == 0) {
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
+      const rec_t rec = {bits, bits ^ (t.seq0 + (unsigned long long)seq + 1)};
+      *(volatile rec_t*)(ring + (seq % kTeamSlots) * 2 + s) = rec;
+    }
+    return own;
+  };
+  bool dead = false;
+  // row `seq` (slot g): the partner's partial (requested a phase ago), the dual step (:344-347, :360), y+[i] * A[i, half]
+  auto finish = [&](int g, long long seq, double own, raw_t early) {
+    const unsigned long long want = t.seq0 + (unsigned long long)seq + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(early)::"memory");
+    unsigned long long v = ((unsigned long long)early[1] << 32) | early[0];
+    unsigned long long chk = ((unsigned long long)early[3] << 32) | early[2];
+    if ((v ^ chk) != want && !dead) {              // not there yet (or half written): poll, bounded
+      const TeamRec* src = ring + (seq % kTeamSlots) * 2 + (1 - s);
+      const long long t0 = wall_clock64();
+      for (;;) {
+        raw_t raw;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(src) : "memory");
+        v = ((unsigned long long)raw[1] << 32) | raw[0];
+        chk = ((unsigned long long)raw[3] << 32) | raw[2];
+        if ((v ^ chk) == want) break;
+        if (wall_clock64() - t0 > 2000000) {       // 20 ms at 100 MHz: give up — the grid must drain
+          dead = true;
+          v = 0;
+          if (lane == 0) atomicExch(t.err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    const double other = __builtin_bit_cast(double, v);
+    const double ax = s == 0 ? own + other : other + own;          // member order: the same sum on both members (:335)
+    const int i = row_begin + (int)seq;
+    double yn = 0.0;
+    if (i < row_end) {
+      const double b = b_in[g];
+      const double w = y_in[g] + sigma * ((1.0 + rho) * ax - rho * axp_in[g]);   // :344
+      yn = prox_conj_elem_s<double>(d.h, w, sigma, i, 0.0, b);                   // :345
+      if (tid == 0 && s == 0) {
+        const double dr = (w - yn) / sigma - ax;                                 // :347
+        e0 += dr * dr;
+        e1 += gval_elem_s<double>(d.h, ax, i, b);
+        Y[i] = yn;
+        AXP[i] = ax;                                                             // :360
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[g][k][e], yn, acc[k][e]);
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, row_begin + g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double own_prev = dots(0, 0);                    // row 0: nothing to finish yet
+  __builtin_amdgcn_sched_barrier(0);
+  load(G - 1, row_begin + G - 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (long long q = 1; q <= nrows; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long seq = q + u;                 // dots of row seq (slot (1 + u) % G) ; finishes row seq - 1 (slot u % G)
+      raw_t early;
+      {
+        const TeamRec* src = ring + ((seq - 1) % kTeamSlots) * 2 + (1 - s);
+        asm volatile("s_load_dwordx4 %0, %1, 0x0 glc" : "=s"(early) : "s"(src) : "memory");
+      }
+      const double own = dots((1 + u) % G, seq);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(u % G, seq - 1, own_prev, early);
+      own_prev = own;
+      __builtin_amdgcn_sched_barrier(0);
+      load(u % G, row_begin + (int)(seq - 1) + G);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BS;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (lv < nvs && j + e < d.n) out[j + e] = acc[k][e];
+  }
+  if (tid == 0 && s == 0) {
+    out[d.n] = e0;
+    out[d.n + 1] = e1;
+  }
+}
+
 // A'y from the block partials (64 columns per block, sixteen loads in flight, fixed order) ; the dual residual and the
 // end of the iteration (:347-354) by block 0
 constexpr int kSlabPdCloseCols = 64;
+constexpr int kSlabPdCloseBlock = 1024;            // (sixteen threads per column: all of a thread's loads in flight at once — csrc/slab.hip)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_slabpd_close(SlabPdDev d, int B, T* __restrict__ aty, apx_record* recs, int64_t rec_cap) {
-  constexpr int S = kBlock / kSlabPdCloseCols;
+__global__ __launch_bounds__(kSlabPdCloseBlock) void k_slabpd_close(SlabPdDev d, int B, T* __restrict__ aty, apx_record* recs, int64_t rec_cap) {
+  constexpr int S = kSlabPdCloseBlock / kSlabPdCloseCols;
   __shared__ double fs[2];
   __shared__ double sub[S][kSlabPdCloseCols];
   if (d.c->done != 0) return;
@@ -233,8 +456,10 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   if (cols <= 2 * 1024) return {1024, 2, 4};
   if (cols <= 5 * 1024) return {1024, 5, 4};
   if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
-  // (C5's row length, 20 000 fp64, is out of reach: x, the accumulator and one row are 480 KB of a CU's 512 KB of
-  //  VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two passes)
+  // C5's row length, 20 000 fp64, is out of reach of ONE workgroup (x, the accumulator and one row are 480 KB of a CU's
+  // 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two
+  // passes): teams of two workgroups, half a row each (k_teampd_rows) — Float64, on a part of 8 XCDs x 32 CUs
+  if (!f32 && cols <= 2 * 14 * 768 && p->ctx->num_cu == 256) return {768, 28, 1};
   return {0, 0, 0};
 }
 
@@ -267,9 +492,24 @@ int32_t slab_pd_setup(apx_solver* s) {
   st->bs = sh.bs;
   st->rows = sh.rows;
   int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
-  int64_t rpb = (A->m + B - 1) / B;
-  rpb = round_up(rpb, 16);                         // (a multiple of every step size)
-  B = (A->m + rpb - 1) / rpb;
+  int64_t rpb = (A->m + B - 1) / B;                // dealt evenly, nothing rounded up: a block's last step may be partial
+  B = (A->m + rpb - 1) / rpb;                      // (csrc/slab.hip: rounding to 16 left CUs without a block)
+  if (st->cpt == 28) {                             // teams of two: 128 slabs, ALL 256 workgroups launched (16 teams per XCD)
+    B = ctx->num_cu / 2;
+    rpb = (A->m + B - 1) / B;
+    const int64_t nvs = ((A->n + 1) / 2 + 1) / 2;  // 16-byte vectors per member
+    st->team_kv = (int)((nvs + 767) / 768);
+    const size_t ring_bytes = (size_t)B * kTeamSlots * 2 * sizeof(TeamRec);
+    APX_TRY(st->team_buf.alloc_zero(ring_bytes + 64, ctx->stream));
+    st->team.ring = (TeamRec*)st->team_buf.p;
+    st->team.tickets = (unsigned*)((char*)st->team_buf.p + ring_bytes);
+    st->team.err = (int*)((char*)st->team_buf.p + ring_bytes + 32);
+    st->team.seq0 = 0;
+    st->team.launch = 0;
+    st->team.rows_per_team = (int32_t)rpb;
+    APX_HIP(hipHostMalloc((void**)&st->h_err, sizeof(int32_t), hipHostMallocDefault));
+    *st->h_err = 0;
+  }
   st->B = (int)B;
   SlabPdDev d{};
   d.AT = A->dT;
@@ -290,11 +530,45 @@ int32_t slab_pd_setup(apx_solver* s) {
   return APX_OK;
 }
 
+// the team kernel for this row length (KV 16-byte vectors per thread and half row ; two rows in registers: with three the
+// KV = 7 shape spills, and tools/split_probe.hip measured no gain from the third — x in LDS to make room: 6.25 vs 6.27 TB/s)
+template <bool NT>
+static bool team_rows_launch(const SlabPdState* st, const SlabPdDev& d, const void* x, hipStream_t q) {
+  const dim3 grid((unsigned)(2 * st->B));
+  switch (st->team_kv) {
+    case 4: hipLaunchKernelGGL((k_teampd_rows<4, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
+    case 5: hipLaunchKernelGGL((k_teampd_rows<5, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
+    case 6: hipLaunchKernelGGL((k_teampd_rows<6, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
+    case 7: {                                      // (x of the half row in LDS: in registers the row state spills, 20 registers)
+      constexpr int lds = 7 * 768 * 2 * (int)sizeof(double);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_teampd_rows<7, 2, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((k_teampd_rows<7, 2, NT, true>), grid, dim3(768), lds, q, d, st->team, x);
+      return true;
+    }
+    default: return false;
+  }
+}
+
 template <typename T>
-static void slab_pd_launch_t(const SlabPdState* st, const SlabPdDev& d, const void* x, void* aty, apx_record* recs, int64_t rec_cap,
+static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x, void* aty, apx_record* recs, int64_t rec_cap,
                              hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   constexpr bool f32 = sizeof(T) == 4;
+  if (st->team_kv != 0) {
+    if constexpr (!f32) {
+      if (st->nt) team_rows_launch<true>(st, d, x, q);
+      else team_rows_launch<false>(st, d, x, q);
+      st->team.launch += 1;                        // (tickets and sequence numbers are never reset: each launch has its own range)
+      st->team.seq0 += (unsigned long long)st->team.rows_per_team + 16;
+      hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
+                         d, st->B, (T*)aty, recs, rec_cap);
+    }
+    return;
+  }
   // two row groups in flight only where it measured faster here — Float32 at two columns per thread (400 000 x 2000: 0.572 ->
   // 0.552 ms) ; with the per-row state of y and A_x_prev on top of the rows, the other shapes lose (200 000 x 5000 fp64
   // 1.31 -> 1.38, 100 000 x 10 000 fp32 0.68 -> 0.71)
@@ -311,7 +585,7 @@ static void slab_pd_launch_t(const SlabPdState* st, const SlabPdDev& d, const vo
     else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
     else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, false>), grid, dim3(768), 0, q, d, x);
   }
-  hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kBlock), 0, q, d,
+  hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q, d,
                      st->B, (T*)aty, recs, rec_cap);
 }
 
@@ -320,7 +594,7 @@ static void slab_pd_launch_t(const SlabPdState* st, const SlabPdDev& d, const vo
 int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
-  const SlabPdState* st = s->slab_pd;
+  SlabPdState* st = s->slab_pd;
   *done_here = false;
   if (p->A_lin->dT == nullptr) return APX_OK;
   SlabPdDev d = st->dev;
@@ -333,6 +607,22 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   APX_HIP(hipGetLastError());
   *done_here = true;
   return APX_OK;
+}
+
+// the error word of the team hand-off (0: fine), read with the convergence flag and with the result
+int32_t slab_pd_check(apx_solver* s) {
+  SlabPdState* st = s->slab_pd;
+  if (st == nullptr || st->team_kv == 0) return APX_OK;
+  apx_ctx* ctx = s->p->ctx;
+  APX_HIP(hipMemcpyAsync(st->h_err, st->team.err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  if (*st->h_err == 0) return APX_OK;
+  return fail(APX_ERR_HIP, *st->h_err == 2
+                               ? "one-pass primal-dual kernel: an XCD received more than 32 workgroups of a launch (the GPU is "
+                                 "shared or partitioned); the result is invalid — switch the policy off (apx_ctx_fused_small(ctx, 0))"
+                               : "one-pass primal-dual kernel: a workgroup waited 20 ms for its team partner (the GPU is shared with "
+                                 "other work, so the 256 workgroups were not resident together); the result is invalid — "
+                                 "switch the policy off (apx_ctx_fused_small(ctx, 0))");
 }
 
 }  // namespace apx

@@ -585,7 +585,7 @@ static int32_t poll_done(apx_solver* s, bool* done) {
   APX_HIP(hipMemcpyAsync(h, dp, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   APX_HIP(hipStreamSynchronize(ctx->stream));
   *done = *h != 0;
-  return APX_OK;
+  return slab_pd_check(s);
 }
 
 int32_t apx_solver_step(apx_solver* s, int64_t iters, int32_t sync) {
@@ -612,6 +612,7 @@ int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* r
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipSetDevice(ctx->device));
+  APX_TRY(slab_pd_check(s));                       // (a timed-out team hand-off invalidates the iterate)
   Ctrl c;
   if (s->small != nullptr) APX_TRY(d2h(ctx, &c, s->small->cb.p, sizeof(Ctrl)));
   else if (s->small_pd != nullptr) APX_TRY(d2h(ctx, &c, small_pd_ctrl(s), sizeof(Ctrl)));

@@ -157,7 +157,15 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              (4100, 10752, "tl1", np.float32),     # 14, four rows per step
                                              (9001, 1900, "tbox", np.float32),
                                              (140000, 200, "tl1", np.float32),     # long slabs: two row groups in flight
-                                             (17000, 6000, "tl1", np.float32)])    # > 384 MB: non-temporal loads
+                                             (17000, 6000, "tl1", np.float32),     # > 384 MB: non-temporal loads
+                                             # rows of 10 753 ... 21 504 Float64 entries: TEAMS of two workgroups, half a row
+                                             # each, partial dot products handed over through the XCD's L2 (k_teampd_rows) —
+                                             # KV = 4 (default-policy loads: < 384 MB), 5, 6, 7 ; 20 000 is BASELINE config C5's row
+                                             (4100, 11000, "tl1", np.float64),
+                                             (4200, 15001, "tbox", np.float64),
+                                             (4099, 18000, "tl1", np.float64),
+                                             (4100, 20000, "tl1", np.float64),
+                                             (4097, 21504, "tl1", np.float64)])
 def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))
@@ -311,4 +319,47 @@ def test_transposed_copy_is_opt_out(apx):
     st = ctx.kernel_stats(reset=True)
     assert st["gemv_t"]["launches"] == 11 and _rel(x, xo) <= 1e-10
     ctx.profile(False)
+    dA.free()
+
+
+def test_team_kernel_is_reproducible_steps_and_terminates(apx):
+    """The two-workgroup teams (rows of C5's length): which physical workgroup becomes which member of which team is decided
+    at run time (a ticket per XCD) — the results must not depend on it: two runs bit for bit, stepping in pieces = one
+    call, termination at the iteration the oracle stops at, and the kernel really ran (one pass over A per iteration)."""
+    rng = np.random.default_rng(12)
+    m, n = 4500, 20000
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+    yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+    nA = float(np.linalg.norm(A))
+    ctx = apx.Context(0)
+    ctx.one_pass_threshold(16 << 20)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    t = dict(f=apx.Zero(), g=apx.NormL1(5.0), h=apx.Translate(apx.NormL1(1.0), -yv), A=dA, ctx=ctx)
+    to = dict(f=O.Zero(), g=O.NormL1(5.0), h=O.Translate(O.NormL1(1.0), -yv), A=A)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    rule = apx.OurRule(t=1.0, norm_A=nA)
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    recs = []
+    x1, y1, _ = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=0.0, maxit=24, record=recs.append, **t)
+    st = ctx.kernel_stats(reset=True)
+    ctx.profile(False)
+    assert st["gemv_t"]["launches"] == 1 and st["gemv_n"]["launches"] == 1 + 24       # the pre-loop products, then one pass each
+    x2, y2, _ = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=0.0, maxit=24, **t)
+    assert np.array_equal(x1, x2) and np.array_equal(y1, y2)
+    s = apx.Solver(x0, y0, rule=rule, tol=0.0, **t)
+    for k in (1, 7, 16):
+        s.step(k)
+        s.result()
+    xs, ys, res = s.result()
+    s.close()
+    assert res.numit == 24 and np.array_equal(xs, x1) and np.array_equal(ys, y1)
+    xo, yo, _ = O.adaptive_primal_dual(x0, y0, rule=O.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=24, **to)
+    assert _rel(x1, xo) <= 1e-10 and _rel(y1, yo) <= 1e-9
+    tol = recs[15]["norm_res"] * (1 + 1e-9)
+    kstar = 1 + next(k for k, r in enumerate(recs) if r["norm_res"] <= tol)
+    xo, yo, ito = O.adaptive_primal_dual(x0, y0, rule=O.OurRule(t=1.0, norm_A=nA), tol=tol, maxit=1000, **to)
+    for poll in (1, 64):
+        x, y, it = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=tol, maxit=1000, poll_every=poll, **t)
+        assert it == kstar == ito and _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-9
     dA.free()
