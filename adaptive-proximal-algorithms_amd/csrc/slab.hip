@@ -27,10 +27,12 @@
 
 #include "skinny_dev.h"
 #include "solver_internal.h"
+#include "team_dev.h"
 #include "vecops_dev.h"
 
 namespace apx {
 
+constexpr int kSlabTeamCpt = 99;      // SlabShape::cpt of the team kernel
 constexpr int kSlabRows = 4;          // rows per step (two columns per thread: 16 ; fourteen fp64 columns: 2, or 1 with the logistic link)
 
 struct SlabDev {
@@ -41,7 +43,8 @@ struct SlabDev {
   double* part;           // [blocks][ldpart]: ncols column partials, then the loss sum(s)
   int64_t ldpart;
   Ctrl* c;
-};
+  double* fsc_out;        // row-sharded f: the closing kernel leaves the two LOCAL loss sums here (they are all-reduced with the
+};                        // gradient, then k_f_final closes f) ; NULL: it closes f itself
 
 struct SlabState {
   DBuf part;
@@ -50,6 +53,12 @@ struct SlabState {
   int kv = 0, bs2 = 768;          // long rows: 16-byte vectors per thread and row of k_slab2_rows (0: k_slab_rows), its block size
   bool v2 = true;                 // (APX_SLAB_V1=1 in the environment: the first-generation kernel for long rows too — A/B runs)
   bool pipe = true, nt = true;    // two row groups in flight ; non-temporal loads of A
+  // rows of more than 10 752 Float64 entries: teams of team_p workgroups (k_team_rows), team_kv vectors per thread
+  int team_p = 0, team_kv = 0;
+  DBuf team_buf;                  // ring, tickets, err
+  TeamDev team{};
+  int32_t* h_err = nullptr;       // pinned copy of err
+  ~SlabState() { if (h_err) (void)hipHostFree(h_err); }
 };
 void slab_destroy(SlabState* st) { delete st; }      // (null is fine)
 
@@ -401,6 +410,198 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Rows too long for one workgroup's registers (10 753 ... 112 640 Float64 entries — BASELINE config C2: 100 000, a row is
+// 800 KB): TEAMS of P = 4 / 8 / 16 workgroups, one per CU, formed inside an XCD at run time, share a slab of rows.  Member
+// s keeps columns [s n/P, (s+1) n/P) of x (in LDS) and of the column accumulator (in registers) and streams that slice
+// of every row.  A workgroup is eleven COMPUTE waves and one COMMUNICATION wave:
+//   * the compute waves form the partial dot product of a row (one barrier per row) and, DEPTH = 2 rows later, take the
+//     row's residual from LDS and accumulate res[i] * A[i, slice] from the registers the row still sits in;
+//   * the communication wave loads no A, so its vector-memory counter is its own (loads return in order per wave: a
+//     poll or a fence in a wave that streams A waits for every load in flight and drains the pipeline — that is what
+//     round 1's probe measured as 23 - 28 us per hand-off).  It sums the workgroup's partial, publishes it (two words
+//     {value, value ^ sequence}, agent scope, no fence: the check word validates the pair), collects the P records of
+//     the row two rows back with ONE vector load (lane q: member q), adds them in member order — the same `A x` on
+//     every member, no atomics on data —, evaluates the residual / the logistic link ONCE and leaves it in LDS; member
+//     0's accumulates the loss sums.  Two rows of slack absorb the hand-off (1 - 3 us) and the slowest member.
+// Every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
+// tools/split_probe.hip (profiles/r02_team_probe_*.log): 5.6 - 5.8 TB/s on rows of C2's length — A read once per
+// evaluation of f and its gradient instead of twice at 7.1 TB/s.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int FK, int P, int KV, bool NT>
+__global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const void* xv) {
+  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P, G = 4, DEPTH = 2;
+  typedef double vec_t __attribute__((ext_vector_type(2)));
+  typedef unsigned raw_t __attribute__((ext_vector_type(4)));
+  extern __shared__ double team_x[];               // the member's slice of x: KV * 704 * 2 doubles
+  __shared__ double wsum[2][CW];
+  __shared__ double res_s[4];
+  __shared__ int ident[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {                                  // (every launch takes its 32 tickets per XCD, a finished loop's too)
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
+    const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
+    ident[0] = k < (unsigned)(TPX * P) ? (int)(xcc * TPX + k / P) : -1;
+    ident[1] = (int)(k % P);
+    if (k >= 32u) atomicExch(t.err, 2);
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
+  const int nvec = (d.ncols + 1) / 2;
+  const int nvs = (nvec + P - 1) / P;              // 16-byte vectors per member
+  const int v0 = s * nvs;
+  const int row_begin = team * t.rows_per_team;
+  const int row_end = min(row_begin + t.rows_per_team, d.m);
+  const int nrows = max(row_end - row_begin, 0);
+  const int nsteps = nrows + DEPTH;                // rows past the slab are dummy rows that every member runs alike
+  TeamRec* ring = t.ring + (int64_t)team * kTeamSlots * P;
+  const double* __restrict__ X = (const double*)xv;
+  if (wv == CW) {
+    // ---- the communication wave -------------------------------------------------------------------------------------
+    const double* __restrict__ bv = (const double*)d.b;
+    const double bias = FK == APX_F_LOGISTIC ? X[d.n - 1] : 0.0;
+    double e0 = 0.0, e1 = 0.0;
+    bool dead = false;
+    for (long long seq = 0; seq < nsteps; ++seq) {
+      const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
+      if (r >= 0) {
+        const int i = row_begin + (int)r;
+        const double bi = bv[min(i, d.m - 1)];     // (this wave's own load: nothing else of it is in flight)
+        const unsigned long long want = t.seq0 + (unsigned long long)r + 1;
+        const TeamRec* src = ring + (r % kTeamSlots) * P + min(lane, P - 1);
+        unsigned long long v = 0;
+        const long long t0 = wall_clock64();
+        while (!dead) {
+          v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long chk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((v ^ chk) == want || lane >= P)) break;
+          if (wall_clock64() - t0 > 2000000) {     // 20 ms at 100 MHz: give up — the grid must drain
+            dead = true;
+            if (lane == 0) atomicExch(t.err, 1);
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const double mine = dead ? 0.0 : __builtin_bit_cast(double, v);
+        double ax = __shfl(mine, 0, 64);
+#pragma unroll
+        for (int q = 1; q < P; ++q) ax += __shfl(mine, q, 64);        // member order: the same sum on every member
+        double res = 0.0;
+        if (i < row_end) {
+          if constexpr (FK == APX_F_LEAST_SQUARES) {
+            res = ax - bi;                                            // experiments/lasso/runme.jl:22
+            e0 += res * res;
+          } else {
+            const double logit = ax + bias;                           // experiments/sparse_logreg/runme.jl:24-36
+            const double e = 1.0 + exp(-logit);
+            e0 += (bi - 1.0) * logit - log(e);
+            res = 1.0 / e - bi;
+            e1 += res;
+          }
+        }
+        if (lane == 0) res_s[r & 3] = res;
+      }
+      __syncthreads();                             // the barrier of step seq
+      const double part = lane < CW ? wsum[seq & 1][lane] : 0.0;     // after it: this workgroup's partial of row seq
+      double own = __shfl(part, 0, 64);
+#pragma unroll
+      for (int w = 1; w < CW; ++w) own += __shfl(part, w, 64);
+      if (lane == 0) {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
+        TeamRec* rec = ring + (seq % kTeamSlots) * P + s;
+        __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rec->chk, bits ^ (t.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (lane == 0 && s == 0) {
+      double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
+      out[d.ncols] = e0;
+      out[d.ncols + 1] = e1;
+    }
+    return;
+  }
+  // ---- the compute waves ----------------------------------------------------------------------------------------------
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      team_x[lv * 2 + e] = (lv < nvs && j + e < d.ncols) ? X[j + e] : 0.0;     // (each thread reads back only what it wrote)
+      acc[k][e] = 0.0;
+    }
+  }
+  const int voff = tid * 16;
+  const int64_t cbase = (int64_t)v0 * 16;
+  const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * 8 - cbase));      // (rows are zero-padded to whole vectors)
+  const double* __restrict__ AT = (const double*)d.AT;
+  vec_t a[G][KV];
+  auto load = [&](int g, int row) {
+    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
+      a[g][k] = __builtin_bit_cast(vec_t, raw);
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, row_begin + g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // step seq: the dots of row seq (slot seq % G) ; the barrier ; row seq - DEPTH (slot (seq - DEPTH) % G) accumulated and
+  // its slot re-loaded with row seq - DEPTH + G.  Unrolled G times: every slot index is a constant.
+#pragma unroll 1
+  for (long long q = 0; q < nsteps; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long seq = q + u;
+      if (seq < nsteps) {                          // (uniform ; the communication wave runs exactly nsteps barriers too)
+        double p = 0.0;
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) p = fma(a[u][k][e], team_x[(tid + k * BSC) * 2 + e], p);
+        p = wave_sum(p);
+        if (lane == 0) wsum[seq & 1][wv] = p;      // (double-buffered by row parity: one barrier per row)
+        __syncthreads();
+        const long long r = seq - DEPTH;
+        constexpr int gs_base = G - DEPTH;
+        const int gs = (u + gs_base) % G;
+        if (r >= 0) {
+          const double rr = res_s[r & 3];
+#pragma unroll
+          for (int k = 0; k < KV; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[gs][k][e], rr, acc[k][e]);
+#pragma unroll                                     // (the sums are complete HERE: see k_slab_rows)
+          for (int k = 0; k < KV; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const long long next = r + G;              // the row that belongs in slot gs next (the prologue left slot G - 1 empty)
+        if (next >= G - 1) load(gs, row_begin + (int)next);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (lv < nvs && j + e < d.ncols) out[j + e] = acc[k][e];
+  }
+}
+
 // 64 columns per block (a wave reads 512 contiguous bytes of a partial row), the B partials of a column dealt to 16
 // threads (b = s, s + 16, ...: with one block per CU in the row kernel that is ALL of a thread's loads in flight at
 // once — 256 threads with four rounds of sixteen took 19.8 us at C3, 3 % of the iteration), then the 16 sub-sums added
@@ -436,7 +637,14 @@ __global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B
     grad[j] = FK == APX_F_LOGISTIC ? (T)((double)gs / N) : gs;
   }
   if (FK == APX_F_LOGISTIC && blockIdx.x == 0 && tid == 0) grad[d.n - 1] = (T)(fs[1] / N);      // grad[end] = mean(probs - y)
-  if (blockIdx.x == 0 && tid == 0) f_finalize(d.c, FK, fs);                  // f(x) (and the bias gradient) -> Ctrl
+  if (blockIdx.x == 0 && tid == 0) {
+    if (d.fsc_out != nullptr) {                                              // row shard: local sums, closed after the all-reduce
+      d.fsc_out[0] = fs[0];
+      d.fsc_out[1] = fs[1];
+    } else {
+      f_finalize(d.c, FK, fs);                                               // f(x) (and the bias gradient) -> Ctrl
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -453,12 +661,17 @@ static SlabShape slab_shape(const apx_problem* p) {
   // step (the same 160 KB) and one with the logistic link (see slab_launch_t).  Measured and dropped: 1024 x 10 x 2
   // (half the bytes in flight: +5 % over the two passes at C3), 512 x 20 x 4 and 1024 x 10 x 4 (spills).
   if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};
+  // longer rows (BASELINE config C2: 100 000): teams of 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
+  // Float64, on a part of 8 XCDs x 32 CUs
+  if (p->dtype == APX_F64 && cols <= 16 * 5 * 704 * 2 && p->ctx->num_cu == 256) return {768, kSlabTeamCpt, 1};
   return {0, 0, 0};
 }
 
 static bool slab_shape_ok(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
-  if (p->A_lin != nullptr || p->sharded()) return false;
+  // (a row shard of f — communicator or callback — is as good as a whole matrix: the rows are local, only the block sums
+  //  travel ; eval_f all-reduces them)
+  if (p->A_lin != nullptr || (p->sharded() && !p->f_sharded)) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
   if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
   // large matrices only: every block walks its slab in steps of R rows with two barriers each, and below ~200 MB
@@ -496,6 +709,25 @@ static int32_t slab_setup(apx_problem* p) {
   const int64_t rpb = (A->m + B - 1) / B;
   B = (A->m + rpb - 1) / rpb;
   st->B = (int)B;
+  int64_t rpb_team = 0;
+  if (st->cpt == kSlabTeamCpt) {           // teams: the fewest members whose slice fits 5 vectors per compute thread
+    const int64_t nvec = (A->n + 1) / 2;
+    int P = 4;
+    while (P < 16 && (nvec + P - 1) / P > 5 * 704) P *= 2;
+    st->team_p = P;
+    st->team_kv = (int)(((nvec + P - 1) / P + 703) / 704);
+    B = ctx->num_cu / P;                   // slabs = teams ; ALL 256 workgroups are launched (32 / P teams per XCD)
+    rpb_team = (A->m + B - 1) / B;
+    st->B = (int)B;
+    const size_t ring_bytes = (size_t)B * kTeamSlots * P * sizeof(TeamRec);
+    APX_TRY(st->team_buf.alloc_zero(ring_bytes + 64, ctx->stream));
+    st->team.ring = (TeamRec*)st->team_buf.p;
+    st->team.tickets = (unsigned*)((char*)st->team_buf.p + ring_bytes);
+    st->team.err = (int*)((char*)st->team_buf.p + ring_bytes + 32);
+    st->team.rows_per_team = (int32_t)rpb_team;
+    APX_HIP(hipHostMalloc((void**)&st->h_err, sizeof(int32_t), hipHostMallocDefault));
+    *st->h_err = 0;
+  }
   if (st->cpt == 14) {                     // long rows: k_slab2_rows, KV 16-byte vectors per thread and row
     const int64_t vw = 16 / (int64_t)dtype_size(p->dtype);
     st->kv = (int)((A->n + vw * 768 - 1) / (vw * 768));
@@ -514,7 +746,7 @@ static int32_t slab_setup(apx_problem* p) {
   d.m = (int32_t)A->m;
   d.ncols = (int32_t)A->n;
   d.n = (int32_t)p->n;
-  d.rows_per_block = (int32_t)rpb;
+  d.rows_per_block = (int32_t)(rpb_team > 0 ? rpb_team : rpb);
   d.b = p->b.p;
   d.ldpart = round_up(d.ncols + 2, 8);
   APX_TRY(st->part.alloc_zero((size_t)B * d.ldpart * sizeof(double), ctx->stream));
@@ -576,9 +808,42 @@ static bool slab2_dispatch(const SlabState* st, dim3 grid, hipStream_t q, const 
   }
 }
 
+// the team kernel for this row length: P members, KV vectors per compute thread (x of the slice in dynamic LDS)
+template <int FK, int P>
+static bool team_rows_launch_p(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
+  const dim3 grid((unsigned)(st->B * P)), block(768);
+  const size_t lds = (size_t)st->team_kv * 704 * 2 * sizeof(double);
+  switch (st->team_kv) {
+    case 1:
+    case 2: hipLaunchKernelGGL((k_team_rows<FK, P, 2, true>), grid, block, (size_t)2 * 704 * 16, q, d, st->team, x); return true;
+    case 3: hipLaunchKernelGGL((k_team_rows<FK, P, 3, true>), grid, block, lds, q, d, st->team, x); return true;
+    case 4: hipLaunchKernelGGL((k_team_rows<FK, P, 4, true>), grid, block, lds, q, d, st->team, x); return true;
+    case 5: hipLaunchKernelGGL((k_team_rows<FK, P, 5, true>), grid, block, lds, q, d, st->team, x); return true;
+    default: return false;
+  }
+}
+template <int FK>
+static bool team_rows_launch(SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
+  bool ok = false;
+  if (st->team_p == 4) ok = team_rows_launch_p<FK, 4>(st, d, x, q);
+  else if (st->team_p == 8) ok = team_rows_launch_p<FK, 8>(st, d, x, q);
+  else if (st->team_p == 16) ok = team_rows_launch_p<FK, 16>(st, d, x, q);
+  st->team.launch += 1;                            // (tickets and sequence numbers are never reset: a range per launch)
+  st->team.seq0 += (unsigned long long)st->team.rows_per_team + 16;
+  return ok;
+}
+
 template <typename T, int FK>
-static void slab_launch_t(const SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
+static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
+  if (st->team_p != 0) {
+    if constexpr (sizeof(T) == 8) {
+      team_rows_launch<FK>(st, d, x, q);
+      hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
+                         dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
+    }
+    return;
+  }
   constexpr int R14 = sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2);
   constexpr bool kPipeOk = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;       // (the others spill as two groups)
   if (st->cpt == 2) slab_rows_launch<T, FK, 2, 16, 1024, kPipeOk>(st, grid, q, d, x);
@@ -599,12 +864,13 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
     p->slab_checked = true;
     if (slab_eligible(p)) APX_TRY(slab_setup(p));
   }
-  const SlabState* st = p->slab;
+  SlabState* st = p->slab;
   if (st == nullptr || p->A_f->dT == nullptr) return APX_OK;      // (dropped copy: A edited in place)
   apx_ctx* ctx = p->ctx;
   SlabDev d = st->dev;
   d.AT = p->A_f->dT;                             // (rebuilt copies may live elsewhere)
   d.ldT = p->A_f->ldT;
+  d.fsc_out = p->f_sharded ? p->fsc() : nullptr;
   const bool ls = p->f_kind == APX_F_LEAST_SQUARES;
   APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)p->A_f->m * (double)p->A_f->n * (double)p->es()));
   if (p->dtype == APX_F32) {
@@ -618,6 +884,22 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   APX_HIP(hipGetLastError());
   *done_here = true;
   return APX_OK;
+}
+
+// the error word of the team hand-off (0: fine)
+int32_t slab_check(apx_problem* p) {
+  SlabState* st = p->slab;
+  if (st == nullptr || st->team_p == 0) return APX_OK;
+  apx_ctx* ctx = p->ctx;
+  APX_HIP(hipMemcpyAsync(st->h_err, st->team.err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  if (*st->h_err == 0) return APX_OK;
+  return fail(APX_ERR_HIP, *st->h_err == 2
+                               ? "one-pass kernel (teams): an XCD received more than 32 workgroups of a launch (the GPU is shared or "
+                                 "partitioned); the result is invalid — switch the policy off (apx_ctx_fused_small(ctx, 0))"
+                               : "one-pass kernel (teams): a workgroup waited 20 ms for its team (the GPU is shared with other work, so "
+                                 "the 256 workgroups were not resident together); the result is invalid — switch the policy off "
+                                 "(apx_ctx_fused_small(ctx, 0))");
 }
 
 }  // namespace apx

@@ -12,6 +12,7 @@
 
 #include "skinny_dev.h"
 #include "solver_internal.h"
+#include "team_dev.h"
 #include "vecops_dev.h"
 
 namespace apx {
@@ -26,20 +27,6 @@ struct SlabPdDev {
   int64_t ldpart;
   Ctrl* c;
   ProxDev h;
-};
-
-// hand-off state of the two-CU teams (k_teampd_rows below)
-struct TeamRec {          // one partial dot product: the value and value ^ sequence
-  unsigned long long v, chk;
-};
-constexpr int kTeamSlots = 8;      // ring of published rows per member (>= 4 suffices: a partner is at most 2 rows ahead)
-struct TeamDev {
-  TeamRec* ring;          // [teams][kTeamSlots][2]
-  unsigned* tickets;      // [8] one counter per XCD, monotonic over the launches
-  int* err;               // != 0: a wait timed out (1) / an XCD received more than 32 workgroups of a launch (2)
-  unsigned long long seq0;   // sequence base of this launch (the ring is never reset)
-  unsigned launch;        // launches so far: the ticket base is launch * 32
-  int32_t rows_per_team;
 };
 
 struct SlabPdState {
@@ -239,8 +226,7 @@ __global__ __launch_bounds__(768) void k_teampd_rows(SlabPdDev d, TeamDev t, con
   __shared__ int ident[2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // (provably wave-uniform: scalar branches, SGPR values)
-  if (d.c->done != 0) return;                      // written by an earlier launch: uniform over the grid
-  if (tid == 0) {
+  if (tid == 0) {                                  // (every launch takes its 32 tickets per XCD, a finished loop's too)
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
     const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
     ident[0] = k < 32u ? (int)(xcc * 16 + k / 2) : -1;
@@ -249,7 +235,7 @@ __global__ __launch_bounds__(768) void k_teampd_rows(SlabPdDev d, TeamDev t, con
   }
   __syncthreads();
   const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
-  if (team < 0) return;
+  if (team < 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
   const double sigma = d.c->sigma, rho = d.c->rho; // this iteration's, set by the rule kernel before this launch
   const double* __restrict__ X = (const double*)xv;
   const int nvs = ((d.n + 1) / 2 + 1) / 2;         // 16-byte vectors per member

@@ -90,8 +90,20 @@ int32_t eval_f(apx_problem* p, const void* x_dev, bool need_f) {
       bool one_pass = false;
       APX_TRY(slab_eval_with_gradient(p, x_dev, &one_pass));
       if (one_pass) {
+        if (p->f_sharded) {
+          // the shard's A_k' r_k (the bias entry and the 1 / N of the logistic gradient included: both linear) and its two
+          // loss sums, summed over the row shards — in fp64 ONE collective, the scalars riding behind the gradient
+          if (p->fsc_packed) {
+            APX_TRY(do_allreduce(p, p->grad.p, p->fsc_off() + 2, p->dtype));
+          } else {
+            APX_TRY(do_allreduce(p, p->grad.p, p->fsc_off(), p->dtype));
+            APX_TRY(do_allreduce(p, p->fsc(), 2, APX_F64));
+          }
+          APX_TRY(vo_f_final(ctx, p->f_kind, p->fsc(), p->ctrl()));
+        }
         p->grad_ready = true;
         p->fsc_reduced = true;
+        if (need_f) APX_TRY(slab_check(p));        // (the caller reads f now: a timed-out team hand-off must not pass for a value)
         break;
       }
       int splits = 0;
@@ -585,6 +597,7 @@ static int32_t poll_done(apx_solver* s, bool* done) {
   APX_HIP(hipMemcpyAsync(h, dp, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   APX_HIP(hipStreamSynchronize(ctx->stream));
   *done = *h != 0;
+  APX_TRY(slab_check(s->p));
   return slab_pd_check(s);
 }
 
@@ -613,6 +626,7 @@ int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* r
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipSetDevice(ctx->device));
   APX_TRY(slab_pd_check(s));                       // (a timed-out team hand-off invalidates the iterate)
+  APX_TRY(slab_check(p));
   Ctrl c;
   if (s->small != nullptr) APX_TRY(d2h(ctx, &c, s->small->cb.p, sizeof(Ctrl)));
   else if (s->small_pd != nullptr) APX_TRY(d2h(ctx, &c, small_pd_ctrl(s), sizeof(Ctrl)));

@@ -86,6 +86,44 @@ def test_init_rank_one_rank_is_bit_equal_to_unsharded(apx, sharded, generic_ctx)
     comm.close()
 
 
+def test_one_pass_kernels_on_a_row_shard(apx, sharded):
+    """A row shard of f is as good as a whole matrix for the one-pass kernels (the rows are local; only the block sums
+    travel): with a communicator the run takes the SAME kernels — first- and second-generation row kernels, the teams of
+    workgroups for rows of C2's kind — and, with one rank, gives the same bits.  This is the path `bench.py --gpus N` times."""
+    ctx = apx.Context(device=0)
+    ctx.one_pass_threshold(16 << 20)
+    comm = sharded.Comm.init_rank(ctx, 1, 0, sharded.Comm.unique_id())
+    rng = np.random.default_rng(17)
+    for m, n, dtype, logistic in ((9000, 1000, np.float64, False), (6000, 6000, np.float32, True), (4200, 12000, np.float64, False),
+                                  (4100, 30000, np.float64, True)):
+        A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        if logistic:
+            b = (rng.uniform(size=m) < 0.5).astype(dtype)
+            mk = lambda **kw: apx.LogisticLoss(dA, b, ctx=ctx, **kw)      # noqa: E731
+            nx, gam, lam = n + 1, 4.0 / (n / 3.0 + 1.0), 0.01
+        else:
+            b = rng.standard_normal(m).astype(dtype)
+            mk = lambda **kw: apx.LinearLeastSquares(dA, b, ctx=ctx, **kw)      # noqa: E731
+            nx, gam, lam = n, 1.0 / (m * n / 3.0), 1.0
+        x0 = (0.01 * rng.standard_normal(nx)).astype(dtype)
+        out = []
+        for f in (mk(), mk(allreduce=comm)):
+            ctx.kernel_stats(reset=True)
+            ctx.profile(True)
+            recs = []
+            x, it = apx.adaptive_proxgrad(x0, f=f, g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=15, ctx=ctx,
+                                          record=recs.append)
+            st = ctx.kernel_stats(reset=True)
+            ctx.profile(False)
+            assert st["gemv_t"]["launches"] == 0 and st["gemv_n"]["launches"] == 16, (m, n, st)      # one pass over A per evaluation
+            out.append((x, [r["objective"] for r in recs], [r["gamma"] for r in recs]))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2], (m, n)
+        dA.free()
+    comm.close()
+    ctx.close()
+
+
 def test_row_sharded_linear_operator_through_the_communicator(apx, sharded, generic_ctx):
     """C5's shape of problem: A_lin sharded (shard_mask bit 1) — A'y, the dual residual and h(Ax) are all-reduced."""
     ctx = generic_ctx

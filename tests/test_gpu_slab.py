@@ -45,7 +45,15 @@ def _rel(a, b):
                                                 (4200, 5500, False, np.float64),
                                                 (4100, 7001, False, np.float64),
                                                 (4100, 9000, False, np.float64),
-                                                (4103, 10752, False, np.float64)])
+                                                (4103, 10752, False, np.float64),
+                                                # rows of more than 10 752 Float64 entries: TEAMS of 4 / 8 / 16 workgroups, a
+                                                # slice of every row each, eleven compute waves + a communication wave
+                                                # (k_team_rows) ; 100 000 is BASELINE config C2's row
+                                                (4100, 11000, False, np.float64),      # P = 4, KV = 2
+                                                (4100, 20000, True, np.float64),       # P = 4, KV = 4, logistic
+                                                (4097, 30001, False, np.float64),      # P = 8, KV = 3
+                                                (4096, 56320, False, np.float64),      # P = 8, KV = 5
+                                                (4099, 100000, False, np.float64)])    # P = 16, KV = 5
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))

@@ -459,6 +459,177 @@ __global__ __launch_bounds__(768) void k_split2(Args d) {
   }
   if (tid == 0 && s == 0) out[d.n] = e0;
 }
+template <int P, int KV, int G, bool NT, bool XLDS = false>
+__global__ __launch_bounds__(768) void k_split3(Args d) {
+  extern __shared__ double xs2[];
+  constexpr int BS = 768, NW = BS / 64, TPX = 32 / P;       // teams per XCD (32 CUs each)
+  __shared__ double wsum[2][NW];
+  __shared__ int ident[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
+    const unsigned t = atomicAdd(d.tickets + xcc, 1u) - d.launch * 32u;
+    ident[0] = t < (unsigned)(TPX * P) ? (int)(xcc * TPX + t / P) : -1;     // (32 % P workgroups per XCD stay idle)
+    ident[1] = (int)(t % P);
+    if (t >= 32u) atomicExch(d.err, 2);
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0) return;
+  const int nvec = (d.n + 1) / 2;
+  const int nvs = (nvec + P - 1) / P;
+  const int v0 = s * nvs;
+  v2d xr[KV];
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BS;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      xr[k][e] = (lv < nvs && j + e < d.n) ? d.x[j + e] : 0.0;
+      acc[k][e] = 0.0;
+      if constexpr (XLDS) xs2[lv * 2 + e] = xr[k][e];
+    }
+  }
+  const int voff = tid * 16;
+  const int64_t cbase = (int64_t)v0 * 16;
+  const int slice_bytes = (int)min((int64_t)nvs * 16, d.ldT * 8 - cbase);
+  const int row_begin = team * d.rows_per_team;
+  const int row_end = min(row_begin + d.rows_per_team, d.m);
+  const int ngroups = row_end - row_begin;
+  double e0 = 0.0;
+  v2d a[G][KV];
+  double b_in[G];
+  auto load = [&](int g, int row) {
+    const int ri = __builtin_amdgcn_readfirstlane(min(row, row_end - 1));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(d.AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BS * 16, NT ? 2 : 0);
+      a[g][k] = __builtin_bit_cast(v2d, raw);
+    }
+    b_in[g] = d.b[ri];                                     // (every thread: the row's entry rides behind its row)
+  };
+  Xch* ring = d.xch + (int64_t)team * kSlots * P;
+  typedef unsigned v4s __attribute__((ext_vector_type(4)));
+  typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
+  // the block's partial dot of group grp (slot g): every thread returns it ; thread 0 publishes it
+  auto dots = [&](int g, long long grp) -> double {
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) p = fma(a[g][k][e], XLDS ? xs2[(tid + k * BS) * 2 + e] : xr[k][e], p);
+    p = wave_sum(p);
+    if (lane == 0) wsum[grp & 1][wv] = p;
+    __syncthreads();
+    double own = wsum[grp & 1][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) own += wsum[grp & 1][w];
+    if (tid == 0) {
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
+      v2ul rec = {bits, bits ^ (d.seq0 + (unsigned long long)grp + 1)};
+      *(volatile v2ul*)&(ring + (grp % kSlots) * P + s)->r[0] = rec;
+    }
+    return own;
+  };
+  bool dead = false;
+  auto finish = [&](int g, long long grp, double own, v4s (&early)[P]) {
+    const unsigned long long want = d.seq0 + (unsigned long long)grp + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double dot = 0.0;
+#pragma unroll
+    for (int qm = 0; qm < P; ++qm) {
+    asm volatile("" : "+s"(early[qm]));
+    unsigned long long v = ((unsigned long long)early[qm][1] << 32) | early[qm][0];
+    unsigned long long chk = ((unsigned long long)early[qm][3] << 32) | early[qm][2];
+    if (qm != s && (v ^ chk) != want && !dead) {           // not there yet (or torn): poll, bounded
+      const Rec* src = &(ring + (grp % kSlots) * P + qm)->r[0];
+      const long long t0 = wall_clock64();
+      for (;;) {
+        v4s raw;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(src) : "memory");
+        v = ((unsigned long long)raw[1] << 32) | raw[0];
+        chk = ((unsigned long long)raw[3] << 32) | raw[2];
+        if ((v ^ chk) == want) break;
+        if (wall_clock64() - t0 > 2000000) {               // 20 ms: give up, the grid must drain
+          dead = true;
+          v = 0;
+          if (tid == 0) atomicExch(d.err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    const double term = qm == s ? own : __builtin_bit_cast(double, v);
+    dot = qm == 0 ? term : dot + term;                      // member order: the same sum on every member
+    }
+    const int i = row_begin + (int)grp;
+    const double rr = i < row_end ? dot - b_in[g] : 0.0;
+    if (tid == 0 && s == 0) e0 += rr * rr;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[g][k][e], rr, acc[k][e]);
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, row_begin + g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double own_prev = dots(0, 0);                            // step 0: nothing to finish yet
+  __builtin_amdgcn_sched_barrier(0);
+  load(G - 1, row_begin + G - 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (long long q = 1; q <= ngroups; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long grp = q + u;                         // slot (1 + u) % G ; finishes group grp - 1 in slot u % G
+      v4s early[P];
+#pragma unroll
+      for (int qm = 0; qm < P; ++qm) {
+        const Rec* src = &(ring + ((grp - 1) % kSlots) * P + qm)->r[0];
+        asm volatile("s_load_dwordx4 %0, %1, 0x0 glc" : "=s"(early[qm]) : "s"(src) : "memory");
+      }
+      const double own = dots((1 + u) % G, grp);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(u % G, grp - 1, own_prev, early);
+      own_prev = own;
+      __builtin_amdgcn_sched_barrier(0);
+      load(u % G, row_begin + (int)(grp - 1) + G);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double* out = d.part + (int64_t)team * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BS;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (lv < nvs && j + e < d.n) out[j + e] = acc[k][e];
+  }
+  if (tid == 0 && s == 0) out[d.n] = e0;
+}
+template <int P, int KV, int G, bool NT, bool XLDS = false>
+static void l_split3(const Args& a, int blocks, hipStream_t st) {
+  static bool once = false;
+  const size_t lds = XLDS ? (size_t)KV * 768 * 2 * 8 : 0;
+  if (!once && lds > 48 * 1024) {
+    CK(hipFuncSetAttribute((const void*)k_split3<P, KV, G, NT, XLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((k_split3<P, KV, G, NT, XLDS>), dim3(blocks), dim3(768), lds, st, a);
+}
 template <int KV, int G, bool NT, bool XLDS = false>
 static void l_split2(const Args& a, int blocks, hipStream_t st) {
   static bool once = false;
@@ -468,6 +639,196 @@ static void l_split2(const Args& a, int blocks, hipStream_t st) {
     once = true;
   }
   hipLaunchKernelGGL((k_split2<KV, G, NT, XLDS>), dim3(blocks), dim3(768), lds, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Third form, for WIDE teams (P = 8 / 16: rows of C2's length, 100 000 fp64 = 800 KB): eleven compute waves and ONE
+// communication wave per workgroup.  The communication wave loads no A, so its vector-memory counter is its own: it
+// publishes the workgroup's partial with an agent-scope store and collects the P records of a row with ONE vector load
+// (lane q: member q's record; agent-scope atomics: correct whatever XCD the members sit on, faster inside one), sums
+// them in member order and leaves the total in LDS — all of it while the compute waves form the dots of the next row(s).
+// One barrier per row.  DEPTH rows between the dots of a row and its use (1: the total of row r is needed one row
+// later ; 2: two rows later, more slack for the slowest member, one more row in registers).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int P, int KV, int G, int DEPTH, bool NT, bool XLDS = false>
+__global__ __launch_bounds__(768) void k_split4(Args d) {
+  extern __shared__ double xs4[];
+  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;      // compute waves / threads ; teams per XCD
+  static_assert(G >= DEPTH + 2, "slots: DEPTH rows awaiting their totals, one computing, one loading");
+  __shared__ double wsum[2][CW];
+  __shared__ double total_s[4];
+  __shared__ int ident[2];
+  __shared__ int bail;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const unsigned t = atomicAdd(d.tickets + xcc, 1u) - d.launch * 32u;
+    ident[0] = t < (unsigned)(TPX * P) ? (int)(xcc * TPX + t / P) : -1;
+    ident[1] = (int)(t % P);
+    if (t >= 32u) atomicExch(d.err, 2);
+    bail = 0;
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0) return;
+  const bool comm = wv == CW;
+  const int nvec = (d.n + 1) / 2;
+  const int nvs = (nvec + P - 1) / P;
+  const int v0 = s * nvs;
+  const int row_begin = team * d.rows_per_team;
+  const int row_end = min(row_begin + d.rows_per_team, d.m);
+  const int nrows = max(row_end - row_begin, 0);
+  const int nsteps = nrows + DEPTH;                        // rows past the slab: dummy rows, all members alike
+  Rec* ring = (Rec*)d.xch + (int64_t)team * kSlots * P;
+  if (comm) {
+    // ---- the communication wave ----
+    for (long long seq = 0; seq < nsteps; ++seq) {
+      // before the barrier of step seq: the total of row seq - DEPTH (its partials were published DEPTH steps ago)
+      const long long r = seq - DEPTH;
+      if (r >= 0) {
+        const unsigned long long want = d.seq0 + (unsigned long long)r + 1;
+        const Rec* src = ring + (r % kSlots) * P + min(lane, P - 1);
+        unsigned long long v = 0;
+        const long long t0 = wall_clock64();
+        for (;;) {
+          v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long chk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool ok = (v ^ chk) == want || lane >= P;
+          if (__all(ok)) break;
+          if (wall_clock64() - t0 > 2000000) {             // 20 ms: give up, the grid must drain
+            if (lane == 0) {
+              bail = 1;
+              atomicExch(d.err, 1);
+            }
+            v = 0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        double tot = __shfl(__builtin_bit_cast(double, v), 0, 64);
+#pragma unroll
+        for (int q = 1; q < P; ++q) tot += __shfl(__builtin_bit_cast(double, v), q, 64);     // member order
+        if (lane == 0) total_s[r & 3] = tot;
+      }
+      __syncthreads();                                     // the barrier of step seq
+      // after it: this workgroup's partial of row seq (every member publishes dummy rows too)
+      double own = lane < CW ? wsum[seq & 1][lane] : 0.0;
+      double t = __shfl(own, 0, 64);
+#pragma unroll
+      for (int w = 1; w < CW; ++w) t += __shfl(own, w, 64);
+      if (lane == 0) {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, t);
+        Rec* mine = ring + (seq % kSlots) * P + s;
+        __hip_atomic_store(&mine->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->chk, bits ^ (d.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  // ---- the compute waves ----
+  v2d xr[KV];
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      xr[k][e] = (lv < nvs && j + e < d.n) ? d.x[j + e] : 0.0;
+      acc[k][e] = 0.0;
+      if constexpr (XLDS) xs4[lv * 2 + e] = xr[k][e];
+    }
+  }
+  const int voff = tid * 16;
+  const int64_t cbase = (int64_t)v0 * 16;
+  const int slice_bytes = (int)min((int64_t)nvs * 16, d.ldT * 8 - cbase);
+  double e0 = 0.0;
+  v2d a[G][KV];
+  double b_in[G];
+  auto load = [&](int g, int row) {
+    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(d.AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
+      a[g][k] = __builtin_bit_cast(v2d, raw);
+    }
+    b_in[g] = d.b[ri];
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, row_begin + g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // step seq: dots of row seq (slot seq % G) ; barrier ; finish row seq - DEPTH (slot (seq - DEPTH) % G) and re-load it
+  // with row seq - DEPTH + G.  Unrolled G times: constant slot indices.  (The first DEPTH steps finish nothing, but
+  // the slot they would re-load — (seq - DEPTH) mod G — is the one the prologue left empty or has not used yet.)
+#pragma unroll 1
+  for (long long q = 0; q < nsteps; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long seq = q + u;
+      if (seq < nsteps) {                                  // (uniform ; the communication wave runs exactly nsteps barriers)
+        double p = 0.0;
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) p = fma(a[u][k][e], XLDS ? xs4[(tid + k * BSC) * 2 + e] : xr[k][e], p);
+        p = wave_sum(p);
+        if (lane == 0) wsum[seq & 1][wv] = p;
+        __syncthreads();
+        constexpr int dummy = 0;
+        (void)dummy;
+        const long long r = seq - DEPTH;
+        const int gs = (u + G - DEPTH) % G;
+        if (r >= 0) {
+          const double tot = total_s[r & 3];
+          const int i = row_begin + (int)r;
+          const double rr = i < row_end ? tot - b_in[gs] : 0.0;
+          if (tid == 0 && s == 0) e0 += rr * rr;
+#pragma unroll
+          for (int k = 0; k < KV; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[gs][k][e], rr, acc[k][e]);
+#pragma unroll
+          for (int k = 0; k < KV; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (r >= 0 || seq == DEPTH - 1 || true) {
+          // slot gs is free: row r is done (or, in the first DEPTH steps, gs is the slot the prologue left empty —
+          // only for seq == 0 .. DEPTH - 1 with gs == G - 1 ... G - DEPTH)
+          const long long next = seq - DEPTH + G;          // the row that belongs in slot gs next
+          if (next >= G - 1) load(gs, row_begin + (int)next);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  double* out = d.part + (int64_t)team * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (lv < nvs && j + e < d.n) out[j + e] = acc[k][e];
+  }
+  if (tid == 0 && s == 0) out[d.n] = e0;
+}
+template <int P, int KV, int G, int DEPTH, bool NT, bool XLDS = false>
+static void l_split4(const Args& a, int blocks, hipStream_t st) {
+  static bool once = false;
+  const size_t lds = XLDS ? (size_t)KV * 704 * 2 * 8 : 0;
+  if (!once && lds > 48 * 1024) {
+    CK(hipFuncSetAttribute((const void*)k_split4<P, KV, G, DEPTH, NT, XLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((k_split4<P, KV, G, DEPTH, NT, XLDS>), dim3(blocks), dim3(768), lds, st, a);
 }
 
 struct Variant {
@@ -505,8 +866,8 @@ int main(int argc, char** argv) {
   double* part;
   CK(hipMalloc(&part, (size_t)256 * ldpart * 8));
   Xch* xch;
-  CK(hipMalloc(&xch, sizeof(Xch) * 256 * kSlots));
-  CK(hipMemset(xch, 0, sizeof(Xch) * 256 * kSlots));
+  CK(hipMalloc(&xch, sizeof(Xch) * 4096 * kSlots));
+  CK(hipMemset(xch, 0, sizeof(Xch) * 4096 * kSlots));
   int* err;
   CK(hipMalloc(&err, 4));
   CK(hipMemset(err, 0, 4));
@@ -530,16 +891,16 @@ int main(int argc, char** argv) {
     for (int i = 0; i < m; ++i) g_ref[c] = fma(gen(1, (uint64_t)i * n + cols[c]), res[i], g_ref[c]);
 
   const Variant vars[] = {
-      {"P2 KV7 H1 G3", l_split<2, 7, 1, 3, true>, 2},
-      {"P2 KV7 H1 G3 x in LDS", l_split<2, 7, 1, 3, true, true>, 2},
-      {"P2 KV7 G3 one barrier, every wave polls", l_split2<7, 3, true>, 2},
-      {"P2 KV7 G2 one barrier, every wave polls", l_split2<7, 2, true>, 2},
-      {"P2 KV7 G3 one barrier, every wave polls, x in LDS", l_split2<7, 3, true, true>, 2},
-      {"P2 KV7 G4 one barrier, every wave polls, x in LDS", l_split2<7, 4, true, true>, 2},
-      {"P2 KV7 H1 G4 x in LDS", l_split<2, 7, 1, 4, true, true>, 2},
-      {"P2 KV7 H1 G3 x in LDS default-policy loads", l_split<2, 7, 1, 3, false, true>, 2},
-      {"P4 KV4 H1 G4", l_split<4, 4, 1, 4, true>, 4},
-      {"P4 KV4 H1 G6", l_split<4, 4, 1, 6, true>, 4},
+      {"P16 KV5 G4 D2 comm wave", l_split4<16, 5, 4, 2, true>, 16},
+      {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
+      {"P16 KV5 G5 D2 comm wave, x in LDS", l_split4<16, 5, 5, 2, true, true>, 16},
+      {"P16 KV5 G5 D3 comm wave, x in LDS", l_split4<16, 5, 5, 3, true, true>, 16},
+      {"P16 KV5 G6 D3 comm wave, x in LDS", l_split4<16, 5, 6, 3, true, true>, 16},
+      {"P16 KV5 G6 D4 comm wave, x in LDS", l_split4<16, 5, 6, 4, true, true>, 16},
+      {"P8 KV9 G4 D2 comm wave, x in LDS", l_split4<8, 9, 4, 2, true, true>, 8},
+      {"P2 KV8 G3 D1 comm wave, x in LDS", l_split4<2, 8, 3, 1, true, true>, 2},
+      {"P2 KV8 G4 D2 comm wave, x in LDS", l_split4<2, 8, 4, 2, true, true>, 2},
+      {"P4 KV4 G4 D2 comm wave", l_split4<4, 4, 4, 2, true>, 4},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -548,11 +909,12 @@ int main(int argc, char** argv) {
   for (const Variant& v : vars) {
     const int nv_member = ((n + 1) / 2 + v.P - 1) / v.P;
     const int kv = atoi(strstr(v.name, "KV") + 2);
-    if (nv_member > kv * 768) {
-      printf("%-16s skipped: %d vectors per member > %d\n", v.name, nv_member, kv * 768);
+    const int cap = kv * (strstr(v.name, "comm wave") ? 704 : 768);
+    if (nv_member > cap) {
+      printf("%-16s skipped: %d vectors per member > %d\n", v.name, nv_member, cap);
       continue;
     }
-    const int nteams = 256 / v.P;
+    const int nteams = 8 * (32 / v.P);
     const int rpt = (m + nteams - 1) / nteams;
     Args a{AT, ldT, m, n, rpt, nteams, b, x, part, ldpart, xch, err, 0, tickets, 0};
     CK(hipMemset(part, 0, (size_t)256 * ldpart * 8));
