@@ -19,7 +19,8 @@ def find(d, pat):
 
 
 def short(name):
-    for key in ("gemv_n_kernel", "gemv_t_kernel", "gemv_t_finish", "k_finish_rows", "k_f_reduce", "k_reduce_n",
+    for key in ("k_team_rows", "k_teampd_rows", "k_slab2_rows", "k_slabpd_rows", "k_slabpd_close", "k_slab_rows", "k_slab_close",
+                "gemv_n_kernel", "gemv_t_kernel", "gemv_t_finish", "k_finish_rows", "k_f_reduce", "k_reduce_n",
                 "k_rule", "k_step", "k_dual", "k_final", "k_fill_uniform", "k_scale_columns", "sum_partials_rows"):
         if key in name:
             return key
@@ -79,6 +80,11 @@ def main():
     # so both passes appear as gemv_t_kernel in the trace
     pt = {"gemv_n": traffic.get("gemv_n_kernel") or traffic.get("gemv_t_kernel", {}),
           "gemv_t": traffic.get("gemv_t_kernel", {})}
+    for k in ("k_team_rows", "k_teampd_rows", "k_slab_rows", "k_slab2_rows"):      # the one-pass kernels (A read once per launch)
+        if k in traffic:
+            pt[k] = traffic[k]
+    if len(sys.argv) > 3:
+        pt["source"] = sys.argv[3]
     json.dump(pt, open(os.path.join(os.path.dirname(out), "pmc_traffic.json"), "w"), indent=1)
     print(open(out + ".md").read())
 
