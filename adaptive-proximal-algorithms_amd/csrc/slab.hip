@@ -421,16 +421,18 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
 //     poll or a fence in a wave that streams A waits for every load in flight and drains the pipeline — that is what
 //     round 1's probe measured as 23 - 28 us per hand-off).  It sums the workgroup's partial, publishes it (two words
 //     {value, value ^ sequence}, agent scope, no fence: the check word validates the pair), collects the P records of
-//     the row two rows back with ONE vector load (lane q: member q), adds them in member order — the same `A x` on
-//     every member, no atomics on data —, evaluates the residual / the logistic link ONCE and leaves it in LDS; member
-//     0's accumulates the loss sums.  Two rows of slack absorb the hand-off (1 - 3 us) and the slowest member.
+//     the row two rows back with ONE vector load (lane q: member q; requested a step ahead), adds them in a fixed tree —
+//     the same `A x` on every member, no atomics on data —, evaluates the residual / the logistic link ONCE and leaves
+//     it in LDS; member 0's accumulates the loss sums.  Two rows of slack absorb the hand-off (1 - 3 us) and the
+//     slowest member.
 // Every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
 // tools/split_probe.hip (profiles/r02_team_probe_*.log): 5.6 - 5.8 TB/s on rows of C2's length — A read once per
 // evaluation of f and its gradient instead of twice at 7.1 TB/s.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int FK, int P, int KV, bool NT>
+template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2>
 __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const void* xv) {
-  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P, G = 4, DEPTH = 2;
+  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;
+  static_assert(G >= DEPTH + 2 && DEPTH <= 3, "slots: DEPTH rows awaiting their residuals, one computing, one loading ; res_s has 4 entries");
   typedef double vec_t __attribute__((ext_vector_type(2)));
   typedef unsigned raw_t __attribute__((ext_vector_type(4)));
   extern __shared__ double team_x[];               // the member's slice of x: KV * 704 * 2 doubles
@@ -464,29 +466,43 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
     const double bias = FK == APX_F_LOGISTIC ? X[d.n - 1] : 0.0;
     double e0 = 0.0, e1 = 0.0;
     bool dead = false;
+    // the records (lane q: member q) and the entry of b of the row whose residual is due NEXT are requested a step ahead:
+    // by the time they are needed they have had a whole step to arrive
+    unsigned long long pv = 0, pchk = 0;
+    double pb = 0.0;
+    auto request = [&](long long r) {
+      const TeamRec* src = ring + (r % kTeamSlots) * P + min(lane, P - 1);
+      pv = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pchk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pb = bv[max(min(row_begin + (int)r, d.m - 1), 0)];
+    };
     for (long long seq = 0; seq < nsteps; ++seq) {
       const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
       if (r >= 0) {
         const int i = row_begin + (int)r;
-        const double bi = bv[min(i, d.m - 1)];     // (this wave's own load: nothing else of it is in flight)
         const unsigned long long want = t.seq0 + (unsigned long long)r + 1;
-        const TeamRec* src = ring + (r % kTeamSlots) * P + min(lane, P - 1);
-        unsigned long long v = 0;
-        const long long t0 = wall_clock64();
-        while (!dead) {
-          v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long chk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__all((v ^ chk) == want || lane >= P)) break;
-          if (wall_clock64() - t0 > 2000000) {     // 20 ms at 100 MHz: give up — the grid must drain
-            dead = true;
-            if (lane == 0) atomicExch(t.err, 1);
+        unsigned long long v = pv, chk = pchk;
+        const double bi = pb;
+        if (!__all((v ^ chk) == want || lane >= P) && !dead) {      // not all there yet (or half written): poll, bounded
+          const TeamRec* src = ring + (r % kTeamSlots) * P + min(lane, P - 1);
+          const long long t0 = wall_clock64();
+          for (;;) {
+            v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            chk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((v ^ chk) == want || lane >= P)) break;
+            if (wall_clock64() - t0 > 2000000) {   // 20 ms at 100 MHz: give up — the grid must drain
+              dead = true;
+              if (lane == 0) atomicExch(t.err, 1);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
           }
-          __builtin_amdgcn_s_sleep(1);
         }
-        const double mine = dead ? 0.0 : __builtin_bit_cast(double, v);
-        double ax = __shfl(mine, 0, 64);
+        // the P partials added in a fixed tree (a butterfly over lanes 0 .. P-1: every lane, and every member, forms the same
+        // sums — IEEE addition commutes)
+        double ax = (dead || lane >= P) ? 0.0 : __builtin_bit_cast(double, v);
 #pragma unroll
-        for (int q = 1; q < P; ++q) ax += __shfl(mine, q, 64);        // member order: the same sum on every member
+        for (int off = 1; off < P; off <<= 1) ax += __shfl_xor(ax, off, 64);
         double res = 0.0;
         if (i < row_end) {
           if constexpr (FK == APX_F_LEAST_SQUARES) {
@@ -503,16 +519,16 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
         if (lane == 0) res_s[r & 3] = res;
       }
       __syncthreads();                             // the barrier of step seq
-      const double part = lane < CW ? wsum[seq & 1][lane] : 0.0;     // after it: this workgroup's partial of row seq
-      double own = __shfl(part, 0, 64);
-#pragma unroll
-      for (int w = 1; w < CW; ++w) own += __shfl(part, w, 64);
+      double own = lane < CW ? wsum[seq & 1][lane] : 0.0;            // after it: this workgroup's partial of row seq,
+#pragma unroll                                                        // the eleven waves' sums in a fixed tree
+      for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
       if (lane == 0) {
         const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
         TeamRec* rec = ring + (seq % kTeamSlots) * P + s;
         __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&rec->chk, bits ^ (t.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (r + 1 >= 0) request(r + 1);
     }
     if (lane == 0 && s == 0) {
       double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
@@ -818,6 +834,8 @@ static bool team_rows_launch_p(const SlabState* st, const SlabDev& d, const void
     case 2: hipLaunchKernelGGL((k_team_rows<FK, P, 2, true>), grid, block, (size_t)2 * 704 * 16, q, d, st->team, x); return true;
     case 3: hipLaunchKernelGGL((k_team_rows<FK, P, 3, true>), grid, block, lds, q, d, st->team, x); return true;
     case 4: hipLaunchKernelGGL((k_team_rows<FK, P, 4, true>), grid, block, lds, q, d, st->team, x); return true;
+    // (measured and dropped, interleaved runs of bench.py: five row slots with two or three rows of slack instead of four
+    //  with two — 148.3 - 149.7 against 148.5 - 150.6 iterations / s at C2: nothing)
     case 5: hipLaunchKernelGGL((k_team_rows<FK, P, 5, true>), grid, block, lds, q, d, st->team, x); return true;
     default: return false;
   }

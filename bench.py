@@ -130,6 +130,24 @@ def cpu_baseline(n: int, m_full: int, rows: int, seconds: float, seed: int) -> d
     }
 
 
+class _StdoutToStderr:
+    """Rank 0 prints ONE JSON line on stdout.  Gloo and RCCL announce themselves from C (`[Gloo] Rank 0 is connected ...`,
+    `RCCL version : ...`) on file descriptor 1 when their groups are created: while that happens, descriptor 1 points at
+    descriptor 2."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def kernel_table(stats: dict) -> dict:
     out = {}
     for k, st in stats.items():
@@ -254,10 +272,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if transport == "torch-nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend="gloo")
+        with _StdoutToStderr():
+            if transport == "torch-nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group(backend="gloo")
 
     # a library built from other sources than the ones in the tree is rebuilt (content hash), never benchmarked
     import __graft_entry__
@@ -285,10 +304,12 @@ def main():
         comm = None
         ar_host = ar_dev = None
         if transport == "rccl":
-            uid = [sharded.Comm.unique_id() if rank == 0 else None]      # ncclGetUniqueId on rank 0 ...
-            dist.broadcast_object_list(uid, src=0)                       # ... carried to every rank by the launcher's group
-            comm = sharded.Comm.init_rank(ctx, world, rank, uid[0])      # ncclCommInitRank on this rank's device
-            rccl_ranks = comm.nranks                                     # (ncclCommCount of the live communicator)
+            with _StdoutToStderr():
+                uid = [sharded.Comm.unique_id() if rank == 0 else None]      # ncclGetUniqueId on rank 0 ...
+                dist.broadcast_object_list(uid, src=0)                       # ... carried to every rank by the launcher's group
+                comm = sharded.Comm.init_rank(ctx, world, rank, uid[0])      # ncclCommInitRank on this rank's device
+                rccl_ranks = comm.nranks                                     # (ncclCommCount of the live communicator)
+                comm(np.zeros(1))                                            # (the first collective: RCCL's banner comes with it)
             if rccl_ranks != world:
                 sys.exit(f"bench.py: the communicator has {rccl_ranks} ranks, the job {world}")
             ar_host = ar_dev = comm

@@ -228,6 +228,7 @@ def test_bench_takes_the_in_library_path(apx):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout.strip().splitlines()) == 1, "rank 0 prints ONE line on stdout:\n" + out.stdout[:600]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["rccl_ranks"] == 1 and line["collective"]["transport"] == "rccl"
     env.pop("APX_BENCH_FORCE_DIST")
