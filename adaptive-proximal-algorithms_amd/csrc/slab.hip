@@ -904,6 +904,9 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   return APX_OK;
 }
 
+// (their launches carry a ticket base and a sequence base that advance on the host: not replayable as a captured graph)
+bool slab_uses_teams(const apx_problem* p) { return p->slab != nullptr && p->slab->team_p != 0; }
+
 // the error word of the team hand-off (0: fine)
 int32_t slab_check(apx_problem* p) {
   SlabState* st = p->slab;

@@ -595,6 +595,8 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   return APX_OK;
 }
 
+bool slab_pd_uses_teams(const apx_solver* s) { return s->slab_pd != nullptr && s->slab_pd->team_kv != 0; }
+
 // the error word of the team hand-off (0: fine), read with the convergence flag and with the result
 int32_t slab_pd_check(apx_solver* s) {
   SlabPdState* st = s->slab_pd;

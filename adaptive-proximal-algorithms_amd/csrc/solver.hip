@@ -566,6 +566,9 @@ static int32_t enqueue_iteration(apx_solver* s) {
 // reference's own 500 x 1000 lasso) this removes the host launch cost of the ~7-12 kernels.
 static int32_t capture_iteration(apx_solver* s) {
   apx_ctx* ctx = s->p->ctx;
+  if (slab_uses_teams(s->p) || slab_pd_uses_teams(s))
+    return fail(APX_ERR_UNSUPPORTED, "hipGraph replay: not with the team kernels of long rows (their launches carry host-side "
+                                     "ticket and sequence counters); use eager launches, or apx_ctx_fused_small(ctx, 0)");
   const bool prof = ctx->profile;
   ctx->profile = false;                          // event records would become graph nodes
   hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);

@@ -227,7 +227,9 @@ const void* small_pd_ctrl(const apx_solver* s);
 bool slab_pd_eligible(const apx_problem* p);
 int32_t slab_pd_setup(apx_solver* s);
 int32_t slab_pd_iteration(apx_solver* s, bool* done_here);
-int32_t slab_pd_check(apx_solver* s);      // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP
+int32_t slab_pd_check(apx_solver* s);
+bool slab_pd_uses_teams(const apx_solver* s);
+bool slab_uses_teams(const apx_problem* p);   // (team kernels: host-side launch counters — no hipGraph replay)      // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP
 // slab.hip: true when f and grad f at x_dev were formed in one pass over A (f -> Ctrl, grad -> p->grad)
 int32_t slab_eval_with_gradient(apx_problem* p, const void* x_dev, bool* done_here);
 int32_t slab_check(apx_problem* p);        // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP

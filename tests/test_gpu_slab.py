@@ -371,3 +371,49 @@ def test_team_kernel_is_reproducible_steps_and_terminates(apx):
         x, y, it = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=tol, maxit=1000, poll_every=poll, **t)
         assert it == kstar == ito and _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-9
     dA.free()
+
+
+def test_team_kernel_proximal_gradient_stepping_termination_replay(apx):
+    """k_team_rows (f and its gradient for rows beyond one workgroup; here teams of four): two runs bit for bit whatever
+    workgroup became which member, stepping = one call, termination at the oracle's iteration with two polling intervals,
+    the linesearch loops on it, and hipGraph replay refused (its launches carry host-side counters)."""
+    rng = np.random.default_rng(41)
+    m, n = 4300, 12000
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    b = rng.standard_normal(m)
+    L = float(np.linalg.norm(A, 2) ** 2)
+    gam = 1.0 / L
+    ctx = apx.Context(0)
+    ctx.one_pass_threshold(16 << 20)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+    f, g = apx.LinearLeastSquares(dA, b, ctx=ctx), apx.NormL1(1.0)
+    fo, go = O.LinearLeastSquares(A, b), O.NormL1(1.0)
+    rule = apx.OurRule(gamma=gam)
+    recs = []
+    x1, _ = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, maxit=30, ctx=ctx, record=recs.append)
+    x2, _ = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, maxit=30, ctx=ctx)
+    assert np.array_equal(x1, x2)
+    xo, _ = O.adaptive_proxgrad(np.zeros(n), f=fo, g=go, rule=O.OurRule(gamma=gam), tol=0.0, maxit=30)
+    assert _rel(x1, xo) <= 1e-10
+    s = apx.Solver(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, ctx=ctx)
+    for k in (1, 9, 20):
+        s.step(k)
+        s.result()
+    xs, _, res = s.result()
+    s.close()
+    assert res.numit == 30 and np.array_equal(xs, x1)
+    tol = recs[19]["norm_res"] * (1 + 1e-9)
+    kstar = 1 + next(k for k, r in enumerate(recs) if r["norm_res"] <= tol)
+    xo, ito = O.adaptive_proxgrad(np.zeros(n), f=fo, g=go, rule=O.OurRule(gamma=gam), tol=tol, maxit=1000)
+    for poll in (1, 64):
+        x, it = apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=tol, maxit=1000, ctx=ctx, poll_every=poll)
+        assert it == kstar == ito and _rel(x, xo) <= 1e-10
+    # the host-driven linesearch (every iteration rejects trials: gamma0 = 1000 / L, xi = 2) on the team kernel
+    of, df = O.Counting(fo), apx.Counting(f)
+    zo, _ = O.backtracking_proxgrad(np.zeros(n), f=of, g=go, gamma0=1e3 / L, xi=2.0, tol=0.0, maxit=8)
+    z, _ = apx.backtracking_proxgrad(np.zeros(n), f=df, g=g, gamma0=1e3 / L, xi=2.0, tol=0.0, maxit=8, ctx=ctx)
+    assert (df.eval_count, df.grad_count) == (of.eval_count, of.grad_count) and of.eval_count > 9
+    assert _rel(z, zo) <= 1e-10
+    with pytest.raises(apx.ApxError, match="hipGraph replay"):
+        apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, maxit=5, ctx=ctx, use_graph=True)
+    dA.free()
