@@ -72,6 +72,30 @@ def host_ram_gb() -> float:
         return 0.0
 
 
+def host_cpu_share() -> int:
+    """Cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box gives a
+    one-GPU job a share of its host — 128 threads on a 16-core quota only fight each other)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // p))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(n: int, m_full: int, rows: int, seconds: float, seed: int) -> dict:
     """The CPU restatement of the reference iteration timed on the host cores on a bounded row sample of the same
     workload (same generator), scaled per byte to the full matrix.  Two legs: C + OpenMP on every host thread
@@ -82,8 +106,11 @@ def cpu_baseline(n: int, m_full: int, rows: int, seconds: float, seed: int) -> d
     from oracle import lasso_omp
     if rows <= 0:
         rows = 10_000 if host_ram_gb() >= 32.0 else 4_000
+    share = host_cpu_share()
+    os.environ["OMP_NUM_THREADS"] = str(share)           # (libgomp reads it when the library below is loaded)
     # rebuilt HERE with -march=native: this leg is about this host's cores
     lib = lasso_omp.load(lasso_omp.build(native=True, out=os.path.join(tempfile.mkdtemp(prefix="apx_omp_"), "liblasso_omp.so")))
+    lib.apx_oracle_omp_set_threads(share)
     threads = int(lib.apx_oracle_omp_threads())
     t0 = time.perf_counter()
     prob = lasso_omp.random_lasso(rows, n, pfactor=10, seed=seed, lib=lib)
@@ -110,17 +137,20 @@ def cpu_baseline(n: int, m_full: int, rows: int, seconds: float, seed: int) -> d
 
     it_c, dt_c, ips_c = leg(lambda k: lasso_omp.adaptive_proxgrad_lasso(prob.A, prob.b, prob.lam, gam, k, lib=lib))
     f, g = O.LinearLeastSquares(prob.A, prob.b), O.NormL1(prob.lam)
-    it_p, dt_p, ips_p = leg(lambda k: O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=k))
     try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
-    except Exception:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        with threadpool_limits(limits=share):              # (OpenBLAS sized for the host, not for this job's share, otherwise)
+            it_p, dt_p, ips_p = leg(lambda k: O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=k))
+            blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+    except ImportError:
+        it_p, dt_p, ips_p = leg(lambda k: O.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=O.OurRule(gamma=gam), tol=0.0, maxit=k))
         blas_threads = os.cpu_count() or 1
     scale = rows / m_full
     return {
         "value": ips_c * scale, "unit": "iters/sec", "cores": threads, "kind": "port",
-        "host_GBps": 2 * sample_bytes * ips_c / 1e9,
-        "sample": f"C + OpenMP restatement of the reference iteration (oracle/lasso_omp.c, {threads} threads) on a {rows}x{n} "
+        "host_GBps": 2 * sample_bytes * ips_c / 1e9, "host_cpu_share": share, "host_logical_cpus": os.cpu_count(),
+        "sample": f"C + OpenMP restatement of the reference iteration (oracle/lasso_omp.c, {threads} threads = this job's CPU share of "
+                  f"the host's {os.cpu_count()} logical CPUs) on a {rows}x{n} "
                   f"fp64 lasso of the same generator ({sample_bytes / 1e9:.1f} GB, built in {t_gen:.1f} s): {it_c} iterations "
                   f"in {dt_c:.2f} s = {ips_c:.2f} it/s on the sample = {2 * sample_bytes * ips_c / 1e9:.0f} GB/s of A streamed, "
                   f"scaled by bytes ({rows}/{m_full}) to the {m_full}x{n} matrix; Julia runtime absent on this image",

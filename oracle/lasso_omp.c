@@ -26,6 +26,16 @@
 #include <omp.h>
 #endif
 
+/* (the host may give this job a share of its CPUs: bench.py sizes the team to it — an environment variable would come too
+ * late when another library has initialised the OpenMP runtime already) */
+void apx_oracle_omp_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int apx_oracle_omp_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

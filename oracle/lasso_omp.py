@@ -30,6 +30,8 @@ def load(path: str = LIB) -> C.CDLL:
         build(out=path)
     lib = C.CDLL(path)
     lib.apx_oracle_omp_threads.restype = C.c_int
+    lib.apx_oracle_omp_set_threads.restype = None
+    lib.apx_oracle_omp_set_threads.argtypes = [C.c_int]
     lib.apx_oracle_lasso_adaptive_proxgrad.restype = C.c_int
     lib.apx_oracle_lasso_adaptive_proxgrad.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_double,
                                                        C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
