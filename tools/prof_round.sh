@@ -1,5 +1,5 @@
 set -e
-P=$GRAFT_REPO_ROOT/gpurun_out/r02d
+P=$GRAFT_REPO_ROOT/gpurun_out/r02g
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py > $P/bench_line.json 2> $P/bench_err.log
@@ -11,7 +11,7 @@ echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>> $P/bench_err.log
 echo "write done"
 cd $GRAFT_REPO_ROOT && python3 tools/summarize_prof.py $P $P/summary "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of round 2 (profiles/r02_rocprofv3_summary.*; FETCH_SIZE x2: the gfx950 correction of MI355X_MICROARCH.md), same build" > $P/summary_stdout.md
-cp $GRAFT_REPO_ROOT/profiles/pmc_traffic.json $P/pmc_traffic.json 2>/dev/null || true
+
 f=$(find $P/trace -name "*kernel_stats.csv" | head -1); cp $f $P/kernel_stats.csv
 # keep the merge small: drop the raw traces
 rm -rf $P/trace $P/pmc_fetch $P/pmc_write

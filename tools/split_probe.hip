@@ -650,7 +650,7 @@ static void l_split2(const Args& a, int blocks, hipStream_t st) {
 // One barrier per row.  DEPTH rows between the dots of a row and its use (1: the total of row r is needed one row
 // later ; 2: two rows later, more slack for the slowest member, one more row in registers).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int P, int KV, int G, int DEPTH, bool NT, bool XLDS = false>
+template <int P, int KV, int G, int DEPTH, bool NT, bool XLDS = false, int MODE = 0>
 __global__ __launch_bounds__(768) void k_split4(Args d) {
   extern __shared__ double xs4[];
   constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;      // compute waves / threads ; teams per XCD
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(768) void k_split4(Args d) {
         for (;;) {
           v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const unsigned long long chk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const bool ok = (v ^ chk) == want || lane >= P;
+          const bool ok = (v ^ chk) == want || lane >= P || (MODE == 2 && lane != s);
           if (__all(ok)) break;
           if (wall_clock64() - t0 > 2000000) {             // 20 ms: give up, the grid must drain
             if (lane == 0) {
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(768) void k_split4(Args d) {
 #pragma unroll
         for (int k = 0; k < KV; ++k)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) p = fma(a[u][k][e], XLDS ? xs4[(tid + k * BSC) * 2 + e] : xr[k][e], p);
+          for (int e = 0; e < 2; ++e) p = MODE == 1 ? p + a[u][k][e] : fma(a[u][k][e], XLDS ? xs4[(tid + k * BSC) * 2 + e] : xr[k][e], p);
         p = wave_sum(p);
         if (lane == 0) wsum[seq & 1][wv] = p;
         __syncthreads();
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(768) void k_split4(Args d) {
 #pragma unroll
           for (int k = 0; k < KV; ++k)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[gs][k][e], rr, acc[k][e]);
+            for (int e = 0; e < 2; ++e) acc[k][e] = MODE == 1 ? acc[k][e] + rr : fma(a[gs][k][e], rr, acc[k][e]);
 #pragma unroll
           for (int k = 0; k < KV; ++k)
 #pragma unroll
@@ -820,15 +820,15 @@ __global__ __launch_bounds__(768) void k_split4(Args d) {
   }
   if (tid == 0 && s == 0) out[d.n] = e0;
 }
-template <int P, int KV, int G, int DEPTH, bool NT, bool XLDS = false>
+template <int P, int KV, int G, int DEPTH, bool NT, bool XLDS = false, int MODE = 0>
 static void l_split4(const Args& a, int blocks, hipStream_t st) {
   static bool once = false;
   const size_t lds = XLDS ? (size_t)KV * 704 * 2 * 8 : 0;
   if (!once && lds > 48 * 1024) {
-    CK(hipFuncSetAttribute((const void*)k_split4<P, KV, G, DEPTH, NT, XLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)k_split4<P, KV, G, DEPTH, NT, XLDS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     once = true;
   }
-  hipLaunchKernelGGL((k_split4<P, KV, G, DEPTH, NT, XLDS>), dim3(blocks), dim3(768), lds, st, a);
+  hipLaunchKernelGGL((k_split4<P, KV, G, DEPTH, NT, XLDS, MODE>), dim3(blocks), dim3(768), lds, st, a);
 }
 
 struct Variant {
@@ -891,16 +891,12 @@ int main(int argc, char** argv) {
     for (int i = 0; i < m; ++i) g_ref[c] = fma(gen(1, (uint64_t)i * n + cols[c]), res[i], g_ref[c]);
 
   const Variant vars[] = {
-      {"P16 KV5 G4 D2 comm wave", l_split4<16, 5, 4, 2, true>, 16},
       {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
-      {"P16 KV5 G5 D2 comm wave, x in LDS", l_split4<16, 5, 5, 2, true, true>, 16},
-      {"P16 KV5 G5 D3 comm wave, x in LDS", l_split4<16, 5, 5, 3, true, true>, 16},
-      {"P16 KV5 G6 D3 comm wave, x in LDS", l_split4<16, 5, 6, 3, true, true>, 16},
-      {"P16 KV5 G6 D4 comm wave, x in LDS", l_split4<16, 5, 6, 4, true, true>, 16},
-      {"P8 KV9 G4 D2 comm wave, x in LDS", l_split4<8, 9, 4, 2, true, true>, 8},
-      {"P2 KV8 G3 D1 comm wave, x in LDS", l_split4<2, 8, 3, 1, true, true>, 2},
-      {"P2 KV8 G4 D2 comm wave, x in LDS", l_split4<2, 8, 4, 2, true, true>, 2},
-      {"P4 KV4 G4 D2 comm wave", l_split4<4, 4, 4, 2, true>, 4},
+      {"P16 KV5 G4 D2 comm wave, x in LDS, no FMAs", l_split4<16, 5, 4, 2, true, true, 1>, 16},
+      {"P16 KV5 G4 D2 comm wave, x in LDS, no waiting for partners", l_split4<16, 5, 4, 2, true, true, 2>, 16},
+      {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
+      {"P16 KV5 G4 D2 comm wave, x in LDS, no FMAs", l_split4<16, 5, 4, 2, true, true, 1>, 16},
+      {"P16 KV5 G4 D2 comm wave, x in LDS, no waiting for partners", l_split4<16, 5, 4, 2, true, true, 2>, 16},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -947,7 +943,7 @@ int main(int argc, char** argv) {
       gerr = fmax(gerr, fabs(g - g_ref[c]));
       gmax = fmax(gmax, fabs(g_ref[c]));
     }
-    printf("%-52s teams %3d rows/team %4d  %.4f ms  %6.0f GB/s   ss rel err %.1e  grad rel err %.1e  timeouts %d\n", v.name, nteams,
+    printf("%-62s teams %3d rows/team %4d  %.4f ms  %6.0f GB/s   ss rel err %.1e  grad rel err %.1e  timeouts %d\n", v.name, nteams,
            rpt, ms, (double)m * n * 8 / (ms * 1e-3) / 1e9, fabs(ss - ss_ref) / ss_ref, gerr / gmax, herr);
     fflush(stdout);
     if (herr) CK(hipMemset(err, 0, 4));
