@@ -457,7 +457,10 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
   const int row_begin = team * t.rows_per_team;
   const int row_end = min(row_begin + t.rows_per_team, d.m);
   const int nrows = max(row_end - row_begin, 0);
-  const int nsteps = nrows + DEPTH;                // rows past the slab are dummy rows that every member runs alike
+  // rows past the slab are dummy rows (clamped loads, residual 0) that every member runs alike: DEPTH steps of prologue,
+  // then whole rounds of G steps — the loop body of the compute waves has no branch between a load and its use, so the
+  // waits the compiler places are counted ones and the rows in the loading slots really stay in flight
+  const int nsteps = DEPTH + (nrows + G - 1) / G * G;
   TeamRec* ring = t.ring + (int64_t)team * kTeamSlots * P;
   const double* __restrict__ X = (const double*)xv;
   if (wv == CW) {
@@ -570,41 +573,47 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
     load(g, row_begin + g);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // step seq: the dots of row seq (slot seq % G) ; the barrier ; row seq - DEPTH (slot (seq - DEPTH) % G) accumulated and
-  // its slot re-loaded with row seq - DEPTH + G.  Unrolled G times: every slot index is a constant.
+  // the dots of the row in slot g (step seq) and the barrier behind them
+  auto dots = [&](int g, long long seq) {
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) p = fma(a[g][k][e], team_x[(tid + k * BSC) * 2 + e], p);
+#pragma unroll                                     // (a butterfly: EVERY lane ends with the wave's sum, so all of them store
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);      //  it and the loop body has no branch)
+    wsum[seq & 1][wv] = p;                         // (double-buffered by row parity: one barrier per row)
+    __syncthreads();
+  };
+  // steps 0 .. DEPTH - 1: nothing to accumulate yet ; the last of them fills slot G - 1, which the prologue left empty
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
+    dots(u, u);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u == DEPTH - 1) load(G - 1, row_begin + G - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // step seq >= DEPTH: the dots of row seq (slot seq % G) ; the barrier ; row seq - DEPTH (slot (seq - DEPTH) % G)
+  // accumulated and its slot re-loaded with row seq - DEPTH + G.  Unrolled G times: every slot index is a constant.
 #pragma unroll 1
-  for (long long q = 0; q < nsteps; q += G) {
+  for (long long q = DEPTH; q < nsteps; q += G) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const long long seq = q + u;
-      if (seq < nsteps) {                          // (uniform ; the communication wave runs exactly nsteps barriers too)
-        double p = 0.0;
+      const long long r = seq - DEPTH;
+      dots((DEPTH + u) % G, seq);
+      const double rr = res_s[r & 3];
 #pragma unroll
-        for (int k = 0; k < KV; ++k)
+      for (int k = 0; k < KV; ++k)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) p = fma(a[u][k][e], team_x[(tid + k * BSC) * 2 + e], p);
-        p = wave_sum(p);
-        if (lane == 0) wsum[seq & 1][wv] = p;      // (double-buffered by row parity: one barrier per row)
-        __syncthreads();
-        const long long r = seq - DEPTH;
-        constexpr int gs_base = G - DEPTH;
-        const int gs = (u + gs_base) % G;
-        if (r >= 0) {
-          const double rr = res_s[r & 3];
-#pragma unroll
-          for (int k = 0; k < KV; ++k)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[gs][k][e], rr, acc[k][e]);
+        for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[u][k][e], rr, acc[k][e]);      // (slot of row r: (seq - DEPTH) % G = u)
 #pragma unroll                                     // (the sums are complete HERE: see k_slab_rows)
-          for (int k = 0; k < KV; ++k)
+      for (int k = 0; k < KV; ++k)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const long long next = r + G;              // the row that belongs in slot gs next (the prologue left slot G - 1 empty)
-        if (next >= G - 1) load(gs, row_begin + (int)next);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+      __builtin_amdgcn_sched_barrier(0);
+      load(u, row_begin + (int)(r + G));
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
@@ -836,6 +845,11 @@ static bool team_rows_launch_p(const SlabState* st, const SlabDev& d, const void
     case 4: hipLaunchKernelGGL((k_team_rows<FK, P, 4, true>), grid, block, lds, q, d, st->team, x); return true;
     // (measured and dropped, interleaved runs of bench.py: five row slots with two or three rows of slack instead of four
     //  with two — 148.3 - 149.7 against 148.5 - 150.6 iterations / s at C2: nothing)
+    // (measured and dropped, interleaved runs of bench.py with COUNTED waits in the loop — rows in the loading slots really
+    //  in flight: five slots with two rows in flight or three rows of slack, six slots with three in flight: 149.2 - 150.1
+    //  iterations / s at C2 against 149.9 - 150.1 for four slots.  Neither the rows in flight, nor the arithmetic, nor the
+    //  hand-off (tools/split_probe.hip: the same kernel without them) — a workgroup per CU taking 50 KB per step is what
+    //  reads at 6.0 TB/s)
     case 5: hipLaunchKernelGGL((k_team_rows<FK, P, 5, true>), grid, block, lds, q, d, st->team, x); return true;
     default: return false;
   }

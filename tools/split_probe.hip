@@ -681,6 +681,7 @@ __global__ __launch_bounds__(768) void k_split4(Args d) {
   const int nrows = max(row_end - row_begin, 0);
   const int nsteps = nrows + DEPTH;                        // rows past the slab: dummy rows, all members alike
   Rec* ring = (Rec*)d.xch + (int64_t)team * kSlots * P;
+  if (comm && MODE >= 3) return;
   if (comm) {
     // ---- the communication wave ----
     for (long long seq = 0; seq < nsteps; ++seq) {
@@ -749,7 +750,8 @@ __global__ __launch_bounds__(768) void k_split4(Args d) {
   auto load = [&](int g, int row) {
     const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)(d.AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+        MODE == 4 ? (void*)((const char*)d.AT + ((int64_t)s * d.m + ri) * ((int64_t)nvs * 16))
+                  : (void*)((const char*)(d.AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
       const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
@@ -779,13 +781,13 @@ __global__ __launch_bounds__(768) void k_split4(Args d) {
           for (int e = 0; e < 2; ++e) p = MODE == 1 ? p + a[u][k][e] : fma(a[u][k][e], XLDS ? xs4[(tid + k * BSC) * 2 + e] : xr[k][e], p);
         p = wave_sum(p);
         if (lane == 0) wsum[seq & 1][wv] = p;
-        __syncthreads();
+        if (MODE < 3) __syncthreads();
         constexpr int dummy = 0;
         (void)dummy;
         const long long r = seq - DEPTH;
         const int gs = (u + G - DEPTH) % G;
         if (r >= 0) {
-          const double tot = total_s[r & 3];
+          const double tot = MODE >= 3 ? p : total_s[r & 3];
           const int i = row_begin + (int)r;
           const double rr = i < row_end ? tot - b_in[gs] : 0.0;
           if (tid == 0 && s == 0) e0 += rr * rr;
@@ -891,12 +893,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < m; ++i) g_ref[c] = fma(gen(1, (uint64_t)i * n + cols[c]), res[i], g_ref[c]);
 
   const Variant vars[] = {
-      {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
-      {"P16 KV5 G4 D2 comm wave, x in LDS, no FMAs", l_split4<16, 5, 4, 2, true, true, 1>, 16},
-      {"P16 KV5 G4 D2 comm wave, x in LDS, no waiting for partners", l_split4<16, 5, 4, 2, true, true, 2>, 16},
-      {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
-      {"P16 KV5 G4 D2 comm wave, x in LDS, no FMAs", l_split4<16, 5, 4, 2, true, true, 1>, 16},
-      {"P16 KV5 G4 D2 comm wave, x in LDS, no waiting for partners", l_split4<16, 5, 4, 2, true, true, 2>, 16},
+      {"P16 KV5 G4 D2 pattern only", l_split4<16, 5, 4, 2, true, true, 3>, 16},
+      {"P16 KV5 G4 D2 pattern only, panel-major (contiguous per member)", l_split4<16, 5, 4, 2, true, true, 4>, 16},
+      {"P16 KV5 G4 D2 pattern only", l_split4<16, 5, 4, 2, true, true, 3>, 16},
+      {"P16 KV5 G4 D2 pattern only, panel-major (contiguous per member)", l_split4<16, 5, 4, 2, true, true, 4>, 16},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -943,7 +943,7 @@ int main(int argc, char** argv) {
       gerr = fmax(gerr, fabs(g - g_ref[c]));
       gmax = fmax(gmax, fabs(g_ref[c]));
     }
-    printf("%-62s teams %3d rows/team %4d  %.4f ms  %6.0f GB/s   ss rel err %.1e  grad rel err %.1e  timeouts %d\n", v.name, nteams,
+    printf("%-66s teams %3d rows/team %4d  %.4f ms  %6.0f GB/s   ss rel err %.1e  grad rel err %.1e  timeouts %d\n", v.name, nteams,
            rpt, ms, (double)m * n * 8 / (ms * 1e-3) / 1e9, fabs(ss - ss_ref) / ss_ref, gerr / gmax, herr);
     fflush(stdout);
     if (herr) CK(hipMemset(err, 0, 4));
