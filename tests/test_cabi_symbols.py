@@ -56,8 +56,9 @@ def test_struct_layouts_match_the_header(apx, tmp_path):
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(apx_prox_desc), sizeof(apx_problem_desc), sizeof(apx_rule),
          sizeof(apx_record), sizeof(apx_result), sizeof(apx_solve_opts), sizeof(apx_kernel_stat));
-  printf("%zu %zu %zu %zu\n", offsetof(apx_problem_desc, g), offsetof(apx_problem_desc, h),
-         offsetof(apx_problem_desc, A_lin), offsetof(apx_problem_desc, allreduce));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(apx_problem_desc, g), offsetof(apx_problem_desc, h),
+         offsetof(apx_problem_desc, A_lin), offsetof(apx_problem_desc, allreduce), offsetof(apx_problem_desc, shard_mask),
+         offsetof(apx_problem_desc, comm));
   printf("%zu %zu %zu\n", offsetof(apx_result, f_evals), offsetof(apx_result, n_records), offsetof(apx_rule, xi));
   return 0;
 }''')
@@ -69,7 +70,7 @@ int main(void) {
                      C.sizeof(L.Result), C.sizeof(L.SolveOpts), C.sizeof(L.KernelStat)]
     offs = list(map(int, lines[1].split()))
     assert offs == [L.ProblemDesc.g.offset, L.ProblemDesc.h.offset, L.ProblemDesc.A_lin.offset,
-                    L.ProblemDesc.allreduce.offset]
+                    L.ProblemDesc.allreduce.offset, L.ProblemDesc.shard_mask.offset, L.ProblemDesc.comm.offset]
     offs = list(map(int, lines[2].split()))
     assert offs == [L.Result.f_evals.offset, L.Result.n_records.offset, L.Rule.xi.offset]
 

@@ -893,10 +893,12 @@ int main(int argc, char** argv) {
     for (int i = 0; i < m; ++i) g_ref[c] = fma(gen(1, (uint64_t)i * n + cols[c]), res[i], g_ref[c]);
 
   const Variant vars[] = {
-      {"P16 KV5 G4 D2 pattern only", l_split4<16, 5, 4, 2, true, true, 3>, 16},
-      {"P16 KV5 G4 D2 pattern only, panel-major (contiguous per member)", l_split4<16, 5, 4, 2, true, true, 4>, 16},
-      {"P16 KV5 G4 D2 pattern only", l_split4<16, 5, 4, 2, true, true, 3>, 16},
-      {"P16 KV5 G4 D2 pattern only, panel-major (contiguous per member)", l_split4<16, 5, 4, 2, true, true, 4>, 16},
+      {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
+      {"P8 KV9 G3 D1 comm wave, x in LDS", l_split4<8, 9, 3, 1, true, true>, 8},
+      {"P8 KV9 G3 D1 pattern only", l_split4<8, 9, 3, 1, true, true, 3>, 8},
+      {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
+      {"P8 KV9 G3 D1 comm wave, x in LDS", l_split4<8, 9, 3, 1, true, true>, 8},
+      {"P8 KV9 G3 D1 pattern only", l_split4<8, 9, 3, 1, true, true, 3>, 8},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
