@@ -837,7 +837,7 @@ static void l_split4(const Args& a, int blocks, hipStream_t st) {
 // Fourth form: the wide teams with H = 2 rows per step (twice the bytes per barrier) — three slots of two rows, one step
 // of slack ; the column accumulator optionally in LDS (next to x) to make room in the registers.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int P, int KV, bool NT, bool ACCLDS>
+template <int P, int KV, bool NT, bool ACCLDS, bool NOWAIT = false>
 __global__ __launch_bounds__(768) void k_split5(Args d) {
   constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P, H = 2, G = 3;
   extern __shared__ double lds5[];                         // x slice [KV * BSC * 2], then (ACCLDS) the accumulator, same shape
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(768) void k_split5(Args d) {
         const unsigned long long want = d.seq0 + (unsigned long long)r + 1;
         unsigned long long v = pv, chk = pchk;
         const bool mine = h < H && q < P;
-        if (!__all((v ^ chk) == want || !mine) && !dead) {
+        if (!NOWAIT && !__all((v ^ chk) == want || !mine) && !dead) {
           const Rec* src = ring + ((r % kSlots) * H + min(h, H - 1)) * P + min(q, P - 1);
           const long long t0 = wall_clock64();
           for (;;) {
@@ -1034,7 +1034,230 @@ __global__ __launch_bounds__(768) void k_split5(Args d) {
       if (lv < nvs && j + e < d.n) out[j + e] = ACCLDS ? as[lv * 2 + e] : acc[k][e];
   }
 }
-template <int P, int KV, bool NT, bool ACCLDS>
+// k_split5 with the communication wave on the SCALAR path (P = 16: 4 x s_load_dwordx16 per row of the step)
+template <int KV, bool NT>
+__global__ __launch_bounds__(768) void k_split6(Args d) {
+  constexpr int P = 16;
+  constexpr bool ACCLDS = false;
+  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P, H = 2, G = 3;
+  extern __shared__ double lds5[];                         // x slice [KV * BSC * 2], then (ACCLDS) the accumulator, same shape
+  double* xs = lds5;
+  double* as = lds5 + KV * BSC * 2;
+  __shared__ double wsum[2][H][16];
+  __shared__ double res_s[4][H];
+  __shared__ int ident[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const unsigned t = atomicAdd(d.tickets + xcc, 1u) - d.launch * 32u;
+    ident[0] = t < (unsigned)(TPX * P) ? (int)(xcc * TPX + t / P) : -1;
+    ident[1] = (int)(t % P);
+    if (t >= 32u) atomicExch(d.err, 2);
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0) return;
+  const int nvec = (d.n + 1) / 2;
+  const int nvs = (nvec + P - 1) / P;
+  const int v0 = s * nvs;
+  const int row_begin = team * d.rows_per_team;
+  const int row_end = min(row_begin + d.rows_per_team, d.m);
+  const int nrows = max(row_end - row_begin, 0);
+  const int nsteps = 1 + ((nrows + H - 1) / H + G - 1) / G * G;      // one step of prologue, then whole rounds of G steps
+  Rec* ring = (Rec*)d.xch + (int64_t)team * kSlots * H * P;
+  if (wv == CW) {
+    // ---- the communication wave: everything wave-uniform, the records through the scalar path ----
+    typedef unsigned v16u __attribute__((ext_vector_type(16)));
+    typedef unsigned long long rec_t __attribute__((ext_vector_type(2)));
+    double e0 = 0.0;
+    bool dead = false;
+    for (long long seq = 0; seq < nsteps; ++seq) {
+      const long long r = seq - 1;
+      if (r >= 0) {
+        const unsigned long long want = d.seq0 + (unsigned long long)r + 1;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const Rec* src = ring + ((r % kSlots) * H + h) * P;
+          double ax = 0.0;
+          const long long t0 = wall_clock64();
+          for (;;) {
+            v16u q0, q1, q2, q3;
+            asm volatile(
+                "s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\ts_load_dwordx16 %2, %4, 0x80 glc\n\t"
+                "s_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
+                : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3)
+                : "s"(src)
+                : "memory");
+            bool ok = true;
+            double sum = 0.0;
+            auto take = [&](const v16u& qq, int i) {
+              const unsigned long long v = ((unsigned long long)qq[4 * i + 1] << 32) | qq[4 * i];
+              const unsigned long long chk = ((unsigned long long)qq[4 * i + 3] << 32) | qq[4 * i + 2];
+              ok = ok && ((v ^ chk) == want);
+              sum += __builtin_bit_cast(double, v);        // member order
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) take(q0, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) take(q1, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) take(q2, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) take(q3, i);
+            if (ok || dead) {
+              ax = sum;
+              break;
+            }
+            if (wall_clock64() - t0 > 2000000) {
+              dead = true;
+              if (lane == 0) atomicExch(d.err, 1);
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          const int i = row_begin + (int)r * H + h;
+          const double bi = d.b[max(min(i, d.m - 1), 0)];
+          const double res = i < row_end ? ax - bi : 0.0;
+          if (lane == 0) {
+            res_s[r & 3][h] = res;
+            if (s == 0) e0 += res * res;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        double own = lane < CW ? wsum[seq & 1][h][lane] : 0.0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
+        if (lane == 0) {
+          const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
+          const rec_t rec = {bits, bits ^ (d.seq0 + (unsigned long long)seq + 1)};
+          *(volatile rec_t*)(ring + ((seq % kSlots) * H + h) * P + s) = rec;
+        }
+      }
+    }
+    if (lane == 0 && s == 0) d.part[(int64_t)team * d.ldpart + d.n] = e0;
+    return;
+  }
+  // ---- the compute waves ----
+  double acc[ACCLDS ? 1 : KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      xs[lv * 2 + e] = (lv < nvs && j + e < d.n) ? d.x[j + e] : 0.0;
+      if constexpr (ACCLDS) as[lv * 2 + e] = 0.0;
+      else acc[k][e] = 0.0;
+    }
+  }
+  const int voff = tid * 16;
+  const int64_t cbase = (int64_t)v0 * 16;
+  const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * 8 - cbase));
+  v2d a[G][H][KV];
+  auto load = [&](int g, long long st) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int ri = __builtin_amdgcn_readfirstlane(max(min(row_begin + (int)st * H + h, row_end - 1), 0));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)(d.AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
+        a[g][h][k] = __builtin_bit_cast(v2d, raw);
+      }
+    }
+  };
+  auto dots = [&](int g, long long seq) {
+    double p[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) p[h] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const v2d xv = *(const v2d*)&xs[(tid + k * BSC) * 2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = fma(a[g][h][k][e], xv[e], p[h]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) p[h] += __shfl_xor(p[h], off, 64);
+      wsum[seq & 1][h][wv] = p[h];
+    }
+    __syncthreads();
+  };
+  __builtin_amdgcn_sched_barrier(0);
+  load(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  dots(0, 0);                                              // step 0: nothing to accumulate yet
+  __builtin_amdgcn_sched_barrier(0);
+  load(2, 2);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (long long q = 1; q < nsteps; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long seq = q + u, r = seq - 1;            // dots of step seq: slot (1 + u) % G ; accumulates step r: slot u
+      dots((1 + u) % G, seq);
+      double rr[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) rr[h] = res_s[r & 3][h];
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        if constexpr (ACCLDS) {
+          v2d av = *(v2d*)&as[(tid + k * BSC) * 2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int h = 0; h < H; ++h) av[e] = fma(a[u][h][k][e], rr[h], av[e]);
+          *(v2d*)&as[(tid + k * BSC) * 2] = av;
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int h = 0; h < H; ++h) acc[k][e] = fma(a[u][h][k][e], rr[h], acc[k][e]);
+        }
+      }
+      if constexpr (!ACCLDS) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load(u, r + G);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double* out = d.part + (int64_t)team * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (lv < nvs && j + e < d.n) out[j + e] = ACCLDS ? as[lv * 2 + e] : acc[k][e];
+  }
+}
+template <int KV, bool NT>
+static void l_split6(const Args& a, int blocks, hipStream_t st) {
+  static bool once = false;
+  const size_t lds = (size_t)KV * 704 * 2 * 8;
+  if (!once && lds > 48 * 1024) {
+    CK(hipFuncSetAttribute((const void*)k_split6<KV, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((k_split6<KV, NT>), dim3(blocks), dim3(768), lds, st, a);
+}
+template <int P, int KV, bool NT, bool ACCLDS, bool NOWAIT = false>
 static void l_split5(const Args& a, int blocks, hipStream_t st) {
   static bool once = false;
   const size_t lds = (size_t)KV * 704 * 2 * 8 * (ACCLDS ? 2 : 1);
@@ -1042,7 +1265,7 @@ static void l_split5(const Args& a, int blocks, hipStream_t st) {
     CK(hipFuncSetAttribute((const void*)k_split5<P, KV, NT, ACCLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     once = true;
   }
-  hipLaunchKernelGGL((k_split5<P, KV, NT, ACCLDS>), dim3(blocks), dim3(768), lds, st, a);
+  hipLaunchKernelGGL((k_split5<P, KV, NT, ACCLDS, NOWAIT>), dim3(blocks), dim3(768), lds, st, a);
 }
 
 struct Variant {
@@ -1106,11 +1329,11 @@ int main(int argc, char** argv) {
 
   const Variant vars[] = {
       {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
-      {"P16 KV5 two rows per step comm wave, acc in registers", l_split5<16, 5, true, false>, 16},
-      {"P16 KV5 two rows per step comm wave, acc in LDS", l_split5<16, 5, true, true>, 16},
+      {"P16 KV5 two rows per step, comm wave on the scalar path", l_split6<5, true>, 16},
+      {"P16 KV5 two rows per step comm wave, NO WAIT (upper bound)", l_split5<16, 5, true, false, true>, 16},
       {"P16 KV5 G4 D2 comm wave, x in LDS", l_split4<16, 5, 4, 2, true, true>, 16},
-      {"P16 KV5 two rows per step comm wave, acc in registers", l_split5<16, 5, true, false>, 16},
-      {"P16 KV5 two rows per step comm wave, acc in LDS", l_split5<16, 5, true, true>, 16},
+      {"P16 KV5 two rows per step, comm wave on the scalar path", l_split6<5, true>, 16},
+      {"P16 KV5 two rows per step comm wave, NO WAIT (upper bound)", l_split5<16, 5, true, false, true>, 16},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
