@@ -236,6 +236,14 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *     grad f in ONE pass over A per iteration instead of two (csrc/slab.hip); it reads the transposed copy of A, which
  *     a matrix of up to 16 GB is given when a solver is created on it (as by apx_matrix_build_transpose).
  *     The primal-dual loop likewise for a separable h (A x, the dual step and A' y in one pass: csrc/slab_pd.hip).
+ *   - the same one pass for Float64 rows too long for one workgroup's registers, by TEAMS of workgroups that split the
+ *     columns of a slab of rows and hand their partial dot products over through L2: f and grad f for rows of
+ *     10 753 ... 112 640 entries (teams of 4 / 8 / 16: BASELINE config C2's 100 000 — csrc/slab.hip k_team_rows), the
+ *     primal-dual form for 10 753 ... 21 504 (teams of two: C5's 20 000 — csrc/slab_pd.hip k_teampd_rows).  These need
+ *     the part's 8 XCDs x 32 CUs to themselves (all 256 workgroups of a launch resident together): every hand-off wait is
+ *     bounded (20 ms) and a timed-out one comes back as APX_ERR_HIP from the polling / result / eval call that follows —
+ *     on a GPU shared with other work switch the policy off.  Not replayable as a hipGraph (APX_ERR_UNSUPPORTED).
+ *     A row shard of f (apx_problem_desc.comm / .allreduce) takes the same one-pass kernels; the block sums are all-reduced.
  * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and
  * the host-driven loops. */
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
@@ -281,6 +289,8 @@ const char* apx_comm_library(void);
  * and carries comm i of apx_comm_init_all; x0 is replicated, y0s[i] / y_outs[i] are shard i of y (NULL arrays when there
  * is no linear operator); x_out, res and opts->records are rank 0's (all ranks take identical steps).  With ndev = 1 and
  * no communicator it is apx_adaptive_primal_dual. */
+/* (A failure on ONE device before its loop's first collective leaves the others waiting in theirs: arguments are checked on
+ * the calling thread first, so this can only be a device-side failure such as an allocation.) */
 int32_t apx_adaptive_primal_dual_group(int32_t ndev, apx_problem* const* ps, const apx_rule* rule, const void* x0,
                                        const void* const* y0s, double tol, int64_t maxit, const apx_solve_opts* opts,
                                        void* x_out, void* const* y_outs, apx_result* res);
