@@ -446,7 +446,7 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
     const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
     ident[0] = k < (unsigned)(TPX * P) ? (int)(xcc * TPX + k / P) : -1;
     ident[1] = (int)(k % P);
-    if (k >= 32u) atomicExch(t.err, 2);
+    if (k >= 32u) atomicCAS(t.err, 0, 2);
   }
   __syncthreads();
   const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
             if (__all((v ^ chk) == want || lane >= P)) break;
             if (wall_clock64() - t0 > 2000000) {   // 20 ms at 100 MHz: give up — the grid must drain
               dead = true;
-              if (lane == 0) atomicExch(t.err, 1);
+              if (lane == 0) atomicCAS(t.err, 0, 1);
               break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -836,7 +836,11 @@ static bool slab2_dispatch(const SlabState* st, dim3 grid, hipStream_t q, const 
 // the team kernel for this row length: P members, KV vectors per compute thread (x of the slice in dynamic LDS)
 template <int FK, int P>
 static bool team_rows_launch_p(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
-  const dim3 grid((unsigned)(st->B * P)), block(768);
+  // (APX_TEAM_FAULT_GRID: a TEST hook — launches that many workgroups instead of all 256, so that some teams miss members:
+  //  what a GPU shared with other work does to this scheme.  tests/test_gpu_team_fault.py checks that the waits time out,
+  //  the grid drains and the error comes back)
+  static const int fault_grid = getenv("APX_TEAM_FAULT_GRID") ? atoi(getenv("APX_TEAM_FAULT_GRID")) : 0;
+  const dim3 grid((unsigned)(fault_grid > 0 ? fault_grid : st->B * P)), block(768);
   const size_t lds = (size_t)st->team_kv * 704 * 2 * sizeof(double);
   switch (st->team_kv) {
     case 1:

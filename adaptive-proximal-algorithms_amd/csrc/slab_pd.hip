@@ -231,7 +231,7 @@ __global__ __launch_bounds__(768) void k_teampd_rows(SlabPdDev d, TeamDev t, con
     const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
     ident[0] = k < 32u ? (int)(xcc * 16 + k / 2) : -1;
     ident[1] = (int)(k % 2);
-    if (k >= 32u) atomicExch(t.err, 2);
+    if (k >= 32u) atomicCAS(t.err, 0, 2);
   }
   __syncthreads();
   const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(768) void k_teampd_rows(SlabPdDev d, TeamDev t, con
         if (wall_clock64() - t0 > 2000000) {       // 20 ms at 100 MHz: give up — the grid must drain
           dead = true;
           v = 0;
-          if (lane == 0) atomicExch(t.err, 1);
+          if (lane == 0) atomicCAS(t.err, 0, 1);
           break;
         }
         __builtin_amdgcn_s_sleep(1);

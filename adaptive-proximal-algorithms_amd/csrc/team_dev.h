@@ -12,7 +12,7 @@ constexpr int kTeamSlots = 8;      // ring of published rows per member (a membe
 struct TeamDev {
   TeamRec* ring;          // [teams][kTeamSlots][members]
   unsigned* tickets;      // [8] one counter per XCD, monotonic over the launches
-  int* err;               // != 0: a wait timed out (1) / an XCD received more than 32 workgroups of a launch (2)
+  int* err;               // != 0, the FIRST failure: a wait timed out (1) / an XCD received more than 32 workgroups of a launch (2)
   unsigned long long seq0;   // sequence base of this launch (the ring is never reset)
   unsigned launch;        // launches so far: the ticket base is launch * 32
   int32_t rows_per_team;
