@@ -902,6 +902,7 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   }
   SlabState* st = p->slab;
   if (st == nullptr || p->A_f->dT == nullptr) return APX_OK;      // (dropped copy: A edited in place)
+  if (st->team_p != 0 && p->teams_off) return APX_OK;             // (a hand-off timed out earlier: the two passes from now on)
   apx_ctx* ctx = p->ctx;
   SlabDev d = st->dev;
   d.AT = p->A_f->dT;                             // (rebuilt copies may live elsewhere)
@@ -928,11 +929,12 @@ bool slab_uses_teams(const apx_problem* p) { return p->slab != nullptr && p->sla
 // the error word of the team hand-off (0: fine)
 int32_t slab_check(apx_problem* p) {
   SlabState* st = p->slab;
-  if (st == nullptr || st->team_p == 0) return APX_OK;
+  if (st == nullptr || st->team_p == 0 || p->teams_off) return APX_OK;
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipMemcpyAsync(st->h_err, st->team.err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   APX_HIP(hipStreamSynchronize(ctx->stream));
   if (*st->h_err == 0) return APX_OK;
+  p->team_failed = true;
   return fail(APX_ERR_HIP, *st->h_err == 2
                                ? "one-pass kernel (teams): an XCD received more than 32 workgroups of a launch (the GPU is shared or "
                                  "partitioned); the result is invalid — switch the policy off (apx_ctx_fused_small(ctx, 0))"

@@ -445,7 +445,7 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   // C5's row length, 20 000 fp64, is out of reach of ONE workgroup (x, the accumulator and one row are 480 KB of a CU's
   // 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two
   // passes): teams of two workgroups, half a row each (k_teampd_rows) — Float64, on a part of 8 XCDs x 32 CUs
-  if (!f32 && cols <= 2 * 14 * 768 && p->ctx->num_cu == 256) return {768, 28, 1};
+  if (!f32 && cols <= 2 * 14 * 768 && p->ctx->num_cu == 256 && !p->teams_off) return {768, 28, 1};
   return {0, 0, 0};
 }
 
@@ -605,6 +605,7 @@ int32_t slab_pd_check(apx_solver* s) {
   APX_HIP(hipMemcpyAsync(st->h_err, st->team.err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   APX_HIP(hipStreamSynchronize(ctx->stream));
   if (*st->h_err == 0) return APX_OK;
+  s->p->team_failed = true;
   return fail(APX_ERR_HIP, *st->h_err == 2
                                ? "one-pass primal-dual kernel: an XCD received more than 32 workgroups of a launch (the GPU is "
                                  "shared or partitioned); the result is invalid — switch the policy off (apx_ctx_fused_small(ctx, 0))"

@@ -698,12 +698,21 @@ int32_t apx_adaptive_primal_dual(apx_problem* p, const apx_rule* rule, const voi
                                  int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out,
                                  apx_result* res) {
   APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
-  apx_solver* s = nullptr;
-  APX_TRY(apx_solver_create(p, rule, x0, y0, tol, opts, &s));
-  int32_t rc = apx_solver_step(s, maxit, 1);
-  if (rc == APX_OK) rc = apx_solver_result(s, x_out, y_out, res);
-  apx_solver_destroy(s);
-  return rc;
+  for (int attempt = 0;; ++attempt) {
+    apx_solver* s = nullptr;
+    APX_TRY(apx_solver_create(p, rule, x0, y0, tol, opts, &s));
+    int32_t rc = apx_solver_step(s, maxit, 1);
+    if (rc == APX_OK) rc = apx_solver_result(s, x_out, y_out, res);
+    apx_solver_destroy(s);
+    // a team hand-off timed out (the GPU is shared with other work: the 256 workgroups of a launch were not resident
+    // together): nothing of that run is used — the solve is repeated from x0 on the two GEMV passes, which need no
+    // co-residency, and the problem stays on them
+    if (rc == APX_ERR_HIP && p->team_failed && !p->teams_off && attempt == 0) {
+      p->teams_off = true;
+      continue;
+    }
+    return rc;
+  }
 }
 
 int32_t apx_adaptive_proxgrad(apx_problem* p, const apx_rule* rule, const void* x0, double tol, int64_t maxit,

@@ -38,6 +38,9 @@ struct apx_problem {
   // evaluation at hand already left the gradient in `grad`, the pullback has nothing to do
   apx::SlabState* slab = nullptr;
   bool slab_checked = false, grad_ready = false;
+  // set when a team hand-off timed out on this problem (the GPU is shared): from then on the two GEMV passes run, and the
+  // one-shot entry point re-runs the solve on them instead of failing
+  bool teams_off = false, team_failed = false;
   ~apx_problem() { apx::slab_destroy(slab); }
 
   apx::Ctrl* ctrl() const { return (apx::Ctrl*)ctrl_buf.p; }

@@ -1,6 +1,7 @@
 """The team kernels need all 256 workgroups of a launch resident together (csrc/slab.hip k_team_rows).  When they are not —
 a GPU shared with other work — some teams miss members.  The design's promise: every wait is bounded (20 ms of wall clock),
-the grid DRAINS, and the host gets APX_ERR_HIP instead of a wrong iterate.  APX_TEAM_FAULT_GRID launches 248 of the 256
+the grid DRAINS, and the host never gets a wrong iterate: the stepping interface returns APX_ERR_HIP, the one-shot entry point
+repeats the solve on the two GEMV passes (and keeps the problem on them).  APX_TEAM_FAULT_GRID launches 248 of the 256
 workgroups (31 per XCD: one team of each XCD is a member short); one fresh child process, which must finish in seconds."""
 import os
 import subprocess
@@ -26,10 +27,22 @@ b = np.random.default_rng(0).standard_normal(m)
 f = apx.LinearLeastSquares(A, b, ctx=ctx)
 t0 = time.perf_counter()
 try:
-    apx.adaptive_proxgrad(np.zeros(n), f=f, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=3, ctx=ctx)
-    print("NO ERROR")
+    s = apx.Solver(np.zeros(n), f=f, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, ctx=ctx)
+    s.step(3, sync=True)
+    s.result()
+    print("STEPPING: NO ERROR")
 except apx.ApxError as e:
-    print("ERROR:", e)
+    print("STEPPING ERROR:", e)
+# the one-shot entry point on a fresh problem: falls back to the two passes by itself
+f2 = apx.LinearLeastSquares(A, b, ctx=ctx)
+ctx.kernel_stats(reset=True); ctx.profile(True)
+x, it = apx.adaptive_proxgrad(np.zeros(n), f=f2, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=3, ctx=ctx)
+st = ctx.kernel_stats(reset=True); ctx.profile(False)
+ctx2 = apx.Context(0); ctx2.fused_small(False)
+A2 = apx.DeviceMatrix.uniform(m, n, seed=5, ctx=ctx2)
+xr, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A2, b, ctx=ctx2), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7),
+                              tol=0.0, maxit=3, ctx=ctx2)
+print("ONE-SHOT it", it, "gemv_t launches", st["gemv_t"]["launches"], "max diff vs two-pass context", float(np.max(np.abs(x - xr))))
 print("seconds %%.2f" %% (time.perf_counter() - t0))
 """
 
@@ -40,10 +53,15 @@ def test_missing_team_members_time_out_and_report():
     out = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=120)
     dt = time.perf_counter() - t0
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "ERROR:" in out.stdout and "waited 20 ms" in out.stdout, out.stdout
+    assert "STEPPING ERROR:" in out.stdout and "waited 20 ms" in out.stdout, out.stdout
+    line = [l for l in out.stdout.splitlines() if l.startswith("ONE-SHOT")][0].split()
+    assert line[2] == "3" and int(line[5]) >= 4, out.stdout          # the repeat ran on the two passes (gemv_t launched)
+    assert float(line[-1]) <= 1e-12, out.stdout                      # ... and gives the two-pass context's iterate
     assert dt < 60.0                                     # (bounded waits: the grid drained)
 
 
 def test_the_same_child_without_the_fault_is_fine():
     out = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=dict(os.environ), capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0 and "NO ERROR" in out.stdout, out.stdout + out.stderr[-1500:]
+    assert out.returncode == 0 and "STEPPING: NO ERROR" in out.stdout, out.stdout + out.stderr[-1500:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("ONE-SHOT")][0].split()
+    assert line[2] == "3" and int(line[5]) == 0, out.stdout           # one pass over A per evaluation: no gemv_t
