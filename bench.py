@@ -356,10 +356,12 @@ def main():
 
         if args.exploit_sparsity:
             ctx.exploit_sparsity(True)
-        f = apx.LinearLeastSquares(prob.A, prob.b, allreduce=ar_dev)
         g = apx.NormL1(prob.lam)
-        solver = apx.Solver(np.zeros(args.n), f=f, g=g, rule=apx.OurRule(gamma=1.0 / prob.Lf), tol=0.0,
-                            ctx=ctx, poll_every=1 << 30)
+
+        def make_solver():
+            f = apx.LinearLeastSquares(prob.A, prob.b, allreduce=ar_dev)
+            return apx.Solver(np.zeros(args.n), f=f, g=g, rule=apx.OurRule(gamma=1.0 / prob.Lf), tol=0.0, ctx=ctx,
+                              poll_every=1 << 30)
 
         def barrier():
             torch.cuda.synchronize()
@@ -367,7 +369,34 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        dt, stats = timed_steps(ctx, solver, args.steps, args.warmup, barrier)
+        # The W warm-up steps, and a look at the error word of the team kernels behind them.  The one-pass kernels for rows
+        # of this length need the GPU to themselves (all 256 workgroups of a launch resident together); if a hand-off
+        # timed out on ANY rank, every rank falls back to the two GEMV passes — loudly: the JSON line says so — instead
+        # of the job dying.  (Every rank has enqueued the same collectives either way.)
+        solver = make_solver()
+        team_failure = 0
+        try:
+            solver.step(args.warmup, sync=True)
+            solver.result()
+        except apx.ApxError as e:
+            if "one-pass kernel (teams)" not in str(e):
+                raise
+            team_failure = 1
+            print(f"bench.py rank {rank}: {e}", file=sys.stderr)
+        if use_dist:
+            tf = torch.tensor([team_failure], dtype=torch.int32,
+                              device=f"cuda:{dev}" if transport == "torch-nccl" else "cpu")
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            team_failure = int(tf.item())
+        if team_failure:
+            try:
+                solver.close()
+            except apx.ApxError:
+                pass
+            ctx.fused_small(False)
+            solver = make_solver()
+            solver.step(args.warmup, sync=True)
+        dt, stats = timed_steps(ctx, solver, args.steps, 0, barrier)
 
         x, _, res = solver.result()
         if not np.all(np.isfinite(x)):
@@ -438,6 +467,9 @@ def main():
             "setup_s": t_setup, "final_objective": final_objective, "lasso_optimum": optimum,
             "lib_srchash": __graft_entry__.source_hash()[:16],
         }
+        if team_failure:
+            out["note_team_kernels"] = ("a hand-off of the one-pass team kernels timed out during the warm-up on at least one rank (the GPU "
+                                        "was shared with other work): ALL ranks ran the timed steps on the two GEMV passes instead")
         if one_pass:
             out["roofline"]["note"] = (
                 "one launch forms A x, the residual AND A' r from ONE read of A (teams of 16 workgroups per slab of rows): "
