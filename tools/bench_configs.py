@@ -56,7 +56,7 @@ if "c5" in which:
     s.close(); p.A.free()
 if "c2bt" in which:
     m, n = 50_000, 100_000
-    p = problems.device_lasso(m, n, seed=0, power_iters=20, ctx=ctx)
+    p = problems.device_lasso(m, n, seed=0, power_iters=20, ctx=ctx, dual_layout=os.environ.get("APX_SINGLE_LAYOUT") != "1")
     f = apx.Counting(apx.LinearLeastSquares(p.A, p.b)); g = apx.NormL1(p.lam)
     apx.backtracking_proxgrad(np.zeros(n), f=f, g=g, gamma0=1 / p.Lf, xi=1.5, tol=0.0, maxit=2)
     e0, g0 = f.eval_count, f.grad_count
