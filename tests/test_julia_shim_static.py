@@ -154,3 +154,27 @@ def test_the_shim_reaches_the_path_entry_points():
                  "apx_comm_unique_id", "apx_comm_init_rank", "apx_comm_init_all", "apx_comm_destroy",
                  "apx_adaptive_primal_dual_group", "apx_ctx_destroy", "apx_matrix_free", "apx_problem_destroy"):
         assert need in used, f"julia/AdaProxHIP.jl never calls {need}"
+
+
+def test_constructor_calls_have_one_argument_per_field():
+    """Julia's default struct constructors are positional: every `ProxDesc(...)`, `ProblemDesc(...)`, `Rule(...)`,
+    `SolveOpts(...)`, `LinesearchParams(...)` call in the shim must pass exactly one argument per field (a field added to the
+    header — apx_problem_desc.comm in ABI 2 — is otherwise a MethodError at run time, where nobody here can see it)."""
+    js = shim_structs()
+    checked = 0
+    for name, (_, fields) in js.items():
+        if name in ("Result", "Record"):          # (Result has an inner constructor ; Record rows are written by the library)
+            continue
+        for m in re.finditer(r"(?<![\w.{])%s\(" % name, SHIM):
+            line_start = SHIM.rfind("\n", 0, m.start()) + 1
+            if SHIM[line_start:m.start()].strip().startswith(("struct", "mutable struct")):
+                continue
+            i = m.end()
+            depth, j = 1, i
+            while depth:
+                depth += {"(": 1, ")": -1}.get(SHIM[j], 0)
+                j += 1
+            args = split_top(SHIM[i:j - 1])
+            assert len(args) == len(fields), f"{name}(...) with {len(args)} arguments, the struct has {len(fields)} fields: {SHIM[m.start():j][:120]}"
+            checked += 1
+    assert checked >= 10
