@@ -421,14 +421,35 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
 //     poll or a fence in a wave that streams A waits for every load in flight and drains the pipeline — that is what
 //     round 1's probe measured as 23 - 28 us per hand-off).  It sums the workgroup's partial, publishes it (two words
 //     {value, value ^ sequence}, agent scope, no fence: the check word validates the pair), collects the P records of
-//     the row two rows back with ONE vector load (lane q: member q; requested a step ahead), adds them in a fixed tree —
-//     the same `A x` on every member, no atomics on data —, evaluates the residual / the logistic link ONCE and leaves
-//     it in LDS; member 0's accumulates the loss sums.  Two rows of slack absorb the hand-off (1 - 3 us) and the
-//     slowest member.
+//     the row two rows back on the SCALAR path (P / 4 `s_load_dwordx16 ... glc`, from the XCD's L2, a step ahead), adds
+//     them in a fixed tree — the same `A x` on every member, no atomics on data —, evaluates the residual / the logistic
+//     link ONCE and leaves it in LDS; member 0's accumulates the loss sums.  Two rows of slack absorb the hand-off
+//     (1 - 3 us) and the slowest member.
 // Every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
-// tools/split_probe.hip (profiles/r02_team_probe_*.log): 5.6 - 5.8 TB/s on rows of C2's length — A read once per
-// evaluation of f and its gradient instead of twice at 7.1 TB/s.
+// tools/split_probe.hip, tools/pattern_probe.hip (profiles/r02_team_probe_*.log, r02_team_handoff_traffic.log): 6.6 - 6.7
+// TB/s on rows of C2's length — A read once per evaluation of f and its gradient instead of twice at 7.1 TB/s.
 // ---------------------------------------------------------------------------------------------------------------------
+// The P records of one row of a team's ring (P x 16 bytes, 64-byte aligned) into SGPRs: P / 4 scalar loads, glc (past
+// the scalar cache), waited for here — nothing may copy the registers before the data is in them.
+typedef unsigned raw16_t __attribute__((ext_vector_type(16)));
+template <int P>
+__device__ __forceinline__ void team_fetch(const TeamRec* row, raw16_t (&q)[P / 4]) {
+  static_assert(P == 4 || P == 8 || P == 16, "teams of 4, 8 or 16");
+  if constexpr (P == 4)
+    asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(q[0]) : "s"(row) : "memory");
+  else if constexpr (P == 8)
+    asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(q[0]), "=&s"(q[1])
+                 : "s"(row)
+                 : "memory");
+  else
+    asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
+                 "s_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(q[0]), "=&s"(q[1]), "=&s"(q[2]), "=&s"(q[3])
+                 : "s"(row)
+                 : "memory");
+}
+
 template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2>
 __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const void* xv) {
   constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;
@@ -469,30 +490,40 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
     const double bias = FK == APX_F_LOGISTIC ? X[d.n - 1] : 0.0;
     double e0 = 0.0, e1 = 0.0;
     bool dead = false;
-    // the records (lane q: member q) and the entry of b of the row whose residual is due NEXT are requested a step ahead:
-    // by the time they are needed they have had a whole step to arrive
-    unsigned long long pv = 0, pchk = 0;
+    // The P records of a row are taken on the SCALAR path: P / 4 loads of 64 bytes (`s_load_dwordx16 ... glc`: past the
+    // scalar cache, from the XCD's L2 — the teams are formed inside an XCD, and the members' agent-scope stores pass
+    // through that L2).  Measured (tools/pattern_probe.hip, profiles/r02_team_handoff_traffic.log): agent-scope VECTOR
+    // loads of lines that other CUs keep storing to are served by the memory side, and that small read-after-write
+    // traffic alone — nothing waited for — takes the stream of A from 7.1 to 5.8 TB/s; stores alone, or loads alone, cost
+    // nothing; the same hand-off with scalar loads runs at 6.6 - 6.7.  The records of the row whose residual is due NEXT
+    // and its entry of b are taken a step ahead, right after this workgroup's own partial has been published.
+    raw16_t q[P / 4];
+#pragma unroll
+    for (int c = 0; c < P / 4; ++c) q[c] = raw16_t{};
     double pb = 0.0;
-    auto request = [&](long long r) {
-      const TeamRec* src = ring + (r % kTeamSlots) * P + min(lane, P - 1);
-      pv = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pchk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pb = bv[max(min(row_begin + (int)r, d.m - 1), 0)];
+    auto fetch = [&](long long r) { team_fetch<P>(ring + (r % kTeamSlots) * P, q); };
+    auto rec_word = [&](int m, int w) -> unsigned long long {        // word w (0: value, 1: check) of member m's record
+      const raw16_t& c = q[m / 4];
+      const int o = (m & 3) * 4 + w * 2;
+      return ((unsigned long long)c[o + 1] << 32) | c[o];
+    };
+    auto all_there = [&](unsigned long long want) {
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < P; ++m) ok &= (rec_word(m, 0) ^ rec_word(m, 1)) == want;
+      return ok;
     };
     for (long long seq = 0; seq < nsteps; ++seq) {
       const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
       if (r >= 0) {
         const int i = row_begin + (int)r;
         const unsigned long long want = t.seq0 + (unsigned long long)r + 1;
-        unsigned long long v = pv, chk = pchk;
         const double bi = pb;
-        if (!__all((v ^ chk) == want || lane >= P) && !dead) {      // not all there yet (or half written): poll, bounded
-          const TeamRec* src = ring + (r % kTeamSlots) * P + min(lane, P - 1);
+        if (!all_there(want) && !dead) {           // not all there yet (or half written): poll, bounded
           const long long t0 = wall_clock64();
           for (;;) {
-            v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            chk = __hip_atomic_load(&src->chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((v ^ chk) == want || lane >= P)) break;
+            fetch(r);
+            if (all_there(want)) break;
             if (wall_clock64() - t0 > 2000000) {   // 20 ms at 100 MHz: give up — the grid must drain
               dead = true;
               if (lane == 0) atomicCAS(t.err, 0, 1);
@@ -501,11 +532,15 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        // the P partials added in a fixed tree (a butterfly over lanes 0 .. P-1: every lane, and every member, forms the same
-        // sums — IEEE addition commutes)
-        double ax = (dead || lane >= P) ? 0.0 : __builtin_bit_cast(double, v);
+        // the P partials added in a fixed pairwise tree, from the same P records on every member: the same `A x` bit for bit
+        double part[P];
 #pragma unroll
-        for (int off = 1; off < P; off <<= 1) ax += __shfl_xor(ax, off, 64);
+        for (int m = 0; m < P; ++m) part[m] = dead ? 0.0 : __builtin_bit_cast(double, rec_word(m, 0));
+#pragma unroll
+        for (int w = 1; w < P; w <<= 1)
+#pragma unroll
+          for (int m = 0; m < P; m += 2 * w) part[m] += part[m + w];
+        const double ax = part[0];
         double res = 0.0;
         if (i < row_end) {
           if constexpr (FK == APX_F_LEAST_SQUARES) {
@@ -531,7 +566,10 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
         __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&rec->chk, bits ^ (t.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (r + 1 >= 0) request(r + 1);
+      if (r + 1 >= 0) {
+        pb = bv[max(min(row_begin + (int)(r + 1), d.m - 1), 0)];
+        fetch(r + 1);
+      }
     }
     if (lane == 0 && s == 0) {
       double* __restrict__ out = d.part + (int64_t)team * d.ldpart;

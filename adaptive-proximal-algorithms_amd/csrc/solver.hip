@@ -706,8 +706,9 @@ int32_t apx_adaptive_primal_dual(apx_problem* p, const apx_rule* rule, const voi
     apx_solver_destroy(s);
     // a team hand-off timed out (the GPU is shared with other work: the 256 workgroups of a launch were not resident
     // together): nothing of that run is used — the solve is repeated from x0 on the two GEMV passes, which need no
-    // co-residency, and the problem stays on them
-    if (rc == APX_ERR_HIP && p->team_failed && !p->teams_off && attempt == 0) {
+    // co-residency, and the problem stays on them.  Not for a row shard: a rank that started again alone would leave the
+    // sequence of collectives its peers are in — there the error is returned (every rank: apx_ctx_fused_small(ctx, 0)).
+    if (rc == APX_ERR_HIP && p->team_failed && !p->teams_off && attempt == 0 && !p->sharded()) {
       p->teams_off = true;
       continue;
     }

@@ -242,8 +242,9 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *     primal-dual form for 10 753 ... 21 504 (teams of two: C5's 20 000 — csrc/slab_pd.hip k_teampd_rows).  These need
  *     the part's 8 XCDs x 32 CUs to themselves (all 256 workgroups of a launch resident together): every hand-off wait is
  *     bounded (20 ms); after a timed-out one the one-shot solver entry points repeat the solve on the two GEMV passes and
- *     keep the problem on them, the stepping interface and apx_eval return APX_ERR_HIP — on a GPU shared with other work
- *     switch the policy off.  Not replayable as a hipGraph (APX_ERR_UNSUPPORTED).
+ *     keep the problem on them (not for a row shard: a rank restarting alone would leave its peers' sequence of
+ *     collectives — the error is returned), the stepping interface and apx_eval return APX_ERR_HIP — on a GPU shared
+ *     with other work switch the policy off.  Not replayable as a hipGraph (APX_ERR_UNSUPPORTED).
  *     A row shard of f (apx_problem_desc.comm / .allreduce) takes the same one-pass kernels; the block sums are all-reduced.
  * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and
  * the host-driven loops. */
