@@ -146,7 +146,6 @@ typedef unsigned raw16_t __attribute__((ext_vector_type(16)));
 template <int KV, int G, int DEPTH, int ST, int LD, bool WAIT, int P = 16>
 __global__ __launch_bounds__(768) void k_pat5(Args5 d) {
   constexpr int CW = 11, BSC = CW * 64, SLOTS = 8, TPX = 32 / P;
-  static_assert(P == 16, "the scalar path below fetches sixteen records");
   const Args& a = d.a;
   __shared__ double xs[BSC * KV * 2];
   __shared__ double wsum[2][16];
@@ -182,6 +181,8 @@ __global__ __launch_bounds__(768) void k_pat5(Args5 d) {
       } else if (LD == 1) {
         pv = __hip_atomic_load(&row[min(lane, P - 1)].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         pchk = __hip_atomic_load(&row[min(lane, P - 1)].chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (LD == 2 && P == 4) {
+        asm volatile("s_load_dwordx16 %0, %1, 0x0 glc" : "=&s"(q0) : "s"(row) : "memory");
       } else if (LD == 2) {
         asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
                      "s_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc"
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(768) void k_pat5(Args5 d) {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3)::"memory");
       unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
+      for (int m = 0; m < P; ++m) {
         const raw16_t& q = m < 4 ? q0 : m < 8 ? q1 : m < 12 ? q2 : q3;
         const int o = (m & 3) * 4;
         if (lane == m) w0 = q[o], w1 = q[o + 1], w2 = q[o + 2], w3 = q[o + 3];
@@ -330,11 +331,222 @@ static int* g_err = nullptr;
 static unsigned* g_tickets = nullptr;
 static unsigned g_launch = 0;
 static unsigned long long g_seq0 = 0;
-template <int KV, int G, int DEPTH, int ST, int LD, bool WAIT>
+template <int KV, int G, int DEPTH, int ST, int LD, bool WAIT, int P = 16>
 static void l_pat5(const Args& a, int nb, hipStream_t q) {
   Args5 d{a, g_ring, g_seq0, g_err, g_tickets, g_launch++};
   g_seq0 += (unsigned long long)a.rows_per_slab + 64;
-  hipLaunchKernelGGL((k_pat5<KV, G, DEPTH, ST, LD, WAIT>), dim3(nb), dim3(768), 0, q, d);
+  hipLaunchKernelGGL((k_pat5<KV, G, DEPTH, ST, LD, WAIT, P>), dim3(nb), dim3(768), 0, q, d);
+}
+
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+
+// Teams of TWO (csrc/slab_pd.hip k_teampd_rows, BASELINE config C5: rows of 20 000): every wave takes the partner's record
+// itself on the scalar path, one barrier per row.
+//   EXTRA: the row's y, A_x_prev and shift ride behind its loads of A (three broadcast vector loads per wave and row)
+//   HS 0: no hand-off   1: the store and every wave's scalar load, nothing waited for   2: the full hand-off
+//      3: the full hand-off, but ONLY wave 0 loads the record (and leaves the sum in LDS: a second barrier per row)
+template <int KV, int G, bool EXTRA, int HS, bool FIRST = false>
+__global__ __launch_bounds__(768) void k_pat2(Args5 d) {
+  constexpr int BS = 768, NW = 12, SLOTS = 8;
+  typedef unsigned raw4_t __attribute__((ext_vector_type(4)));
+  typedef unsigned long long rec_t __attribute__((ext_vector_type(2)));
+  const Args& a = d.a;
+  extern __shared__ double xs2[];
+  __shared__ double wsum[2][NW];
+  __shared__ double other_s[2];
+  __shared__ int ident[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const unsigned k = atomicAdd(d.tickets + xcc, 1u) - d.launch * 32u;
+    ident[0] = k < 32u ? (int)(xcc * 16 + k / 2) : -1;
+    ident[1] = (int)(k % 2);
+    if (k >= 32u) atomicCAS(d.err, 0, 2);
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0) return;
+  const int row_begin = team * a.rows_per_slab;
+  const int row_end = min(row_begin + a.rows_per_slab, a.m);
+  const int nrows = max(row_end - row_begin, 0);
+  Rec5* ring = d.ring + (int64_t)team * SLOTS * 2;
+  const int64_t cbase = (int64_t)s * a.nvs * 16;
+  const int slice_bytes = (int)max((int64_t)0, min((int64_t)a.nvs * 16, a.ld * 8 - cbase));
+  vec_t v[G][KV];
+  double y_in[G], axp_in[G], b_in[G];
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    acc[k][0] = acc[k][1] = 0.0;
+    xs2[(tid + k * BS) * 2] = 0.5, xs2[(tid + k * BS) * 2 + 1] = 0.25;
+  }
+  const double* __restrict__ Y = a.out + 1024;         // (three vectors of m entries behind the out word)
+  const double* __restrict__ AXP = Y + a.m;
+  const double* __restrict__ SH = AXP + a.m;
+  auto load = [&](int g, int row) {
+    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(a.A + (int64_t)ri * a.ld) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+      v[g][k] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, k * BS * 16, 2));
+    if (EXTRA) {
+      y_in[g] = Y[ri];
+      axp_in[g] = AXP[ri];
+      b_in[g] = SH[ri];
+    } else {
+      y_in[g] = axp_in[g] = b_in[g] = 0.0;
+    }
+  };
+  auto dots = [&](int g, long long seq) -> double {
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) p = fma(v[g][k][e], xs2[(tid + k * BS) * 2 + e], p);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    wsum[seq & 1][wv] = p;
+    __syncthreads();
+    double own = wsum[seq & 1][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) own += wsum[seq & 1][w];
+    if (HS != 0 && tid == 0) {
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
+      const rec_t rec = {bits, bits ^ (d.seq0 + (unsigned long long)seq + 1)};
+      *(volatile rec_t*)(ring + (seq % SLOTS) * 2 + s) = rec;
+    }
+    return own;
+  };
+  bool dead = false;
+  double keep = 0.0;
+  auto finish = [&](int g, long long seq, double own, raw4_t early) {
+    double other = 0.0;
+    if (HS == 1 || HS == 2) {
+      const unsigned long long want = d.seq0 + (unsigned long long)seq + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(early)::"memory");
+      unsigned long long vv = ((unsigned long long)early[1] << 32) | early[0];
+      unsigned long long chk = ((unsigned long long)early[3] << 32) | early[2];
+      if (HS == 2 && (vv ^ chk) != want && !dead) {
+        const Rec5* src = uniform_ptr(ring + (seq % SLOTS) * 2 + (1 - s));
+        const long long t0 = wall_clock64();
+        for (;;) {
+          raw4_t raw;
+          asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(src) : "memory");
+          vv = ((unsigned long long)raw[1] << 32) | raw[0];
+          chk = ((unsigned long long)raw[3] << 32) | raw[2];
+          if ((vv ^ chk) == want) break;
+          if (wall_clock64() - t0 > 2000000) {
+            dead = true;
+            vv = 0;
+            if (lane == 0) atomicCAS(d.err, 0, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      other = __builtin_bit_cast(double, vv);
+    } else if (HS == 3) {
+      if (wv == 0) {
+        const unsigned long long want = d.seq0 + (unsigned long long)seq + 1;
+        const Rec5* src = uniform_ptr(ring + (seq % SLOTS) * 2 + (1 - s));
+        unsigned long long vv = 0, chk = 0;
+        const long long t0 = wall_clock64();
+        for (;;) {
+          raw4_t raw;
+          asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(src) : "memory");
+          vv = ((unsigned long long)raw[1] << 32) | raw[0];
+          chk = ((unsigned long long)raw[3] << 32) | raw[2];
+          if ((vv ^ chk) == want || dead) break;
+          if (wall_clock64() - t0 > 2000000) {
+            dead = true;
+            vv = 0;
+            if (lane == 0) atomicCAS(d.err, 0, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) other_s[seq & 1] = __builtin_bit_cast(double, vv);
+      }
+      __syncthreads();
+      other = other_s[seq & 1];
+    }
+    const double ax = s == 0 ? own + other : other + own;
+    const double w = y_in[g] + 0.5 * (1.5 * ax - 0.5 * axp_in[g]);
+    const double yn = fmin(fmax(w - 0.5 * b_in[g], -1.0), 1.0) * 1e-30 + 1.0;
+    keep += yn;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) acc[k][e] = fma(v[g][k][e], yn, acc[k][e]);
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, row_begin + g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double own_prev = dots(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load(G - 1, row_begin + G - 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (long long q = 1; q <= nrows; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long seq = q + u;
+      raw4_t early = {};
+      if (HS == 1 || HS == 2) {
+        const Rec5* src = uniform_ptr(ring + ((seq - 1) % SLOTS) * 2 + (1 - s));
+        asm volatile("s_load_dwordx4 %0, %1, 0x0 glc" : "=s"(early) : "s"(src) : "memory");
+      }
+      if (FIRST) {
+        // FIRST: row seq - 1 is finished and its slot re-loaded BEFORE the dots of row seq — the load of row seq + 1 then has a
+        // whole step to arrive (two slots, yet a row always in flight) ; the hand-off is on the critical path instead
+        finish(u % G, seq - 1, own_prev, early);
+        __builtin_amdgcn_sched_barrier(0);
+        load(u % G, row_begin + (int)(seq - 1) + G);
+        __builtin_amdgcn_sched_barrier(0);
+        own_prev = dots((1 + u) % G, seq);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        const double own = dots((1 + u) % G, seq);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(u % G, seq - 1, own_prev, early);
+        own_prev = own;
+        __builtin_amdgcn_sched_barrier(0);
+        load(u % G, row_begin + (int)(seq - 1) + G);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  double t = keep;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) t += acc[k][0] + acc[k][1];
+  if (t == 12345.678) a.out[0] = t;
+}
+
+template <int KV, int G, bool EXTRA, int HS, bool FIRST = false>
+static void l_pat2(const Args& a, int nb, hipStream_t q) {
+  static bool once = false;
+  const int lds = KV * 768 * 16;
+  if (!once) {
+    CK(hipFuncSetAttribute((const void*)k_pat2<KV, G, EXTRA, HS, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once = true;
+  }
+  Args5 d{a, g_ring, g_seq0, g_err, g_tickets, g_launch++};
+  g_seq0 += (unsigned long long)a.rows_per_slab + 64;
+  hipLaunchKernelGGL((k_pat2<KV, G, EXTRA, HS, FIRST>), dim3(nb), dim3(768), lds, q, d);
 }
 
 // contiguous stream of the same bytes, the shape of the two-pass kernels: block b walks a contiguous chunk
@@ -395,7 +607,8 @@ int main(int argc, char** argv) {
   const int64_t total = (int64_t)m * ld;
   double *A, *out;
   CK(hipMalloc(&A, total * 8));
-  CK(hipMalloc(&out, 64));
+  CK(hipMalloc(&out, (1024 + 3 * (size_t)m) * 8));
+  CK(hipMemset(out, 0, (1024 + 3 * (size_t)m) * 8));
   const int fill_mode = argc > 3 ? atoi(argv[3]) : 0;
   const int ncases = argc > 4 ? atoi(argv[4]) : 1000;
   hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, total, fill_mode);
@@ -413,6 +626,23 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   const int nvec = (n + 1) / 2;
   const std::vector<Case> cases = {
+      {"teams of two KV7 G2 (product order): dots, finish, load", l_pat2<7, 2, true, 2>, 768, 7, 1, 2},
+      {"teams of two KV7 G2, finish and re-load BEFORE the dots", l_pat2<7, 2, true, 2, true>, 768, 7, 1, 2},
+      {"   the same, no hand-off", l_pat2<7, 2, true, 0, true>, 768, 7, 1, 2},
+      {"teams of two KV7 G3 no row state (spills with it)", l_pat2<7, 3, false, 2>, 768, 7, 1, 2},
+      {"teams of FOUR, comm wave, KV4 G4 D2, scalar path (C5 shape)", l_pat5<4, 4, 2, 0, 2, true, 4>, 704, 4, 1, 4},
+      {"teams of FOUR, comm wave, KV4 G5 D3, scalar path", l_pat5<4, 5, 3, 0, 2, true, 4>, 704, 4, 1, 4},
+      {"teams of FOUR, comm wave, KV4 G4 D2, no hand-off", l_pat5<4, 4, 2, 2, 3, false, 4>, 704, 4, 1, 4},
+      {"teams of two KV7 G2: no hand-off, no row state", l_pat2<7, 2, false, 0>, 768, 7, 1, 2},
+      {"   + y, A_x_prev, shift behind the row", l_pat2<7, 2, true, 0>, 768, 7, 1, 2},
+      {"   + store, every wave's scalar load, not waited for", l_pat2<7, 2, true, 1>, 768, 7, 1, 2},
+      {"   + waited for (product)", l_pat2<7, 2, true, 2>, 768, 7, 1, 2},
+      {"   wave 0 alone loads the record, second barrier", l_pat2<7, 2, true, 3>, 768, 7, 1, 2},
+      {"teams of two KV7 G3: no hand-off, no row state", l_pat2<7, 3, false, 0>, 768, 7, 1, 2},
+      {"   G3, full hand-off", l_pat2<7, 3, true, 2>, 768, 7, 1, 2},
+      {"   G3, full hand-off, no row state", l_pat2<7, 3, false, 2>, 768, 7, 1, 2},
+      {"   G2, full hand-off, no row state", l_pat2<7, 2, false, 2>, 768, 7, 1, 2},
+      {"contiguous stream reference ", nullptr, 0, 0, 0, -1},
       {"hand-off: sc1 stores, sc1 loads, waited for (product)", l_pat5<5, 4, 2, 0, 0, true>, 704, 5, 1, 16},
       {"   sc1 stores, scalar glc loads, waited for, G4 D2", l_pat5<5, 4, 2, 0, 2, true>, 704, 5, 1, 16},
       {"   sc1 stores, scalar glc loads, waited for, G5 D3", l_pat5<5, 5, 3, 0, 2, true>, 704, 5, 1, 16},
