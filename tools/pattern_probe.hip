@@ -350,7 +350,7 @@ __device__ __forceinline__ const T* uniform_ptr(const T* p) {
 //   EXTRA: the row's y, A_x_prev and shift ride behind its loads of A (three broadcast vector loads per wave and row)
 //   HS 0: no hand-off   1: the store and every wave's scalar load, nothing waited for   2: the full hand-off
 //      3: the full hand-off, but ONLY wave 0 loads the record (and leaves the sum in LDS: a second barrier per row)
-template <int KV, int G, bool EXTRA, int HS, bool FIRST = false>
+template <int KV, int G, bool EXTRA, int HS, bool FIRST = false, bool ASMST = false>
 __global__ __launch_bounds__(768) void k_pat2(Args5 d) {
   constexpr int BS = 768, NW = 12, SLOTS = 8;
   typedef unsigned raw4_t __attribute__((ext_vector_type(4)));
@@ -420,7 +420,10 @@ __global__ __launch_bounds__(768) void k_pat2(Args5 d) {
     if (HS != 0 && tid == 0) {
       const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
       const rec_t rec = {bits, bits ^ (d.seq0 + (unsigned long long)seq + 1)};
-      *(volatile rec_t*)(ring + (seq % SLOTS) * 2 + s) = rec;
+      // (a volatile store is followed by `s_waitcnt vmcnt(0)`: wave 0 then waits for the store's acknowledgement before it goes
+      //  on to finish the previous row and to re-load its slot — ASMST: the same store, fire and forget)
+      if (ASMST) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ring + (seq % SLOTS) * 2 + s), "v"(rec) : "memory");
+      else *(volatile rec_t*)(ring + (seq % SLOTS) * 2 + s) = rec;
     }
     return own;
   };
@@ -536,17 +539,17 @@ __global__ __launch_bounds__(768) void k_pat2(Args5 d) {
   if (t == 12345.678) a.out[0] = t;
 }
 
-template <int KV, int G, bool EXTRA, int HS, bool FIRST = false>
+template <int KV, int G, bool EXTRA, int HS, bool FIRST = false, bool ASMST = false>
 static void l_pat2(const Args& a, int nb, hipStream_t q) {
   static bool once = false;
   const int lds = KV * 768 * 16;
   if (!once) {
-    CK(hipFuncSetAttribute((const void*)k_pat2<KV, G, EXTRA, HS, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void*)k_pat2<KV, G, EXTRA, HS, FIRST, ASMST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
   Args5 d{a, g_ring, g_seq0, g_err, g_tickets, g_launch++};
   g_seq0 += (unsigned long long)a.rows_per_slab + 64;
-  hipLaunchKernelGGL((k_pat2<KV, G, EXTRA, HS, FIRST>), dim3(nb), dim3(768), lds, q, d);
+  hipLaunchKernelGGL((k_pat2<KV, G, EXTRA, HS, FIRST, ASMST>), dim3(nb), dim3(768), lds, q, d);
 }
 
 // contiguous stream of the same bytes, the shape of the two-pass kernels: block b walks a contiguous chunk
@@ -626,6 +629,9 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   const int nvec = (n + 1) / 2;
   const std::vector<Case> cases = {
+      {"teams of two KV7 G2 (product): volatile store of the record", l_pat2<7, 2, true, 2>, 768, 7, 1, 2},
+      {"   the same store, fire and forget (no wait behind it)", l_pat2<7, 2, true, 2, false, true>, 768, 7, 1, 2},
+      {"   no hand-off", l_pat2<7, 2, true, 0>, 768, 7, 1, 2},
       {"teams of two KV7 G2 (product order): dots, finish, load", l_pat2<7, 2, true, 2>, 768, 7, 1, 2},
       {"teams of two KV7 G2, finish and re-load BEFORE the dots", l_pat2<7, 2, true, 2, true>, 768, 7, 1, 2},
       {"   the same, no hand-off", l_pat2<7, 2, true, 0, true>, 768, 7, 1, 2},
