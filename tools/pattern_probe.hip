@@ -24,6 +24,13 @@
 typedef double vec_t __attribute__((ext_vector_type(2)));
 typedef unsigned raw_t __attribute__((ext_vector_type(4)));
 
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+
 struct Args {
   const double* A;
   int64_t ld;
@@ -326,6 +333,208 @@ __global__ __launch_bounds__(768) void k_pat5(Args5 d) {
   if (t == 12345.678) a.out[0] = t;
 }
 
+// A two-level hand-off: member 0 of a team (the leader) collects the sixteen partials of a row, adds them and publishes ONE
+// record with the sum, padded to a 64-byte line of its own ; every member takes that record with one s_load_dwordx4.  A row's
+// residual is then due three steps after its dots (DEPTH = 3, five row slots).  80 scalar loads of 64 bytes per team and row
+// become 4 + 16 of 16.
+template <int KV, int G, int DEPTH, int P = 16>
+__global__ __launch_bounds__(768) void k_pat6(Args5 d) {
+  constexpr int ST = 0, LD = 2;
+  constexpr bool WAIT = true;
+  constexpr int CW = 11, BSC = CW * 64, SLOTS = 8, TPX = 32 / P;
+  const Args& a = d.a;
+  __shared__ double xs[BSC * KV * 2];
+  __shared__ double wsum[2][16];
+  __shared__ double res_s[4];
+  __shared__ int ident[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const unsigned k = atomicAdd(d.tickets + xcc, 1u) - d.launch * 32u;
+    ident[0] = k < (unsigned)(TPX * P) ? (int)(xcc * TPX + k / P) : -1;
+    ident[1] = (int)(k % P);
+    if (k >= 32u) atomicCAS(d.err, 0, 2);
+  }
+  if (tid < 4) res_s[tid] = 1.0;
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0) return;
+  const int row_begin = team * a.rows_per_slab;
+  const int row_end = min(row_begin + a.rows_per_slab, a.m);
+  const int nrows = max(row_end - row_begin, 0);
+  const int nsteps = DEPTH + (nrows + G - 1) / G * G;
+  Rec5* ring = d.ring + (int64_t)team * SLOTS * P;
+  if (wv == CW) {
+    static_assert(DEPTH == 3 && P == 16, "leader tree: sixteen members, three steps");
+    typedef unsigned raw4_t __attribute__((ext_vector_type(4)));
+    __syncthreads();
+    Rec5* bring = d.ring + 8 * 256 + (int64_t)team * SLOTS * 4;          // (the sums: one 64-byte line per row slot)
+    raw16_t q0 = {}, q1 = {}, q2 = {}, q3 = {};
+    raw4_t bq = {};
+    auto fetch16 = [&](long long r) {
+      const Rec5* row = uniform_ptr(ring + (r % SLOTS) * P);
+      asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
+                   "s_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3)
+                   : "s"(row)
+                   : "memory");
+    };
+    auto fetch1 = [&](long long r) {
+      const Rec5* src = uniform_ptr(bring + (r % SLOTS) * 4);
+      asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(bq) : "s"(src) : "memory");
+    };
+    auto word = [&](int m, int w) -> unsigned long long {
+      const raw16_t& c = m < 4 ? q0 : m < 8 ? q1 : m < 12 ? q2 : q3;
+      const int o = (m & 3) * 4 + w * 2;
+      return ((unsigned long long)c[o + 1] << 32) | c[o];
+    };
+    auto all16 = [&](unsigned long long want) {
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < P; ++m) ok &= (word(m, 0) ^ word(m, 1)) == want;
+      return ok;
+    };
+    bool dead = false;
+    double keepc = 0.0;
+    for (long long seq = 0; seq < nsteps; ++seq) {
+      if (s == 0 && seq - 2 >= 0) {                 // the leader: the sixteen partials of row seq - 2 -> their sum
+        const long long r1 = seq - 2;
+        const unsigned long long want = d.seq0 + (unsigned long long)r1 + 1;
+        if (!all16(want) && !dead) {
+          const long long t0 = wall_clock64();
+          for (;;) {
+            fetch16(r1);
+            if (all16(want)) break;
+            if (wall_clock64() - t0 > 2000000) {
+              dead = true;
+              if (lane == 0) atomicCAS(d.err, 0, 1);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        double part[P];
+#pragma unroll
+        for (int m = 0; m < P; ++m) part[m] = dead ? 0.0 : __builtin_bit_cast(double, word(m, 0));
+#pragma unroll
+        for (int w = 1; w < P; w <<= 1)
+#pragma unroll
+          for (int m = 0; m < P; m += 2 * w) part[m] += part[m + w];
+        if (lane == 0) {
+          const unsigned long long bits = __builtin_bit_cast(unsigned long long, part[0]);
+          Rec5* rec = bring + (r1 % SLOTS) * 4;
+          __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&rec->chk, bits ^ want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      const long long r = seq - DEPTH;
+      if (r >= 0) {                                 // every member: the sum of row seq - 3
+        const unsigned long long want = d.seq0 + (unsigned long long)r + 1;
+        auto got = [&]() { return ((((unsigned long long)bq[1] << 32) | bq[0]) ^ (((unsigned long long)bq[3] << 32) | bq[2])) == want; };
+        if (!got() && !dead) {
+          const long long t0 = wall_clock64();
+          for (;;) {
+            fetch1(r);
+            if (got()) break;
+            if (wall_clock64() - t0 > 2000000) {
+              dead = true;
+              if (lane == 0) atomicCAS(d.err, 0, 1);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const double ax = dead ? 0.0 : __builtin_bit_cast(double, ((unsigned long long)bq[1] << 32) | bq[0]);
+        keepc += ax;
+        if (lane == 0) res_s[r & 3] = ax * 1e-300 + 1.0;
+      }
+      __syncthreads();
+      double own = lane < CW ? wsum[seq & 1][lane] : 0.0;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
+      keepc += own;
+      if (lane == 0) {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
+        Rec5* rec = ring + (seq % SLOTS) * P + s;
+        __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rec->chk, bits ^ (d.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (s == 0 && seq - 1 >= 0) fetch16(seq - 1);        // (published a step ago)
+      if (seq - 2 >= 0) fetch1(seq - 2);                   // (the leader stored it before this step's barrier)
+    }
+    if (keepc == 12345.678) a.out[1] = keepc;
+    return;
+  }
+  const int64_t cbase = (int64_t)s * a.nvs * 16;
+  const int slice_bytes = (int)max((int64_t)0, min((int64_t)a.nvs * 16, a.ld * 8 - cbase));
+  vec_t v[G][KV];
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    acc[k][0] = acc[k][1] = 0.0;
+    xs[(tid + k * BSC) * 2] = 0.5, xs[(tid + k * BSC) * 2 + 1] = 0.25;
+  }
+  __syncthreads();
+  auto load = [&](int g, int row) {
+    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(a.A + (int64_t)ri * a.ld) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+      v[g][k] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, k * BSC * 16, 2));
+  };
+  auto dots = [&](int g, long long seq) {
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) p = fma(v[g][k][e], xs[(tid + k * BSC) * 2 + e], p);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    wsum[seq & 1][wv] = p;
+    __syncthreads();
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, row_begin + g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
+    dots(u, u);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u == DEPTH - 1) load(G - 1, row_begin + G - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll 1
+  for (long long q = DEPTH; q < nsteps; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long seq = q + u;
+      const long long r = seq - DEPTH;
+      dots((DEPTH + u) % G, seq);
+      const double rr = res_s[r & 3];
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[k][e] = fma(v[u][k][e], rr, acc[k][e]);
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+      __builtin_amdgcn_sched_barrier(0);
+      load(u, row_begin + (int)(r + G));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) t += acc[k][0] + acc[k][1];
+  if (t == 12345.678) a.out[0] = t;
+}
+
 static Rec5* g_ring = nullptr;
 static int* g_err = nullptr;
 static unsigned* g_tickets = nullptr;
@@ -338,11 +547,11 @@ static void l_pat5(const Args& a, int nb, hipStream_t q) {
   hipLaunchKernelGGL((k_pat5<KV, G, DEPTH, ST, LD, WAIT, P>), dim3(nb), dim3(768), 0, q, d);
 }
 
-template <class T>
-__device__ __forceinline__ const T* uniform_ptr(const T* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const T*)(((unsigned long long)hi << 32) | lo);
+template <int KV, int G, int DEPTH>
+static void l_pat6(const Args& a, int nb, hipStream_t q) {
+  Args5 d{a, g_ring, g_seq0, g_err, g_tickets, g_launch++};
+  g_seq0 += (unsigned long long)a.rows_per_slab + 64;
+  hipLaunchKernelGGL((k_pat6<KV, G, DEPTH>), dim3(nb), dim3(768), 0, q, d);
 }
 
 // Teams of TWO (csrc/slab_pd.hip k_teampd_rows, BASELINE config C5: rows of 20 000): every wave takes the partner's record
@@ -617,8 +826,8 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, total, fill_mode);
   printf("fill mode %d\n", fill_mode);
   CK(hipDeviceSynchronize());
-  CK(hipMalloc(&g_ring, sizeof(Rec5) * 8 * 256));
-  CK(hipMemset(g_ring, 0, sizeof(Rec5) * 8 * 256));
+  CK(hipMalloc(&g_ring, sizeof(Rec5) * (8 * 256 + 64 * 8 * 4)));
+  CK(hipMemset(g_ring, 0, sizeof(Rec5) * (8 * 256 + 64 * 8 * 4)));
   CK(hipMalloc(&g_err, 4));
   CK(hipMemset(g_err, 0, 4));
   CK(hipMalloc(&g_tickets, 32));
@@ -629,6 +838,11 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   const int nvec = (n + 1) / 2;
   const std::vector<Case> cases = {
+      {"wide teams, scalar path, G4 D2 (product)", l_pat5<5, 4, 2, 0, 2, true>, 704, 5, 1, 16},
+      {"wide teams, scalar path, G5 D3", l_pat5<5, 5, 3, 0, 2, true>, 704, 5, 1, 16},
+      {"wide teams, LEADER tree (one sum record per row), G5 D3", l_pat6<5, 5, 3>, 704, 5, 1, 16},
+      {"wide teams, no hand-off traffic", l_pat5<5, 4, 2, 2, 3, false>, 704, 5, 1, 16},
+      {"contiguous stream reference  ", nullptr, 0, 0, 0, -1},
       {"teams of two KV7 G2 (product): volatile store of the record", l_pat2<7, 2, true, 2>, 768, 7, 1, 2},
       {"   the same store, fire and forget (no wait behind it)", l_pat2<7, 2, true, 2, false, true>, 768, 7, 1, 2},
       {"   no hand-off", l_pat2<7, 2, true, 0>, 768, 7, 1, 2},
