@@ -210,7 +210,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     (2 m n sizeof(T) per iteration: above 1 where one pass over A serves both products)."""
     out = {}
 
-    def report(m, n, es, steps, dt, stats, res, one_pass_note):
+    def report(m, n, es, steps, dt, stats, res, one_pass_note, one_pass_kernel):
         k = kernel_table(stats)
         dom = max(k, key=lambda q: k[q]["avg_ms"] * k[q]["launches"])
         its = steps / dt
@@ -225,6 +225,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
              "objective": res.objective, "norm_res": res.norm_res}
         if passes < 1.5:
             r["note"] = one_pass_note
+            r["roofline"]["kernel"] = one_pass_kernel + " (HIP events booked under the library's gemv_n slot)"
         return r
 
     # C3: sparse_logreg, dense synthetic X 100 000 x 10 000 fp32, logistic gradient + NormL1 prox
@@ -241,7 +242,8 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
         sys.exit("bench.py: C3 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
     out["C3"] = report(m, n, 4, 200, dt, st, res,
                        "f and grad f in ONE pass over X per iteration (csrc/slab.hip, booked under gemv_n): "
-                       "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read")
+                       "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read",
+                       "k_slab_rows + k_slab_close")
     out["C3"]["workload"] = "sparse_logreg, dense synthetic A 100000x10000 fp32, logistic grad + NormL1 prox, adaptive_proxgrad (OurRule)"
     s.close()
     p.X.free()
@@ -259,7 +261,8 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     if not np.all(np.isfinite(x)) or int(res.numit) != 210 or res.converged:
         sys.exit("bench.py: C5 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
     out["C5"] = report(m, n, 8, 200, dt, st, res,
-                       "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip)")
+                       "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip)",
+                       "k_teampd_rows + k_slabpd_close")
     out["C5"]["workload"] = "least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50000x20000 fp64 (Ax / A'y pair + conj-prox)"
     s.close()
     p.A.free()

@@ -190,6 +190,12 @@ __global__ __launch_bounds__(768) void k_pat5(Args5 d) {
         pchk = __hip_atomic_load(&row[min(lane, P - 1)].chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (LD == 2 && P == 4) {
         asm volatile("s_load_dwordx16 %0, %1, 0x0 glc" : "=&s"(q0) : "s"(row) : "memory");
+      } else if (LD == 2 && P == 2) {
+        typedef unsigned raw8_t __attribute__((ext_vector_type(8)));
+        raw8_t h;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(row) : "memory");
+#pragma unroll
+        for (int c = 0; c < 8; ++c) q0[c] = h[c];
       } else if (LD == 2) {
         asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
                      "s_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc"
@@ -838,6 +844,10 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   const int nvec = (n + 1) / 2;
   const std::vector<Case> cases = {
+      {"teams of TWO with a communication wave, KV8 G3 D1 (C5)", l_pat5<8, 3, 1, 0, 2, true, 2>, 704, 8, 1, 2},
+      {"   the same, no hand-off traffic", l_pat5<8, 3, 1, 2, 3, false, 2>, 704, 8, 1, 2},
+      {"teams of two, every wave on the scalar path, KV7 G2 (product)", l_pat2<7, 2, true, 2>, 768, 7, 1, 2},
+      {"contiguous stream reference   ", nullptr, 0, 0, 0, -1},
       {"wide teams, scalar path, G4 D2 (product)", l_pat5<5, 4, 2, 0, 2, true>, 704, 5, 1, 16},
       {"wide teams, scalar path, G5 D3", l_pat5<5, 5, 3, 0, 2, true>, 704, 5, 1, 16},
       {"wide teams, LEADER tree (one sum record per row), G5 D3", l_pat6<5, 5, 3>, 704, 5, 1, 16},
