@@ -118,6 +118,34 @@ def test_lasso_c2_solver_at_full_size(apx):
     prob.A.free()
 
 
+def test_lasso_c2_reaches_the_analytic_optimum_at_full_size(apx):
+    """BASELINE config C2 solved to the reference's default tolerance on its product path (the team kernels: f and grad f
+    from ONE read of the 40 GB): the generator of experiments/lasso/runme.jl:40-77 comes with its solution — the run must
+    end at x*, on x*'s support, at the objective 0.5 + lam ||x*||_1 (pin 3), by the residual test of
+    src/AdaProx.jl:341 and not by maxit."""
+    problems = importlib.import_module("adaptive-proximal-algorithms_amd.problems")
+    ctx = apx.Context(0)
+    prob = problems.device_lasso(50_000, 100_000, pfactor=10, seed=0, power_iters=30, ctx=ctx, dual_layout=True)
+    f, g = apx.LinearLeastSquares(prob.A, prob.b, ctx=ctx), apx.NormL1(prob.lam)
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    x, it = apx.adaptive_proxgrad(np.zeros(100_000), f=f, g=g, rule=apx.OurRule(gamma=1.0 / prob.Lf), tol=1e-5, maxit=20_000,
+                                  ctx=ctx)
+    st = ctx.kernel_stats(reset=True)
+    ctx.profile(False)
+    # one pass over A per evaluation (the launches enqueued between the convergence and the poll that sees it are no-ops)
+    assert st["gemv_t"]["launches"] == 0 and it + 1 <= st["gemv_n"]["launches"] <= it + 1 + 256, st
+    assert 1000 < it < 10_000, it
+    fx, _ = apx.eval_with_pullback(f, x)
+    obj = fx + prob.lam * float(np.sum(np.abs(x)))
+    print("C2 to tol 1e-5: iterations", it, "objective - optimum", obj - prob.optimum,
+          "max |x - x*|", float(np.max(np.abs(x - prob.x_star))))
+    assert obj == pytest.approx(prob.optimum, rel=1e-10)
+    assert np.array_equal(x != 0, prob.x_star != 0)                      # the support, exactly (10 000 of 100 000)
+    assert np.max(np.abs(x - prob.x_star)) <= 1e-5 * np.max(np.abs(prob.x_star))
+    prob.A.free()
+
+
 def test_logreg_c3_solver_at_full_size(apx):
     """BASELINE config C3 on its own product path: 100 000 x 10 000 fp32, logistic, f and grad f in one pass over X
     (k_slab_rows<float, LOGISTIC, 14 columns, 4 rows, 768 threads, two groups, non-temporal loads> — csrc/slab.hip).

@@ -1,0 +1,72 @@
+"""Soak of the team kernels: tens of thousands of launches of k_team_rows (C2's shape) and k_teampd_rows (C5's) in one
+process — sequence numbers, ring re-use and the per-XCD tickets run far past their first wrap of the 8-slot rings; any
+timed-out hand-off raises (the error word is read with every poll and with the result).  Prints one JSON line per leg."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import adaprox_amd as apx  # noqa: E402
+
+apx.load()
+from importlib import import_module  # noqa: E402
+
+problems = import_module("adaptive-proximal-algorithms_amd.problems")
+
+
+def leg_c2(iters):
+    ctx = apx.Context(0)
+    p = problems.device_lasso(50_000, 100_000, pfactor=10, seed=0, power_iters=30, ctx=ctx, dual_layout=True)
+    f = apx.LinearLeastSquares(p.A, p.b)
+    t0 = time.perf_counter()
+    obj = []
+    # (with tol = 0 the loop runs past its fixed point, where the reference's rule lets gamma grow without bound — NaN in the
+    #  oracle too: so ten solves of 2000 iterations from x0 = 0 instead of one of 20 000 ; each must end at the same objective
+    #  bit for bit, the team kernels being deterministic)
+    for rep in range(iters // 2000):
+        s = apx.Solver(np.zeros(100_000), f=f, g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=1.0 / p.Lf), tol=0.0, ctx=ctx, poll_every=64)
+        s.step(2000)
+        x, _, res = s.result()
+        assert np.all(np.isfinite(x)) and int(res.numit) == 2000
+        obj.append(res.objective)
+        s.close()
+    dt = time.perf_counter() - t0
+    assert len(set(obj)) == 1, obj
+    print(json.dumps({"leg": "C2 k_team_rows", "solves": len(obj), "iterations_each": 2000, "seconds": dt, "it_per_s": iters / dt,
+                      "objective_after_2000": obj[0], "optimum": p.optimum, "identical_objectives": True}), flush=True)
+    p.A.free()
+
+
+def leg_c5(iters):
+    ctx = apx.Context(0)
+    m, n = 50_000, 20_000
+    p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx)
+    p.A.build_transpose()
+    gamma = 1.0 / p.norm_A
+    sigma = 0.99 / p.norm_A
+    s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=p.A,
+                   rule=apx.FixedStepsize(gamma, np.sqrt(sigma / gamma)), tol=0.0, ctx=ctx, poll_every=64)
+    t0 = time.perf_counter()
+    res_hist = []
+    done = 0
+    while done < iters:
+        s.step(min(5000, iters - done))
+        done += min(5000, iters - done)
+        x, y, res = s.result()
+        res_hist.append((res.objective, res.norm_res))
+    dt = time.perf_counter() - t0
+    assert np.all(np.isfinite(x)) and np.all(np.isfinite(y))
+    print(json.dumps({"leg": "C5 k_teampd_rows", "iterations": int(res.numit), "seconds": dt, "it_per_s": iters / dt,
+                      "objective_norm_res_every_5000": res_hist}), flush=True)
+    s.close()
+    p.A.free()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c5"]
+    if "c2" in which:
+        leg_c2(int(20000))
+    if "c5" in which:
+        leg_c5(int(60000))
