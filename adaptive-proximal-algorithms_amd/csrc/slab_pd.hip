@@ -7,6 +7,7 @@
 // form A_x[i], update y[i] and add y[i] * A[i,:] to a private column accumulator from the SAME registers.  The B
 // partial n-vectors and the dual-residual sums are closed by a second small kernel, which also runs the end of the
 // iteration (norm_res, record, termination: :348-354).  No atomics: bit-reproducible.
+#include <atomic>
 #include <cstdlib>
 #include <memory>
 
@@ -527,10 +528,15 @@ static bool team_rows_launch(const SlabPdState* st, const SlabPdDev& d, const vo
     case 6: hipLaunchKernelGGL((k_teampd_rows<6, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
     case 7: {                                      // (x of the half row in LDS: in registers the row state spills, 20 registers)
       constexpr int lds = 7 * 768 * 2 * (int)sizeof(double);
-      static bool attr_set = false;
-      if (!attr_set) {
+      // (the attribute belongs to the function ON A DEVICE: once per device of the process — the single-process group entry
+      //  point drives one context per device, each from its own host thread)
+      static std::atomic<unsigned long long> attr_devs{0};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      const unsigned long long bit = 1ull << (dev & 63);
+      if ((attr_devs.load(std::memory_order_relaxed) & bit) == 0) {
         (void)hipFuncSetAttribute((const void*)k_teampd_rows<7, 2, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+        attr_devs.fetch_or(bit, std::memory_order_relaxed);
       }
       hipLaunchKernelGGL((k_teampd_rows<7, 2, NT, true>), grid, dim3(768), lds, q, d, st->team, x);
       return true;
