@@ -2,6 +2,7 @@
 // small_pd.hip: primal-dual): in-block dot products with the vector operand in LDS, block sums, grid sizing.
 #pragma once
 #include <algorithm>
+#include <atomic>
 
 #include "solver_internal.h"
 #include "vecops_dev.h"
@@ -106,13 +107,17 @@ __device__ __forceinline__ void block_sums_t0(double (&v)[Q]) {
 // a workgroup of gfx950 may allocate all 160 KB of LDS (tools/lds_probe.hip); dynamic allocations above 64 KB
 // are opted into per kernel — 144 KB: the kernels also hold a few KB of static LDS, and dynamic + static
 // beyond 160 KB is refused
+// (the attribute belongs to the function ON A DEVICE: once per device of the process, from whichever host thread drives it)
 template <auto KERNEL>
 inline void allow_big_lds() {
-  static bool done = false;
-  if (!done) {
+  static std::atomic<unsigned long long> done_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if ((done_devs.load(std::memory_order_relaxed) & bit) == 0) {
     if (hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
       (void)hipGetLastError();       // (not sticky: a launch that really needs more than the default fails by itself)
-    done = true;
+    done_devs.fetch_or(bit, std::memory_order_relaxed);
   }
 }
 inline size_t m_vector_lds_bytes(int m) { return (size_t)round_up(m, 32) * sizeof(double); }
