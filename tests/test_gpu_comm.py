@@ -239,3 +239,21 @@ def test_bench_takes_the_in_library_path(apx):
     assert "rccl_ranks" not in plain
     # 3000 x 12000 is on the generic kernels either way (rows too long for the one-pass kernel, too many for the small paths)
     assert line["final_objective"] == plain["final_objective"]
+
+
+def test_bench_falls_back_when_the_communicator_cannot_be_set_up(apx):
+    """If the in-library communicator cannot be set up on any rank, bench.py's N-rank path agrees on the callback transport
+    over the launcher's gloo group and says so in its line, instead of dying without a number (APX_BENCH_SIMULATE_RCCL_FAILURE
+    is the test hook; the sums are the same, so the iterates are)."""
+    env = dict(os.environ, APX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    args = ["--rows", "3000", "--cols", "12000", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"]
+    ok = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    env["APX_BENCH_SIMULATE_RCCL_FAILURE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RCCL inside the library is not available" in out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["collective"]["transport"] == "gloo-fallback" and line["rccl_ranks"] is None
+    assert "FALLBACK" in line["collective"]["what"]
+    assert line["final_objective"] == json.loads(ok.stdout.strip().splitlines()[-1])["final_objective"]
