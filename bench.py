@@ -234,13 +234,16 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     p.X.build_transpose()
     s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(p.X, p.y), g=apx.NormL1(p.lam),
                    rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
-    # (200 timed iterations: in fp32 this run reaches a bit-for-bit fixed point a few hundred iterations in, after which
-    # the frozen loop's launches are no-ops — the check below refuses such a run)
-    dt, st = timed_steps(ctx, s, 200, 20, barrier)
+    # (150 timed iterations after 10: this problem — SURVEY 8d's lambda, step size and generator — is solved to sixteen digits
+    # by iteration 40; in Float32 rounding noise keeps the loop moving until iteration ~230, where it meets an exact fixed point
+    # and the reference's rule lets gamma grow without bound (Float64: by iteration 80).  The kernels do the same work per
+    # iteration either way ; the check below refuses a run whose iterate is no longer finite)
+    dt, st = timed_steps(ctx, s, 150, 10, barrier)
     x, _, res = s.result()
-    if not np.all(np.isfinite(x)) or int(res.numit) != 220 or res.converged:
-        sys.exit("bench.py: C3 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
-    out["C3"] = report(m, n, 4, 200, dt, st, res,
+    if not np.all(np.isfinite(x)) or int(res.numit) != 160 or res.converged:
+        raise RuntimeError("C3 leg: the loop stopped after %d iterations or left the finite numbers: the timed steps were not all real"
+                           % int(res.numit))
+    out["C3"] = report(m, n, 4, 150, dt, st, res,
                        "f and grad f in ONE pass over X per iteration (csrc/slab.hip, booked under gemv_n): "
                        "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read",
                        "k_slab_rows + k_slab_close")
@@ -259,7 +262,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     dt, st = timed_steps(ctx, s, 200, 10, barrier)
     x, _, res = s.result()
     if not np.all(np.isfinite(x)) or int(res.numit) != 210 or res.converged:
-        sys.exit("bench.py: C5 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
+        raise RuntimeError("C5 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
     out["C5"] = report(m, n, 8, 200, dt, st, res,
                        "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip)",
                        "k_teampd_rows + k_slabpd_close")
@@ -432,7 +435,11 @@ def main():
         final_objective, optimum = res.objective, prob.optimum
         if world == 1 and not use_dist and not args.no_other_configs and (args.m, args.n) == (50_000, 100_000):
             prob.A.free()                                  # give the 80 GB back before the other configs
-            other = other_configs(apx, problems, ctx, barrier)
+            try:                                           # (a side leg that fails must not take the headline line with it)
+                other = other_configs(apx, problems, ctx, barrier)
+            except (Exception, SystemExit) as e:           # noqa: BLE001
+                other = {"error": f"{type(e).__name__}: {e}"}
+                print(f"bench.py: other_configs failed: {other['error']}", file=sys.stderr)
 
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}" if transport == "torch-nccl" else "cpu")

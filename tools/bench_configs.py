@@ -43,6 +43,21 @@ if "c3" in which:
     s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=f, g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
     out["C3 sparse_logreg dense 100000x10000 fp32, adaptive_proxgrad"] = timed(s, 200, 20, 2 * m * n * 4)
     s.close(); p.X.free()
+if "c3f64" in which:      # C3's shape in the reference's own precision (experiments/sparse_logreg/runme.jl runs Float64)
+    m, n = 100_000, 10_000
+    p = problems.device_logreg(m, n, seed=0, lam=0.01, dtype=np.float64, ctx=ctx)
+    p.X.build_transpose()
+    f = apx.LogisticLoss(p.X, p.y)
+    s = apx.Solver(np.zeros(n + 1), f=f, g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    out["C3 shape in Float64: logistic 100000x10000 fp64, adaptive_proxgrad"] = timed(s, 200, 20, 2 * m * n * 8)
+    s.close(); p.X.free()
+    # and the least-squares term on the same matrix (the second-generation row kernel)
+    A = apx.DeviceMatrix.uniform(m, n, seed=3, ctx=ctx)
+    A.build_transpose()
+    b = np.random.default_rng(0).standard_normal(m)
+    s = apx.Solver(np.zeros(n), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1.0 / (m * n / 3.0)), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    out["least squares 100000x10000 fp64, adaptive_proxgrad"] = timed(s, 200, 20, 2 * m * n * 8)
+    s.close(); A.free()
 if "c5" in which:
     m, n = 50_000, 20_000
     p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx)
