@@ -195,3 +195,28 @@ def test_prox_definitions():
     assert np.allclose(y, u / max(1.0, np.linalg.norm(u)), atol=1e-14)
     assert isinstance(O.convex_conjugate(O.Zero()), O.IndZero)
     assert isinstance(O.convex_conjugate(O.IndZero()), O.Zero)
+
+
+def test_tol_zero_runs_past_the_fixed_point_into_nan():
+    """Reference semantics worth knowing before timing a loop with tol = 0: once the iterates have stopped
+    moving, OurRule's C = |dg|^2 / <dg, dx> is x / 0 = Inf (nan_to_zero maps only NaN, src/AdaProx.jl:24), L = 0,
+    D = gamma L (gamma C - 1) = 0 * Inf = NaN, and Julia's min hands the NaN on (:264-271).  The oracle restates that: a small
+    lasso reaches its analytic optimum, and some iterations later gamma is NaN for good."""
+    import warnings
+
+    from oracle import adaprox_oracle as O
+    from oracle import problems as P
+
+    p = P.random_lasso(60, 120, seed=0)
+    Lf = np.linalg.norm(p.A, 2) ** 2
+    recs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        O.adaptive_proxgrad(np.zeros(120), f=O.LinearLeastSquares(p.A, p.b), g=O.NormL1(p.lam), rule=O.OurRule(gamma=1.0 / Lf),
+                            tol=0.0, maxit=3000, record=recs.append)
+    gam = np.array([r["gamma"] for r in recs])
+    obj = np.array([r["objective"] for r in recs])
+    bad = np.flatnonzero(~np.isfinite(gam))
+    assert bad.size and bad[0] > 100                      # it does happen, and only after the problem is solved:
+    assert obj[bad[0] - 1] == pytest.approx(p.optimum, rel=1e-12)
+    assert not np.isfinite(gam[bad[0]:]).any()            # NaN for good
