@@ -26,6 +26,7 @@
 #include <memory>
 
 #include "skinny_dev.h"
+#include "small_dev.h"
 #include "solver_internal.h"
 #include "team_dev.h"
 #include "vecops_dev.h"
@@ -33,6 +34,7 @@
 namespace apx {
 
 constexpr int kSlabTeamCpt = 99;      // SlabShape::cpt of the team kernel
+constexpr int kTeamSingleKv = 8;      // P = 1: up to 8 vectors per compute thread (11 264 Float64 columns)
 constexpr int kSlabRows = 4;          // rows per step (two columns per thread: 16 ; fourteen fp64 columns: 2, or 1 with the logistic link)
 
 struct SlabDev {
@@ -454,6 +456,7 @@ template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2>
 __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const void* xv) {
   constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;
   static_assert(G >= DEPTH + 2 && DEPTH <= 3, "slots: DEPTH rows awaiting their residuals, one computing, one loading ; res_s has 4 entries");
+  static_assert(P > 1 || DEPTH == 1, "a workgroup on its own has its row sum one step later");
   typedef double vec_t __attribute__((ext_vector_type(2)));
   typedef unsigned raw_t __attribute__((ext_vector_type(4)));
   extern __shared__ double team_x[];               // the member's slice of x: KV * 704 * 2 doubles
@@ -462,12 +465,16 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
   __shared__ int ident[2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid == 0) {                                  // (every launch takes its 32 tickets per XCD, a finished loop's too)
+  if (P > 1 && tid == 0) {                         // (every launch takes its 32 tickets per XCD, a finished loop's too)
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
     const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
     ident[0] = k < (unsigned)(TPX * P) ? (int)(xcc * TPX + k / P) : -1;
     ident[1] = (int)(k % P);
     if (k >= 32u) atomicCAS(t.err, 0, 2);
+  }
+  if (P == 1 && tid == 0) {                        // P = 1: a workgroup on its own — no team to form, nothing to hand over
+    ident[0] = (int)blockIdx.x;
+    ident[1] = 0;
   }
   __syncthreads();
   const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
@@ -490,6 +497,46 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
     const double bias = FK == APX_F_LOGISTIC ? X[d.n - 1] : 0.0;
     double e0 = 0.0, e1 = 0.0;
     bool dead = false;
+    if constexpr (P == 1) {
+      // a workgroup on its own: the sum of its eleven waves IS `A x` of the row — formed after the barrier of step seq, used
+      // before the barrier of step seq + 1 (DEPTH = 1).  What this wave is for here: the link function of a Float64 row
+      // (exp, log: ~50 registers) is evaluated where no row of A is held, so the compute waves keep three rows in registers
+      // without spilling (the row kernels that evaluate it next to their rows hold ONE row per step: 5.7 against 6.7 TB/s).
+      double own_prev = 0.0, pb1 = 0.0;
+      for (long long seq = 0; seq < nsteps; ++seq) {
+        const long long r = seq - 1;
+        if (r >= 0) {
+          const int i = row_begin + (int)r;
+          double res = 0.0;
+          if (i < row_end) {
+            const double ax = own_prev, bi = pb1;
+            if constexpr (FK == APX_F_LEAST_SQUARES) {
+              res = ax - bi;
+              e0 += res * res;
+            } else {
+              const double logit = ax + bias;
+              const double e = 1.0 + exp(-logit);
+              e0 += (bi - 1.0) * logit - log(e);
+              res = 1.0 / e - bi;
+              e1 += res;
+            }
+          }
+          if (lane == 0) res_s[r & 3] = res;
+        }
+        __syncthreads();
+        double own = lane < CW ? wsum[seq & 1][lane] : 0.0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
+        own_prev = own;
+        pb1 = bv[max(min(row_begin + (int)seq, d.m - 1), 0)];
+      }
+      if (lane == 0) {
+        double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
+        out[d.ncols] = e0;
+        out[d.ncols + 1] = e1;
+      }
+      return;
+    } else {
     // The P records of a row are taken on the SCALAR path: P / 4 loads of 64 bytes (`s_load_dwordx16 ... glc`: past the
     // scalar cache, from the XCD's L2 — the teams are formed inside an XCD, and the members' agent-scope stores pass
     // through that L2).  Measured (tools/pattern_probe.hip, profiles/r02_team_handoff_traffic.log): agent-scope VECTOR
@@ -577,6 +624,7 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
       out[d.ncols + 1] = e1;
     }
     return;
+    }      // (P > 1)
   }
   // ---- the compute waves ----------------------------------------------------------------------------------------------
   double acc[KV][2];
@@ -723,6 +771,10 @@ static SlabShape slab_shape(const apx_problem* p) {
   // longer rows: 768 threads x 14 columns in the ~170 VGPRs that twelve waves per CU leave; fp64 takes two rows per
   // step (the same 160 KB) and one with the logistic link (see slab_launch_t).  Measured and dropped: 1024 x 10 x 2
   // (half the bytes in flight: +5 % over the two passes at C3), 512 x 20 x 4 and 1024 x 10 x 4 (spills).
+  // Float64 logistic: the link function next to the rows costs the row kernels two of their three rows in flight (exp, log:
+  // ~50 registers) — the communication-wave kernel with a "team" of ONE evaluates it where no row is held (k_team_rows, P = 1)
+  if (p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC && cols > 5 * 1024 && cols <= 2 * kTeamSingleKv * 704 && !p->teams_off)
+    return {768, kSlabTeamCpt, 1};
   if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};
   // longer rows (BASELINE config C2: 100 000): teams of 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
   // Float64, on a part of 8 XCDs x 32 CUs
@@ -775,8 +827,8 @@ static int32_t slab_setup(apx_problem* p) {
   int64_t rpb_team = 0;
   if (st->cpt == kSlabTeamCpt) {           // teams: the fewest members whose slice fits 5 vectors per compute thread
     const int64_t nvec = (A->n + 1) / 2;
-    int P = 4;
-    while (P < 16 && (nvec + P - 1) / P > 5 * 704) P *= 2;
+    int P = (p->f_kind == APX_F_LOGISTIC && nvec <= kTeamSingleKv * 704) ? 1 : 4;   // (one workgroup where a logistic row fits it)
+    while (P >= 4 && P < 16 && (nvec + P - 1) / P > 5 * 704) P *= 2;
     st->team_p = P;
     st->team_kv = (int)(((nvec + P - 1) / P + 703) / 704);
     B = ctx->num_cu / P;                   // slabs = teams ; ALL 256 workgroups are launched (32 / P teams per XCD)
@@ -859,7 +911,7 @@ static bool slab2_dispatch(const SlabState* st, dim3 grid, hipStream_t q, const 
     }
   } else {
     // (Float64 logistic: exp / log in Float64 take ~50 registers of their own and every shape of this kernel spills
-    // with them — the first-generation kernel, one row per step, stays)
+    // with them — such rows take k_team_rows with P = 1, whose communication wave evaluates the link: slab_shape)
     if constexpr (FK == APX_F_LOGISTIC) return false;
     else switch (st->kv) {                 // 2 columns per vector: up to 6144 / 7680 / 9216 / 10 752 columns
       case 4: slab2_rows_launch<T, FK, 4, 2, 2>(st, grid, q, d, x); return true;
@@ -896,10 +948,32 @@ static bool team_rows_launch_p(const SlabState* st, const SlabDev& d, const void
     default: return false;
   }
 }
+// P = 1 (Float64 logistic rows that fit one workgroup): three row slots, the row sum a step later ; x of the row in LDS
+// (up to 90 KB: opted into per kernel and device)
+template <int FK, int KV, bool NT>
+static void team_single_launch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
+  constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);
+  if constexpr (lds > 64 * 1024) allow_big_lds<k_team_rows<FK, 1, KV, NT, 3, 1>>();
+  hipLaunchKernelGGL((k_team_rows<FK, 1, KV, NT, 3, 1>), dim3((unsigned)st->B), dim3(768), lds, q, d, st->team, x);
+}
+template <int FK, bool NT>
+static bool team_single_dispatch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
+  switch (st->team_kv) {
+    case 4: team_single_launch<FK, 4, NT>(st, d, x, q); return true;
+    case 5: team_single_launch<FK, 5, NT>(st, d, x, q); return true;
+    case 6: team_single_launch<FK, 6, NT>(st, d, x, q); return true;
+    case 7: team_single_launch<FK, 7, NT>(st, d, x, q); return true;
+    case 8: team_single_launch<FK, 8, NT>(st, d, x, q); return true;
+    default: return false;
+  }
+}
+
 template <int FK>
 static bool team_rows_launch(SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
   bool ok = false;
-  if (st->team_p == 4) ok = team_rows_launch_p<FK, 4>(st, d, x, q);
+  if (st->team_p == 1) {
+    if constexpr (FK == APX_F_LOGISTIC) ok = st->nt ? team_single_dispatch<FK, true>(st, d, x, q) : team_single_dispatch<FK, false>(st, d, x, q);
+  } else if (st->team_p == 4) ok = team_rows_launch_p<FK, 4>(st, d, x, q);
   else if (st->team_p == 8) ok = team_rows_launch_p<FK, 8>(st, d, x, q);
   else if (st->team_p == 16) ok = team_rows_launch_p<FK, 16>(st, d, x, q);
   st->team.launch += 1;                            // (tickets and sequence numbers are never reset: a range per launch)

@@ -245,6 +245,8 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *     keep the problem on them (not for a row shard: a rank restarting alone would leave its peers' sequence of
  *     collectives — the error is returned), the stepping interface and apx_eval return APX_ERR_HIP — on a GPU shared
  *     with other work switch the policy off.  Not replayable as a hipGraph (APX_ERR_UNSUPPORTED).
+ *     (Float64 logistic rows of 5121 ... 11 264 columns take the same kernel with a "team" of ONE workgroup — its
+ *     communication wave evaluates the link function; nothing is handed over and no co-residency is needed.)
  *     A row shard of f (apx_problem_desc.comm / .allreduce) takes the same one-pass kernels; the block sums are all-reduced.
  * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and
  * the host-driven loops. */

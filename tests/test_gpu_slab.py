@@ -25,7 +25,7 @@ def _rel(a, b):
                                                 (4097, 2049, True, np.float64),       # 5 columns per thread, ragged rows
                                                 (4200, 5120, False, np.float64),
                                                 (4098, 10000, False, np.float64),     # 14 columns per thread, two rows per step
-                                                (4101, 8000, True, np.float64),       # ... logistic fp64: one row per step
+                                                (4101, 8000, True, np.float64),       # ... logistic fp64 (round 2: k_team_rows, P = 1)
                                                 (9000, 1900, True, np.float32),
                                                 (4099, 10239, True, np.float32),      # 10 columns per thread (fp32 only)
                                                 (4100, 10240, False, np.float32),
@@ -53,7 +53,16 @@ def _rel(a, b):
                                                 (4100, 20000, True, np.float64),       # P = 4, KV = 4, logistic
                                                 (4097, 30001, False, np.float64),      # P = 8, KV = 3
                                                 (4096, 56320, False, np.float64),      # P = 8, KV = 5
-                                                (4099, 100000, False, np.float64)])    # P = 16, KV = 5
+                                                (4099, 100000, False, np.float64),     # P = 16, KV = 5
+                                                # Float64 logistic rows that fit ONE workgroup: the same kernel with a "team"
+                                                # of one — the communication wave evaluates the link, three rows in registers
+                                                # (KV = 4 ... 8 vectors per compute thread: 5121 ... 11 264 columns)
+                                                (4100, 5121, True, np.float64),
+                                                (4099, 7000, True, np.float64),
+                                                (4098, 8448, True, np.float64),
+                                                (4097, 9857, True, np.float64),
+                                                (4101, 10000, True, np.float64),       # C3's shape in the reference's precision
+                                                (4100, 11264, True, np.float64)])
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))

@@ -49,7 +49,8 @@ if "c3f64" in which:      # C3's shape in the reference's own precision (experim
     p.X.build_transpose()
     f = apx.LogisticLoss(p.X, p.y)
     s = apx.Solver(np.zeros(n + 1), f=f, g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
-    out["C3 shape in Float64: logistic 100000x10000 fp64, adaptive_proxgrad"] = timed(s, 200, 20, 2 * m * n * 8)
+    # (solved by iteration 40 and NaN by 80 with tol = 0, DESIGN.md 9: 10 + 40 iterations)
+    out["C3 shape in Float64: logistic 100000x10000 fp64, adaptive_proxgrad"] = timed(s, 40, 10, 2 * m * n * 8)
     s.close(); p.X.free()
     # and the least-squares term on the same matrix (the second-generation row kernel)
     A = apx.DeviceMatrix.uniform(m, n, seed=3, ctx=ctx)
