@@ -767,6 +767,10 @@ struct SlabShape {
 static SlabShape slab_shape(const apx_problem* p) {
   const int64_t cols = p->A_f->n;
   if (cols <= 2 * 1024) return {1024, 2, kSlabRows};
+  // (three and four columns per thread: with five, a row of 2100 entries keeps 420 of the 1024 lanes busy — 3.8 TB/s against
+  //  6.5 for 2000 entries on the two-column kernel ; measured, tools/shape_bench.py)
+  if (cols <= 3 * 1024) return {1024, 3, kSlabRows};
+  if (cols <= 4 * 1024) return {1024, 4, kSlabRows};
   if (cols <= 5 * 1024) return {1024, 5, kSlabRows};
   // longer rows: 768 threads x 14 columns in the ~170 VGPRs that twelve waves per CU leave; fp64 takes two rows per
   // step (the same 160 KB) and one with the logistic link (see slab_launch_t).  Measured and dropped: 1024 x 10 x 2
@@ -995,6 +999,8 @@ static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* 
   constexpr int R14 = sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2);
   constexpr bool kPipeOk = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;       // (the others spill as two groups)
   if (st->cpt == 2) slab_rows_launch<T, FK, 2, 16, 1024, kPipeOk>(st, grid, q, d, x);
+  else if (st->cpt == 3) slab_rows_launch<T, FK, 3, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
+  else if (st->cpt == 4) slab_rows_launch<T, FK, 4, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
   else if (st->cpt == 5) slab_rows_launch<T, FK, 5, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
   else if (!(st->kv != 0 && st->v2 && slab2_dispatch<T, FK>(st, grid, q, d, x)))
     slab_rows_launch<T, FK, 14, R14, 768, (sizeof(T) == 4)>(st, grid, q, d, x);

@@ -441,6 +441,8 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   const int64_t cols = p->A_lin->n;
   const bool f32 = p->dtype == APX_F32;
   if (cols <= 2 * 1024) return {1024, 2, 4};
+  if (cols <= 3 * 1024) return {1024, 3, 4};       // (three / four columns per thread: csrc/slab.hip slab_shape, measured)
+  if (cols <= 4 * 1024) return {1024, 4, 4};
   if (cols <= 5 * 1024) return {1024, 5, 4};
   if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
   // C5's row length, 20 000 fp64, is out of reach of ONE workgroup (x, the accumulator and one row are 480 KB of a CU's
@@ -569,11 +571,15 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
   if (st->nt) {
     if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, true>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 3) hipLaunchKernelGGL((k_slabpd_rows<T, 3, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 4) hipLaunchKernelGGL((k_slabpd_rows<T, 4, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
     else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, true>), grid, dim3(768), 0, q, d, x);
   } else {
     if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, false>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 3) hipLaunchKernelGGL((k_slabpd_rows<T, 3, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 4) hipLaunchKernelGGL((k_slabpd_rows<T, 4, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
     else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, false>), grid, dim3(768), 0, q, d, x);
   }

@@ -24,6 +24,10 @@ def _rel(a, b):
 @pytest.mark.parametrize("m,n,logistic,dtype", [(8500, 1000, False, np.float64),      # 2 columns per thread
                                                 (4097, 2049, True, np.float64),       # 5 columns per thread, ragged rows
                                                 (4200, 5120, False, np.float64),
+                                                (4100, 3000, False, np.float64),      # 3 columns per thread
+                                                (4200, 3072, True, np.float32),
+                                                (4099, 3500, False, np.float32),      # 4 columns per thread
+                                                (4101, 4096, True, np.float64),
                                                 (4098, 10000, False, np.float64),     # 14 columns per thread, two rows per step
                                                 (4101, 8000, True, np.float64),       # ... logistic fp64 (round 2: k_team_rows, P = 1)
                                                 (9000, 1900, True, np.float32),
@@ -169,7 +173,9 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
 # the primal-dual loop: A x, the dual step and A' y in one pass over A (csrc/slab_pd.hip)
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,hkind,dtype", [(9000, 1000, "tl1", np.float64),      # 2 columns per thread
-                                             (4099, 2100, "tbox", np.float64),     # 5
+                                             (4099, 2100, "tbox", np.float64),     # 3
+                                             (4100, 4000, "tl1", np.float32),      # 4
+                                             (4098, 5000, "tl1", np.float64),      # 5
                                              (4097, 9000, "tl1", np.float64),      # 14, two rows per step
                                              (4100, 10752, "tl1", np.float32),     # 14, four rows per step
                                              (9001, 1900, "tbox", np.float32),
