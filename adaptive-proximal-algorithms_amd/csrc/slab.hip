@@ -57,6 +57,7 @@ struct SlabState {
   bool pipe = true, nt = true;    // two row groups in flight ; non-temporal loads of A
   // rows of more than 10 752 Float64 entries: teams of team_p workgroups (k_team_rows), team_kv vectors per thread
   int team_p = 0, team_kv = 0;
+  bool team_big = false;          // slices of 6 ... 8 vectors per thread: three row slots, ONE row of slack (k_team_rows<..., 3, 1>)
   DBuf team_buf;                  // ring, tickets, err
   TeamDev team{};
   int32_t* h_err = nullptr;       // pinned copy of err
@@ -413,8 +414,8 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Rows too long for one workgroup's registers (10 753 ... 112 640 Float64 entries — BASELINE config C2: 100 000, a row is
-// 800 KB): TEAMS of P = 4 / 8 / 16 workgroups, one per CU, formed inside an XCD at run time, share a slab of rows.  Member
+// Rows too long for one workgroup's registers (10 753 ... 180 224 Float64 entries — BASELINE config C2: 100 000, a row is
+// 800 KB): TEAMS of P = 2 / 4 / 8 / 16 workgroups, one per CU, formed inside an XCD at run time, share a slab of rows.  Member
 // s keeps columns [s n/P, (s+1) n/P) of x (in LDS) and of the column accumulator (in registers) and streams that slice
 // of every row.  A workgroup is eleven COMPUTE waves and one COMMUNICATION wave:
 //   * the compute waves form the partial dot product of a row (one barrier per row) and, DEPTH = 2 rows later, take the
@@ -431,13 +432,20 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
 // tools/split_probe.hip, tools/pattern_probe.hip (profiles/r02_team_probe_*.log, r02_team_handoff_traffic.log): 6.6 - 6.7
 // TB/s on rows of C2's length — A read once per evaluation of f and its gradient instead of twice at 7.1 TB/s.
 // ---------------------------------------------------------------------------------------------------------------------
-// The P records of one row of a team's ring (P x 16 bytes, 64-byte aligned) into SGPRs: P / 4 scalar loads, glc (past
+// The P records of one row of a team's ring (P x 16 bytes, aligned to their size up to 64) into SGPRs: P / 4 scalar loads
+// of 64 bytes (teams of two: one of 32), glc (past
 // the scalar cache), waited for here — nothing may copy the registers before the data is in them.
 typedef unsigned raw16_t __attribute__((ext_vector_type(16)));
 template <int P>
-__device__ __forceinline__ void team_fetch(const TeamRec* row, raw16_t (&q)[P / 4]) {
-  static_assert(P == 4 || P == 8 || P == 16, "teams of 4, 8 or 16");
-  if constexpr (P == 4)
+__device__ __forceinline__ void team_fetch(const TeamRec* row, raw16_t (&q)[(P + 3) / 4]) {
+  static_assert(P == 2 || P == 4 || P == 8 || P == 16, "teams of 2, 4, 8 or 16");
+  if constexpr (P == 2) {
+    typedef unsigned raw8_t __attribute__((ext_vector_type(8)));
+    raw8_t h;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(h) : "s"(row) : "memory");
+#pragma unroll
+    for (int c = 0; c < 8; ++c) q[0][c] = h[c];
+  } else if constexpr (P == 4)
     asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(q[0]) : "s"(row) : "memory");
   else if constexpr (P == 8)
     asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
@@ -544,9 +552,9 @@ __global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const v
     // traffic alone — nothing waited for — takes the stream of A from 7.1 to 5.8 TB/s; stores alone, or loads alone, cost
     // nothing; the same hand-off with scalar loads runs at 6.6 - 6.7.  The records of the row whose residual is due NEXT
     // and its entry of b are taken a step ahead, right after this workgroup's own partial has been published.
-    raw16_t q[P / 4];
+    raw16_t q[(P + 3) / 4];
 #pragma unroll
-    for (int c = 0; c < P / 4; ++c) q[c] = raw16_t{};
+    for (int c = 0; c < (P + 3) / 4; ++c) q[c] = raw16_t{};
     double pb = 0.0;
     auto fetch = [&](long long r) { team_fetch<P>(ring + (r % kTeamSlots) * P, q); };
     auto rec_word = [&](int m, int w) -> unsigned long long {        // word w (0: value, 1: check) of member m's record
@@ -780,9 +788,9 @@ static SlabShape slab_shape(const apx_problem* p) {
   if (p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC && cols > 5 * 1024 && cols <= 2 * kTeamSingleKv * 704 && !p->teams_off)
     return {768, kSlabTeamCpt, 1};
   if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};
-  // longer rows (BASELINE config C2: 100 000): teams of 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
+  // longer rows (BASELINE config C2: 100 000): teams of 2 / 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
   // Float64, on a part of 8 XCDs x 32 CUs
-  if (p->dtype == APX_F64 && cols <= 16 * 5 * 704 * 2 && p->ctx->num_cu == 256) return {768, kSlabTeamCpt, 1};
+  if (p->dtype == APX_F64 && cols <= 16 * kTeamSingleKv * 704 * 2 && p->ctx->num_cu == 256) return {768, kSlabTeamCpt, 1};
   return {0, 0, 0};
 }
 
@@ -831,8 +839,24 @@ static int32_t slab_setup(apx_problem* p) {
   int64_t rpb_team = 0;
   if (st->cpt == kSlabTeamCpt) {           // teams: the fewest members whose slice fits 5 vectors per compute thread
     const int64_t nvec = (A->n + 1) / 2;
-    int P = (p->f_kind == APX_F_LOGISTIC && nvec <= kTeamSingleKv * 704) ? 1 : 4;   // (one workgroup where a logistic row fits it)
-    while (P >= 4 && P < 16 && (nvec + P - 1) / P > 5 * 704) P *= 2;
+    // One workgroup where the row fits its eight vectors per thread (three row slots, nothing to hand over).  Else the
+    // members' slices as large as the registers allow, because a step costs a barrier and a hand-off whatever its bytes:
+    //   five vectors per thread with four row slots and TWO rows of slack for the hand-off, or
+    //   six to eight with three slots and ONE row of slack — which teams of two and four absorb (a step is 50 - 90 KB per
+    //   member: tools/pattern_probe.hip, 6.6 and 6.9 TB/s) but teams of eight and sixteen do not (6.2 and 5.5 against
+    //   6.6 with two rows of slack) ; sixteen members take it only beyond 112 640 columns, where the alternative is two passes.
+    const int64_t v5 = 5 * 704, v8 = (int64_t)kTeamSingleKv * 704;
+    int P = 16;
+    bool big = false;
+    if (nvec <= v8) P = 1;
+    else if (nvec <= 2 * v5) P = 2;
+    else if (nvec <= 2 * v8) P = 2, big = true;
+    else if (nvec <= 4 * v5) P = 4;
+    else if (nvec <= 4 * v8) P = 4, big = true;
+    else if (nvec <= 8 * v5) P = 8;
+    else if (nvec <= 16 * v5) P = 16;
+    else big = true;
+    st->team_big = big;
     st->team_p = P;
     st->team_kv = (int)(((nvec + P - 1) / P + 703) / 704);
     B = ctx->num_cu / P;                   // slabs = teams ; ALL 256 workgroups are launched (32 / P teams per XCD)
@@ -972,12 +996,35 @@ static bool team_single_dispatch(const SlabState* st, const SlabDev& d, const vo
   }
 }
 
+// slices of 6 ... 8 vectors per thread: three row slots, one row of slack ; x of the slice in up to 90 KB of LDS
+template <int FK, int P, int KV>
+static void team_big_launch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
+  static const int fault_grid = getenv("APX_TEAM_FAULT_GRID") ? atoi(getenv("APX_TEAM_FAULT_GRID")) : 0;      // (test hook, as above)
+  constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);
+  allow_big_lds<k_team_rows<FK, P, KV, true, 3, 1>>();
+  hipLaunchKernelGGL((k_team_rows<FK, P, KV, true, 3, 1>), dim3((unsigned)(fault_grid > 0 ? fault_grid : st->B * P)), dim3(768), lds, q, d,
+                     st->team, x);
+}
+template <int FK, int P>
+static bool team_big_dispatch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
+  switch (st->team_kv) {
+    case 6: team_big_launch<FK, P, 6>(st, d, x, q); return true;
+    case 7: team_big_launch<FK, P, 7>(st, d, x, q); return true;
+    case 8: team_big_launch<FK, P, 8>(st, d, x, q); return true;
+    default: return false;
+  }
+}
+
 template <int FK>
 static bool team_rows_launch(SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
   bool ok = false;
-  if (st->team_p == 1) {
-    if constexpr (FK == APX_F_LOGISTIC) ok = st->nt ? team_single_dispatch<FK, true>(st, d, x, q) : team_single_dispatch<FK, false>(st, d, x, q);
-  } else if (st->team_p == 4) ok = team_rows_launch_p<FK, 4>(st, d, x, q);
+  if (st->team_big) {
+    if (st->team_p == 2) ok = team_big_dispatch<FK, 2>(st, d, x, q);
+    else if (st->team_p == 4) ok = team_big_dispatch<FK, 4>(st, d, x, q);
+    else if (st->team_p == 16) ok = team_big_dispatch<FK, 16>(st, d, x, q);
+  } else if (st->team_p == 1) ok = st->nt ? team_single_dispatch<FK, true>(st, d, x, q) : team_single_dispatch<FK, false>(st, d, x, q);
+  else if (st->team_p == 2) ok = team_rows_launch_p<FK, 2>(st, d, x, q);
+  else if (st->team_p == 4) ok = team_rows_launch_p<FK, 4>(st, d, x, q);
   else if (st->team_p == 8) ok = team_rows_launch_p<FK, 8>(st, d, x, q);
   else if (st->team_p == 16) ok = team_rows_launch_p<FK, 16>(st, d, x, q);
   st->team.launch += 1;                            // (tickets and sequence numbers are never reset: a range per launch)

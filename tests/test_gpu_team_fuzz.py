@@ -35,7 +35,8 @@ def _cpu_rows(seed, rows, m, n):
     return out
 
 
-# (m, n): teams of 4 up to 28 160 columns, of 8 up to 56 320, of 16 beyond ; KV = ceil(n / 2 / P / 704)
+# (m, n): the boundaries of the team sizes and slice widths of round 2's first policy (teams of 4 up to 28 160 columns, of 8 up
+# to 56 320, of 16 beyond) — still boundaries of KV = ceil(n / 2 / P / 704) under the present one (csrc/slab.hip slab_setup)
 PG_SHAPES = [(4096, 10753), (4097, 11263), (4099, 11265), (5000, 16897), (4111, 28160), (4096, 28161), (4098, 33793),
              (4101, 56320), (4096, 56321), (4100, 67585), (4097, 112640), (4300, 99999)]
 

@@ -190,6 +190,8 @@ __global__ __launch_bounds__(768) void k_pat5(Args5 d) {
         pchk = __hip_atomic_load(&row[min(lane, P - 1)].chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (LD == 2 && P == 4) {
         asm volatile("s_load_dwordx16 %0, %1, 0x0 glc" : "=&s"(q0) : "s"(row) : "memory");
+      } else if (LD == 2 && P == 8) {
+        asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc" : "=&s"(q0), "=&s"(q1) : "s"(row) : "memory");
       } else if (LD == 2 && P == 2) {
         typedef unsigned raw8_t __attribute__((ext_vector_type(8)));
         raw8_t h;
@@ -844,6 +846,15 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   const int nvec = (n + 1) / 2;
   const std::vector<Case> cases = {
+      {"n = 90000: teams of EIGHT, KV8 G3 D1 (one step of slack)", l_pat5<8, 3, 1, 0, 2, true, 8>, 704, 8, 1, 8},
+      {"n = 90000: teams of SIXTEEN, KV4 G4 D2 (product)", l_pat5<4, 4, 2, 0, 2, true, 16>, 704, 4, 1, 16},
+      {"n = 90000: teams of EIGHT, no hand-off traffic", l_pat5<8, 3, 1, 2, 3, false, 8>, 704, 8, 1, 8},
+      {"n = 180000: teams of SIXTEEN, KV8 G3 D1 (one step of slack)", l_pat5<8, 3, 1, 0, 2, true, 16>, 704, 8, 1, 16},
+      {"n = 180000: teams of SIXTEEN, KV8 G3 D1, no hand-off traffic", l_pat5<8, 3, 1, 2, 3, false, 16>, 704, 8, 1, 16},
+      {"contiguous stream reference     ", nullptr, 0, 0, 0, -1},
+      {"n = 40000: teams of FOUR, KV8 G3 D1 (one step of slack)", l_pat5<8, 3, 1, 0, 2, true, 4>, 704, 8, 1, 4},
+      {"n = 40000: teams of FOUR, KV8 G3 D1, no hand-off traffic", l_pat5<8, 3, 1, 2, 3, false, 4>, 704, 8, 1, 4},
+      {"contiguous stream reference    ", nullptr, 0, 0, 0, -1},
       {"teams of TWO with a communication wave, KV8 G3 D1 (C5)", l_pat5<8, 3, 1, 0, 2, true, 2>, 704, 8, 1, 2},
       {"   the same, no hand-off traffic", l_pat5<8, 3, 1, 2, 3, false, 2>, 704, 8, 1, 2},
       {"teams of two, every wave on the scalar path, KV7 G2 (product)", l_pat2<7, 2, true, 2>, 768, 7, 1, 2},
