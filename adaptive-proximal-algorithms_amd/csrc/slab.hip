@@ -841,20 +841,20 @@ static int32_t slab_setup(apx_problem* p) {
     const int64_t nvec = (A->n + 1) / 2;
     // One workgroup where the row fits its eight vectors per thread (three row slots, nothing to hand over).  Else the
     // members' slices as large as the registers allow, because a step costs a barrier and a hand-off whatever its bytes:
-    //   five vectors per thread with four row slots and TWO rows of slack for the hand-off, or
-    //   six to eight with three slots and ONE row of slack — which teams of two and four absorb (a step is 50 - 90 KB per
+    //   up to six vectors per thread with four row slots and TWO rows of slack for the hand-off, or
+    //   seven or eight with three slots and ONE row of slack — which teams of two and four absorb (a step is 50 - 90 KB per
     //   member: tools/pattern_probe.hip, 6.6 and 6.9 TB/s) but teams of eight and sixteen do not (6.2 and 5.5 against
-    //   6.6 with two rows of slack) ; sixteen members take it only beyond 112 640 columns, where the alternative is two passes.
-    const int64_t v5 = 5 * 704, v8 = (int64_t)kTeamSingleKv * 704;
+    //   6.6 with two rows of slack) ; sixteen members take it only beyond 135 168 columns, where the alternative is two passes.
+    const int64_t v6 = 6 * 704, v8 = (int64_t)kTeamSingleKv * 704;      // (six vectors: 168 registers, the four-slot shape's limit)
     int P = 16;
     bool big = false;
     if (nvec <= v8) P = 1;
-    else if (nvec <= 2 * v5) P = 2;
+    else if (nvec <= 2 * v6) P = 2;
     else if (nvec <= 2 * v8) P = 2, big = true;
-    else if (nvec <= 4 * v5) P = 4;
+    else if (nvec <= 4 * v6) P = 4;
     else if (nvec <= 4 * v8) P = 4, big = true;
-    else if (nvec <= 8 * v5) P = 8;
-    else if (nvec <= 16 * v5) P = 16;
+    else if (nvec <= 8 * v6) P = 8;
+    else if (nvec <= 16 * v6) P = 16;
     else big = true;
     st->team_big = big;
     st->team_p = P;
@@ -973,6 +973,10 @@ static bool team_rows_launch_p(const SlabState* st, const SlabDev& d, const void
     //  hand-off (tools/split_probe.hip: the same kernel without them) — a workgroup per CU taking 50 KB per step is what
     //  reads at 6.0 TB/s)
     case 5: hipLaunchKernelGGL((k_team_rows<FK, P, 5, true>), grid, block, lds, q, d, st->team, x); return true;
+    case 6:
+      allow_big_lds<k_team_rows<FK, P, 6, true>>();
+      hipLaunchKernelGGL((k_team_rows<FK, P, 6, true>), grid, block, lds, q, d, st->team, x);
+      return true;
     default: return false;
   }
 }
@@ -1008,7 +1012,6 @@ static void team_big_launch(const SlabState* st, const SlabDev& d, const void* x
 template <int FK, int P>
 static bool team_big_dispatch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
   switch (st->team_kv) {
-    case 6: team_big_launch<FK, P, 6>(st, d, x, q); return true;
     case 7: team_big_launch<FK, P, 7>(st, d, x, q); return true;
     case 8: team_big_launch<FK, P, 8>(st, d, x, q); return true;
     default: return false;

@@ -56,14 +56,16 @@ def _rel(a, b):
                                                 (4100, 11000, False, np.float64),      # one workgroup, KV = 8 (least squares)
                                                 (4100, 12000, False, np.float64),      # teams of two, KV = 5
                                                 (4099, 14080, True, np.float64),       # teams of two, KV = 5, logistic
-                                                (4100, 15000, False, np.float64),      # teams of two, 6 vectors, one row of slack
+                                                (4100, 15000, False, np.float64),      # teams of two, 6 vectors (four slots)
                                                 (4101, 22528, True, np.float64),       # teams of two, 8 vectors, logistic
                                                 (4100, 26000, False, np.float64),      # P = 4, KV = 5
                                                 (4098, 40000, False, np.float64),      # P = 4, 8 vectors, one row of slack
-                                                (4097, 130001, False, np.float64),     # P = 16, 6 vectors, one row of slack
+                                                (4097, 130001, False, np.float64),     # P = 16, 6 vectors (four slots)
+                                                (4099, 150000, False, np.float64),     # P = 16, 7 vectors, one row of slack
+                                                (4100, 19000, True, np.float64),       # teams of two, 7 vectors, one row of slack
                                                 (4100, 180224, True, np.float64),      # P = 16, 8 vectors: the longest row
                                                 (4100, 20000, True, np.float64),       # P = 4, KV = 4, logistic
-                                                (4097, 30001, False, np.float64),      # P = 4, 6 vectors, one row of slack
+                                                (4097, 30001, False, np.float64),      # P = 4, 6 vectors (four slots)
                                                 (4096, 56320, False, np.float64),      # P = 8, KV = 5
                                                 (4099, 100000, False, np.float64),     # P = 16, KV = 5
                                                 # Float64 logistic rows that fit ONE workgroup: the same kernel with a "team"

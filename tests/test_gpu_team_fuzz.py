@@ -40,7 +40,8 @@ def _cpu_rows(seed, rows, m, n):
 PG_SHAPES = [(4096, 10753), (4097, 11263), (4099, 11265), (5000, 16897), (4111, 28160), (4096, 28161), (4098, 33793),
              (4101, 56320), (4096, 56321), (4100, 67585), (4097, 112640), (4300, 99999),
              # ... and of the present one: one workgroup / teams of two, five / six vectors, two / four, four / eight, the longest row
-             (4100, 14080), (4099, 14081), (4100, 22528), (4097, 22529), (4098, 45056), (4096, 45057), (4100, 112641), (4097, 180223)]
+             (4100, 14080), (4099, 14081), (4100, 16896), (4101, 16897), (4100, 22528), (4097, 22529), (4098, 33793), (4098, 45056), (4096, 45057),
+             (4100, 67585), (4100, 112641), (4099, 135169), (4097, 180223)]
 
 
 @pytest.mark.parametrize("m,n", PG_SHAPES)
