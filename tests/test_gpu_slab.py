@@ -34,8 +34,8 @@ def _rel(a, b):
                                                 (4099, 10239, True, np.float32),      # 10 columns per thread (fp32 only)
                                                 (4100, 10240, False, np.float32),
                                                 # long slabs (>= 16 steps per block): two row groups in flight
-                                                (140000, 200, False, np.float32),
-                                                (140000, 300, False, np.float64),
+                                                (140000, 320, False, np.float32),
+                                                (140000, 400, False, np.float64),
                                                 (20000, 2500, True, np.float32),
                                                 (17000, 6000, False, np.float32),     # ... and > 384 MB: non-temporal loads
                                                 # BASELINE config C3's own kernel: fp32 logistic, 14 columns per thread, four rows
