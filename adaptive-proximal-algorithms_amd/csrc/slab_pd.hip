@@ -444,6 +444,10 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   if (cols <= 3 * 1024) return {1024, 3, 4};       // (three / four columns per thread: csrc/slab.hip slab_shape, measured)
   if (cols <= 4 * 1024) return {1024, 4, 4};
   if (cols <= 5 * 1024) return {1024, 5, 4};
+  // (between five columns of 1024 threads and fourteen of 768: seven and ten — a row of 5200 entries kept 37 % of the
+  //  fourteen-column shape's lanes busy, 3.6 TB/s ; tools/shape_sweep.py)
+  if (cols <= 7 * 768) return {768, 7, 4};
+  if (cols <= 10 * 768) return {768, 10, f32 ? 4 : 2};
   if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
   // C5's row length, 20 000 fp64, is out of reach of ONE workgroup (x, the accumulator and one row are 480 KB of a CU's
   // 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two
@@ -525,8 +529,8 @@ template <bool NT>
 static bool team_rows_launch(const SlabPdState* st, const SlabPdDev& d, const void* x, hipStream_t q) {
   const dim3 grid((unsigned)(2 * st->B));
   switch (st->team_kv) {
-    case 4: hipLaunchKernelGGL((k_teampd_rows<4, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
-    case 5: hipLaunchKernelGGL((k_teampd_rows<5, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
+    case 4: hipLaunchKernelGGL((k_teampd_rows<4, 3, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
+    case 5: hipLaunchKernelGGL((k_teampd_rows<5, 3, NT, true>), grid, dim3(768), (size_t)5 * 768 * 16, q, d, st->team, x); return true;   // (x in LDS: 60 KB)
     case 6: hipLaunchKernelGGL((k_teampd_rows<6, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
     case 7: {                                      // (x of the half row in LDS: in registers the row state spills, 20 registers)
       constexpr int lds = 7 * 768 * 2 * (int)sizeof(double);
@@ -574,6 +578,8 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
     else if (st->cpt == 3) hipLaunchKernelGGL((k_slabpd_rows<T, 3, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 4) hipLaunchKernelGGL((k_slabpd_rows<T, 4, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 7) hipLaunchKernelGGL((k_slabpd_rows<T, 7, 4, 768, false, true>), grid, dim3(768), 0, q, d, x);
+    else if (st->cpt == 10) hipLaunchKernelGGL((k_slabpd_rows<T, 10, (f32 ? 4 : 2), 768, false, true>), grid, dim3(768), 0, q, d, x);
     else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, true>), grid, dim3(768), 0, q, d, x);
   } else {
     if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, false>), grid, dim3(1024), 0, q, d, x);
@@ -581,6 +587,8 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
     else if (st->cpt == 3) hipLaunchKernelGGL((k_slabpd_rows<T, 3, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 4) hipLaunchKernelGGL((k_slabpd_rows<T, 4, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 5) hipLaunchKernelGGL((k_slabpd_rows<T, 5, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 7) hipLaunchKernelGGL((k_slabpd_rows<T, 7, 4, 768, false, false>), grid, dim3(768), 0, q, d, x);
+    else if (st->cpt == 10) hipLaunchKernelGGL((k_slabpd_rows<T, 10, (f32 ? 4 : 2), 768, false, false>), grid, dim3(768), 0, q, d, x);
     else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, false>), grid, dim3(768), 0, q, d, x);
   }
   hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q, d,

@@ -31,13 +31,20 @@ for n in NS:
         continue
     A = apx.DeviceMatrix.uniform(m, n, seed=3, dtype=dtype, ctx=ctx)
     A.build_transpose()
-    if kind == "log":
+    if kind == "pd":      # least absolute deviation by Condat-Vu (FixedStepsize): A x, the dual step and A' y
+        y = rng.standard_normal(m).astype(dtype)
+        nA = float(np.sqrt(m * n / 3.0))
+        gam, sig = 1.0 / nA, 0.99 / nA
+        s = apx.Solver(np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype), f=apx.Zero(), g=apx.NormL1(10.0), h=apx.Translate(apx.NormL1(1.0), -y), A=A,
+                       rule=apx.FixedStepsize(gam, np.sqrt(sig / gam)), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    elif kind == "log":
         f = apx.LogisticLoss(A, (rng.uniform(size=m) < 0.5).astype(dtype), ctx=ctx)
         x0, gam, lam = np.zeros(n + 1, dtype=dtype), 4.0 / (n / 3.0 + 1.0), 1e-3
     else:
         f = apx.LinearLeastSquares(A, rng.standard_normal(m).astype(dtype), ctx=ctx)
         x0, gam, lam = np.zeros(n, dtype=dtype), 1.0 / (m * n / 3.0), 1.0
-    s = apx.Solver(x0, f=f, g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    if kind != "pd":
+        s = apx.Solver(x0, f=f, g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, ctx=ctx, poll_every=1 << 30)
     s.step(4, sync=True)
     ctx.kernel_stats(reset=True)
     ctx.profile(True)
