@@ -29,12 +29,12 @@
 #include "small_dev.h"
 #include "solver_internal.h"
 #include "team_dev.h"
+#include "team_rows.h"
 #include "vecops_dev.h"
 
 namespace apx {
 
 constexpr int kSlabTeamCpt = 99;      // SlabShape::cpt of the team kernel
-constexpr int kTeamSingleKv = 8;      // P = 1: up to 8 vectors per compute thread (11 264 Float64 columns)
 constexpr int kSlabRows = 4;          // rows per step (two columns per thread: 16 ; fourteen fp64 columns: 2, or 1 with the logistic link)
 
 struct SlabDev {
@@ -413,313 +413,7 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Rows too long for one workgroup's registers (10 753 ... 180 224 Float64 entries — BASELINE config C2: 100 000, a row is
-// 800 KB): TEAMS of P = 2 / 4 / 8 / 16 workgroups, one per CU, formed inside an XCD at run time, share a slab of rows.  Member
-// s keeps columns [s n/P, (s+1) n/P) of x (in LDS) and of the column accumulator (in registers) and streams that slice
-// of every row.  A workgroup is eleven COMPUTE waves and one COMMUNICATION wave:
-//   * the compute waves form the partial dot product of a row (one barrier per row) and, DEPTH = 2 rows later, take the
-//     row's residual from LDS and accumulate res[i] * A[i, slice] from the registers the row still sits in;
-//   * the communication wave loads no A, so its vector-memory counter is its own (loads return in order per wave: a
-//     poll or a fence in a wave that streams A waits for every load in flight and drains the pipeline — that is what
-//     round 1's probe measured as 23 - 28 us per hand-off).  It sums the workgroup's partial, publishes it (two words
-//     {value, value ^ sequence}, agent scope, no fence: the check word validates the pair), collects the P records of
-//     the row two rows back on the SCALAR path (P / 4 `s_load_dwordx16 ... glc`, from the XCD's L2, a step ahead), adds
-//     them in a fixed tree — the same `A x` on every member, no atomics on data —, evaluates the residual / the logistic
-//     link ONCE and leaves it in LDS; member 0's accumulates the loss sums.  Two rows of slack absorb the hand-off
-//     (1 - 3 us) and the slowest member.
-// Every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
-// tools/split_probe.hip, tools/pattern_probe.hip (profiles/r02_team_probe_*.log, r02_team_handoff_traffic.log): 6.6 - 6.7
-// TB/s on rows of C2's length — A read once per evaluation of f and its gradient instead of twice at 7.1 TB/s.
-// ---------------------------------------------------------------------------------------------------------------------
-// The P records of one row of a team's ring (P x 16 bytes, aligned to their size up to 64) into SGPRs: P / 4 scalar loads
-// of 64 bytes (teams of two: one of 32), glc (past
-// the scalar cache), waited for here — nothing may copy the registers before the data is in them.
-typedef unsigned raw16_t __attribute__((ext_vector_type(16)));
-template <int P>
-__device__ __forceinline__ void team_fetch(const TeamRec* row, raw16_t (&q)[(P + 3) / 4]) {
-  static_assert(P == 2 || P == 4 || P == 8 || P == 16, "teams of 2, 4, 8 or 16");
-  if constexpr (P == 2) {
-    typedef unsigned raw8_t __attribute__((ext_vector_type(8)));
-    raw8_t h;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(h) : "s"(row) : "memory");
-#pragma unroll
-    for (int c = 0; c < 8; ++c) q[0][c] = h[c];
-  } else if constexpr (P == 4)
-    asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(q[0]) : "s"(row) : "memory");
-  else if constexpr (P == 8)
-    asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(q[0]), "=&s"(q[1])
-                 : "s"(row)
-                 : "memory");
-  else
-    asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
-                 "s_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(q[0]), "=&s"(q[1]), "=&s"(q[2]), "=&s"(q[3])
-                 : "s"(row)
-                 : "memory");
-}
-
-template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2>
-__global__ __launch_bounds__(768) void k_team_rows(SlabDev d, TeamDev t, const void* xv) {
-  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;
-  static_assert(G >= DEPTH + 2 && DEPTH <= 3, "slots: DEPTH rows awaiting their residuals, one computing, one loading ; res_s has 4 entries");
-  static_assert(P > 1 || DEPTH == 1, "a workgroup on its own has its row sum one step later");
-  typedef double vec_t __attribute__((ext_vector_type(2)));
-  typedef unsigned raw_t __attribute__((ext_vector_type(4)));
-  extern __shared__ double team_x[];               // the member's slice of x: KV * 704 * 2 doubles
-  __shared__ double wsum[2][CW];
-  __shared__ double res_s[4];
-  __shared__ int ident[2];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (P > 1 && tid == 0) {                         // (every launch takes its 32 tickets per XCD, a finished loop's too)
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
-    const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
-    ident[0] = k < (unsigned)(TPX * P) ? (int)(xcc * TPX + k / P) : -1;
-    ident[1] = (int)(k % P);
-    if (k >= 32u) atomicCAS(t.err, 0, 2);
-  }
-  if (P == 1 && tid == 0) {                        // P = 1: a workgroup on its own — no team to form, nothing to hand over
-    ident[0] = (int)blockIdx.x;
-    ident[1] = 0;
-  }
-  __syncthreads();
-  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
-  if (team < 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
-  const int nvec = (d.ncols + 1) / 2;
-  const int nvs = (nvec + P - 1) / P;              // 16-byte vectors per member
-  const int v0 = s * nvs;
-  const int row_begin = team * t.rows_per_team;
-  const int row_end = min(row_begin + t.rows_per_team, d.m);
-  const int nrows = max(row_end - row_begin, 0);
-  // rows past the slab are dummy rows (clamped loads, residual 0) that every member runs alike: DEPTH steps of prologue,
-  // then whole rounds of G steps — the loop body of the compute waves has no branch between a load and its use, so the
-  // waits the compiler places are counted ones and the rows in the loading slots really stay in flight
-  const int nsteps = DEPTH + (nrows + G - 1) / G * G;
-  TeamRec* ring = t.ring + (int64_t)team * kTeamSlots * P;
-  const double* __restrict__ X = (const double*)xv;
-  if (wv == CW) {
-    // ---- the communication wave -------------------------------------------------------------------------------------
-    const double* __restrict__ bv = (const double*)d.b;
-    const double bias = FK == APX_F_LOGISTIC ? X[d.n - 1] : 0.0;
-    double e0 = 0.0, e1 = 0.0;
-    bool dead = false;
-    if constexpr (P == 1) {
-      // a workgroup on its own: the sum of its eleven waves IS `A x` of the row — formed after the barrier of step seq, used
-      // before the barrier of step seq + 1 (DEPTH = 1).  What this wave is for here: the link function of a Float64 row
-      // (exp, log: ~50 registers) is evaluated where no row of A is held, so the compute waves keep three rows in registers
-      // without spilling (the row kernels that evaluate it next to their rows hold ONE row per step: 5.7 against 6.7 TB/s).
-      double own_prev = 0.0, pb1 = 0.0;
-      for (long long seq = 0; seq < nsteps; ++seq) {
-        const long long r = seq - 1;
-        if (r >= 0) {
-          const int i = row_begin + (int)r;
-          double res = 0.0;
-          if (i < row_end) {
-            const double ax = own_prev, bi = pb1;
-            if constexpr (FK == APX_F_LEAST_SQUARES) {
-              res = ax - bi;
-              e0 += res * res;
-            } else {
-              const double logit = ax + bias;
-              const double e = 1.0 + exp(-logit);
-              e0 += (bi - 1.0) * logit - log(e);
-              res = 1.0 / e - bi;
-              e1 += res;
-            }
-          }
-          if (lane == 0) res_s[r & 3] = res;
-        }
-        __syncthreads();
-        double own = lane < CW ? wsum[seq & 1][lane] : 0.0;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
-        own_prev = own;
-        pb1 = bv[max(min(row_begin + (int)seq, d.m - 1), 0)];
-      }
-      if (lane == 0) {
-        double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
-        out[d.ncols] = e0;
-        out[d.ncols + 1] = e1;
-      }
-      return;
-    } else {
-    // The P records of a row are taken on the SCALAR path: P / 4 loads of 64 bytes (`s_load_dwordx16 ... glc`: past the
-    // scalar cache, from the XCD's L2 — the teams are formed inside an XCD, and the members' agent-scope stores pass
-    // through that L2).  Measured (tools/pattern_probe.hip, profiles/r02_team_handoff_traffic.log): agent-scope VECTOR
-    // loads of lines that other CUs keep storing to are served by the memory side, and that small read-after-write
-    // traffic alone — nothing waited for — takes the stream of A from 7.1 to 5.8 TB/s; stores alone, or loads alone, cost
-    // nothing; the same hand-off with scalar loads runs at 6.6 - 6.7.  The records of the row whose residual is due NEXT
-    // and its entry of b are taken a step ahead, right after this workgroup's own partial has been published.
-    raw16_t q[(P + 3) / 4];
-#pragma unroll
-    for (int c = 0; c < (P + 3) / 4; ++c) q[c] = raw16_t{};
-    double pb = 0.0;
-    auto fetch = [&](long long r) { team_fetch<P>(ring + (r % kTeamSlots) * P, q); };
-    auto rec_word = [&](int m, int w) -> unsigned long long {        // word w (0: value, 1: check) of member m's record
-      const raw16_t& c = q[m / 4];
-      const int o = (m & 3) * 4 + w * 2;
-      return ((unsigned long long)c[o + 1] << 32) | c[o];
-    };
-    auto all_there = [&](unsigned long long want) {
-      bool ok = true;
-#pragma unroll
-      for (int m = 0; m < P; ++m) ok &= (rec_word(m, 0) ^ rec_word(m, 1)) == want;
-      return ok;
-    };
-    for (long long seq = 0; seq < nsteps; ++seq) {
-      const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
-      if (r >= 0) {
-        const int i = row_begin + (int)r;
-        const unsigned long long want = t.seq0 + (unsigned long long)r + 1;
-        const double bi = pb;
-        if (!all_there(want) && !dead) {           // not all there yet (or half written): poll, bounded
-          const long long t0 = wall_clock64();
-          for (;;) {
-            fetch(r);
-            if (all_there(want)) break;
-            if (wall_clock64() - t0 > 2000000) {   // 20 ms at 100 MHz: give up — the grid must drain
-              dead = true;
-              if (lane == 0) atomicCAS(t.err, 0, 1);
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        // the P partials added in a fixed pairwise tree, from the same P records on every member: the same `A x` bit for bit
-        double part[P];
-#pragma unroll
-        for (int m = 0; m < P; ++m) part[m] = dead ? 0.0 : __builtin_bit_cast(double, rec_word(m, 0));
-#pragma unroll
-        for (int w = 1; w < P; w <<= 1)
-#pragma unroll
-          for (int m = 0; m < P; m += 2 * w) part[m] += part[m + w];
-        const double ax = part[0];
-        double res = 0.0;
-        if (i < row_end) {
-          if constexpr (FK == APX_F_LEAST_SQUARES) {
-            res = ax - bi;                                            // experiments/lasso/runme.jl:22
-            e0 += res * res;
-          } else {
-            const double logit = ax + bias;                           // experiments/sparse_logreg/runme.jl:24-36
-            const double e = 1.0 + exp(-logit);
-            e0 += (bi - 1.0) * logit - log(e);
-            res = 1.0 / e - bi;
-            e1 += res;
-          }
-        }
-        if (lane == 0) res_s[r & 3] = res;
-      }
-      __syncthreads();                             // the barrier of step seq
-      double own = lane < CW ? wsum[seq & 1][lane] : 0.0;            // after it: this workgroup's partial of row seq,
-#pragma unroll                                                        // the eleven waves' sums in a fixed tree
-      for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
-      if (lane == 0) {
-        const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
-        TeamRec* rec = ring + (seq % kTeamSlots) * P + s;
-        __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&rec->chk, bits ^ (t.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (r + 1 >= 0) {
-        pb = bv[max(min(row_begin + (int)(r + 1), d.m - 1), 0)];
-        fetch(r + 1);
-      }
-    }
-    if (lane == 0 && s == 0) {
-      double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
-      out[d.ncols] = e0;
-      out[d.ncols + 1] = e1;
-    }
-    return;
-    }      // (P > 1)
-  }
-  // ---- the compute waves ----------------------------------------------------------------------------------------------
-  double acc[KV][2];
-#pragma unroll
-  for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BSC;
-    const int j = (v0 + lv) * 2;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      team_x[lv * 2 + e] = (lv < nvs && j + e < d.ncols) ? X[j + e] : 0.0;     // (each thread reads back only what it wrote)
-      acc[k][e] = 0.0;
-    }
-  }
-  const int voff = tid * 16;
-  const int64_t cbase = (int64_t)v0 * 16;
-  const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * 8 - cbase));      // (rows are zero-padded to whole vectors)
-  const double* __restrict__ AT = (const double*)d.AT;
-  vec_t a[G][KV];
-  auto load = [&](int g, int row) {
-    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-      const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
-      a[g][k] = __builtin_bit_cast(vec_t, raw);
-    }
-  };
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int g = 0; g < G - 1; ++g) {
-    load(g, row_begin + g);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // the dots of the row in slot g (step seq) and the barrier behind them
-  auto dots = [&](int g, long long seq) {
-    double p = 0.0;
-#pragma unroll
-    for (int k = 0; k < KV; ++k)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) p = fma(a[g][k][e], team_x[(tid + k * BSC) * 2 + e], p);
-#pragma unroll                                     // (a butterfly: EVERY lane ends with the wave's sum, so all of them store
-    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);      //  it and the loop body has no branch)
-    wsum[seq & 1][wv] = p;                         // (double-buffered by row parity: one barrier per row)
-    __syncthreads();
-  };
-  // steps 0 .. DEPTH - 1: nothing to accumulate yet ; the last of them fills slot G - 1, which the prologue left empty
-#pragma unroll
-  for (int u = 0; u < DEPTH; ++u) {
-    dots(u, u);
-    __builtin_amdgcn_sched_barrier(0);
-    if (u == DEPTH - 1) load(G - 1, row_begin + G - 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // step seq >= DEPTH: the dots of row seq (slot seq % G) ; the barrier ; row seq - DEPTH (slot (seq - DEPTH) % G)
-  // accumulated and its slot re-loaded with row seq - DEPTH + G.  Unrolled G times: every slot index is a constant.
-#pragma unroll 1
-  for (long long q = DEPTH; q < nsteps; q += G) {
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const long long seq = q + u;
-      const long long r = seq - DEPTH;
-      dots((DEPTH + u) % G, seq);
-      const double rr = res_s[r & 3];
-#pragma unroll
-      for (int k = 0; k < KV; ++k)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[u][k][e], rr, acc[k][e]);      // (slot of row r: (seq - DEPTH) % G = u)
-#pragma unroll                                     // (the sums are complete HERE: see k_slab_rows)
-      for (int k = 0; k < KV; ++k)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
-      __builtin_amdgcn_sched_barrier(0);
-      load(u, row_begin + (int)(r + G));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
-#pragma unroll
-  for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BSC;
-    const int j = (v0 + lv) * 2;
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-      if (lv < nvs && j + e < d.ncols) out[j + e] = acc[k][e];
-  }
-}
+// (k_team_rows: csrc/team_rows.h — shared with the primal-dual loop, csrc/slab_pd.hip)
 
 // 64 columns per block (a wave reads 512 contiguous bytes of a partial row), the B partials of a column dealt to 16
 // threads (b = s, s + 16, ...: with one block per CU in the row kernel that is ALL of a thread's loads in flight at
@@ -790,7 +484,7 @@ static SlabShape slab_shape(const apx_problem* p) {
   if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};
   // longer rows (BASELINE config C2: 100 000): teams of 2 / 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
   // Float64, on a part of 8 XCDs x 32 CUs
-  if (p->dtype == APX_F64 && cols <= 16 * kTeamSingleKv * 704 * 2 && p->ctx->num_cu == 256) return {768, kSlabTeamCpt, 1};
+  if (p->dtype == APX_F64 && cols <= kTeamMaxCols && p->ctx->num_cu == 256) return {768, kSlabTeamCpt, 1};
   return {0, 0, 0};
 }
 
@@ -842,27 +536,11 @@ static int32_t slab_setup(apx_problem* p) {
   st->B = (int)B;
   int64_t rpb_team = 0;
   if (st->cpt == kSlabTeamCpt) {           // teams: the fewest members whose slice fits 5 vectors per compute thread
-    const int64_t nvec = (A->n + 1) / 2;
-    // One workgroup where the row fits its eight vectors per thread (three row slots, nothing to hand over).  Else the
-    // members' slices as large as the registers allow, because a step costs a barrier and a hand-off whatever its bytes:
-    //   up to six vectors per thread with four row slots and TWO rows of slack for the hand-off, or
-    //   seven or eight with three slots and ONE row of slack — which teams of two and four absorb (a step is 50 - 90 KB per
-    //   member: tools/pattern_probe.hip, 6.6 and 6.9 TB/s) but teams of eight and sixteen do not (6.2 and 5.5 against
-    //   6.6 with two rows of slack) ; sixteen members take it only beyond 135 168 columns, where the alternative is two passes.
-    const int64_t v6 = 6 * 704, v8 = (int64_t)kTeamSingleKv * 704;      // (six vectors: 168 registers, the four-slot shape's limit)
-    int P = 16;
-    bool big = false;
-    if (nvec <= v8) P = 1;
-    else if (nvec <= 2 * v6) P = 2;
-    else if (nvec <= 2 * v8) P = 2, big = true;
-    else if (nvec <= 4 * v6) P = 4;
-    else if (nvec <= 4 * v8) P = 4, big = true;
-    else if (nvec <= 8 * v6) P = 8;
-    else if (nvec <= 16 * v6) P = 16;
-    else big = true;
-    st->team_big = big;
-    st->team_p = P;
-    st->team_kv = (int)(((nvec + P - 1) / P + 703) / 704);
+    const TeamPlan pl = team_plan(A->n);      // (csrc/team_rows.h)
+    const int P = pl.P;
+    st->team_big = pl.big;
+    st->team_p = pl.P;
+    st->team_kv = pl.kv;
     B = ctx->num_cu / P;                   // slabs = teams ; ALL 256 workgroups are launched (32 / P teams per XCD)
     rpb_team = (A->m + B - 1) / B;
     st->B = (int)B;
@@ -955,96 +633,12 @@ static bool slab2_dispatch(const SlabState* st, dim3 grid, hipStream_t q, const 
   }
 }
 
-// the team kernel for this row length: P members, KV vectors per compute thread (x of the slice in dynamic LDS)
-template <int FK, int P>
-static bool team_rows_launch_p(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
-  // (APX_TEAM_FAULT_GRID: a TEST hook — launches that many workgroups instead of all 256, so that some teams miss members:
-  //  what a GPU shared with other work does to this scheme.  tests/test_gpu_team_fault.py checks that the waits time out,
-  //  the grid drains and the error comes back)
-  static const int fault_grid = getenv("APX_TEAM_FAULT_GRID") ? atoi(getenv("APX_TEAM_FAULT_GRID")) : 0;
-  const dim3 grid((unsigned)(fault_grid > 0 ? fault_grid : st->B * P)), block(768);
-  const size_t lds = (size_t)st->team_kv * 704 * 2 * sizeof(double);
-  switch (st->team_kv) {
-    case 1:
-    case 2: hipLaunchKernelGGL((k_team_rows<FK, P, 2, true>), grid, block, (size_t)2 * 704 * 16, q, d, st->team, x); return true;
-    case 3: hipLaunchKernelGGL((k_team_rows<FK, P, 3, true>), grid, block, lds, q, d, st->team, x); return true;
-    case 4: hipLaunchKernelGGL((k_team_rows<FK, P, 4, true>), grid, block, lds, q, d, st->team, x); return true;
-    // (measured and dropped, interleaved runs of bench.py: five row slots with two or three rows of slack instead of four
-    //  with two — 148.3 - 149.7 against 148.5 - 150.6 iterations / s at C2: nothing)
-    // (measured and dropped, interleaved runs of bench.py with COUNTED waits in the loop — rows in the loading slots really
-    //  in flight: five slots with two rows in flight or three rows of slack, six slots with three in flight: 149.2 - 150.1
-    //  iterations / s at C2 against 149.9 - 150.1 for four slots.  Neither the rows in flight, nor the arithmetic, nor the
-    //  hand-off (tools/split_probe.hip: the same kernel without them) — a workgroup per CU taking 50 KB per step is what
-    //  reads at 6.0 TB/s)
-    case 5: hipLaunchKernelGGL((k_team_rows<FK, P, 5, true>), grid, block, lds, q, d, st->team, x); return true;
-    case 6:
-      allow_big_lds<k_team_rows<FK, P, 6, true>>();
-      hipLaunchKernelGGL((k_team_rows<FK, P, 6, true>), grid, block, lds, q, d, st->team, x);
-      return true;
-    default: return false;
-  }
-}
-// P = 1 (Float64 logistic rows that fit one workgroup): three row slots, the row sum a step later ; x of the row in LDS
-// (up to 90 KB: opted into per kernel and device)
-template <int FK, int KV, bool NT>
-static void team_single_launch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
-  constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);
-  if constexpr (lds > 64 * 1024) allow_big_lds<k_team_rows<FK, 1, KV, NT, 3, 1>>();
-  hipLaunchKernelGGL((k_team_rows<FK, 1, KV, NT, 3, 1>), dim3((unsigned)st->B), dim3(768), lds, q, d, st->team, x);
-}
-template <int FK, bool NT>
-static bool team_single_dispatch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
-  switch (st->team_kv) {
-    case 4: team_single_launch<FK, 4, NT>(st, d, x, q); return true;
-    case 5: team_single_launch<FK, 5, NT>(st, d, x, q); return true;
-    case 6: team_single_launch<FK, 6, NT>(st, d, x, q); return true;
-    case 7: team_single_launch<FK, 7, NT>(st, d, x, q); return true;
-    case 8: team_single_launch<FK, 8, NT>(st, d, x, q); return true;
-    default: return false;
-  }
-}
-
-// slices of 6 ... 8 vectors per thread: three row slots, one row of slack ; x of the slice in up to 90 KB of LDS
-template <int FK, int P, int KV>
-static void team_big_launch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
-  static const int fault_grid = getenv("APX_TEAM_FAULT_GRID") ? atoi(getenv("APX_TEAM_FAULT_GRID")) : 0;      // (test hook, as above)
-  constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);
-  allow_big_lds<k_team_rows<FK, P, KV, true, 3, 1>>();
-  hipLaunchKernelGGL((k_team_rows<FK, P, KV, true, 3, 1>), dim3((unsigned)(fault_grid > 0 ? fault_grid : st->B * P)), dim3(768), lds, q, d,
-                     st->team, x);
-}
-template <int FK, int P>
-static bool team_big_dispatch(const SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
-  switch (st->team_kv) {
-    case 7: team_big_launch<FK, P, 7>(st, d, x, q); return true;
-    case 8: team_big_launch<FK, P, 8>(st, d, x, q); return true;
-    default: return false;
-  }
-}
-
-template <int FK>
-static bool team_rows_launch(SlabState* st, const SlabDev& d, const void* x, hipStream_t q) {
-  bool ok = false;
-  if (st->team_big) {
-    if (st->team_p == 2) ok = team_big_dispatch<FK, 2>(st, d, x, q);
-    else if (st->team_p == 4) ok = team_big_dispatch<FK, 4>(st, d, x, q);
-    else if (st->team_p == 16) ok = team_big_dispatch<FK, 16>(st, d, x, q);
-  } else if (st->team_p == 1) ok = st->nt ? team_single_dispatch<FK, true>(st, d, x, q) : team_single_dispatch<FK, false>(st, d, x, q);
-  else if (st->team_p == 2) ok = team_rows_launch_p<FK, 2>(st, d, x, q);
-  else if (st->team_p == 4) ok = team_rows_launch_p<FK, 4>(st, d, x, q);
-  else if (st->team_p == 8) ok = team_rows_launch_p<FK, 8>(st, d, x, q);
-  else if (st->team_p == 16) ok = team_rows_launch_p<FK, 16>(st, d, x, q);
-  st->team.launch += 1;                            // (tickets and sequence numbers are never reset: a range per launch)
-  st->team.seq0 += (unsigned long long)st->team.rows_per_team + 16;
-  return ok;
-}
-
 template <typename T, int FK>
 static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   if (st->team_p != 0) {
     if constexpr (sizeof(T) == 8) {
-      team_rows_launch<FK>(st, d, x, q);
+      team_launch<FK, SlabDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, d, st->team, x, q);
       hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
                          dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
     }

@@ -14,6 +14,7 @@
 #include "skinny_dev.h"
 #include "solver_internal.h"
 #include "team_dev.h"
+#include "team_rows.h"
 #include "vecops_dev.h"
 
 namespace apx {
@@ -21,7 +22,7 @@ namespace apx {
 struct SlabPdDev {
   const void* AT;         // A' column-major: row i of A at AT + i * ldT, contiguous
   int64_t ldT;
-  int32_t m, n, rows_per_block, _pad;
+  int32_t m, n, rows_per_block, ncols;      // (ncols = n: the name csrc/team_rows.h reads)
   void* Y;                // y (T), updated in place
   void* AXP;              // A_x_prev (T), updated in place (:360)
   double* part;           // [blocks][ldpart]: n column partials of A' y, then sum dual_res^2, raw h(A_x)
@@ -35,8 +36,9 @@ struct SlabPdState {
   SlabPdDev dev{};
   int B = 0, cpt = 0, bs = 0, rows = 0;
   bool nt = true;         // non-temporal loads of A (a matrix beyond the Infinity Cache)
-  // rows of 10 753 ... 21 504 Float64 entries: teams of two workgroups (k_teampd_rows)
-  int team_kv = 0;        // 16-byte vectors per thread and row of a member's half (0: not this scheme)
+  // rows of more than 10 752 Float64 entries: k_team_rows (csrc/team_rows.h) — one workgroup, or teams of 2 ... 16
+  int team_p = 0, team_kv = 0;      // members ; 16-byte vectors per thread and row of a member's slice (0: not this scheme)
+  bool team_big = false;
   DBuf team_buf;          // ring, tickets, err
   TeamDev team{};
   int32_t* h_err = nullptr;  // pinned copy of err
@@ -193,206 +195,8 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Rows too long for one workgroup's registers (10 753 ... 21 504 Float64 entries — BASELINE config C5: 20 000, a row is
-// 160 KB): TEAMS of two workgroups, one per CU, share a slab of rows.  Member s keeps columns [s n/2, (s+1) n/2) of x and
-// of the column accumulator in registers and streams that half of every row (16-byte buffer loads, csrc/slab.hip's
-// second-generation mapping).  Per row a member forms its partial dot product, PUBLISHES it, goes on to the dots of the
-// next row, and only then takes the partner's partial of the first — the hand-off (1 - 3 us, MI355X_MICROARCH.md) is off
-// the critical path.  Both members add the two partials in member order: the same `A x`, the same y+, no atomics on data.
-//
-// What the hand-off must not do is touch the vector-memory counter.  Loads return in order per wave, so a release
-// fence, or a polling vector load, waits for every load of A the wave has in flight and the pipeline drains at every
-// row: that is the 23 - 28 us per hand-off of round 1's probe.  Hence:
-//   * a record is two words {value, value ^ sequence} stored by one lane, fire and forget — no fence; the check word
-//     validates the pair, whatever order the words become visible in;
-//   * every WAVE takes the partner's record itself with a scalar load (`s_load_dwordx4 ... glc`: its own counter, past
-//     the scalar cache) requested before the dots of the next row and validated after them — no broadcast through LDS,
-//     ONE barrier per row (the partial dots of the waves; each wave sums them itself);
-//   * scalar loads see the L2 of the XCD, so teams are formed INSIDE an XCD at run time (XCC_ID + a ticket per XCD),
-//     whatever order the dispatcher deals workgroups in;
-//   * every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
-// Rows past the slab are dummy rows (clamped loads, weight 0) that both members run alike, so the loop body has no
-// branch between a request and its use.  tools/split_probe.hip: 8.0 GB of C5 in 1.28 ms = 6.3 TB/s, against 2 x 1.13 ms
-// for the two GEMV passes.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int KV, int G, bool NT, bool XLDS>
-__global__ __launch_bounds__(768) void k_teampd_rows(SlabPdDev d, TeamDev t, const void* xv) {
-  extern __shared__ double team_xs[];              // XLDS: the member's half of x in LDS (KV * 768 * 2 doubles: 84 KB at KV = 7),
-  constexpr int BS = 768, NW = BS / 64;            //       where x in registers would make the row state spill
-  typedef double vec_t __attribute__((ext_vector_type(2)));
-  typedef unsigned raw_t __attribute__((ext_vector_type(4)));
-  typedef unsigned long long rec_t __attribute__((ext_vector_type(2)));
-  __shared__ double wsum[2][NW];
-  __shared__ int ident[2];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // (provably wave-uniform: scalar branches, SGPR values)
-  if (tid == 0) {                                  // (every launch takes its 32 tickets per XCD, a finished loop's too)
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
-    const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
-    ident[0] = k < 32u ? (int)(xcc * 16 + k / 2) : -1;
-    ident[1] = (int)(k % 2);
-    if (k >= 32u) atomicCAS(t.err, 0, 2);
-  }
-  __syncthreads();
-  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
-  if (team < 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
-  const double sigma = d.c->sigma, rho = d.c->rho; // this iteration's, set by the rule kernel before this launch
-  const double* __restrict__ X = (const double*)xv;
-  const int nvs = ((d.n + 1) / 2 + 1) / 2;         // 16-byte vectors per member
-  const int v0 = s * nvs;
-  vec_t xr[KV];
-  double acc[KV][2];
-#pragma unroll
-  for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BS;
-    const int j = (v0 + lv) * 2;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      xr[k][e] = (lv < nvs && j + e < d.n) ? X[j + e] : 0.0;
-      acc[k][e] = 0.0;
-      if constexpr (XLDS) team_xs[lv * 2 + e] = xr[k][e];      // (each thread reads back only what it wrote: no barrier)
-    }
-  }
-  const int voff = tid * 16;
-  const int64_t cbase = (int64_t)v0 * 16;
-  const int slice_bytes = (int)min((int64_t)nvs * 16, d.ldT * 8 - cbase);      // (rows are zero-padded to whole vectors)
-  const int row_begin = team * t.rows_per_team;
-  const int row_end = min(row_begin + t.rows_per_team, d.m);
-  const int nrows = max(row_end - row_begin, 0);
-  double e0 = 0.0, e1 = 0.0;
-  vec_t a[G][KV];
-  double y_in[G], axp_in[G], b_in[G];              // the row's state rides behind its loads of A (every thread: one address)
-  const double* __restrict__ AT = (const double*)d.AT;
-  double* __restrict__ Y = (double*)d.Y;
-  double* __restrict__ AXP = (double*)d.AXP;
-  auto load = [&](int g, int row) {
-    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-      const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BS * 16, NT ? 2 : 0);
-      a[g][k] = __builtin_bit_cast(vec_t, raw);
-    }
-    y_in[g] = Y[ri];
-    axp_in[g] = AXP[ri];
-    b_in[g] = d.h.has_shift ? ((const double*)d.h.shift)[ri] : 0.0;
-  };
-  TeamRec* ring = t.ring + (int64_t)team * kTeamSlots * 2;
-  // the workgroup's partial dot of row `seq` of the slab (slot g): every thread returns it ; thread 0 publishes it
-  auto dots = [&](int g, long long seq) -> double {
-    double p = 0.0;
-#pragma unroll
-    for (int k = 0; k < KV; ++k)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) p = fma(a[g][k][e], XLDS ? team_xs[(tid + k * BS) * 2 + e] : xr[k][e], p);
-    p = wave_sum(p);
-    if (lane == 0) wsum[seq & 1][wv] = p;          // (double-buffered by row parity: one barrier per row)
-    __syncthreads();
-    double own = wsum[seq & 1][0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) own += wsum[seq & 1][w];
-    if (tid == 0) {
-      const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
-      const rec_t rec = {bits, bits ^ (t.seq0 + (unsigned long long)seq + 1)};
-      *(volatile rec_t*)(ring + (seq % kTeamSlots) * 2 + s) = rec;
-    }
-    return own;
-  };
-  bool dead = false;
-  // row `seq` (slot g): the partner's partial (requested a phase ago), the dual step (:344-347, :360), y+[i] * A[i, half]
-  auto finish = [&](int g, long long seq, double own, raw_t early) {
-    const unsigned long long want = t.seq0 + (unsigned long long)seq + 1;
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(early)::"memory");
-    unsigned long long v = ((unsigned long long)early[1] << 32) | early[0];
-    unsigned long long chk = ((unsigned long long)early[3] << 32) | early[2];
-    if ((v ^ chk) != want && !dead) {              // not there yet (or half written): poll, bounded
-      const TeamRec* src = ring + (seq % kTeamSlots) * 2 + (1 - s);
-      const long long t0 = wall_clock64();
-      for (;;) {
-        raw_t raw;
-        asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(src) : "memory");
-        v = ((unsigned long long)raw[1] << 32) | raw[0];
-        chk = ((unsigned long long)raw[3] << 32) | raw[2];
-        if ((v ^ chk) == want) break;
-        if (wall_clock64() - t0 > 2000000) {       // 20 ms at 100 MHz: give up — the grid must drain
-          dead = true;
-          v = 0;
-          if (lane == 0) atomicCAS(t.err, 0, 1);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    const double other = __builtin_bit_cast(double, v);
-    const double ax = s == 0 ? own + other : other + own;          // member order: the same sum on both members (:335)
-    const int i = row_begin + (int)seq;
-    double yn = 0.0;
-    if (i < row_end) {
-      const double b = b_in[g];
-      const double w = y_in[g] + sigma * ((1.0 + rho) * ax - rho * axp_in[g]);   // :344
-      yn = prox_conj_elem_s<double>(d.h, w, sigma, i, 0.0, b);                   // :345
-      if (tid == 0 && s == 0) {
-        const double dr = (w - yn) / sigma - ax;                                 // :347
-        e0 += dr * dr;
-        e1 += gval_elem_s<double>(d.h, ax, i, b);
-        Y[i] = yn;
-        AXP[i] = ax;                                                             // :360
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < KV; ++k)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[g][k][e], yn, acc[k][e]);
-#pragma unroll
-    for (int k = 0; k < KV; ++k)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
-  };
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int g = 0; g < G - 1; ++g) {
-    load(g, row_begin + g);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  double own_prev = dots(0, 0);                    // row 0: nothing to finish yet
-  __builtin_amdgcn_sched_barrier(0);
-  load(G - 1, row_begin + G - 1);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-  for (long long q = 1; q <= nrows; q += G) {
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const long long seq = q + u;                 // dots of row seq (slot (1 + u) % G) ; finishes row seq - 1 (slot u % G)
-      raw_t early;
-      {
-        const TeamRec* src = ring + ((seq - 1) % kTeamSlots) * 2 + (1 - s);
-        asm volatile("s_load_dwordx4 %0, %1, 0x0 glc" : "=s"(early) : "s"(src) : "memory");
-      }
-      const double own = dots((1 + u) % G, seq);
-      __builtin_amdgcn_sched_barrier(0);
-      finish(u % G, seq - 1, own_prev, early);
-      own_prev = own;
-      __builtin_amdgcn_sched_barrier(0);
-      load(u % G, row_begin + (int)(seq - 1) + G);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
-#pragma unroll
-  for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BS;
-    const int j = (v0 + lv) * 2;
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-      if (lv < nvs && j + e < d.n) out[j + e] = acc[k][e];
-  }
-  if (tid == 0 && s == 0) {
-    out[d.n] = e0;
-    out[d.n + 1] = e1;
-  }
-}
+// (rows too long for one workgroup's registers: k_team_rows<kTeamFkPd, ...>, csrc/team_rows.h — its communication wave takes
+//  the dual step of a row ONCE, where no row of A is held, and the compute waves multiply the row by y+[i])
 
 // A'y from the block partials (64 columns per block, sixteen loads in flight, fixed order) ; the dual residual and the
 // end of the iteration (:347-354) by block 0
@@ -449,10 +253,11 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   if (cols <= 7 * 768) return {768, 7, 4};
   if (cols <= 10 * 768) return {768, 10, f32 ? 4 : 2};
   if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
-  // C5's row length, 20 000 fp64, is out of reach of ONE workgroup (x, the accumulator and one row are 480 KB of a CU's
-  // 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two
-  // passes): teams of two workgroups, half a row each (k_teampd_rows) — Float64, on a part of 8 XCDs x 32 CUs
-  if (!f32 && cols <= 2 * 14 * 768 && p->ctx->num_cu == 256 && !p->teams_off) return {768, 28, 1};
+  // C5's row length, 20 000 fp64, is out of reach of ONE workgroup's row kernel (x, the accumulator and one row are 480 KB of
+  // a CU's 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two
+  // passes): k_team_rows — one workgroup with x in LDS up to 11 264 columns, teams of 2 ... 16 workgroups, a slice of every
+  // row each, up to 180 224 (csrc/team_rows.h team_plan) — Float64 ; the teams need a part of 8 XCDs x 32 CUs
+  if (!f32 && cols <= kTeamMaxCols && (p->ctx->num_cu == 256 || cols <= 2 * kTeamSingleKv * 704) && !p->teams_off) return {768, 28, 1};
   return {0, 0, 0};
 }
 
@@ -487,12 +292,14 @@ int32_t slab_pd_setup(apx_solver* s) {
   int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
   int64_t rpb = (A->m + B - 1) / B;                // dealt evenly, nothing rounded up: a block's last step may be partial
   B = (A->m + rpb - 1) / rpb;                      // (csrc/slab.hip: rounding to 16 left CUs without a block)
-  if (st->cpt == 28) {                             // teams of two: 128 slabs, ALL 256 workgroups launched (16 teams per XCD)
-    B = ctx->num_cu / 2;
+  if (st->cpt == 28) {                             // k_team_rows: slabs = teams, ALL P x B workgroups launched
+    const TeamPlan pl = team_plan(A->n);
+    st->team_p = pl.P;
+    st->team_kv = pl.kv;
+    st->team_big = pl.big;
+    B = ctx->num_cu / pl.P;
     rpb = (A->m + B - 1) / B;
-    const int64_t nvs = ((A->n + 1) / 2 + 1) / 2;  // 16-byte vectors per member
-    st->team_kv = (int)((nvs + 767) / 768);
-    const size_t ring_bytes = (size_t)B * kTeamSlots * 2 * sizeof(TeamRec);
+    const size_t ring_bytes = (size_t)B * kTeamSlots * pl.P * sizeof(TeamRec);
     APX_TRY(st->team_buf.alloc_zero(ring_bytes + 64, ctx->stream));
     st->team.ring = (TeamRec*)st->team_buf.p;
     st->team.tickets = (unsigned*)((char*)st->team_buf.p + ring_bytes);
@@ -509,6 +316,7 @@ int32_t slab_pd_setup(apx_solver* s) {
   d.ldT = A->ldT;
   d.m = (int32_t)A->m;
   d.n = (int32_t)p->n;
+  d.ncols = d.n;
   d.rows_per_block = (int32_t)rpb;
   d.Y = s->y.p;
   d.AXP = s->axprev.p;
@@ -523,34 +331,6 @@ int32_t slab_pd_setup(apx_solver* s) {
   return APX_OK;
 }
 
-// the team kernel for this row length (KV 16-byte vectors per thread and half row ; two rows in registers: with three the
-// KV = 7 shape spills, and tools/split_probe.hip measured no gain from the third — x in LDS to make room: 6.25 vs 6.27 TB/s)
-template <bool NT>
-static bool team_rows_launch(const SlabPdState* st, const SlabPdDev& d, const void* x, hipStream_t q) {
-  const dim3 grid((unsigned)(2 * st->B));
-  switch (st->team_kv) {
-    case 4: hipLaunchKernelGGL((k_teampd_rows<4, 3, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
-    case 5: hipLaunchKernelGGL((k_teampd_rows<5, 3, NT, true>), grid, dim3(768), (size_t)5 * 768 * 16, q, d, st->team, x); return true;   // (x in LDS: 60 KB)
-    case 6: hipLaunchKernelGGL((k_teampd_rows<6, 2, NT, false>), grid, dim3(768), 0, q, d, st->team, x); return true;
-    case 7: {                                      // (x of the half row in LDS: in registers the row state spills, 20 registers)
-      constexpr int lds = 7 * 768 * 2 * (int)sizeof(double);
-      // (the attribute belongs to the function ON A DEVICE: once per device of the process — the single-process group entry
-      //  point drives one context per device, each from its own host thread)
-      static std::atomic<unsigned long long> attr_devs{0};
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      const unsigned long long bit = 1ull << (dev & 63);
-      if ((attr_devs.load(std::memory_order_relaxed) & bit) == 0) {
-        (void)hipFuncSetAttribute((const void*)k_teampd_rows<7, 2, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_devs.fetch_or(bit, std::memory_order_relaxed);
-      }
-      hipLaunchKernelGGL((k_teampd_rows<7, 2, NT, true>), grid, dim3(768), lds, q, d, st->team, x);
-      return true;
-    }
-    default: return false;
-  }
-}
-
 template <typename T>
 static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x, void* aty, apx_record* recs, int64_t rec_cap,
                              hipStream_t q) {
@@ -558,10 +338,7 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
   constexpr bool f32 = sizeof(T) == 4;
   if (st->team_kv != 0) {
     if constexpr (!f32) {
-      if (st->nt) team_rows_launch<true>(st, d, x, q);
-      else team_rows_launch<false>(st, d, x, q);
-      st->team.launch += 1;                        // (tickets and sequence numbers are never reset: each launch has its own range)
-      st->team.seq0 += (unsigned long long)st->team.rows_per_team + 16;
+      team_launch<kTeamFkPd, SlabPdDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, d, st->team, x, q);
       hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
                          d, st->B, (T*)aty, recs, rec_cap);
     }

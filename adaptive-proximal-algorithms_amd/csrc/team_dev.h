@@ -1,5 +1,6 @@
 // team_dev.h — hand-off state of the workgroup TEAMS of the one-pass kernels for rows too long for one workgroup's
-// registers (csrc/slab_pd.hip k_teampd_rows: two members ; csrc/slab.hip k_team_rows: 4 / 8 / 16 members).
+// registers (csrc/team_rows.h k_team_rows: 2 / 4 / 8 / 16 members — f and its gradient, csrc/slab.hip ; the primal-dual loop,
+// csrc/slab_pd.hip).
 #pragma once
 #include <stdint.h>
 

@@ -1,0 +1,466 @@
+// team_rows.h — k_team_rows: f and grad f (csrc/slab.hip), or A x, the dual step and A' y of the primal-dual loop
+// (csrc/slab_pd.hip), from ONE read of A for Float64 rows of up to 180 224 entries — one workgroup, or teams of workgroups.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdlib>
+
+#include "solver_internal.h"
+#include "team_dev.h"
+#include "vecops_dev.h"
+
+namespace apx {
+
+struct SlabDev;
+
+// ---- what the communication wave does with a row ---------------------------------------------------------------------
+constexpr int kTeamFkPd = 100;        // FK of the primal-dual loop: A x, the dual step, y+ * A[i, :]  (csrc/slab_pd.hip)
+struct TeamRowState {                 // b[i]  /  y[i], A_x_prev[i], shift[i]
+  double a = 0.0, b = 0.0, c = 0.0;
+};
+template <int FK>
+struct TeamRowConsts {
+  double bias = 0.0, sigma = 0.0, rho = 0.0;
+  template <class DEV>
+  __device__ TeamRowConsts(const DEV& d, const void* xv) {
+    if constexpr (FK == APX_F_LOGISTIC) bias = ((const double*)xv)[d.n - 1];
+    if constexpr (FK == kTeamFkPd) {
+      sigma = d.c->sigma;             // this iteration's, set by the rule kernel before this launch
+      rho = d.c->rho;
+    }
+  }
+};
+template <int FK, class DEV>
+__device__ __forceinline__ TeamRowState team_row_state(const DEV& d, int i) {
+  TeamRowState s;
+  if constexpr (FK == kTeamFkPd) {
+    s.a = ((const double*)d.Y)[i];
+    s.b = ((const double*)d.AXP)[i];
+    s.c = d.h.has_shift ? ((const double*)d.h.shift)[i] : 0.0;
+  } else {
+    s.a = ((const double*)d.b)[i];
+  }
+  return s;
+}
+template <int FK>
+__device__ __forceinline__ void team_row_state_landed(TeamRowState& s) {
+  if constexpr (FK == kTeamFkPd) asm volatile("" : "+v"(s.a), "+v"(s.b), "+v"(s.c));      // (a use: the compiler waits for the loads)
+}
+// the value the compute waves multiply row i by ; the loss sums (every member forms them — member 0's are the ones stored)
+template <int FK, class DEV>
+__device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowConsts<FK>& kc, const TeamRowState& st, double ax, int i,
+                                                  bool writer, double& e0, double& e1) {
+  if constexpr (FK == APX_F_LEAST_SQUARES) {
+    const double res = ax - st.a;                                     // experiments/lasso/runme.jl:22
+    e0 += res * res;
+    return res;
+  } else if constexpr (FK == APX_F_LOGISTIC) {
+    const double logit = ax + kc.bias;                                // experiments/sparse_logreg/runme.jl:24-36
+    const double e = 1.0 + exp(-logit);
+    e0 += (st.a - 1.0) * logit - log(e);
+    const double res = 1.0 / e - st.a;
+    e1 += res;
+    return res;
+  } else {
+    const double w = st.a + kc.sigma * ((1.0 + kc.rho) * ax - kc.rho * st.b);      // src/AdaProx.jl:344
+    const double yn = prox_conj_elem_s<double>(d.h, w, kc.sigma, i, 0.0, st.c);    // :345
+    const double dr = (w - yn) / kc.sigma - ax;                                    // :347
+    e0 += dr * dr;
+    e1 += gval_elem_s<double>(d.h, ax, i, st.c);
+    if (writer) {
+      ((double*)d.Y)[i] = yn;
+      ((double*)d.AXP)[i] = ax;                                                    // :360
+    }
+    return yn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Rows too long for one workgroup's registers (10 753 ... 180 224 Float64 entries — BASELINE config C2: 100 000, a row is
+// 800 KB): TEAMS of P = 2 / 4 / 8 / 16 workgroups, one per CU, formed inside an XCD at run time, share a slab of rows.  Member
+// s keeps columns [s n/P, (s+1) n/P) of x (in LDS) and of the column accumulator (in registers) and streams that slice
+// of every row.  A workgroup is eleven COMPUTE waves and one COMMUNICATION wave:
+//   * the compute waves form the partial dot product of a row (one barrier per row) and, DEPTH = 2 rows later, take the
+//     row's residual from LDS and accumulate res[i] * A[i, slice] from the registers the row still sits in;
+//   * the communication wave loads no A, so its vector-memory counter is its own (loads return in order per wave: a
+//     poll or a fence in a wave that streams A waits for every load in flight and drains the pipeline — that is what
+//     round 1's probe measured as 23 - 28 us per hand-off).  It sums the workgroup's partial, publishes it (two words
+//     {value, value ^ sequence}, agent scope, no fence: the check word validates the pair), collects the P records of
+//     the row two rows back on the SCALAR path (P / 4 `s_load_dwordx16 ... glc`, from the XCD's L2, a step ahead), adds
+//     them in a fixed tree — the same `A x` on every member, no atomics on data —, evaluates the residual / the logistic
+//     link ONCE and leaves it in LDS; member 0's accumulates the loss sums.  Two rows of slack absorb the hand-off
+//     (1 - 3 us) and the slowest member.
+// Every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
+// tools/split_probe.hip, tools/pattern_probe.hip (profiles/r02_team_probe_*.log, r02_team_handoff_traffic.log): 6.6 - 6.7
+// TB/s on rows of C2's length — A read once per evaluation of f and its gradient instead of twice at 7.1 TB/s.
+// ---------------------------------------------------------------------------------------------------------------------
+// The P records of one row of a team's ring (P x 16 bytes, aligned to their size up to 64) into SGPRs: P / 4 scalar loads
+// of 64 bytes (teams of two: one of 32), glc (past
+// the scalar cache), waited for here — nothing may copy the registers before the data is in them.
+typedef unsigned raw16_t __attribute__((ext_vector_type(16)));
+template <int P>
+__device__ __forceinline__ void team_fetch(const TeamRec* row, raw16_t (&q)[(P + 3) / 4]) {
+  static_assert(P == 2 || P == 4 || P == 8 || P == 16, "teams of 2, 4, 8 or 16");
+  if constexpr (P == 2) {
+    typedef unsigned raw8_t __attribute__((ext_vector_type(8)));
+    raw8_t h;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(h) : "s"(row) : "memory");
+#pragma unroll
+    for (int c = 0; c < 8; ++c) q[0][c] = h[c];
+  } else if constexpr (P == 4)
+    asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(q[0]) : "s"(row) : "memory");
+  else if constexpr (P == 8)
+    asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(q[0]), "=&s"(q[1])
+                 : "s"(row)
+                 : "memory");
+  else
+    asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
+                 "s_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(q[0]), "=&s"(q[1]), "=&s"(q[2]), "=&s"(q[3])
+                 : "s"(row)
+                 : "memory");
+}
+
+template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2, class DEV = SlabDev>
+__global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void* xv) {
+  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;
+  static_assert(G >= DEPTH + 2 && DEPTH <= 3, "slots: DEPTH rows awaiting their residuals, one computing, one loading ; res_s has 4 entries");
+  static_assert(P > 1 || DEPTH == 1, "a workgroup on its own has its row sum one step later");
+  typedef double vec_t __attribute__((ext_vector_type(2)));
+  typedef unsigned raw_t __attribute__((ext_vector_type(4)));
+  extern __shared__ double team_x[];               // the member's slice of x: KV * 704 * 2 doubles
+  __shared__ double wsum[2][CW];
+  __shared__ double res_s[4];
+  __shared__ int ident[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (P > 1 && tid == 0) {                         // (every launch takes its 32 tickets per XCD, a finished loop's too)
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID
+    const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
+    ident[0] = k < (unsigned)(TPX * P) ? (int)(xcc * TPX + k / P) : -1;
+    ident[1] = (int)(k % P);
+    if (k >= 32u) atomicCAS(t.err, 0, 2);
+  }
+  if (P == 1 && tid == 0) {                        // P = 1: a workgroup on its own — no team to form, nothing to hand over
+    ident[0] = (int)blockIdx.x;
+    ident[1] = 0;
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
+  if (team < 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
+  const int nvec = (d.ncols + 1) / 2;
+  const int nvs = (nvec + P - 1) / P;              // 16-byte vectors per member
+  const int v0 = s * nvs;
+  const int row_begin = team * t.rows_per_team;
+  const int row_end = min(row_begin + t.rows_per_team, d.m);
+  const int nrows = max(row_end - row_begin, 0);
+  // rows past the slab are dummy rows (clamped loads, residual 0) that every member runs alike: DEPTH steps of prologue,
+  // then whole rounds of G steps — the loop body of the compute waves has no branch between a load and its use, so the
+  // waits the compiler places are counted ones and the rows in the loading slots really stay in flight
+  const int nsteps = DEPTH + (nrows + G - 1) / G * G;
+  TeamRec* ring = t.ring + (int64_t)team * kTeamSlots * P;
+  const double* __restrict__ X = (const double*)xv;
+  if (wv == CW) {
+    // ---- the communication wave -------------------------------------------------------------------------------------
+    // What it needs of a row besides `A x` — b[i] (least squares, logistic) or y[i], A_x_prev[i] and the shift of h (the
+    // primal-dual loop) — is loaded at the top of step i, BEFORE this workgroup's partial of row i is published: in the
+    // primal-dual loop member 0 overwrites y[i] and A_x_prev[i] as soon as it has all partials of row i, so a member that
+    // read them after publishing its own could see the new values.  The rows in between wait in h[0 .. DEPTH - 1].
+    TeamRowState h[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) h[j] = TeamRowState{};
+    const TeamRowConsts<FK> kc(d, xv);
+    double e0 = 0.0, e1 = 0.0;
+    bool dead = false;
+    [[maybe_unused]] double own_prev = 0.0;        // P = 1: the workgroup's own row sum, one step later
+    // The P records of a row are taken on the SCALAR path: P / 4 loads of 64 bytes (`s_load_dwordx16 ... glc`: past the
+    // scalar cache, from the XCD's L2 — the teams are formed inside an XCD, and the members' agent-scope stores pass
+    // through that L2).  Measured (tools/pattern_probe.hip, profiles/r02_team_handoff_traffic.log): agent-scope VECTOR
+    // loads of lines that other CUs keep storing to are served by the memory side, and that small read-after-write
+    // traffic alone — nothing waited for — takes the stream of A from 7.1 to 5.8 TB/s; stores alone, or loads alone, cost
+    // nothing; the same hand-off with scalar loads runs at 6.6 - 6.7.  The records of the row whose residual is due NEXT
+    // are taken a step ahead, right after this workgroup's own partial has been published.
+    raw16_t q[(P + 3) / 4];
+#pragma unroll
+    for (int c = 0; c < (P + 3) / 4; ++c) q[c] = raw16_t{};
+    auto fetch = [&](long long r) {
+      if constexpr (P > 1) team_fetch<P>(ring + (r % kTeamSlots) * P, q);
+    };
+    auto rec_word = [&](int m, int w) -> unsigned long long {        // word w (0: value, 1: check) of member m's record
+      const raw16_t& c = q[m / 4];
+      const int o = (m & 3) * 4 + w * 2;
+      return ((unsigned long long)c[o + 1] << 32) | c[o];
+    };
+    auto all_there = [&](unsigned long long want) {
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < P; ++m) ok &= (rec_word(m, 0) ^ rec_word(m, 1)) == want;
+      return ok;
+    };
+    for (long long seq = 0; seq < nsteps; ++seq) {
+      const TeamRowState snew = team_row_state<FK>(d, max(min(row_begin + (int)seq, row_end - 1), 0));
+      const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
+      if (r >= 0) {
+        const int i = row_begin + (int)r;
+        double ax;
+        if constexpr (P == 1) {
+          // a workgroup on its own: the sum of its eleven waves IS `A x` of the row — formed after the barrier of step
+          // seq, used before the barrier of step seq + 1 (DEPTH = 1)
+          ax = own_prev;
+        } else {
+          const unsigned long long want = t.seq0 + (unsigned long long)r + 1;
+          if (!all_there(want) && !dead) {         // not all there yet (or half written): poll, bounded
+            const long long t0 = wall_clock64();
+            for (;;) {
+              fetch(r);
+              if (all_there(want)) break;
+              if (wall_clock64() - t0 > 2000000) { // 20 ms at 100 MHz: give up — the grid must drain
+                dead = true;
+                if (lane == 0) atomicCAS(t.err, 0, 1);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          // the P partials added in a fixed pairwise tree, from the same P records on every member: the same `A x` bit for bit
+          double part[P];
+#pragma unroll
+          for (int m = 0; m < P; ++m) part[m] = dead ? 0.0 : __builtin_bit_cast(double, rec_word(m, 0));
+#pragma unroll
+          for (int w = 1; w < P; w <<= 1)
+#pragma unroll
+            for (int m = 0; m < P; m += 2 * w) part[m] += part[m + w];
+          ax = part[0];
+        }
+        // the residual / the logistic link / the dual step, ONCE per row, where no row of A is held (exp and log in Float64
+        // take ~50 registers: next to the rows they cost the row kernels two of their three rows in flight)
+        const double res = i < row_end ? team_row_finish<FK>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
+        if (lane == 0) res_s[r & 3] = res;
+      }
+#pragma unroll
+      for (int j = 0; j + 1 < DEPTH; ++j) h[j] = h[j + 1];
+      h[DEPTH - 1] = snew;
+      __syncthreads();                             // the barrier of step seq
+      double own = lane < CW ? wsum[seq & 1][lane] : 0.0;            // after it: this workgroup's partial of row seq,
+#pragma unroll                                                        // the eleven waves' sums in a fixed tree
+      for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
+      if constexpr (P == 1) {
+        own_prev = own;
+      } else {
+        team_row_state_landed<FK>(h[DEPTH - 1]);   // (the primal-dual loop: the row's state is HERE before the partial goes out)
+        if (lane == 0) {
+          const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
+          TeamRec* rec = ring + (seq % kTeamSlots) * P + s;
+          __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&rec->chk, bits ^ (t.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (r + 1 >= 0) fetch(r + 1);
+      }
+    }
+    if (lane == 0 && s == 0) {
+      double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
+      out[d.ncols] = e0;
+      out[d.ncols + 1] = e1;
+    }
+    return;
+  }
+  // ---- the compute waves ----------------------------------------------------------------------------------------------
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      team_x[lv * 2 + e] = (lv < nvs && j + e < d.ncols) ? X[j + e] : 0.0;     // (each thread reads back only what it wrote)
+      acc[k][e] = 0.0;
+    }
+  }
+  const int voff = tid * 16;
+  const int64_t cbase = (int64_t)v0 * 16;
+  const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * 8 - cbase));      // (rows are zero-padded to whole vectors)
+  const double* __restrict__ AT = (const double*)d.AT;
+  vec_t a[G][KV];
+  auto load = [&](int g, int row) {
+    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
+      a[g][k] = __builtin_bit_cast(vec_t, raw);
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, row_begin + g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the dots of the row in slot g (step seq) and the barrier behind them
+  auto dots = [&](int g, long long seq) {
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) p = fma(a[g][k][e], team_x[(tid + k * BSC) * 2 + e], p);
+#pragma unroll                                     // (a butterfly: EVERY lane ends with the wave's sum, so all of them store
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);      //  it and the loop body has no branch)
+    wsum[seq & 1][wv] = p;                         // (double-buffered by row parity: one barrier per row)
+    __syncthreads();
+  };
+  // steps 0 .. DEPTH - 1: nothing to accumulate yet ; the last of them fills slot G - 1, which the prologue left empty
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
+    dots(u, u);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u == DEPTH - 1) load(G - 1, row_begin + G - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // step seq >= DEPTH: the dots of row seq (slot seq % G) ; the barrier ; row seq - DEPTH (slot (seq - DEPTH) % G)
+  // accumulated and its slot re-loaded with row seq - DEPTH + G.  Unrolled G times: every slot index is a constant.
+#pragma unroll 1
+  for (long long q = DEPTH; q < nsteps; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const long long seq = q + u;
+      const long long r = seq - DEPTH;
+      dots((DEPTH + u) % G, seq);
+      const double rr = res_s[r & 3];
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[u][k][e], rr, acc[k][e]);      // (slot of row r: (seq - DEPTH) % G = u)
+#pragma unroll                                     // (the sums are complete HERE: see k_slab_rows)
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+      __builtin_amdgcn_sched_barrier(0);
+      load(u, row_begin + (int)(r + G));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (lv < nvs && j + e < d.ncols) out[j + e] = acc[k][e];
+  }
+}
+
+
+// ---- host side: the plan for a row length, and the launch ----------------------------------------------------------------
+constexpr int kTeamSingleKv = 8;      // one workgroup / the three-slot shape: up to 8 vectors per compute thread
+constexpr int64_t kTeamMaxCols = (int64_t)16 * kTeamSingleKv * 704 * 2;      // 180 224 Float64 columns
+
+struct TeamPlan {
+  int P = 0, kv = 0;                  // members ; 16-byte vectors per compute thread and row of a member's slice
+  bool big = false;                   // seven or eight vectors: three row slots, ONE row of slack
+};
+// One workgroup where the row fits its eight vectors per thread (three row slots, nothing to hand over).  Else the members'
+// slices as large as the registers allow, because a step costs a barrier and a hand-off whatever its bytes:
+//   up to six vectors per thread with four row slots and TWO rows of slack for the hand-off (168 registers), or
+//   seven or eight with three slots and ONE row of slack — which teams of two and four absorb (a step is 60 - 90 KB per
+//   member: tools/pattern_probe.hip, 6.6 and 6.9 TB/s) but teams of eight and sixteen do not (6.2 and 5.5 against 6.6 with
+//   two rows of slack) ; sixteen members take it only beyond 135 168 columns, where the alternative is two passes.
+inline TeamPlan team_plan(int64_t ncols) {
+  const int64_t nvec = (ncols + 1) / 2, v6 = 6 * 704, v8 = (int64_t)kTeamSingleKv * 704;
+  TeamPlan pl;
+  pl.P = 16;
+  if (nvec <= v8) pl.P = 1;
+  else if (nvec <= 2 * v6) pl.P = 2;
+  else if (nvec <= 2 * v8) pl.P = 2, pl.big = true;
+  else if (nvec <= 4 * v6) pl.P = 4;
+  else if (nvec <= 4 * v8) pl.P = 4, pl.big = true;
+  else if (nvec <= 8 * v6) pl.P = 8;
+  else if (nvec <= 16 * v6) pl.P = 16;
+  else pl.big = true;
+  pl.kv = (int)(((nvec + pl.P - 1) / pl.P + 703) / 704);
+  return pl;
+}
+
+// (the dynamic-LDS attribute belongs to the function ON A DEVICE: once per device of the process — csrc/small_dev.h)
+template <auto KERNEL>
+inline void team_allow_lds() {
+  static std::atomic<unsigned long long> done_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if ((done_devs.load(std::memory_order_relaxed) & bit) == 0) {
+    if (hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) (void)hipGetLastError();
+    done_devs.fetch_or(bit, std::memory_order_relaxed);
+  }
+}
+// (APX_TEAM_FAULT_GRID: a TEST hook — launches that many workgroups instead of all of them, so that some teams miss members:
+//  what a GPU shared with other work does to this scheme.  tests/test_gpu_team_fault.py checks that the waits time out,
+//  the grid drains and the error comes back)
+inline unsigned team_grid(int nteams, int P) {
+  static const int fault_grid = getenv("APX_TEAM_FAULT_GRID") ? atoi(getenv("APX_TEAM_FAULT_GRID")) : 0;
+  return (unsigned)(fault_grid > 0 && P > 1 ? fault_grid : nteams * P);
+}
+template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV>
+inline void team_launch_one(int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+  constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);      // the slice of x
+  if constexpr (lds > 48 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>>();
+  hipLaunchKernelGGL((k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>), dim3(team_grid(nteams, P)), dim3(768), lds, q, d, t, x);
+}
+// four row slots, two rows of slack: 2 ... 6 vectors
+// (measured and dropped at C2, interleaved runs of bench.py: five and six slots, two or three rows of slack, one to three rows
+//  really in flight — nothing ; profiles/r02_team_handoff_traffic.log has what the gap to the streaming rate was instead)
+template <int FK, int P, class DEV>
+inline bool team_launch_d2(int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+  switch (kv) {
+    case 1:
+    case 2: team_launch_one<FK, P, 2, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
+    case 3: team_launch_one<FK, P, 3, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
+    case 4: team_launch_one<FK, P, 4, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
+    case 5: team_launch_one<FK, P, 5, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
+    case 6: team_launch_one<FK, P, 6, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
+    default: return false;
+  }
+}
+// three row slots, one row of slack: 7 or 8 vectors (a workgroup on its own: 4 ... 8, non-temporal loads by the matrix size)
+template <int FK, int P, bool NT, class DEV>
+inline bool team_launch_d1(int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+  switch (kv) {
+    case 7: team_launch_one<FK, P, 7, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
+    case 8: team_launch_one<FK, P, 8, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
+    default: break;
+  }
+  if constexpr (P == 1) {
+    switch (kv) {
+      case 1:
+      case 2:
+      case 3:
+      case 4: team_launch_one<FK, 1, 4, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
+      case 5: team_launch_one<FK, 1, 5, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
+      case 6: team_launch_one<FK, 1, 6, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
+      default: break;
+    }
+  }
+  return false;
+}
+// the launch of a plan ; advances the launch's ranges of tickets and sequence numbers (never reset)
+template <int FK, class DEV>
+inline bool team_launch(const TeamPlan& pl, int nteams, bool nt, const DEV& d, TeamDev& t, const void* x, hipStream_t q) {
+  bool ok = false;
+  if (pl.P == 1) ok = nt ? team_launch_d1<FK, 1, true, DEV>(pl.kv, nteams, d, t, x, q) : team_launch_d1<FK, 1, false, DEV>(pl.kv, nteams, d, t, x, q);
+  else if (pl.big) {
+    if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV>(pl.kv, nteams, d, t, x, q);
+    else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV>(pl.kv, nteams, d, t, x, q);
+    else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV>(pl.kv, nteams, d, t, x, q);
+  } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV>(pl.kv, nteams, d, t, x, q);
+  else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV>(pl.kv, nteams, d, t, x, q);
+  else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV>(pl.kv, nteams, d, t, x, q);
+  else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV>(pl.kv, nteams, d, t, x, q);
+  t.launch += 1;
+  t.seq0 += (unsigned long long)t.rows_per_team + 16;
+  return ok;
+}
+
+}  // namespace apx

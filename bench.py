@@ -265,7 +265,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
         raise RuntimeError("C5 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
     out["C5"] = report(m, n, 8, 200, dt, st, res,
                        "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip)",
-                       "k_teampd_rows + k_slabpd_close")
+                       "k_team_rows (the primal-dual form: csrc/team_rows.h) + k_slabpd_close")
     out["C5"]["workload"] = "least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50000x20000 fp64 (Ax / A'y pair + conj-prox)"
     s.close()
     p.A.free()

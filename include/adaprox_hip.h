@@ -239,7 +239,8 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *   - the same one pass for Float64 rows too long for one workgroup's registers, by TEAMS of workgroups that split the
  *     columns of a slab of rows and hand their partial dot products over through L2: f and grad f for rows of
  *     10 753 ... 180 224 entries (teams of 2 / 4 / 8 / 16: BASELINE config C2's 100 000 — csrc/slab.hip k_team_rows), the
- *     primal-dual form for 10 753 ... 21 504 (teams of two: C5's 20 000 — csrc/slab_pd.hip k_teampd_rows).  These need
+ *     primal-dual loop for the same lengths with the dual step in the kernel's communication wave (C5's 20 000: teams of
+ *     two — csrc/team_rows.h).  The teams need
  *     the part's 8 XCDs x 32 CUs to themselves (all 256 workgroups of a launch resident together): every hand-off wait is
  *     bounded (20 ms); after a timed-out one the one-shot solver entry points repeat the solve on the two GEMV passes and
  *     keep the problem on them (not for a row shard: a rank restarting alone would leave its peers' sequence of

@@ -194,14 +194,18 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              (9001, 1900, "tbox", np.float32),
                                              (140000, 200, "tl1", np.float32),     # long slabs: two row groups in flight
                                              (17000, 6000, "tl1", np.float32),     # > 384 MB: non-temporal loads
-                                             # rows of 10 753 ... 21 504 Float64 entries: TEAMS of two workgroups, half a row
-                                             # each, partial dot products handed over through the XCD's L2 (k_teampd_rows) —
-                                             # KV = 4 (default-policy loads: < 384 MB), 5, 6, 7 ; 20 000 is BASELINE config C5's row
+                                             # rows of more than 10 752 Float64 entries: k_team_rows with the dual step in its
+                                             # communication wave (one workgroup to 11 264 columns, then teams) ; 20 000 is
+                                             # BASELINE config C5's row (teams of two, eight vectors, one row of slack)
                                              (4100, 11000, "tl1", np.float64),
                                              (4200, 15001, "tbox", np.float64),
                                              (4099, 18000, "tl1", np.float64),
                                              (4100, 20000, "tl1", np.float64),
-                                             (4097, 21504, "tl1", np.float64)])
+                                             (4097, 21504, "tl1", np.float64),
+                                             # ... and beyond, since the loop shares k_team_rows with f's gradient: teams of 4, 8, 16
+                                             (4100, 30000, "tl1", np.float64),
+                                             (4099, 60001, "tbox", np.float64),
+                                             (4098, 150000, "tl1", np.float64)])
 def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))

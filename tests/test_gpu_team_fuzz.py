@@ -1,5 +1,5 @@
-"""Ragged shapes for the team kernels (csrc/slab.hip k_team_rows: 4 / 8 / 16 workgroups per slab ; csrc/slab_pd.hip
-k_teampd_rows: two): row counts that do not divide by the number of teams (down to 64 rows per team), odd column counts, slice boundaries at the edges of the KV vectors per thread, the boundaries between team sizes.
+"""Ragged shapes for the team kernel (csrc/team_rows.h k_team_rows: one workgroup, or 2 / 4 / 8 / 16 per slab of rows — f and
+its gradient, csrc/slab.hip ; the primal-dual loop, csrc/slab_pd.hip): row counts that do not divide by the number of teams (down to 64 rows per team), odd column counts, slice boundaries at the edges of the KV vectors per thread, the boundaries between team sizes.
 Matrices are generated on the device; the one-pass run is compared with the two GEMV passes on the same data (fp64: the two
 differ by summation order only) and its first evaluation with values recomputed on the CPU from spot rows and columns."""
 import importlib
@@ -103,7 +103,10 @@ def test_team_rows_ragged_shapes(apx, m, n, logistic):
 
 
 # two-member teams: 10 753 ... 21 504 columns, KV = ceil(n / 4 / 768)
-PD_SHAPES = [(4096, 10753), (4097, 12289), (4099, 15361), (4098, 18433), (4500, 21503), (4096, 21504), (6007, 19999)]
+PD_SHAPES = [(4096, 10753), (4097, 12289), (4099, 15361), (4098, 18433), (4500, 21503), (4096, 21504), (6007, 19999),
+             # the primal-dual loop on k_team_rows (round 2, last): every boundary of csrc/team_rows.h team_plan, and the longest row
+             (4100, 11264), (4099, 11265), (4100, 16896), (4101, 16897), (4100, 22528), (4097, 22529), (4098, 33793), (4098, 45057),
+             (4100, 67585), (4100, 135169), (4097, 180223)]
 
 
 @pytest.mark.parametrize("m,n", PD_SHAPES)
