@@ -251,13 +251,15 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   // (between five columns of 1024 threads and fourteen of 768: seven and ten — a row of 5200 entries kept 37 % of the
   //  fourteen-column shape's lanes busy, 3.6 TB/s ; tools/shape_sweep.py)
   if (cols <= 7 * 768) return {768, 7, 4};
+  // Float64 rows beyond that: k_team_rows (csrc/team_rows.h), whose slice width adapts to the row — one workgroup with x in LDS
+  // up to 11 264 columns (6.2 - 6.9 TB/s throughout ; the ten / fourteen-column shapes below leave a sawtooth — 5400: 4.9,
+  // 7700: 5.0 — and stay for Float32), teams of 2 ... 16 workgroups, a slice of every row each, up to 180 224 ; the teams
+  // need a part of 8 XCDs x 32 CUs
+  if (!f32 && cols <= kTeamMaxCols && (p->ctx->num_cu == 256 || cols <= 2 * kTeamSingleKv * 704) && !p->teams_off) return {768, 28, 1};
   if (cols <= 10 * 768) return {768, 10, f32 ? 4 : 2};
   if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
-  // C5's row length, 20 000 fp64, is out of reach of ONE workgroup's row kernel (x, the accumulator and one row are 480 KB of
-  // a CU's 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two
-  // passes): k_team_rows — one workgroup with x in LDS up to 11 264 columns, teams of 2 ... 16 workgroups, a slice of every
-  // row each, up to 180 224 (csrc/team_rows.h team_plan) — Float64 ; the teams need a part of 8 XCDs x 32 CUs
-  if (!f32 && cols <= kTeamMaxCols && (p->ctx->num_cu == 256 || cols <= 2 * kTeamSingleKv * 704) && !p->teams_off) return {768, 28, 1};
+  // (C5's row length, 20 000 fp64, is out of reach of ONE workgroup's row kernel: x, the accumulator and one row are 480 KB of
+  //  a CU's 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two passes)
   return {0, 0, 0};
 }
 

@@ -187,6 +187,8 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              (4100, 4000, "tl1", np.float32),      # 4
                                              (4098, 5000, "tl1", np.float64),      # 5
                                              (4100, 5300, "tl1", np.float64),      # 7 (768 threads)
+                                             (4100, 6000, "tl1", np.float64),      # k_team_rows, one workgroup, 5 vectors
+                                             (4099, 9000, "tbox", np.float64),     # ... 7 vectors
                                              (4099, 7000, "tbox", np.float32),     # 10
                                              (4101, 7680, "tl1", np.float64),
                                              (4097, 9000, "tl1", np.float64),      # 14, two rows per step
