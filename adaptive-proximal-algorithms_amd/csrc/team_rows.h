@@ -239,10 +239,12 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         const double res = i < row_end ? team_row_finish<FK>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
         if (lane == 0) res_s[r & 3] = res;
       }
+      __syncthreads();                             // the barrier of step seq
+      // (the loads of snew are consumed only HERE, behind the barrier: a use before it would make this wave wait for them
+      //  — a round trip to memory — while the compute waves wait for this wave)
 #pragma unroll
       for (int j = 0; j + 1 < DEPTH; ++j) h[j] = h[j + 1];
       h[DEPTH - 1] = snew;
-      __syncthreads();                             // the barrier of step seq
       double own = lane < CW ? wsum[seq & 1][lane] : 0.0;            // after it: this workgroup's partial of row seq,
 #pragma unroll                                                        // the eleven waves' sums in a fixed tree
       for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
