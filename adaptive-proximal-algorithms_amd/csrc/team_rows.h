@@ -200,7 +200,8 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       return ok;
     };
     for (long long seq = 0; seq < nsteps; ++seq) {
-      const TeamRowState snew = team_row_state<FK>(d, max(min(row_begin + (int)seq, row_end - 1), 0));
+      TeamRowState snew{};
+      if constexpr (FK == kTeamFkPd) snew = team_row_state<FK>(d, max(min(row_begin + (int)seq, row_end - 1), 0));
       const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
       if (r >= 0) {
         const int i = row_begin + (int)r;
@@ -240,24 +241,34 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         if (lane == 0) res_s[r & 3] = res;
       }
       __syncthreads();                             // the barrier of step seq
-      // (the loads of snew are consumed only HERE, behind the barrier: a use before it would make this wave wait for them
-      //  — a round trip to memory — while the compute waves wait for this wave)
-#pragma unroll
-      for (int j = 0; j + 1 < DEPTH; ++j) h[j] = h[j + 1];
-      h[DEPTH - 1] = snew;
       double own = lane < CW ? wsum[seq & 1][lane] : 0.0;            // after it: this workgroup's partial of row seq,
 #pragma unroll                                                        // the eleven waves' sums in a fixed tree
       for (int off = 1; off < 16; off <<= 1) own += __shfl_xor(own, off, 64);
       if constexpr (P == 1) {
         own_prev = own;
       } else {
-        team_row_state_landed<FK>(h[DEPTH - 1]);   // (the primal-dual loop: the row's state is HERE before the partial goes out)
+        // (only the primal-dual loop must have the row's state before it publishes ; for b[i] see below)
+        if constexpr (FK == kTeamFkPd) team_row_state_landed<FK>(snew);
         if (lane == 0) {
           const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
           TeamRec* rec = ring + (seq % kTeamSlots) * P + s;
           __hip_atomic_store(&rec->v, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&rec->chk, bits ^ (t.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+      }
+      if constexpr (FK == kTeamFkPd) {
+#pragma unroll
+        for (int j = 0; j + 1 < DEPTH; ++j) h[j] = h[j + 1];
+        h[DEPTH - 1] = snew;
+      } else {
+        // b[i] is read-only: it is taken HERE, behind the publication of the partial and a step ahead of its use, for the row
+        // whose residual is due next.  (Taken at the top of the step — the order the primal-dual loop needs — the same load
+        // cost C2 3 % of its iterations, measured three times over against the build before: the wait for it, which the
+        // in-order return per wave extends to the acknowledgement of the stores in front of it, then falls between a
+        // step's records and its barrier.)
+        if (r + 1 >= 0) h[0] = team_row_state<FK>(d, max(min(row_begin + (int)(r + 1), row_end - 1), 0));
+      }
+      if constexpr (P > 1) {
         if (r + 1 >= 0) fetch(r + 1);
       }
     }
@@ -408,7 +419,7 @@ inline unsigned team_grid(int nteams, int P) {
 template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV>
 inline void team_launch_one(int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);      // the slice of x
-  if constexpr (lds > 48 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>>();
+  if constexpr (lds > 64 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>>();
   hipLaunchKernelGGL((k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>), dim3(team_grid(nteams, P)), dim3(768), lds, q, d, t, x);
 }
 // four row slots, two rows of slack: 2 ... 6 vectors
