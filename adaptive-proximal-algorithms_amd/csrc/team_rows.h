@@ -213,11 +213,15 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         } else {
           const unsigned long long want = t.seq0 + (unsigned long long)r + 1;
           if (!all_there(want) && !dead) {         // not all there yet (or half written): poll, bounded
+            // Bounded twice over: 20 ms of wall clock AND 4096 polls.  The clock alone would also expire in a wave that was
+            // merely descheduled in the middle of a poll — a queue preempted for another process's work has all its waves saved
+            // and restored, the clock running on — and a partner that is only late would pass for a missing one.
             const long long t0 = wall_clock64();
+            int polls = 0;
             for (;;) {
               fetch(r);
               if (all_there(want)) break;
-              if (wall_clock64() - t0 > 2000000) { // 20 ms at 100 MHz: give up — the grid must drain
+              if (++polls > 4096 && wall_clock64() - t0 > 2000000) {      // (20 ms at 100 MHz: give up — the grid must drain)
                 dead = true;
                 if (lane == 0) atomicCAS(t.err, 0, 1);
                 break;
