@@ -1,4 +1,4 @@
-"""Soak of the team kernels: tens of thousands of launches of k_team_rows (C2's shape) and k_teampd_rows (C5's) in one
+"""Soak of the team kernels: tens of thousands of launches of k_team_rows (C2's shape) and k_team_rows in its primal-dual form (C5's) in one
 process — sequence numbers, ring re-use and the per-XCD tickets run far past their first wrap of the 8-slot rings; any
 timed-out hand-off raises (the error word is read with every poll and with the result).  Prints one JSON line per leg."""
 import json
@@ -58,7 +58,7 @@ def leg_c5(iters):
         res_hist.append((res.objective, res.norm_res))
     dt = time.perf_counter() - t0
     assert np.all(np.isfinite(x)) and np.all(np.isfinite(y))
-    print(json.dumps({"leg": "C5 k_teampd_rows", "iterations": int(res.numit), "seconds": dt, "it_per_s": iters / dt,
+    print(json.dumps({"leg": "C5 k_team_rows (primal-dual)", "iterations": int(res.numit), "seconds": dt, "it_per_s": iters / dt,
                       "objective_norm_res_every_5000": res_hist}), flush=True)
     s.close()
     p.A.free()
