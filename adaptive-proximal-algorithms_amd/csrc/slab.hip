@@ -468,6 +468,8 @@ struct SlabShape {
 };
 static SlabShape slab_shape(const apx_problem* p) {
   const int64_t cols = p->A_f->n;
+  if (cols <= 1024) return {1024, 1, kSlabRows};      // (one column per thread, 32 rows per step: with two, half the loads of such a row are clamped away)
+  if (cols <= 2 * 768) return {768, 2, kSlabRows};    // (1025 ... 1536 entries: two columns of 768 threads keep more lanes busy than of 1024)
   if (cols <= 2 * 1024) return {1024, 2, kSlabRows};
   // (three and four columns per thread: with five, a row of 2100 entries keeps 420 of the 1024 lanes busy — 3.8 TB/s against
   //  6.5 for 2000 entries on the two-column kernel ; measured, tools/shape_bench.py)
@@ -528,7 +530,7 @@ static int32_t slab_setup(apx_problem* p) {
   st->bs = sh.bs;
   // as many blocks as fit the chip at once — one per CU, two of the two-columns-per-thread kind (~58 VGPRs): rows in
   // contiguous slabs, a multiple of the step ; fewer blocks = fewer partial vectors for the closing kernel
-  int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
+  int64_t B = (int64_t)ctx->num_cu * (st->cpt <= 2 ? 2 : 1);
   // rows dealt evenly: a block's last step may be partial (rows past its slab are clamped and weigh nothing), so nothing
   // is rounded up — rounding to 16 left 6 of C3's 256 CUs without a block
   const int64_t rpb = (A->m + B - 1) / B;
@@ -582,7 +584,7 @@ static int32_t slab_setup(apx_problem* p) {
   // 87 us ; from 512 MB on they win, 121 vs 130) ; two row groups in flight pay from ~16 steps per block on (their
   // prologue and the doubled barrier count cost more than the overlap gains on a short slab)
   st->nt = (int64_t)A->m * A->n * (int64_t)dtype_size(p->dtype) >= ((int64_t)384 << 20);
-  const int rows_per_step = st->cpt == 2 ? 16 : kSlabRows;
+  const int rows_per_step = st->cpt == 1 ? 32 : st->cpt == 2 ? 16 : kSlabRows;
   st->pipe = rpb / rows_per_step >= 16;
   st->dev = d;
   p->slab = st.release();
@@ -646,7 +648,9 @@ static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* 
   }
   constexpr int R14 = sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2);
   constexpr bool kPipeOk = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;       // (the others spill as two groups)
-  if (st->cpt == 2) slab_rows_launch<T, FK, 2, 16, 1024, kPipeOk>(st, grid, q, d, x);
+  if (st->cpt == 1) slab_rows_launch<T, FK, 1, 32, 1024, kPipeOk>(st, grid, q, d, x);
+  else if (st->cpt == 2 && st->bs == 768) slab_rows_launch<T, FK, 2, 16, 768, kPipeOk>(st, grid, q, d, x);
+  else if (st->cpt == 2) slab_rows_launch<T, FK, 2, 16, 1024, kPipeOk>(st, grid, q, d, x);
   else if (st->cpt == 3) slab_rows_launch<T, FK, 3, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
   else if (st->cpt == 4) slab_rows_launch<T, FK, 4, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
   else if (st->cpt == 5) slab_rows_launch<T, FK, 5, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);

@@ -244,6 +244,8 @@ struct SlabPdShape {
 static SlabPdShape slab_pd_shape(const apx_problem* p) {
   const int64_t cols = p->A_lin->n;
   const bool f32 = p->dtype == APX_F32;
+  if (cols <= 1024) return {1024, 1, 4};           // (one column per thread, sixteen rows per step — 32 spill here: csrc/slab.hip slab_shape)
+  if (cols <= 2 * 768) return {768, 2, 4};         // (1025 ... 1536 entries: csrc/slab.hip slab_shape)
   if (cols <= 2 * 1024) return {1024, 2, 4};
   if (cols <= 3 * 1024) return {1024, 3, 4};       // (three / four columns per thread: csrc/slab.hip slab_shape, measured)
   if (cols <= 4 * 1024) return {1024, 4, 4};
@@ -294,7 +296,7 @@ int32_t slab_pd_setup(apx_solver* s) {
   st->cpt = sh.cpt;
   st->bs = sh.bs;
   st->rows = sh.rows;
-  int64_t B = (int64_t)ctx->num_cu * (st->cpt == 2 ? 2 : 1);
+  int64_t B = (int64_t)ctx->num_cu * (st->cpt <= 2 ? 2 : 1);
   int64_t rpb = (A->m + B - 1) / B;                // dealt evenly, nothing rounded up: a block's last step may be partial
   B = (A->m + rpb - 1) / rpb;                      // (csrc/slab.hip: rounding to 16 left CUs without a block)
   if (st->cpt == 28) {                             // k_team_rows: slabs = teams, ALL P x B workgroups launched
@@ -355,7 +357,9 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
   // (from ~16 steps per block on, as in csrc/slab.hip ; non-temporal loads for a matrix beyond the Infinity Cache: st->nt)
   const bool pipe = f32 && d.rows_per_block / 16 >= 16;
   if (st->nt) {
-    if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, true>), grid, dim3(1024), 0, q, d, x);
+    if (st->cpt == 1) hipLaunchKernelGGL((k_slabpd_rows<T, 1, 16, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 2 && st->bs == 768) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 768, false, true>), grid, dim3(768), 0, q, d, x);
+    else if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, true>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 3) hipLaunchKernelGGL((k_slabpd_rows<T, 3, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 4) hipLaunchKernelGGL((k_slabpd_rows<T, 4, 4, 1024, false, true>), grid, dim3(1024), 0, q, d, x);
@@ -364,7 +368,9 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
     else if (st->cpt == 10) hipLaunchKernelGGL((k_slabpd_rows<T, 10, (f32 ? 4 : 2), 768, false, true>), grid, dim3(768), 0, q, d, x);
     else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, true>), grid, dim3(768), 0, q, d, x);
   } else {
-    if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, false>), grid, dim3(1024), 0, q, d, x);
+    if (st->cpt == 1) hipLaunchKernelGGL((k_slabpd_rows<T, 1, 16, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
+    else if (st->cpt == 2 && st->bs == 768) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 768, false, false>), grid, dim3(768), 0, q, d, x);
+    else if (st->cpt == 2 && pipe) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, f32, false>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 2) hipLaunchKernelGGL((k_slabpd_rows<T, 2, 16, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 3) hipLaunchKernelGGL((k_slabpd_rows<T, 3, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);
     else if (st->cpt == 4) hipLaunchKernelGGL((k_slabpd_rows<T, 4, 4, 1024, false, false>), grid, dim3(1024), 0, q, d, x);

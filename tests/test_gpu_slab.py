@@ -21,7 +21,13 @@ def _rel(a, b):
 
 
 # (the path starts at 192 MB of A by default — its measured break-even ; the contexts below lower that to 16 MB)
-@pytest.mark.parametrize("m,n,logistic,dtype", [(8500, 1000, False, np.float64),      # 2 columns per thread
+@pytest.mark.parametrize("m,n,logistic,dtype", [(8500, 1000, False, np.float64),      # 1 column per thread, 32 rows per step
+                                                (8600, 1024, True, np.float64),
+                                                (8700, 600, False, np.float32),
+                                                (9000, 900, True, np.float32),
+                                                (8500, 1300, False, np.float64),      # 2 columns per thread, 768 threads
+                                                (8600, 1536, True, np.float32),
+                                                (8500, 2000, False, np.float64),      # 2 columns per thread, 1024 threads
                                                 (4097, 2049, True, np.float64),       # 5 columns per thread, ragged rows
                                                 (4200, 5120, False, np.float64),
                                                 (4100, 3000, False, np.float64),      # 3 columns per thread
@@ -182,7 +188,10 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
 # ---------------------------------------------------------------------------------------
 # the primal-dual loop: A x, the dual step and A' y in one pass over A (csrc/slab_pd.hip)
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("m,n,hkind,dtype", [(9000, 1000, "tl1", np.float64),      # 2 columns per thread
+@pytest.mark.parametrize("m,n,hkind,dtype", [(9000, 1000, "tl1", np.float64),      # 1 column per thread
+                                             (9000, 700, "tbox", np.float32),
+                                             (9100, 1300, "tl1", np.float64),      # 2 columns per thread, 768 threads
+                                             (9000, 1800, "tl1", np.float64),      # 2 columns per thread, 1024 threads
                                              (4099, 2100, "tbox", np.float64),     # 3
                                              (4100, 4000, "tl1", np.float32),      # 4
                                              (4098, 5000, "tl1", np.float64),      # 5
