@@ -502,10 +502,10 @@ static bool slab_shape_ok(const apx_problem* p) {
   // passes: 8300 x 1024 (65 MB) 59 / 49 us, 16 384 x 1024 (128 MB) 77 / 72, 32 768 x 1024 (256 MB) 105 / 118,
   // 8300 x 4096 (259 MB) 77 / 107, 16 384 x 8192 (1 GB) 239 / 343
   if ((double)p->A_f->m * (double)p->A_f->n * (double)p->es() < (double)p->ctx->one_pass_min_bytes) return false;
-  // rows of fewer than 320 entries: each lane loads ONE element per row here, and most of a 1024-thread block idles — the
-  // two passes are as fast or faster (measured at 6 GB, one pass / two passes: n = 130 7.7 / 7.0 ms, 200 5.1 / 4.9,
-  // 300 3.60 / 3.63, 450 2.6 / 2.9 ; tools/shape_sweep.py)
-  if (p->A_f->n < 320) return false;
+  // (very short rows: with two columns per thread and sixteen rows per step the two passes were as fast or faster below 320
+  //  entries — 130: 7.7 against 7.0 ms at 6 GB ; the one-column shape with 32 rows per step reversed that: 130: 4.4, 200: 3.0,
+  //  300: 2.1 ms against 7.0, 4.9, 3.6 — tools/shape_sweep.py.  Below ~125 columns the tall-skinny family takes over.)
+  if (p->A_f->n < 128) return false;
   return p->A_f->m >= 4096 && p->A_f->m < ((int64_t)1 << 30) && slab_shape(p).bs != 0;
 }
 

@@ -271,9 +271,9 @@ static bool slab_pd_shape_ok(const apx_problem* p) {
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   if (p->hd.kind == APX_G_L2) return false;        // (its conjugate prox needs a norm over all rows first)
   if ((double)p->A_lin->m * (double)p->A_lin->n * (double)p->es() < (double)p->ctx->one_pass_min_bytes) return false;   // (see slab.hip)
-  // rows of fewer than 512 entries: one element per lane and load, most of a 1024-thread block idle — the two passes are
-  // faster (measured at 6 GB, one pass / two passes: n = 130 8.8 / 7.0 ms, 300 4.1 / 3.7, 450 2.90 / 2.82, 600 2.30 / 2.69)
-  if (p->A_lin->n < 512) return false;
+  // (very short rows: with two columns per thread the two passes were faster below 512 entries — 130: 7.0 against 8.8 ms at
+  //  6 GB ; with one column per thread and sixteen rows per step: 130: 5.5, 200: 3.6, 450: 1.9 ms against 7.0, 4.9, 2.8)
+  if (p->A_lin->n < 128) return false;
   return p->A_lin->m >= 4096 && p->A_lin->m < ((int64_t)1 << 30) && slab_pd_shape(p).bs != 0;
 }
 

@@ -40,8 +40,8 @@ def _rel(a, b):
                                                 (4099, 10239, True, np.float32),      # 10 columns per thread (fp32 only)
                                                 (4100, 10240, False, np.float32),
                                                 # long slabs (>= 16 steps per block): two row groups in flight
-                                                (140000, 320, False, np.float32),
-                                                (140000, 400, False, np.float64),
+                                                (140000, 200, False, np.float32),
+                                                (140000, 300, False, np.float64),
                                                 (20000, 2500, True, np.float32),
                                                 (17000, 6000, False, np.float32),     # ... and > 384 MB: non-temporal loads
                                                 # BASELINE config C3's own kernel: fp32 logistic, 14 columns per thread, four rows
@@ -203,7 +203,7 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              (4097, 9000, "tl1", np.float64),      # 14, two rows per step
                                              (4100, 10752, "tl1", np.float32),     # 14, four rows per step
                                              (9001, 1900, "tbox", np.float32),
-                                             (140000, 512, "tl1", np.float32),     # long slabs: two row groups in flight
+                                             (140000, 200, "tl1", np.float32),     # long slabs: two row groups in flight
                                              (17000, 6000, "tl1", np.float32),     # > 384 MB: non-temporal loads
                                              # rows of more than 10 752 Float64 entries: k_team_rows with the dual step in its
                                              # communication wave (one workgroup to 11 264 columns, then teams) ; 20 000 is
