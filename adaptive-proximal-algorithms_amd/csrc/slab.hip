@@ -35,6 +35,7 @@
 namespace apx {
 
 constexpr int kSlabTeamCpt = 99;      // SlabShape::cpt of the team kernel
+constexpr int kSlabMultiCpt = 98;     // ... of the H-rows-per-step kernel for short Float64 rows (csrc/team_rows.h k_multi_rows)
 constexpr int kSlabRows = 4;          // rows per step (two columns per thread: 16 ; fourteen fp64 columns: 2, or 1 with the logistic link)
 
 struct SlabDev {
@@ -468,6 +469,14 @@ struct SlabShape {
 };
 static SlabShape slab_shape(const apx_problem* p) {
   const int64_t cols = p->A_f->n;
+  // Float64 rows of up to 5632 entries: k_multi_rows (csrc/team_rows.h) — 16-byte loads, H rows per step, the residual / the
+  // link of the H rows in the lanes of a row wave that holds no row of A.  Against the shapes below (one element per lane and
+  // load, the link next to the rows), tools/shape_sweep.py at 6 GB, TB/s of the bytes read: least squares 600: 4.7 -> 5.7,
+  // 1100: 5.7 -> 6.4, 2100: 5.2 -> 6.3, else within +- 5 % ; logistic 400: 1.8 -> 4.6, 1000: 3.9 -> 6.2, 2100: 4.6 -> 6.3,
+  // 4224: 5.5 -> 6.7.  (APX_MULTI in the environment, bit 0 least squares / bit 1 logistic / bit 2 the primal-dual loop: an A/B
+  // switch — 0 runs the first-generation shapes, which stay for Float32 ; tests/test_gpu_slab.py::test_first_generation_shapes)
+  static const int multi = getenv("APX_MULTI") ? atoi(getenv("APX_MULTI")) : 7;
+  if (p->dtype == APX_F64 && cols <= 2 * 4 * 704 && ((p->f_kind == APX_F_LOGISTIC ? 2 : 1) & multi)) return {768, kSlabMultiCpt, 1};
   if (cols <= 1024) return {1024, 1, kSlabRows};      // (one column per thread, 32 rows per step: with two, half the loads of such a row are clamped away)
   if (cols <= 2 * 768) return {768, 2, kSlabRows};    // (1025 ... 1536 entries: two columns of 768 threads keep more lanes busy than of 1024)
   if (cols <= 2 * 1024) return {1024, 2, kSlabRows};
@@ -481,7 +490,7 @@ static SlabShape slab_shape(const apx_problem* p) {
   // (half the bytes in flight: +5 % over the two passes at C3), 512 x 20 x 4 and 1024 x 10 x 4 (spills).
   // Float64 logistic: the link function next to the rows costs the row kernels two of their three rows in flight (exp, log:
   // ~50 registers) — the communication-wave kernel with a "team" of ONE evaluates it where no row is held (k_team_rows, P = 1)
-  if (p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC && cols > 5 * 1024 && cols <= 2 * kTeamSingleKv * 704 && !p->teams_off)
+  if (p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC && cols > 5 * 1024 && cols <= 2 * kTeamSingleKv * 704 && !p->teams_off)      // (5633 ... 11 264 by default)
     return {768, kSlabTeamCpt, 1};
   if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};
   // longer rows (BASELINE config C2: 100 000): teams of 2 / 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
@@ -530,7 +539,7 @@ static int32_t slab_setup(apx_problem* p) {
   st->bs = sh.bs;
   // as many blocks as fit the chip at once — one per CU, two of the two-columns-per-thread kind (~58 VGPRs): rows in
   // contiguous slabs, a multiple of the step ; fewer blocks = fewer partial vectors for the closing kernel
-  int64_t B = (int64_t)ctx->num_cu * (st->cpt <= 2 ? 2 : 1);
+  int64_t B = (int64_t)ctx->num_cu * (st->cpt <= 2 ? 2 : 1);      // (kSlabMultiCpt, kSlabTeamCpt > 2: one block per CU)
   // rows dealt evenly: a block's last step may be partial (rows past its slab are clamped and weigh nothing), so nothing
   // is rounded up — rounding to 16 left 6 of C3's 256 CUs without a block
   const int64_t rpb = (A->m + B - 1) / B;
@@ -641,6 +650,15 @@ static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* 
   if (st->team_p != 0) {
     if constexpr (sizeof(T) == 8) {
       team_launch<FK, SlabDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, d, st->team, x, q);
+      hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
+                         dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
+    }
+    return;
+  }
+  if (st->cpt == kSlabMultiCpt) {
+    if constexpr (sizeof(T) == 8) {
+      if (st->nt) multi_launch<FK, true, SlabDev>(d.ncols, st->B, d, x, q);
+      else multi_launch<FK, false, SlabDev>(d.ncols, st->B, d, x, q);
       hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
                          dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
     }

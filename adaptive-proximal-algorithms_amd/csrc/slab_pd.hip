@@ -244,6 +244,10 @@ struct SlabPdShape {
 static SlabPdShape slab_pd_shape(const apx_problem* p) {
   const int64_t cols = p->A_lin->n;
   const bool f32 = p->dtype == APX_F32;
+  // Float64 rows of up to 5632 entries: k_multi_rows (csrc/team_rows.h ; the A/B switch APX_MULTI, bit 2: csrc/slab.hip slab_shape) —
+  // against the shapes below, TB/s of the bytes read at 6 GB: 600: 4.0 -> 5.7, 1000: 5.8 -> 6.3, 2100: 4.2 -> 6.3, 5632: 6.0 -> 6.9
+  static const int multi = getenv("APX_MULTI") ? atoi(getenv("APX_MULTI")) : 7;
+  if (!f32 && cols <= 2 * 4 * 704 && (multi & 4)) return {768, 27, 1};
   if (cols <= 1024) return {1024, 1, 4};           // (one column per thread, sixteen rows per step — 32 spill here: csrc/slab.hip slab_shape)
   if (cols <= 2 * 768) return {768, 2, 4};         // (1025 ... 1536 entries: csrc/slab.hip slab_shape)
   if (cols <= 2 * 1024) return {1024, 2, 4};
@@ -343,6 +347,15 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
                              hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   constexpr bool f32 = sizeof(T) == 4;
+  if (st->cpt == 27) {                             // k_multi_rows: H rows per step, the dual steps of a step in the row wave's lanes
+    if constexpr (!f32) {
+      if (st->nt) multi_launch<kTeamFkPd, true, SlabPdDev>(d.n, st->B, d, x, q);
+      else multi_launch<kTeamFkPd, false, SlabPdDev>(d.n, st->B, d, x, q);
+      hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
+                         d, st->B, (T*)aty, recs, rec_cap);
+    }
+    return;
+  }
   if (st->team_kv != 0) {
     if constexpr (!f32) {
       team_launch<kTeamFkPd, SlabPdDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, d, st->team, x, q);

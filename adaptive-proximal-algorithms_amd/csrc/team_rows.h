@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstdlib>
 
+#include "skinny_dev.h"
 #include "solver_internal.h"
 #include "team_dev.h"
 #include "vecops_dev.h"
@@ -370,6 +371,172 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SHORT rows (a few hundred ... 5632 Float64 entries) by the same division of labour, H rows per step: a workgroup on its
+// own, eleven compute waves that hold G = 3 steps of H rows in registers (KV 16-byte vectors per thread and row, H KV <= 8),
+// and a ROW wave whose lane h takes row h of the step — it adds the eleven waves' partial dots, evaluates the residual /
+// the logistic link / the dual step for H rows AT ONCE (exp and log across the lanes, where no row of A is held) and leaves
+// the H multipliers in LDS.  One barrier per step of H rows.  The first-generation row kernels (csrc/slab.hip k_slab_rows:
+// one element per lane and load, the link next to the rows) stay for Float32 and wherever they measure faster.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int FK, int KV, int H, bool NT, class DEV = SlabDev>
+__global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
+  constexpr int CW = 11, BSC = CW * 64, G = 3;
+  static_assert(H * KV <= 8 && (H == 1 || H == 2 || H == 4 || H == 8), "rows per step x vectors per row: the registers of three steps");
+  typedef double vec_t __attribute__((ext_vector_type(2)));
+  typedef unsigned raw_t __attribute__((ext_vector_type(4)));
+  extern __shared__ double multi_x[];              // x: KV * 704 * 2 doubles
+  __shared__ double wsum[2][CW][H];
+  __shared__ double res_s[4][H];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (d.c->done != 0) return;                      // (written by an earlier launch: uniform over the grid)
+  const int row_begin = (int)blockIdx.x * d.rows_per_block;
+  const int row_end = min(row_begin + d.rows_per_block, d.m);
+  const int nrows = max(row_end - row_begin, 0);
+  const int nsteps = 1 + ((nrows + H - 1) / H + G - 1) / G * G;      // one step of prologue, then whole rounds of G steps
+  if (wv == CW) {
+    // ---- the row wave: lane h < H is row h of a step ---------------------------------------------------------------------
+    const TeamRowConsts<FK> kc(d, xv);
+    double e0 = 0.0, e1 = 0.0, own_prev = 0.0;
+    TeamRowState st_prev{};
+    const int hh = min(lane, H - 1);
+    for (int step = 0; step < nsteps; ++step) {
+      // (the state of THIS step's rows, taken before the barrier behind which their dots complete ; the same wave writes
+      //  y+ and A_x a step later: no other reader)
+      const int inew = row_begin + step * H + hh;
+      const TeamRowState snew = team_row_state<FK>(d, max(min(inew, row_end - 1), 0));
+      const int r = step - 1;
+      if (r >= 0) {
+        const int i = row_begin + r * H + hh;
+        double res = 0.0;
+        if (lane < H && i < row_end) res = team_row_finish<FK>(d, kc, st_prev, own_prev, i, true, e0, e1);
+        if (lane < H) res_s[r & 3][lane] = res;
+      }
+      __syncthreads();                             // the barrier of the step
+      double own = 0.0;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) own += wsum[step & 1][w][hh];      // the eleven waves' partials of row hh, in order
+      own_prev = own;
+      st_prev = snew;
+    }
+    if (lane >= H) e0 = e1 = 0.0;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {        // (H <= 8 lanes hold sums, in a fixed tree)
+      e0 += __shfl_xor(e0, off, 64);
+      e1 += __shfl_xor(e1, off, 64);
+    }
+    if (lane == 0) {
+      double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
+      out[d.ncols] = e0;
+      out[d.ncols + 1] = e1;
+    }
+    return;
+  }
+  // ---- the compute waves ----------------------------------------------------------------------------------------------
+  const double* __restrict__ X = (const double*)xv;
+  const int nvec = (d.ncols + 1) / 2;
+  double acc[KV][2];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = lv * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      multi_x[lv * 2 + e] = (lv < nvec && j + e < d.ncols) ? X[j + e] : 0.0;     // (each thread reads back only what it wrote)
+      acc[k][e] = 0.0;
+    }
+  }
+  const int voff = tid * 16;
+  const int row_bytes = (int)min((int64_t)nvec * 16, d.ldT * 8);      // (rows are zero-padded to whole vectors)
+  const double* __restrict__ AT = (const double*)d.AT;
+  vec_t a[G][H][KV];
+  auto load = [&](int g, int step) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int ri = __builtin_amdgcn_readfirstlane(max(min(row_begin + step * H + h, row_end - 1), 0));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, row_bytes, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
+        a[g][h][k] = __builtin_bit_cast(vec_t, raw);
+      }
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G - 1; ++g) {
+    load(g, g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  auto dots = [&](int g, int step) {
+    double p[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) p[h] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const double xe = multi_x[(tid + k * BSC) * 2 + e];
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = fma(a[g][h][k][e], xe, p[h]);
+      }
+    wave_sum_multi<H>(p);                          // lane l: the wave's sum for row l / (64 / H), the same in all its lanes
+    wsum[step & 1][wv][lane / (64 / H)] = p[0];    // (every lane stores: no branch in the loop body)
+    __syncthreads();
+  };
+  dots(0, 0);                                      // step 0: nothing to accumulate yet ; fills the slot the prologue left empty
+  __builtin_amdgcn_sched_barrier(0);
+  load(G - 1, G - 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int q = 1; q < nsteps; q += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int step = q + u, r = step - 1;
+      dots((1 + u) % G, step);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const double rr = res_s[r & 3][h];
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[u][h][k][e], rr, acc[k][e]);      // (slot of step r: (step - 1) % G = u)
+      }
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+      __builtin_amdgcn_sched_barrier(0);
+      load(u, r + G);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = lv * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (lv < nvec && j + e < d.ncols) out[j + e] = acc[k][e];
+  }
+}
+
+// the launch for a row length: KV = vectors per compute thread and row, H = 8 / KV rows per step (H KV <= 8)
+template <int FK, bool NT, class DEV>
+inline bool multi_launch(int64_t ncols, int nblocks, const DEV& d, const void* x, hipStream_t q) {
+  const int kv = (int)(((ncols + 1) / 2 + 703) / 704);
+  const dim3 grid((unsigned)nblocks), block(768);
+  switch (kv) {
+    case 1: hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV>), grid, block, (size_t)1 * 704 * 16, q, d, x); return true;
+    case 2: hipLaunchKernelGGL((k_multi_rows<FK, 2, 4, NT, DEV>), grid, block, (size_t)2 * 704 * 16, q, d, x); return true;
+    case 3: hipLaunchKernelGGL((k_multi_rows<FK, 3, 2, NT, DEV>), grid, block, (size_t)3 * 704 * 16, q, d, x); return true;
+    case 4: hipLaunchKernelGGL((k_multi_rows<FK, 4, 2, NT, DEV>), grid, block, (size_t)4 * 704 * 16, q, d, x); return true;
+    default: return false;
+  }
+}
 
 // ---- host side: the plan for a row length, and the launch ----------------------------------------------------------------
 constexpr int kTeamSingleKv = 8;      // one workgroup / the three-slot shape: up to 8 vectors per compute thread

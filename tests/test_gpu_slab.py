@@ -460,3 +460,22 @@ def test_team_kernel_proximal_gradient_stepping_termination_replay(apx):
     with pytest.raises(apx.ApxError, match="hipGraph replay"):
         apx.adaptive_proxgrad(np.zeros(n), f=f, g=g, rule=rule, tol=0.0, maxit=5, ctx=ctx, use_graph=True)
     dA.free()
+
+
+def test_first_generation_shapes():
+    """The Float64 rows of up to 5632 entries run on k_multi_rows by default ; the first-generation shapes they replaced (one
+    element per lane and load, 1 ... 5 columns per thread, the link next to the rows) remain behind APX_MULTI=0 — the A/B
+    switch — and are what Float32 runs: the same parity cases once more with the switch off, in a process of its own (the
+    switch is read once)."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, APX_MULTI="0")
+    ids = "8500-1000-False-float64 or 8600-1024-True-float64 or 8500-1300-False-float64 or 4097-2049-True-float64 or " \
+          "4100-3000-False-float64 or 4101-4096-True-float64 or 4200-5120-False-float64 or 9000-1000-tl1-float64 or " \
+          "9100-1300-tl1-float64 or 4099-2100-tbox-float64 or 4098-5000-tl1-float64"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", ids],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout and "11 passed" in out.stdout, out.stdout[-500:]
