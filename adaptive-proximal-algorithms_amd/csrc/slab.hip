@@ -585,7 +585,9 @@ static int32_t slab_setup(apx_problem* p) {
   d.rows_per_block = (int32_t)(rpb_team > 0 ? rpb_team : rpb);
   d.b = p->b.p;
   d.ldpart = round_up(d.ncols + 2, 8);
-  APX_TRY(st->part.alloc_zero((size_t)B * d.ldpart * sizeof(double), ctx->stream));
+  // (k_multi_rows on very short rows leaves multi_groups(n) partial vectors per workgroup)
+  const int64_t nparts = B * (st->cpt == kSlabMultiCpt ? multi_groups(A->n) : 1);
+  APX_TRY(st->part.alloc_zero((size_t)nparts * d.ldpart * sizeof(double), ctx->stream));
   d.part = (double*)st->part.p;
   d.c = p->ctrl();
   // measured (tools/slab_bench.py threshold, profiles/r01g_one_pass_variants.md): a matrix of up to 256 MB is partly
@@ -660,7 +662,7 @@ static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* 
       if (st->nt) multi_launch<FK, true, SlabDev>(d.ncols, st->B, d, x, q);
       else multi_launch<FK, false, SlabDev>(d.ncols, st->B, d, x, q);
       hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
-                         dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
+                         dim3(kSlabCloseBlock), 0, q, d, st->B * multi_groups(d.ncols), (T*)grad);
     }
     return;
   }

@@ -332,7 +332,8 @@ int32_t slab_pd_setup(apx_solver* s) {
   d.Y = s->y.p;
   d.AXP = s->axprev.p;
   d.ldpart = round_up(d.n + 2, 8);
-  APX_TRY(st->part.alloc_zero((size_t)B * d.ldpart * sizeof(double), ctx->stream));
+  const int64_t nparts = B * (st->cpt == 27 ? multi_groups(A->n) : 1);      // (k_multi_rows on very short rows: csrc/team_rows.h)
+  APX_TRY(st->part.alloc_zero((size_t)nparts * d.ldpart * sizeof(double), ctx->stream));
   d.part = (double*)st->part.p;
   d.c = p->ctrl();
   d.h = p->hd;
@@ -352,7 +353,7 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
       if (st->nt) multi_launch<kTeamFkPd, true, SlabPdDev>(d.n, st->B, d, x, q);
       else multi_launch<kTeamFkPd, false, SlabPdDev>(d.n, st->B, d, x, q);
       hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
-                         d, st->B, (T*)aty, recs, rec_cap);
+                         d, st->B * multi_groups(d.n), (T*)aty, recs, rec_cap);
     }
     return;
   }

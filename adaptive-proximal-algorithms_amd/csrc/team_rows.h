@@ -380,82 +380,91 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 // the H multipliers in LDS.  One barrier per step of H rows.  The first-generation row kernels (csrc/slab.hip k_slab_rows:
 // one element per lane and load, the link next to the rows) stay for Float32 and wherever they measure faster.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int FK, int KV, int H, bool NT, class DEV = SlabDev>
+// GR > 1 (rows of fewer than ~700 entries, KV = 1): the compute waves form GR groups of WG waves, each group its own H rows of
+// a step — GR H rows per step, one lane of the row wave each — and its own column accumulator, stored as a block partial of
+// its own (the closing kernel sums GR partials per workgroup).
+template <int FK, int KV, int H, bool NT, class DEV = SlabDev, int GR = 1, int WG = 11>
 __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
-  constexpr int CW = 11, BSC = CW * 64, G = 3;
+  constexpr int CW = 11, BSC = WG * 64, G = 3, RS = GR * H;          // (BSC: threads of a group ; RS: rows per step)
   static_assert(H * KV <= 8 && (H == 1 || H == 2 || H == 4 || H == 8), "rows per step x vectors per row: the registers of three steps");
+  static_assert(GR * WG <= CW && RS <= 64 && (GR == 1 || KV == 1), "groups of whole waves ; a lane of the row wave per row");
   typedef double vec_t __attribute__((ext_vector_type(2)));
   typedef unsigned raw_t __attribute__((ext_vector_type(4)));
-  extern __shared__ double multi_x[];              // x: KV * 704 * 2 doubles
+  extern __shared__ double multi_x[];              // x: KV * BSC * 2 doubles
   __shared__ double wsum[2][CW][H];
-  __shared__ double res_s[4][H];
+  __shared__ double res_s[4][RS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (d.c->done != 0) return;                      // (written by an earlier launch: uniform over the grid)
   const int row_begin = (int)blockIdx.x * d.rows_per_block;
   const int row_end = min(row_begin + d.rows_per_block, d.m);
   const int nrows = max(row_end - row_begin, 0);
-  const int nsteps = 1 + ((nrows + H - 1) / H + G - 1) / G * G;      // one step of prologue, then whole rounds of G steps
+  const int nsteps = 1 + ((nrows + RS - 1) / RS + G - 1) / G * G;    // one step of prologue, then whole rounds of G steps
   if (wv == CW) {
-    // ---- the row wave: lane h < H is row h of a step ---------------------------------------------------------------------
+    // ---- the row wave: lane L < RS is row L of a step (group L / H, its row L % H) ---------------------------------------
     const TeamRowConsts<FK> kc(d, xv);
     double e0 = 0.0, e1 = 0.0, own_prev = 0.0;
     TeamRowState st_prev{};
-    const int hh = min(lane, H - 1);
+    const int ll = min(lane, RS - 1), lg = ll / H, lh = ll % H;
     for (int step = 0; step < nsteps; ++step) {
       // (the state of THIS step's rows, taken before the barrier behind which their dots complete ; the same wave writes
       //  y+ and A_x a step later: no other reader)
-      const int inew = row_begin + step * H + hh;
+      const int inew = row_begin + step * RS + ll;
       const TeamRowState snew = team_row_state<FK>(d, max(min(inew, row_end - 1), 0));
       const int r = step - 1;
       if (r >= 0) {
-        const int i = row_begin + r * H + hh;
+        const int i = row_begin + r * RS + ll;
         double res = 0.0;
-        if (lane < H && i < row_end) res = team_row_finish<FK>(d, kc, st_prev, own_prev, i, true, e0, e1);
-        if (lane < H) res_s[r & 3][lane] = res;
+        if (lane < RS && i < row_end) res = team_row_finish<FK>(d, kc, st_prev, own_prev, i, true, e0, e1);
+        if (lane < RS) res_s[r & 3][lane] = res;
       }
       __syncthreads();                             // the barrier of the step
       double own = 0.0;
 #pragma unroll
-      for (int w = 0; w < CW; ++w) own += wsum[step & 1][w][hh];      // the eleven waves' partials of row hh, in order
+      for (int w = 0; w < WG; ++w) own += wsum[step & 1][lg * WG + w][lh];      // the group's waves' partials of the row, in order
       own_prev = own;
       st_prev = snew;
     }
-    if (lane >= H) e0 = e1 = 0.0;
+    if (lane >= RS) e0 = e1 = 0.0;
 #pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {        // (H <= 8 lanes hold sums, in a fixed tree)
+    for (int off = 1; off < 64; off <<= 1) {       // (RS <= 64 lanes hold sums, in a fixed tree)
       e0 += __shfl_xor(e0, off, 64);
       e1 += __shfl_xor(e1, off, 64);
     }
-    if (lane == 0) {
-      double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
-      out[d.ncols] = e0;
-      out[d.ncols + 1] = e1;
+    if (lane < GR) {                               // the loss sums in the first of the workgroup's GR partials, zeros in the others
+      double* __restrict__ out = d.part + ((int64_t)blockIdx.x * GR + lane) * d.ldpart;
+      out[d.ncols] = lane == 0 ? e0 : 0.0;
+      out[d.ncols + 1] = lane == 0 ? e1 : 0.0;
     }
     return;
   }
   // ---- the compute waves ----------------------------------------------------------------------------------------------
+  const int grp = __builtin_amdgcn_readfirstlane(GR == 1 ? 0 : wv / WG);      // (waves beyond GR WG: no group — they only keep the barriers)
+  const bool idle = GR > 1 && grp >= GR;
+  const int gt = GR == 1 ? tid : tid - grp * BSC;  // the thread within its group
   const double* __restrict__ X = (const double*)xv;
   const int nvec = (d.ncols + 1) / 2;
   double acc[KV][2];
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BSC;
+    const int lv = gt + k * BSC;
     const int j = lv * 2;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      multi_x[lv * 2 + e] = (lv < nvec && j + e < d.ncols) ? X[j + e] : 0.0;     // (each thread reads back only what it wrote)
+      // (each thread reads back only the entries it wrote — with GR > 1 the same thread of every group writes them, the same
+      //  values: no barrier)
+      if (!idle) multi_x[lv * 2 + e] = (lv < nvec && j + e < d.ncols) ? X[j + e] : 0.0;
       acc[k][e] = 0.0;
     }
   }
-  const int voff = tid * 16;
-  const int row_bytes = (int)min((int64_t)nvec * 16, d.ldT * 8);      // (rows are zero-padded to whole vectors)
+  const int voff = gt * 16;
+  const int row_bytes = idle ? 0 : (int)min((int64_t)nvec * 16, d.ldT * 8);      // (rows are zero-padded to whole vectors ; idle waves load nothing)
   const double* __restrict__ AT = (const double*)d.AT;
   vec_t a[G][H][KV];
   auto load = [&](int g, int step) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      const int ri = __builtin_amdgcn_readfirstlane(max(min(row_begin + step * H + h, row_end - 1), 0));
+      const int ri = __builtin_amdgcn_readfirstlane(max(min(row_begin + step * RS + (idle ? 0 : grp) * H + h, row_end - 1), 0));
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, row_bytes, 0x00020000);
 #pragma unroll
       for (int k = 0; k < KV; ++k) {
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
     for (int k = 0; k < KV; ++k)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const double xe = multi_x[(tid + k * BSC) * 2 + e];
+        const double xe = multi_x[(gt + k * BSC) * 2 + e];
 #pragma unroll
         for (int h = 0; h < H; ++h) p[h] = fma(a[g][h][k][e], xe, p[h]);
       }
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
       dots((1 + u) % G, step);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        const double rr = res_s[r & 3][h];
+        const double rr = res_s[r & 3][(idle ? 0 : grp) * H + h];
 #pragma unroll
         for (int k = 0; k < KV; ++k)
 #pragma unroll
@@ -513,10 +522,11 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  double* __restrict__ out = d.part + (int64_t)blockIdx.x * d.ldpart;
+  if (idle) return;
+  double* __restrict__ out = d.part + ((int64_t)blockIdx.x * GR + grp) * d.ldpart;
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BSC;
+    const int lv = gt + k * BSC;
     const int j = lv * 2;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -525,10 +535,20 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
 }
 
 // the launch for a row length: KV = vectors per compute thread and row, H = 8 / KV rows per step (H KV <= 8)
+// rows per workgroup partial: the workgroup's GR groups each leave one (the closing kernels sum nblocks * multi_groups(ncols))
+inline int multi_groups(int64_t ncols) {
+  const int64_t nvec = (ncols + 1) / 2;
+  return nvec <= 128 ? 5 : nvec <= 192 ? 3 : nvec <= 320 ? 2 : 1;
+}
 template <int FK, bool NT, class DEV>
 inline bool multi_launch(int64_t ncols, int nblocks, const DEV& d, const void* x, hipStream_t q) {
-  const int kv = (int)(((ncols + 1) / 2 + 703) / 704);
+  const int64_t nvec = (ncols + 1) / 2;
+  const int kv = (int)((nvec + 703) / 704);
   const dim3 grid((unsigned)nblocks), block(768);
+  // very short rows: GR groups of WG waves, eight rows each per step (40 / 24 / 16 rows per step)
+  if (nvec <= 128) { hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV, 5, 2>), grid, block, (size_t)128 * 16, q, d, x); return true; }
+  if (nvec <= 192) { hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV, 3, 3>), grid, block, (size_t)192 * 16, q, d, x); return true; }
+  if (nvec <= 320) { hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV, 2, 5>), grid, block, (size_t)320 * 16, q, d, x); return true; }
   switch (kv) {
     case 1: hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV>), grid, block, (size_t)1 * 704 * 16, q, d, x); return true;
     case 2: hipLaunchKernelGGL((k_multi_rows<FK, 2, 4, NT, DEV>), grid, block, (size_t)2 * 704 * 16, q, d, x); return true;

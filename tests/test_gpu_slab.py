@@ -41,7 +41,12 @@ def _rel(a, b):
                                                 (4100, 10240, False, np.float32),
                                                 # long slabs (>= 16 steps per block): two row groups in flight
                                                 (140000, 200, False, np.float32),
-                                                (140000, 300, False, np.float64),
+                                                (140000, 300, False, np.float64),     # k_multi_rows: three groups of three waves
+                                                (150000, 200, True, np.float64),      # ... five groups of two waves, logistic
+                                                (130000, 255, False, np.float64),
+                                                (90000, 500, True, np.float64),       # ... two groups of five waves
+                                                (90001, 640, False, np.float64),
+                                                (100000, 130, False, np.float64),
                                                 (20000, 2500, True, np.float32),
                                                 (17000, 6000, False, np.float32),     # ... and > 384 MB: non-temporal loads
                                                 # BASELINE config C3's own kernel: fp32 logistic, 14 columns per thread, four rows
@@ -190,6 +195,9 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,hkind,dtype", [(9000, 1000, "tl1", np.float64),      # 1 column per thread
                                              (9000, 700, "tbox", np.float32),
+                                             (100000, 250, "tl1", np.float64),     # k_multi_rows: five groups of two waves
+                                             (90000, 380, "tbox", np.float64),     # ... three groups
+                                             (80000, 600, "tl1", np.float64),      # ... two groups
                                              (9100, 1300, "tl1", np.float64),      # 2 columns per thread, 768 threads
                                              (9000, 1800, "tl1", np.float64),      # 2 columns per thread, 1024 threads
                                              (4099, 2100, "tbox", np.float64),     # 3
