@@ -1,5 +1,5 @@
 set -e
-P=$GRAFT_REPO_ROOT/gpurun_out/r02q
+P=$GRAFT_REPO_ROOT/gpurun_out/r02r
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py > $P/bench_line.json 2> $P/bench_err.log
