@@ -22,7 +22,7 @@ def short(name):
     # k_team_rows serves f's gradient (FK 1 / 2) and the primal-dual loop (FK 100, csrc/team_rows.h kTeamFkPd): two entries
     if "k_team_rows" in name:
         return "k_team_rows (primal-dual)" if "k_team_rows<100" in name.replace(" ", "") else "k_team_rows"
-    for key in ("k_teampd_rows", "k_slab2_rows", "k_slabpd_rows", "k_slabpd_close", "k_slab_rows", "k_slab_close",
+    for key in ("k_multi_rows", "k_teampd_rows", "k_slab2_rows", "k_slabpd_rows", "k_slabpd_close", "k_slab_rows", "k_slab_close",
                 "gemv_n_kernel", "gemv_t_kernel", "gemv_t_finish", "k_finish_rows", "k_f_reduce", "k_reduce_n",
                 "k_rule", "k_step", "k_dual", "k_final", "k_fill_uniform", "k_scale_columns", "sum_partials_rows"):
         if key in name:
@@ -83,7 +83,7 @@ def main():
     # so both passes appear as gemv_t_kernel in the trace
     pt = {"gemv_n": traffic.get("gemv_n_kernel") or traffic.get("gemv_t_kernel", {}),
           "gemv_t": traffic.get("gemv_t_kernel", {})}
-    for k in ("k_team_rows", "k_team_rows (primal-dual)", "k_teampd_rows", "k_slab_rows", "k_slab2_rows"):      # the one-pass kernels (A read once per launch)
+    for k in ("k_team_rows", "k_team_rows (primal-dual)", "k_multi_rows", "k_teampd_rows", "k_slab_rows", "k_slab2_rows"):      # the one-pass kernels (A read once per launch)
         if k in traffic:
             pt[k] = traffic[k]
     if len(sys.argv) > 3:
