@@ -17,7 +17,7 @@ from .api import (  # noqa: F401
     FixedStepsize, MalitskyMishchenkoRule, OurRule, OurRulePlus,
     adaptive_primal_dual, adaptive_proxgrad, fixed_proxgrad, condat_vu, backtracking_proxgrad,
     adaptive_linesearch_primal_dual,
-    Solver,
+    Solver, last_incident,
 )
 
 from .baselines import backtracking_nesterov, fixed_nesterov, agraal, malitsky_pock  # noqa: F401,E402

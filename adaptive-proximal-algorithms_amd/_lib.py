@@ -16,14 +16,16 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libadaprox_hip.so")
 
 # ---- enums (include/adaprox_hip.h) ---------------------------------------------------
 APX_OK, APX_ERR_INVALID, APX_ERR_HIP, APX_ERR_UNSUPPORTED, APX_ERR_DOMAIN, APX_ERR_CALLBACK, APX_ERR_COMM = range(7)
-APX_ABI_VERSION = 2
+APX_ABI_VERSION = 3
 APX_COMM_ID_BYTES = 128
-APX_FLAG_TINY_GAMMA, APX_FLAG_NAN_GAMMA, APX_FLAG_DOMAIN = 1, 2, 4
+APX_FLAG_TINY_GAMMA, APX_FLAG_NAN_GAMMA, APX_FLAG_DOMAIN, APX_FLAG_TEAM_FALLBACK = 1, 2, 4, 8
 APX_F64, APX_F32 = 0, 1
 APX_F_ZERO, APX_F_LEAST_SQUARES, APX_F_LOGISTIC, APX_F_CALLBACK, APX_F_QUADRATIC = range(5)
 APX_G_ZERO, APX_G_L1, APX_G_BOX, APX_G_BOXV, APX_G_INDZERO, APX_G_L2 = range(6)
 APX_RULE_FIXED, APX_RULE_MM, APX_RULE_OURS, APX_RULE_OURS_PLUS = range(4)
-APX_KSTAT_GEMV_N, APX_KSTAT_GEMV_T, APX_KSTAT_COUNT = 0, 1, 2
+APX_KSTAT_GEMV_N, APX_KSTAT_GEMV_T, APX_KSTAT_ONE_PASS, APX_KSTAT_COUNT = 0, 1, 2, 3
+(APX_OPT_MULTI_ROWS_MASK, APX_OPT_SLAB_GENERATION, APX_OPT_TEAM_WAIT_MS, APX_OPT_TEAM_COOPERATIVE, APX_OPT_TEAM_FAULT_GRID,
+ APX_OPT_GEMV_N_VARIANT, APX_OPT_GEMV_T_VARIANT, APX_OPT_GEMV_N_BLOCKS, APX_OPT_GEMV_T_BLOCKS, APX_OPT_FUSED_TAIL) = range(1, 11)
 
 c_void_p, c_int32, c_int64, c_double = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 
@@ -93,6 +95,12 @@ PROTOTYPES = {
     "apx_ctx_set_gemv_config": (c_int32, [c_void_p, c_int32, c_int32, c_int64, c_int64]),
     "apx_ctx_exploit_sparsity": (c_int32, [c_void_p, c_int32]),
     "apx_ctx_fused_small": (c_int32, [c_void_p, c_int32]),
+    "apx_ctx_one_pass": (c_int32, [c_void_p, c_int32]),
+    "apx_ctx_kernel_name": (C.c_char_p, [c_void_p, c_int32]),
+    "apx_ctx_set_option": (c_int32, [c_void_p, c_int32, c_int64]),
+    "apx_ctx_get_option": (c_int32, [c_void_p, c_int32, _P(c_int64)]),
+    "apx_last_incident": (C.c_char_p, []),
+    "apx_problem_team_waits": (c_int32, [c_void_p, _P(c_int64)]),
     "apx_ctx_one_pass_threshold": (c_int32, [c_void_p, c_int64]),
     "apx_ctx_auto_transpose": (c_int32, [c_void_p, c_int32]),
     "apx_comm_unique_id": (c_int32, [c_void_p]),

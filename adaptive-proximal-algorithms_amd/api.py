@@ -83,9 +83,30 @@ class Context:
         arr = (L.KernelStat * L.APX_KSTAT_COUNT)()
         L.check(self._lib.apx_ctx_kernel_stats(self._h, arr, 1 if reset else 0))
         out = {}
-        for name, k in (("gemv_n", L.APX_KSTAT_GEMV_N), ("gemv_t", L.APX_KSTAT_GEMV_T)):
+        for name, k in (("gemv_n", L.APX_KSTAT_GEMV_N), ("gemv_t", L.APX_KSTAT_GEMV_T), ("one_pass", L.APX_KSTAT_ONE_PASS)):
             out[name] = dict(launches=int(arr[k].launches), total_ms=float(arr[k].total_ms), bytes=float(arr[k].bytes))
         return out
+
+    def kernel_name(self, slot: str) -> str:
+        """The kernels last booked under a timing slot ("gemv_n", "gemv_t", "one_pass"), as the library launched them."""
+        k = {"gemv_n": L.APX_KSTAT_GEMV_N, "gemv_t": L.APX_KSTAT_GEMV_T, "one_pass": L.APX_KSTAT_ONE_PASS}[slot]
+        return self._lib.apx_ctx_kernel_name(self._h, k).decode()
+
+    def one_pass(self, mode: int = 1):
+        """apx_ctx_one_pass: 0 = the two GEMV passes, 1 = one pass over A per iteration for large dense matrices (default),
+        2 = one pass, but never the team kernels (a GPU shared with other work)."""
+        L.check(self._lib.apx_ctx_one_pass(self._h, int(mode)))
+        return self
+
+    def set_option(self, key: int, value: int):
+        """apx_ctx_set_option (keys: _lib.APX_OPT_*): A/B switches and test hooks — the library reads no environment."""
+        L.check(self._lib.apx_ctx_set_option(self._h, int(key), int(value)))
+        return self
+
+    def get_option(self, key: int) -> int:
+        v = C.c_int64()
+        L.check(self._lib.apx_ctx_get_option(self._h, int(key), C.byref(v)))
+        return int(v.value)
 
     def set_gemv_config(self, n_variant: int = -1, t_variant: int = -1, n_blocks: int = 0, t_blocks: int = 0):
         L.check(self._lib.apx_ctx_set_gemv_config(self._h, n_variant, t_variant, n_blocks, t_blocks))
@@ -102,9 +123,12 @@ class Context:
         L.check(self._lib.apx_ctx_auto_transpose(self._h, 1 if enable else 0))
         return self
 
-    def fused_small(self, enable: bool = True):
-        """Default on: small dense proximal-gradient problems run as two kernels per iteration (csrc/small.hip)."""
+    def fused_small(self, enable: bool = True, one_pass: Optional[bool] = None):
+        """Both fused execution policies at once — the tests' way to the generic kernels: apx_ctx_fused_small (small dense
+        problems as two kernels per iteration, csrc/small.hip and its family) and, unless ``one_pass`` says otherwise,
+        apx_ctx_one_pass (large matrices: one pass over A per iteration).  The C-ABI has one switch for each."""
         L.check(self._lib.apx_ctx_fused_small(self._h, 1 if enable else 0))
+        L.check(self._lib.apx_ctx_one_pass(self._h, 1 if (enable if one_pass is None else one_pass) else 0))
 
     def exploit_sparsity(self, enable: bool = True):
         """Opt-in: `A*x` streams only the columns with x_j != 0 (dense column-major A)."""
@@ -961,7 +985,20 @@ def _at(base, key, inc):
     return None if base[key] is None else base[key] + inc
 
 
+def last_incident() -> str:
+    """apx_last_incident(): what the last team-kernel failure on this thread looked like ("" if none)."""
+    return L.load().apx_last_incident().decode("utf-8", "replace")
+
+
+def _warn_team_fallback(res):
+    if int(res.flags) & L.APX_FLAG_TEAM_FALLBACK:
+        import warnings
+        warnings.warn("adaprox_hip: a hand-off of the one-pass team kernels failed; the call was run again on the two GEMV "
+                      "passes and its result is valid (APX_FLAG_TEAM_FALLBACK). " + last_incident(), RuntimeWarning, stacklevel=3)
+
+
 def _advance_counts(f, g, h, A, res, f_is_callback):
+    _warn_team_fallback(res)          # (every one-shot wrapper comes through here with its apx_result)
     # a callback f went through Counting.eval_with_pullback itself
     if isinstance(f, Counting) and not f_is_callback:
         f.eval_count += int(res.f_evals)
@@ -1097,15 +1134,29 @@ class Solver:
         no_lin = A is None or (np.isscalar(_unwrap(A)) and _unwrap(A) == 0)
         self.prob = _Problem(f, g, h if h is not None else Zero(), None if no_lin else A, dtype, ctx).finalize(x.size)
         self.n, self.m, self.dtype = x.size, int(self.prob._d.m), dtype
-        yv = None if no_lin else _as_vec(y, dtype)
-        opts = L.SolveOpts()
-        opts.poll_every = poll_every
-        opts.use_graph = _graph_flag(use_graph)
+        self._no_lin, self._rule, self._tol = no_lin, rule, float(tol)
+        self._opts = L.SolveOpts()
+        self._opts.poll_every = poll_every
+        self._opts.use_graph = _graph_flag(use_graph)
+        self._h = None
+        self._create(x, y)
+
+    def _create(self, x, y):
+        yv = None if self._no_lin else _as_vec(y, self.dtype)
         h_ = C.c_void_p()
-        r = rule._rule()
-        self.prob.check(self.prob.lib.apx_solver_create(self.prob.h, C.byref(r), _ptr(x), _ptr(yv), float(tol),
-                                                        C.byref(opts), C.byref(h_)))
+        r = self._rule._rule()
+        self.prob.check(self.prob.lib.apx_solver_create(self.prob.h, C.byref(r), _ptr(x), _ptr(yv), self._tol,
+                                                        C.byref(self._opts), C.byref(h_)))
         self._h = h_
+
+    def restart(self, x, y=None):
+        """A new native solver on the SAME problem, from (x, y): what a caller does after the stepping interface reported a
+        failed team hand-off (APX_ERR_HIP) — the problem has been taken off the team kernels, the new solver runs on the two
+        GEMV passes."""
+        if self._h:
+            self.prob.lib.apx_solver_destroy(self._h)
+            self._h = None
+        self._create(_as_vec(x, self.dtype), y)
 
     def step(self, iters: int, sync: bool = False):
         self.prob.check(self.prob.lib.apx_solver_step(self._h, int(iters), 1 if sync else 0))
@@ -1116,6 +1167,12 @@ class Solver:
         y = np.empty(self.m, dtype=self.dtype) if self.m else None
         self.prob.check(self.prob.lib.apx_solver_result(self._h, _ptr(x), _ptr(y), C.byref(res)))
         return x, y, res
+
+    def team_waits(self) -> dict:
+        """apx_problem_team_waits: hand-off statistics of this problem's team kernels since it was set up."""
+        out = (C.c_int64 * 4)()
+        self.prob.check(self.prob.lib.apx_problem_team_waits(self.prob.h, out))
+        return dict(waits=int(out[0]), max_polls=int(out[1]), max_wait_ns=int(out[2]), team_launches=int(out[3]))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -12,6 +12,7 @@ namespace apx {
 // ---- error plumbing: nothing throws across the C boundary ------------------------
 void set_error(const std::string& msg);
 int32_t fail(int32_t code, const std::string& msg);
+void note_incident(const std::string& msg);      // apx_last_incident(): what the last team-kernel failure looked like
 
 #define APX_HIP(expr)                                                                       \
   do {                                                                                      \
@@ -94,6 +95,15 @@ struct apx_ctx {
   double* h_scal = nullptr;      // pinned host scalars (64 doubles): read-backs of scal / Ctrl fields
   // opt-in: A*x streams only the columns with x_j != 0 (apx_ctx_exploit_sparsity)
   bool fused_small = true;       // small dense proximal-gradient problems run as two kernels per iteration (small.hip)
+  bool one_pass = true;          // large dense matrices: one pass over A per iteration (apx_ctx_one_pass: slab.hip, slab_pd.hip)
+  bool teams = true;             // ... and its team kernels for rows too long for one workgroup (team_rows.h ; mode 2 switches them off)
+  // options by key (apx_ctx_set_option)
+  int multi_mask = 7;            // APX_OPT_MULTI_ROWS_MASK
+  int slab_generation = 0;       // APX_OPT_SLAB_GENERATION
+  int team_wait_ms = 1000;       // APX_OPT_TEAM_WAIT_MS
+  bool team_cooperative = false; // APX_OPT_TEAM_COOPERATIVE
+  int team_fault_grid = 0;       // APX_OPT_TEAM_FAULT_GRID (test hook)
+  bool fused_tail = true;        // APX_OPT_FUSED_TAIL
   int64_t one_pass_min_bytes = 192ll << 20;   // slab.hip / slab_pd.hip take matrices from this size on (apx_ctx_one_pass_threshold)
   bool auto_transpose = true;    // a one-pass-eligible problem may give its matrix the transposed copy (apx_ctx_auto_transpose)
   bool skip_zero_cols = false;
@@ -105,6 +115,7 @@ struct apx_ctx {
   std::vector<Ev> ev_pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
   apx_kernel_stat stats[APX_KSTAT_COUNT] = {};
+  std::string kname[APX_KSTAT_COUNT];   // the kernels last booked under a slot (apx_ctx_kernel_name)
   apx::GemvConfig cfg;
 };
 
@@ -143,6 +154,8 @@ bool process_exiting();
 // comm.hip: in-place sum over the ranks of `count` elements at the device pointer buf, on the context's stream
 int32_t comm_allreduce(apx_comm* c, void* buf, int64_t count, int32_t dtype);
 apx_ctx* comm_ctx(const apx_comm* c);
+void comm_retain(apx_comm* c);      // a problem on the communicator keeps it alive (apx_comm_destroy is deferred to the last one)
+void comm_release(apx_comm* c);
 
 // ---- launchers implemented in gemv.hip -------------------------------------------
 int32_t ensure_part(apx_ctx* ctx, size_t bytes);

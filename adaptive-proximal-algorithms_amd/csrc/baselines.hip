@@ -96,7 +96,14 @@ void fill_result(apx_result* res, const apx_solve_opts* opts, int64_t it, bool c
 extern "C" {
 
 // backtracking_nesterov(x0; f, g, gamma0, shrink, tol, maxit) — src/AdaProx.jl:66-84
+static int32_t backtracking_nesterov_run(apx_problem* p, const void* x0, double gamma0, double shrink, double tol,
+                                  int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
 int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0, double shrink, double tol,
+                                  int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
+  // (a failed team hand-off of the one-pass kernels: the call runs again on the two passes — solver_internal.h with_team_fallback)
+  return with_team_fallback(p, res, [&] { return backtracking_nesterov_run(p, x0, gamma0, shrink, tol, maxit, opts, x_out, res); });
+}
+static int32_t backtracking_nesterov_run(apx_problem* p, const void* x0, double gamma0, double shrink, double tol,
                                   int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_TRY(begin(p, maxit, false));
   APX_REQUIRE(x0 != nullptr && x_out != nullptr, "apx_backtracking_nesterov: NULL argument");
@@ -178,7 +185,14 @@ int32_t apx_backtracking_nesterov(apx_problem* p, const void* x0, double gamma0,
 
 // fixed_nesterov(x0; f, g, gamma, muf, mug, theta, tol, maxit) — src/AdaProx.jl:91-142
 // (gamma is given; `Lf` of the reference is 1/gamma on the host side.  theta < 0 <=> `nothing`.)
+static int32_t fixed_nesterov_run(apx_problem* p, const void* x0, double gamma, double muf, double mug, double theta,
+                           double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
 int32_t apx_fixed_nesterov(apx_problem* p, const void* x0, double gamma, double muf, double mug, double theta,
+                           double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
+  // (a failed team hand-off of the one-pass kernels: the call runs again on the two passes — solver_internal.h with_team_fallback)
+  return with_team_fallback(p, res, [&] { return fixed_nesterov_run(p, x0, gamma, muf, mug, theta, tol, maxit, opts, x_out, res); });
+}
+static int32_t fixed_nesterov_run(apx_problem* p, const void* x0, double gamma, double muf, double mug, double theta,
                            double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_TRY(begin(p, maxit, false));
   APX_REQUIRE(x0 != nullptr && x_out != nullptr, "apx_fixed_nesterov: NULL argument");
@@ -247,6 +261,7 @@ int32_t apx_fixed_nesterov(apx_problem* p, const void* x0, double gamma, double 
       break;
     }
   }
+  APX_TRY(slab_check(p));                       // (evaluations whose value nobody read: a failed team hand-off must not pass for an iterate)
   APX_TRY(d2h(ctx, x_out, x, (size_t)p->n * es));
   fill_result(res, opts, it_done, conv, 0, gamma, kNaN, norm_res, objective, f_evals, grad_evals, prox_evals, -1, -1, -1);
   return APX_OK;
@@ -254,7 +269,14 @@ int32_t apx_fixed_nesterov(apx_problem* p, const void* x0, double gamma, double 
 
 // agraal(x1; f, g, x0, gamma0, gamma_max, phi, tol, maxit) — src/AdaProx.jl:150-192
 // (x0 must be supplied: the host draws `x1 + randn` when the caller passes `nothing`; gamma0 <= 0 <=> `nothing`)
+static int32_t agraal_run(apx_problem* p, const void* x1, const void* x0, double gamma0, double gamma_max, double phi,
+                   double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
 int32_t apx_agraal(apx_problem* p, const void* x1, const void* x0, double gamma0, double gamma_max, double phi,
+                   double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
+  // (a failed team hand-off of the one-pass kernels: the call runs again on the two passes — solver_internal.h with_team_fallback)
+  return with_team_fallback(p, res, [&] { return agraal_run(p, x1, x0, gamma0, gamma_max, phi, tol, maxit, opts, x_out, res); });
+}
+static int32_t agraal_run(apx_problem* p, const void* x1, const void* x0, double gamma0, double gamma_max, double phi,
                    double tol, int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_TRY(begin(p, maxit, false));
   APX_REQUIRE(x1 != nullptr && x0 != nullptr && x_out != nullptr, "apx_agraal: NULL argument");
@@ -339,6 +361,7 @@ int32_t apx_agraal(apx_problem* p, const void* x1, const void* x0, double gamma0
     f_evals++;
     grad_evals++;
   }
+  APX_TRY(slab_check(p));                       // (evaluations whose value nobody read: a failed team hand-off must not pass for an iterate)
   APX_TRY(d2h(ctx, x_out, x, (size_t)p->n * es));
   fill_result(res, opts, it_done, conv, 0, gamma, kNaN, norm_res, objective, f_evals, grad_evals, prox_evals, -1, -1, -1);
   return APX_OK;

@@ -39,6 +39,10 @@ struct apx_comm {
   ncclComm_t comm = nullptr;
   int nranks = 0, rank = 0;
   apx::DBuf scratch;          // device staging of apx_comm_allreduce_host
+  // problems created on this communicator keep it alive, like matrices keep their context: apx_comm_destroy on a communicator
+  // that still has problems only marks it, and the last problem to go destroys it (finalizers run in any order)
+  int64_t users = 0;
+  bool zombie = false;
 };
 
 namespace apx {
@@ -138,6 +142,23 @@ int32_t comm_allreduce(apx_comm* c, void* buf, int64_t count, int32_t dtype) {
 
 apx_ctx* comm_ctx(const apx_comm* c) { return c->ctx; }
 
+static void comm_free(apx_comm* c) {
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->comm != nullptr) (void)rccl_api()->CommDestroy(c->comm);
+  apx_ctx* ctx = c->ctx;
+  delete c;
+  ctx_release(ctx);
+}
+void comm_retain(apx_comm* c) {
+  if (c != nullptr) c->users += 1;
+}
+void comm_release(apx_comm* c) {
+  if (c == nullptr) return;
+  c->users -= 1;
+  if (c->users <= 0 && c->zombie) comm_free(c);
+}
+
 }  // namespace apx
 
 using namespace apx;
@@ -165,8 +186,12 @@ int32_t apx_comm_init_rank(apx_ctx* ctx, int32_t nranks, int32_t rank, const voi
   std::unique_ptr<apx_comm> c(new apx_comm());
   c->ctx = ctx;
   APX_NCCL(R->CommInitRank(&c->comm, nranks, uid, rank), nullptr);
-  APX_NCCL(R->CommCount(c->comm, &c->nranks), c->comm);
-  APX_NCCL(R->CommUserRank(c->comm, &c->rank), c->comm);
+  ncclResult_t r1 = R->CommCount(c->comm, &c->nranks), r2 = r1 == ncclSuccess ? R->CommUserRank(c->comm, &c->rank) : r1;
+  if (r2 != ncclSuccess) {                         // (do not leak the communicator that did initialise)
+    const int32_t rc = nccl_fail("ncclCommCount / ncclCommUserRank", r2, c->comm);
+    (void)R->CommDestroy(c->comm);
+    return rc;
+  }
   ctx_retain(ctx);
   *out = c.release();
   return APX_OK;
@@ -227,13 +252,12 @@ int32_t apx_comm_allreduce_host(apx_comm* c, double* buf, int64_t count) {
 
 int32_t apx_comm_destroy(apx_comm* c) {
   if (c == nullptr || process_exiting()) return APX_OK;
+  if (c->users > 0) {        // problems still enqueue collectives on it: deferred to the last of them
+    c->zombie = true;
+    return APX_OK;
+  }
   try {
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->comm != nullptr) (void)rccl_api()->CommDestroy(c->comm);
-    apx_ctx* ctx = c->ctx;
-    delete c;
-    ctx_release(ctx);
+    comm_free(c);
   } catch (...) {
   }
   return APX_OK;

@@ -17,7 +17,9 @@
 namespace apx {
 
 static thread_local std::string g_last_error;
+static thread_local std::string g_last_incident;
 void set_error(const std::string& msg) { g_last_error = msg; }
+void note_incident(const std::string& msg) { g_last_incident = msg; }
 int32_t fail(int32_t code, const std::string& msg) {
   g_last_error = msg;
   return code;
@@ -156,6 +158,7 @@ extern "C" {
 
 int32_t apx_abi_version(void) { return APX_ABI_VERSION; }
 const char* apx_last_error(void) { return g_last_error.c_str(); }
+const char* apx_last_incident(void) { return g_last_incident.c_str(); }
 
 int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
   APX_REQUIRE(out != nullptr, "apx_ctx_create: out is NULL");
@@ -194,12 +197,7 @@ int32_t apx_ctx_create(int32_t device, void* stream, apx_ctx** out) {
   ctx->cfg.n_auto = true;
   ctx->cfg.n_variant_narrow = 0;   // n_rpt1_unr8_nt
   ctx->cfg.t_target_blocks = 8 * (int64_t)ctx->num_cu;
-  if (const char* s = getenv("APX_GEMV_N_VARIANT")) { ctx->cfg.n_variant = atoi(s); ctx->cfg.n_auto = false; }
-  if (const char* s = getenv("APX_GEMV_T_VARIANT")) ctx->cfg.t_variant = atoi(s);
-  if (const char* s = getenv("APX_GEMV_N_BLOCKS")) ctx->cfg.n_target_blocks = atoll(s);
-  if (const char* s = getenv("APX_GEMV_T_BLOCKS")) ctx->cfg.t_target_blocks = atoll(s);
-  if (ctx->cfg.n_variant < 0 || ctx->cfg.n_variant >= gemv_n_variant_count()) ctx->cfg.n_variant = 0;
-  if (ctx->cfg.t_variant < 0 || ctx->cfg.t_variant >= gemv_t_variant_count()) ctx->cfg.t_variant = 0;
+  // (no environment variables: sweeps use apx_ctx_set_gemv_config / apx_ctx_set_option)
   *out = ctx;
   return APX_OK;
 }
@@ -290,6 +288,71 @@ int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable) {
   APX_REQUIRE(ctx != nullptr, "apx_ctx_fused_small: ctx is NULL");
   ctx->fused_small = enable != 0;
   return APX_OK;
+}
+
+int32_t apx_ctx_one_pass(apx_ctx* ctx, int32_t mode) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_one_pass: ctx is NULL");
+  APX_REQUIRE(mode >= 0 && mode <= 2, "apx_ctx_one_pass: mode 0 (off), 1 (on) or 2 (on, without the team kernels)");
+  ctx->one_pass = mode != 0;
+  ctx->teams = mode == 1;
+  return APX_OK;
+}
+
+const char* apx_ctx_kernel_name(apx_ctx* ctx, int32_t slot) {
+  if (ctx == nullptr || slot < 0 || slot >= APX_KSTAT_COUNT) return "";
+  return ctx->kname[slot].c_str();
+}
+
+int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
+  APX_REQUIRE(ctx != nullptr, "apx_ctx_set_option: ctx is NULL");
+  switch (key) {
+    case APX_OPT_MULTI_ROWS_MASK:
+      APX_REQUIRE(value >= 0 && value <= 7, "APX_OPT_MULTI_ROWS_MASK: a mask of three bits");
+      ctx->multi_mask = (int)value;
+      return APX_OK;
+    case APX_OPT_SLAB_GENERATION:
+      APX_REQUIRE(value >= 0 && value <= 2, "APX_OPT_SLAB_GENERATION: 0 (by measurement), 1 or 2");
+      ctx->slab_generation = (int)value;
+      return APX_OK;
+    case APX_OPT_TEAM_WAIT_MS:
+      APX_REQUIRE(value >= 1 && value <= 60000, "APX_OPT_TEAM_WAIT_MS: 1 ... 60000 ms");
+      ctx->team_wait_ms = (int)value;
+      return APX_OK;
+    case APX_OPT_TEAM_COOPERATIVE:
+      ctx->team_cooperative = value != 0;
+      return APX_OK;
+    case APX_OPT_TEAM_FAULT_GRID:
+      APX_REQUIRE(value >= 0 && value <= 256, "APX_OPT_TEAM_FAULT_GRID: 0 (off) ... 256 workgroups");
+      ctx->team_fault_grid = (int)value;
+      return APX_OK;
+    case APX_OPT_GEMV_N_VARIANT: return apx_ctx_set_gemv_config(ctx, (int32_t)value, -1, 0, 0);
+    case APX_OPT_GEMV_T_VARIANT: return apx_ctx_set_gemv_config(ctx, -1, (int32_t)value, 0, 0);
+    case APX_OPT_GEMV_N_BLOCKS: return apx_ctx_set_gemv_config(ctx, -1, -1, value, 0);
+    case APX_OPT_GEMV_T_BLOCKS: return apx_ctx_set_gemv_config(ctx, -1, -1, 0, value);
+    case APX_OPT_FUSED_TAIL:
+      ctx->fused_tail = value != 0;
+      return APX_OK;
+    default:
+      return fail(APX_ERR_INVALID, "apx_ctx_set_option: unknown key");
+  }
+}
+
+int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
+  APX_REQUIRE(ctx != nullptr && value != nullptr, "apx_ctx_get_option: NULL argument");
+  switch (key) {
+    case APX_OPT_MULTI_ROWS_MASK: *value = ctx->multi_mask; return APX_OK;
+    case APX_OPT_SLAB_GENERATION: *value = ctx->slab_generation; return APX_OK;
+    case APX_OPT_TEAM_WAIT_MS: *value = ctx->team_wait_ms; return APX_OK;
+    case APX_OPT_TEAM_COOPERATIVE: *value = ctx->team_cooperative ? 1 : 0; return APX_OK;
+    case APX_OPT_TEAM_FAULT_GRID: *value = ctx->team_fault_grid; return APX_OK;
+    case APX_OPT_GEMV_N_VARIANT: *value = ctx->cfg.n_variant; return APX_OK;
+    case APX_OPT_GEMV_T_VARIANT: *value = ctx->cfg.t_variant; return APX_OK;
+    case APX_OPT_GEMV_N_BLOCKS: *value = ctx->cfg.n_target_blocks; return APX_OK;
+    case APX_OPT_GEMV_T_BLOCKS: *value = ctx->cfg.t_target_blocks; return APX_OK;
+    case APX_OPT_FUSED_TAIL: *value = ctx->fused_tail ? 1 : 0; return APX_OK;
+    default:
+      return fail(APX_ERR_INVALID, "apx_ctx_get_option: unknown key");
+  }
 }
 
 int32_t apx_ctx_set_gemv_config(apx_ctx* ctx, int32_t n_variant, int32_t t_variant, int64_t n_blocks,

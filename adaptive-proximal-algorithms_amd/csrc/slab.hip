@@ -49,6 +49,19 @@ struct SlabDev {
   double* fsc_out;        // row-sharded f: the closing kernel leaves the two LOCAL loss sums here (they are all-reduced with the
 };                        // gradient, then k_f_final closes f) ; NULL: it closes f itself
 
+// The end of a proximal-gradient iteration riding in the closing kernel (no linear operator, no row shard): the primal
+// residual and the step-size reductions (src/AdaProx.jl:338, :260-261 — k_reduce_n) over the 64 columns whose gradient a
+// block has just formed, and — by the block that arrives LAST — their totals, the rule and the end of the iteration
+// (:340-342, :348-354 — k_rule).  Two kernels between consecutive passes over A (this one and k_step) instead of four.
+// The sums are formed in exactly the order of k_reduce_n + k_rule (a block's 64 columns are one wave of k_reduce_n's
+// 256-element block: wave partials here, the same two-level tree there), so the iterates are bit-identical to the
+// separate kernels (tests/test_gpu_slab.py::test_fused_tail_is_bit_identical).
+struct SlabTail : SlabTailReq {          // (the solver's n-vectors, g, the record sink: solver_internal.h)
+  double* wred;                          // [5][ldw] wave partials (entries beyond the last wave stay zero)
+  unsigned* arrive;                      // blocks that have stored theirs (reset by the last one)
+  int32_t ldw, enabled;
+};
+
 struct SlabState {
   DBuf part;
   SlabDev dev{};
@@ -59,10 +72,9 @@ struct SlabState {
   // rows of more than 10 752 Float64 entries: teams of team_p workgroups (k_team_rows), team_kv vectors per thread
   int team_p = 0, team_kv = 0;
   bool team_big = false;          // slices of 6 ... 8 vectors per thread: three row slots, ONE row of slack (k_team_rows<..., 3, 1>)
-  DBuf team_buf;                  // ring, tickets, err
-  TeamDev team{};
-  int32_t* h_err = nullptr;       // pinned copy of err
-  ~SlabState() { if (h_err) (void)hipHostFree(h_err); }
+  TeamHost team;                  // ring, tickets, the error word and its diagnostic record, wait statistics (csrc/team_rows.h)
+  DBuf tail_buf;                  // the fused end of the iteration (SlabTail): wave partials of the five reductions + the arrival counter
+  std::string kname;              // the row kernel as launched (apx_ctx_kernel_name)
 };
 void slab_destroy(SlabState* st) { delete st; }      // (null is fine)
 
@@ -422,15 +434,29 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
 // in order.
 constexpr int kSlabCloseCols = 64;
 constexpr int kSlabCloseBlock = 1024;
-template <typename T, int FK>
-__global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B, T* __restrict__ grad) {
+template <typename T, int FK, bool TAIL = false>
+__global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B, T* __restrict__ grad, SlabTail tl) {
   constexpr int S = kSlabCloseBlock / kSlabCloseCols;
   __shared__ double fs[2];
   __shared__ double sub[S][kSlabCloseCols];
+  __shared__ double tsh[kBlock / 64][5];
+  __shared__ unsigned last_s;
   if (d.c->done != 0) return;
   const int tid = threadIdx.x;
   const int c = tid % kSlabCloseCols, sl = tid / kSlabCloseCols;
   const int j = blockIdx.x * kSlabCloseCols + c;
+  // (TAIL: this column's entries of the solver's vectors, in flight with the partials)
+  [[maybe_unused]] T tx = (T)0, txp = (T)0, tgp = (T)0, tv = (T)0;
+  [[maybe_unused]] double gamma = 0.0;
+  if constexpr (TAIL) {
+    if (sl == 0 && j < d.n) {
+      tx = ((const T*)tl.x)[j];
+      txp = ((const T*)tl.xprev)[j];
+      tgp = ((const T*)tl.gprev)[j];
+      tv = ((const T*)tl.v)[j];
+    }
+    gamma = d.c->gamma;
+  }
   const double part_sum = j < d.ncols ? skinny_strided_sum(d.part, d.ldpart, j, sl, S, B) : 0.0;
   // the loss sums over the B blocks, by every block in the same fixed order (waves 0 and 1: one column each)
   if (tid < 128) {
@@ -443,21 +469,88 @@ __global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B
   sub[sl][c] = part_sum;
   __syncthreads();
   const double N = d.c->n_mean;
+  T gj = (T)0;
   if (sl == 0 && j < d.ncols) {
     double g = sub[0][c];
 #pragma unroll
     for (int k = 1; k < S; ++k) g += sub[k][c];
     const T gs = (T)g;                                                       // A' * res
-    grad[j] = FK == APX_F_LOGISTIC ? (T)((double)gs / N) : gs;
+    gj = FK == APX_F_LOGISTIC ? (T)((double)gs / N) : gs;
+    grad[j] = gj;
   }
-  if (FK == APX_F_LOGISTIC && blockIdx.x == 0 && tid == 0) grad[d.n - 1] = (T)(fs[1] / N);      // grad[end] = mean(probs - y)
-  if (blockIdx.x == 0 && tid == 0) {
-    if (d.fsc_out != nullptr) {                                              // row shard: local sums, closed after the all-reduce
-      d.fsc_out[0] = fs[0];
-      d.fsc_out[1] = fs[1];
-    } else {
-      f_finalize(d.c, FK, fs);                                               // f(x) (and the bias gradient) -> Ctrl
+  if constexpr (!TAIL) {
+    if (FK == APX_F_LOGISTIC && blockIdx.x == 0 && tid == 0) grad[d.n - 1] = (T)(fs[1] / N);      // grad[end] = mean(probs - y)
+    if (blockIdx.x == 0 && tid == 0) {
+      if (d.fsc_out != nullptr) {                                            // row shard: local sums, closed after the all-reduce
+        d.fsc_out[0] = fs[0];
+        d.fsc_out[1] = fs[1];
+      } else {
+        f_finalize(d.c, FK, fs);                                             // f(x) (and the bias gradient) -> Ctrl
+      }
     }
+  } else {
+    // grad[end] = mean(probs - y) by the lane whose element it is (the grid covers n = ncols + 1 entries)
+    if (FK == APX_F_LOGISTIC && sl == 0 && j == d.n - 1) {
+      gj = (T)(fs[1] / N);
+      grad[j] = gj;
+    }
+    // ---- k_reduce_n's terms of this block's 64 entries: one wave of its 256-entry block ---------------------------------
+    if (tid < 64) {
+      double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      if (j < d.n) {
+        const double xi = (double)tx, gi = (double)gj;
+        const double pr = ((double)tv - xi) / gamma + gi;                    // :338 (A = 0: no At_y term)
+        const double dg = gi - (double)tgp;
+        const double dx = xi - (double)txp;
+        q[0] = fma(pr, pr, q[0]);
+        q[1] = fma(dg, dg, q[1]);
+        q[2] = fma(dg, dx, q[2]);
+        q[3] = fma(dx, dx, q[3]);
+        q[4] += gval_elem<T>(tl.g, xi, j);
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const double w = wave_sum(q[k]);
+        if (tid == 0) tl.wred[(int64_t)k * tl.ldw + blockIdx.x] = w;
+      }
+    }
+    // ---- the block that arrives last closes the iteration ----------------------------------------------------------------
+    if (tid == 0) {
+      __threadfence();                                                       // (this block's partials before its arrival)
+      last_s = atomicAdd(tl.arrive, 1u);
+    }
+    __syncthreads();
+    if (last_s != gridDim.x - 1) return;
+    __threadfence();                                                         // (the others' partials after theirs)
+    if (tid == 0) *tl.arrive = 0u;                                           // (everybody has arrived: the next launch starts at 0)
+    // k_rule's totals: blocks of four waves ((W0 + W1) + W2) + W3 — block_partials_store —, thread t the blocks t, t + 256,
+    // ..., wave sums, the four waves in order — reduce_partials
+    const int nblk = (d.n + kBlock - 1) / kBlock;
+    double tot[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (tid < kBlock) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const double* __restrict__ w = tl.wred + (int64_t)k * tl.ldw;
+        double s = 0.0;
+        for (int b = tid; b < nblk; b += kBlock) s += ((w[4 * b] + w[4 * b + 1]) + w[4 * b + 2]) + w[4 * b + 3];
+        s = wave_sum(s);
+        if ((tid & 63) == 0) tsh[tid >> 6][k] = s;
+      }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) tot[k] = ((tsh[0][k] + tsh[1][k]) + tsh[2][k]) + tsh[3][k];
+    Ctrl* cc = d.c;
+    f_finalize(cc, FK, fs);
+    cc->it += 1;
+    const double npr = sqrt(tot[0]);
+    cc->npr2 = npr * npr;
+    cc->g_x = gval_final(tl.g, tot[4]);
+    rule_update(cc, tot[1], tot[2], tot[3]);
+    cc->ndr2 = 0.0;
+    cc->h_Ax = 0.0;
+    finish_iteration(cc, tl.recs, tl.rec_cap);
   }
 }
 
@@ -473,9 +566,9 @@ static SlabShape slab_shape(const apx_problem* p) {
   // link of the H rows in the lanes of a row wave that holds no row of A.  Against the shapes below (one element per lane and
   // load, the link next to the rows), tools/shape_sweep.py at 6 GB, TB/s of the bytes read: least squares 600: 4.7 -> 5.7,
   // 1100: 5.7 -> 6.4, 2100: 5.2 -> 6.3, else within +- 5 % ; logistic 400: 1.8 -> 4.6, 1000: 3.9 -> 6.2, 2100: 4.6 -> 6.3,
-  // 4224: 5.5 -> 6.7.  (APX_MULTI in the environment, bit 0 least squares / bit 1 logistic / bit 2 the primal-dual loop: an A/B
+  // 4224: 5.5 -> 6.7.  (APX_OPT_MULTI_ROWS_MASK, bit 0 least squares / bit 1 logistic / bit 2 the primal-dual loop: an A/B
   // switch — 0 runs the first-generation shapes, which stay for Float32 ; tests/test_gpu_slab.py::test_first_generation_shapes)
-  static const int multi = getenv("APX_MULTI") ? atoi(getenv("APX_MULTI")) : 7;
+  const int multi = p->ctx->multi_mask;
   if (p->dtype == APX_F64 && cols <= 2 * 4 * 704 && ((p->f_kind == APX_F_LOGISTIC ? 2 : 1) & multi)) return {768, kSlabMultiCpt, 1};
   if (cols <= 1024) return {1024, 1, kSlabRows};      // (one column per thread, 32 rows per step: with two, half the loads of such a row are clamped away)
   if (cols <= 2 * 768) return {768, 2, kSlabRows};    // (1025 ... 1536 entries: two columns of 768 threads keep more lanes busy than of 1024)
@@ -490,17 +583,18 @@ static SlabShape slab_shape(const apx_problem* p) {
   // (half the bytes in flight: +5 % over the two passes at C3), 512 x 20 x 4 and 1024 x 10 x 4 (spills).
   // Float64 logistic: the link function next to the rows costs the row kernels two of their three rows in flight (exp, log:
   // ~50 registers) — the communication-wave kernel with a "team" of ONE evaluates it where no row is held (k_team_rows, P = 1)
-  if (p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC && cols > 5 * 1024 && cols <= 2 * kTeamSingleKv * 704 && !p->teams_off)      // (5633 ... 11 264 by default)
+  // (a "team" of ONE hands nothing over and needs no co-residency: it stays when the team kernels are switched off)
+  if (p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC && cols > 5 * 1024 && cols <= 2 * kTeamSingleKv * 704)      // (5633 ... 11 264 by default)
     return {768, kSlabTeamCpt, 1};
   if (cols <= 14 * 768) return {768, 14, p->dtype == APX_F32 ? kSlabRows : kSlabRows / 2};
   // longer rows (BASELINE config C2: 100 000): teams of 2 / 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
   // Float64, on a part of 8 XCDs x 32 CUs
-  if (p->dtype == APX_F64 && cols <= kTeamMaxCols && p->ctx->num_cu == 256) return {768, kSlabTeamCpt, 1};
+  if (p->dtype == APX_F64 && cols <= kTeamMaxCols && p->ctx->num_cu == 256 && p->ctx->teams && !p->teams_dead()) return {768, kSlabTeamCpt, 1};
   return {0, 0, 0};
 }
 
 static bool slab_shape_ok(const apx_problem* p) {
-  if (!p->ctx->fused_small) return false;
+  if (!p->ctx->one_pass) return false;
   // (a row shard of f — communicator or callback — is as good as a whole matrix: the rows are local, only the block sums
   //  travel ; eval_f all-reduces them)
   if (p->A_lin != nullptr || (p->sharded() && !p->f_sharded)) return false;
@@ -555,14 +649,14 @@ static int32_t slab_setup(apx_problem* p) {
     B = ctx->num_cu / P;                   // slabs = teams ; ALL 256 workgroups are launched (32 / P teams per XCD)
     rpb_team = (A->m + B - 1) / B;
     st->B = (int)B;
-    const size_t ring_bytes = (size_t)B * kTeamSlots * P * sizeof(TeamRec);
-    APX_TRY(st->team_buf.alloc_zero(ring_bytes + 64, ctx->stream));
-    st->team.ring = (TeamRec*)st->team_buf.p;
-    st->team.tickets = (unsigned*)((char*)st->team_buf.p + ring_bytes);
-    st->team.err = (int*)((char*)st->team_buf.p + ring_bytes + 32);
-    st->team.rows_per_team = (int32_t)rpb_team;
-    APX_HIP(hipHostMalloc((void**)&st->h_err, sizeof(int32_t), hipHostMallocDefault));
-    *st->h_err = 0;
+    if (P > 1) {
+      // the scheme's precondition, as far as it can be known up front: one workgroup of THIS kernel per CU, 256 of them
+      const bool nt_q = true;
+      const int per_cu = p->f_kind == APX_F_LOGISTIC ? team_blocks_per_cu<APX_F_LOGISTIC, SlabDev>(pl, nt_q)
+                                                     : team_blocks_per_cu<APX_F_LEAST_SQUARES, SlabDev>(pl, nt_q);
+      if (per_cu < 1) return APX_OK;         // (it does not fit: no state, the two passes run)
+    }
+    APX_TRY(team_alloc(ctx, &st->team, (int)B, P, rpb_team));
   }
   if (st->cpt == 14) {                     // long rows: k_slab2_rows, KV 16-byte vectors per thread and row
     const int64_t vw = 16 / (int64_t)dtype_size(p->dtype);
@@ -574,7 +668,7 @@ static int32_t slab_setup(apx_problem* p) {
     // column slots fit 10 000 columns better than 16 x 768 — while the second generation wins wherever its KV adapts:
     // 120 000 x 6000 fp32 0.47 vs 0.60 ms per iteration, 60 000 x 8000 fp64 0.60 vs 0.68, 50 000 x 10 000 fp64 0.64 vs 0.66)
     if (p->dtype == APX_F32 && st->kv == 4) st->v2 = false;
-    if (const char* e = getenv("APX_SLAB_V1")) st->v2 = atoi(e) == 0;
+    if (ctx->slab_generation != 0) st->v2 = ctx->slab_generation == 2;      // (APX_OPT_SLAB_GENERATION: A/B runs)
   }
   SlabDev d{};
   d.AT = A->dT;
@@ -598,6 +692,10 @@ static int32_t slab_setup(apx_problem* p) {
   const int rows_per_step = st->cpt == 1 ? 32 : st->cpt == 2 ? 16 : kSlabRows;
   st->pipe = rpb / rows_per_step >= 16;
   st->dev = d;
+  // the fused end of the iteration (SlabTail): five rows of wave partials (one per closing block, the entries beyond the last
+  // wave of k_reduce_n's last block stay zero) and the arrival counter
+  const int64_t ldw = round_up(4 * ((p->n + kBlock - 1) / kBlock), 64) + 64;
+  APX_TRY(st->tail_buf.alloc_zero((size_t)(5 * ldw) * sizeof(double) + 64, ctx->stream));
   p->slab = st.release();
   return APX_OK;
 }
@@ -646,25 +744,36 @@ static bool slab2_dispatch(const SlabState* st, dim3 grid, hipStream_t q, const 
   }
 }
 
+// the closing kernel: with the end of the iteration riding in it (SlabTail) its grid covers all n entries of the solver's
+// vectors — the logistic bias, entry ncols, included
 template <typename T, int FK>
-static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* grad, hipStream_t q) {
+static void slab_close_launch(const SlabDev& d, int nparts, void* grad, const SlabTail& tl, hipStream_t q) {
+  if (tl.enabled)
+    hipLaunchKernelGGL((k_slab_close<T, FK, true>), dim3((unsigned)((d.n + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kSlabCloseBlock), 0, q,
+                       d, nparts, (T*)grad, tl);
+  else
+    hipLaunchKernelGGL((k_slab_close<T, FK, false>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)), dim3(kSlabCloseBlock), 0,
+                       q, d, nparts, (T*)grad, tl);
+}
+
+template <typename T, int FK>
+static bool slab_launch_t(SlabState* st, bool cooperative, const SlabDev& d, const void* x, void* grad, const SlabTail& tl, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   if (st->team_p != 0) {
+    bool ok = true;
     if constexpr (sizeof(T) == 8) {
-      team_launch<FK, SlabDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, d, st->team, x, q);
-      hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
-                         dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
+      ok = team_launch<FK, SlabDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+      slab_close_launch<T, FK>(d, st->B, grad, tl, q);
     }
-    return;
+    return ok;
   }
   if (st->cpt == kSlabMultiCpt) {
     if constexpr (sizeof(T) == 8) {
       if (st->nt) multi_launch<FK, true, SlabDev>(d.ncols, st->B, d, x, q);
       else multi_launch<FK, false, SlabDev>(d.ncols, st->B, d, x, q);
-      hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
-                         dim3(kSlabCloseBlock), 0, q, d, st->B * multi_groups(d.ncols), (T*)grad);
+      slab_close_launch<T, FK>(d, st->B * multi_groups(d.ncols), grad, tl, q);
     }
-    return;
+    return true;
   }
   constexpr int R14 = sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2);
   constexpr bool kPipeOk = sizeof(T) == 4 || FK == APX_F_LEAST_SQUARES;       // (the others spill as two groups)
@@ -676,8 +785,28 @@ static void slab_launch_t(SlabState* st, const SlabDev& d, const void* x, void* 
   else if (st->cpt == 5) slab_rows_launch<T, FK, 5, kSlabRows, 1024, kPipeOk>(st, grid, q, d, x);
   else if (!(st->kv != 0 && st->v2 && slab2_dispatch<T, FK>(st, grid, q, d, x)))
     slab_rows_launch<T, FK, 14, R14, 768, (sizeof(T) == 4)>(st, grid, q, d, x);
-  hipLaunchKernelGGL((k_slab_close<T, FK>), dim3((unsigned)((d.ncols + kSlabCloseCols - 1) / kSlabCloseCols)),
-                     dim3(kSlabCloseBlock), 0, q, d, st->B, (T*)grad);
+  slab_close_launch<T, FK>(d, st->B, grad, tl, q);
+  return true;
+}
+
+// the row kernel of this state in words (apx_ctx_kernel_name: the bench line quotes the library, not a string of its own)
+static std::string slab_kernel_name(const SlabState* st, const apx_problem* p) {
+  char b[256];
+  const char* fk = p->f_kind == APX_F_LOGISTIC ? "logistic" : "least_squares";
+  const char* ty = p->dtype == APX_F32 ? "float" : "double";
+  if (st->team_p != 0)
+    snprintf(b, sizeof b, "k_team_rows<%s, %d member%s, %d vectors per thread, %d row slots, %d row%s of slack>", fk, st->team_p,
+             st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), (st->team_big || st->team_p == 1) ? 3 : 4,
+             (st->team_big || st->team_p == 1) ? 1 : 2, (st->team_big || st->team_p == 1) ? "" : "s");
+  else if (st->cpt == kSlabMultiCpt)
+    snprintf(b, sizeof b, "k_multi_rows<%s, %d vectors per thread, %d row group%s>", fk, (int)((((int64_t)st->dev.ncols + 1) / 2 + 703) / 704),
+             multi_groups(st->dev.ncols), multi_groups(st->dev.ncols) == 1 ? "" : "s");
+  else if (st->cpt == 14 && st->kv != 0 && st->v2 && !(p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC))
+    snprintf(b, sizeof b, "k_slab2_rows<%s, %s, %d vectors per thread>", ty, fk, st->kv);
+  else
+    snprintf(b, sizeof b, "k_slab_rows<%s, %s, %d columns per thread, %d threads%s%s>", ty, fk, st->cpt, st->bs, st->pipe ? ", two row groups" : "",
+             st->nt ? ", non-temporal loads" : "");
+  return std::string(b) + " + k_slab_close";
 }
 
 // f(x) -> Ctrl, grad f(x) -> p->grad for the device vector x: what eval_f + pullback_f leave behind.  Called by eval_f
@@ -688,49 +817,95 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   *done_here = false;
   if (!p->slab_checked) {
     p->slab_checked = true;
-    if (slab_eligible(p)) APX_TRY(slab_setup(p));
+    // Every rank of a row-sharded problem must take the same path — the two paths enqueue different collectives — but whether
+    // THIS rank can take the one pass depends on its own shard (its row count against the thresholds, whether its transposed
+    // copy could be allocated, its device): the ranks agree once, here, on the first evaluation of the problem (all of them
+    // reach it together), and take the one pass only if every one of them can.
+    int32_t rc = APX_OK;
+    bool mine = slab_eligible(p);
+    if (mine) {
+      rc = slab_setup(p);
+      mine = rc == APX_OK && p->slab != nullptr;
+    }
+    double cannot = mine ? 0.0 : 1.0;
+    APX_TRY(ranks_sum(p, cannot, &cannot));
+    if (cannot != 0.0 && p->slab != nullptr) {
+      slab_destroy(p->slab);
+      p->slab = nullptr;
+    }
+    APX_TRY(rc);
   }
   SlabState* st = p->slab;
-  if (st == nullptr || p->A_f->dT == nullptr) return APX_OK;      // (dropped copy: A edited in place)
-  if (st->team_p != 0 && p->teams_off) return APX_OK;             // (a hand-off timed out earlier: the two passes from now on)
+  if (st == nullptr || p->A_f->dT == nullptr) return APX_OK;      // (dropped copy: A edited in place — every rank's, if any's)
+  if (st->team_p > 1 && p->teams_dead()) return APX_OK;           // (a hand-off failed earlier: the two passes from now on)
   apx_ctx* ctx = p->ctx;
   SlabDev d = st->dev;
   d.AT = p->A_f->dT;                             // (rebuilt copies may live elsewhere)
   d.ldT = p->A_f->ldT;
   d.fsc_out = p->f_sharded ? p->fsc() : nullptr;
+  // the end of the iteration in the closing kernel, when the caller is the generic loop and has asked for it (solver.hip
+  // enqueue_iteration ; not for a row shard: the all-reduce of the gradient sits between the two)
+  SlabTail tl{};
+  if (p->tail_req != nullptr && !p->f_sharded && ctx->fused_tail && p->n <= (int64_t)kMaxRedBlocks * kBlock) {
+    static_cast<SlabTailReq&>(tl) = *(const SlabTailReq*)p->tail_req;
+    tl.ldw = (int32_t)(round_up(4 * ((p->n + kBlock - 1) / kBlock), 64) + 64);
+    tl.wred = (double*)st->tail_buf.p;
+    tl.arrive = (unsigned*)((char*)st->tail_buf.p + (size_t)5 * tl.ldw * sizeof(double));
+    tl.enabled = 1;
+    p->tail_done = true;
+  }
   const bool ls = p->f_kind == APX_F_LEAST_SQUARES;
-  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)p->A_f->m * (double)p->A_f->n * (double)p->es()));
+  if (st->kname.empty()) st->kname = slab_kernel_name(st, p);
+  ctx->kname[APX_KSTAT_ONE_PASS] = st->kname;
+  APX_TRY(prof_begin(ctx, APX_KSTAT_ONE_PASS, (double)p->A_f->m * (double)p->A_f->n * (double)p->es()));
+  bool launched;
   if (p->dtype == APX_F32) {
-    if (ls) slab_launch_t<float, APX_F_LEAST_SQUARES>(st, d, x, p->grad.p, ctx->stream);
-    else slab_launch_t<float, APX_F_LOGISTIC>(st, d, x, p->grad.p, ctx->stream);
+    launched = ls ? slab_launch_t<float, APX_F_LEAST_SQUARES>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream)
+                  : slab_launch_t<float, APX_F_LOGISTIC>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream);
   } else {
-    if (ls) slab_launch_t<double, APX_F_LEAST_SQUARES>(st, d, x, p->grad.p, ctx->stream);
-    else slab_launch_t<double, APX_F_LOGISTIC>(st, d, x, p->grad.p, ctx->stream);
+    launched = ls ? slab_launch_t<double, APX_F_LEAST_SQUARES>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream)
+                  : slab_launch_t<double, APX_F_LOGISTIC>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream);
   }
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
+  if (!launched) return fail(APX_ERR_HIP, "one-pass kernel (teams): the launch was refused (a cooperative launch whose grid cannot be co-resident)");
   *done_here = true;
   return APX_OK;
 }
 
 // (their launches carry a ticket base and a sequence base that advance on the host: not replayable as a captured graph)
-bool slab_uses_teams(const apx_problem* p) { return p->slab != nullptr && p->slab->team_p != 0; }
+bool slab_uses_teams(const apx_problem* p) { return p->slab != nullptr && p->slab->team_p > 1 && !p->teams_dead(); }
 
-// the error word of the team hand-off (0: fine)
+// The error word of the team hand-off (0: fine), read wherever a result is about to be used.  On a row shard the word is
+// SUMMED over the ranks: every rank reads it at the same points of the same control flow (the convergence poll at fixed
+// iteration numbers, the result, an evaluation whose value is needed), so a failure on any rank is a failure on all of them at
+// the same iteration — nobody is left inside a collective its peers have abandoned, and all of them fall back together.
 int32_t slab_check(apx_problem* p) {
   SlabState* st = p->slab;
-  if (st == nullptr || st->team_p == 0 || p->teams_off) return APX_OK;
+  if (st == nullptr || st->team_p <= 1 || p->teams_dead()) return APX_OK;      // (reported once: the failure is the problem's state now)
   apx_ctx* ctx = p->ctx;
-  APX_HIP(hipMemcpyAsync(st->h_err, st->team.err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  APX_HIP(hipStreamSynchronize(ctx->stream));
-  if (*st->h_err == 0) return APX_OK;
+  int32_t err = 0;
+  APX_TRY(team_read_err(ctx, &st->team, &err));
+  double any = err != 0 ? 1.0 : 0.0;
+  APX_TRY(ranks_sum(p, any, &any));
+  if (any == 0.0) return APX_OK;
   p->team_failed = true;
-  return fail(APX_ERR_HIP, *st->h_err == 2
-                               ? "one-pass kernel (teams): an XCD received more than 32 workgroups of a launch (the GPU is shared or "
-                                 "partitioned); the result is invalid — switch the policy off (apx_ctx_fused_small(ctx, 0))"
-                               : "one-pass kernel (teams): a workgroup waited 20 ms for its team (the GPU is shared with other work, so "
-                                 "the 256 workgroups were not resident together); the result is invalid — switch the policy off "
-                                 "(apx_ctx_fused_small(ctx, 0))");
+  const std::string what = err != 0 ? team_describe(st->team.pinned->diag, "one-pass kernel (teams)")
+                                    : std::string("one-pass kernel (teams): a team hand-off failed on another rank of this row-sharded problem "
+                                                  "(its message has the details); the result is invalid and was discarded");
+  note_incident(what);
+  return fail(APX_ERR_HIP, what);
+}
+
+// hand-off statistics of the problem's team launches (apx_problem_team_waits)
+int32_t slab_team_waits(apx_problem* p, int64_t out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0;
+  SlabState* st = p->slab;
+  if (st == nullptr || st->team_p <= 1) return APX_OK;
+  APX_TRY(team_read_waits(p->ctx, &st->team, out));
+  out[2] *= 10;                                  // ticks of 10 ns
+  out[3] = st->team.dev.launch;
+  return APX_OK;
 }
 
 }  // namespace apx

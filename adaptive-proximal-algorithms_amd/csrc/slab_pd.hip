@@ -39,10 +39,8 @@ struct SlabPdState {
   // rows of more than 10 752 Float64 entries: k_team_rows (csrc/team_rows.h) — one workgroup, or teams of 2 ... 16
   int team_p = 0, team_kv = 0;      // members ; 16-byte vectors per thread and row of a member's slice (0: not this scheme)
   bool team_big = false;
-  DBuf team_buf;          // ring, tickets, err
-  TeamDev team{};
-  int32_t* h_err = nullptr;  // pinned copy of err
-  ~SlabPdState() { if (h_err) (void)hipHostFree(h_err); }
+  TeamHost team;          // ring, tickets, the error word and its diagnostic record, wait statistics (csrc/team_rows.h)
+  std::string kname;      // the row kernel as launched (apx_ctx_kernel_name)
 };
 void slab_pd_destroy(SlabPdState* st) { delete st; }
 
@@ -244,9 +242,9 @@ struct SlabPdShape {
 static SlabPdShape slab_pd_shape(const apx_problem* p) {
   const int64_t cols = p->A_lin->n;
   const bool f32 = p->dtype == APX_F32;
-  // Float64 rows of up to 5632 entries: k_multi_rows (csrc/team_rows.h ; the A/B switch APX_MULTI, bit 2: csrc/slab.hip slab_shape) —
-  // against the shapes below, TB/s of the bytes read at 6 GB: 600: 4.0 -> 5.7, 1000: 5.8 -> 6.3, 2100: 4.2 -> 6.3, 5632: 6.0 -> 6.9
-  static const int multi = getenv("APX_MULTI") ? atoi(getenv("APX_MULTI")) : 7;
+  // Float64 rows of up to 5632 entries: k_multi_rows (csrc/team_rows.h ; the A/B switch APX_OPT_MULTI_ROWS_MASK, bit 2: csrc/slab.hip
+  // slab_shape) — against the shapes below, TB/s of the bytes read at 6 GB: 600: 4.0 -> 5.7, 1000: 5.8 -> 6.3, 2100: 4.2 -> 6.3, 5632: 6.0 -> 6.9
+  const int multi = p->ctx->multi_mask;
   if (!f32 && cols <= 2 * 4 * 704 && (multi & 4)) return {768, 27, 1};
   if (cols <= 1024) return {1024, 1, 4};           // (one column per thread, sixteen rows per step — 32 spill here: csrc/slab.hip slab_shape)
   if (cols <= 2 * 768) return {768, 2, 4};         // (1025 ... 1536 entries: csrc/slab.hip slab_shape)
@@ -261,7 +259,8 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   // up to 11 264 columns (6.2 - 6.9 TB/s throughout ; the ten / fourteen-column shapes below leave a sawtooth — 5400: 4.9,
   // 7700: 5.0 — and stay for Float32), teams of 2 ... 16 workgroups, a slice of every row each, up to 180 224 ; the teams
   // need a part of 8 XCDs x 32 CUs
-  if (!f32 && cols <= kTeamMaxCols && (p->ctx->num_cu == 256 || cols <= 2 * kTeamSingleKv * 704) && !p->teams_off) return {768, 28, 1};
+  // (one workgroup up to 11 264 columns hands nothing over: it stays when the team kernels proper are switched off)
+  if (!f32 && (cols <= 2 * kTeamSingleKv * 704 || (cols <= kTeamMaxCols && p->ctx->num_cu == 256 && p->ctx->teams && !p->teams_dead()))) return {768, 28, 1};
   if (cols <= 10 * 768) return {768, 10, f32 ? 4 : 2};
   if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
   // (C5's row length, 20 000 fp64, is out of reach of ONE workgroup's row kernel: x, the accumulator and one row are 480 KB of
@@ -270,7 +269,7 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
 }
 
 static bool slab_pd_shape_ok(const apx_problem* p) {
-  if (!p->ctx->fused_small) return false;
+  if (!p->ctx->one_pass) return false;
   if (p->A_lin == nullptr || p->sharded()) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   if (p->hd.kind == APX_G_L2) return false;        // (its conjugate prox needs a norm over all rows first)
@@ -310,16 +309,8 @@ int32_t slab_pd_setup(apx_solver* s) {
     st->team_big = pl.big;
     B = ctx->num_cu / pl.P;
     rpb = (A->m + B - 1) / B;
-    const size_t ring_bytes = (size_t)B * kTeamSlots * pl.P * sizeof(TeamRec);
-    APX_TRY(st->team_buf.alloc_zero(ring_bytes + 64, ctx->stream));
-    st->team.ring = (TeamRec*)st->team_buf.p;
-    st->team.tickets = (unsigned*)((char*)st->team_buf.p + ring_bytes);
-    st->team.err = (int*)((char*)st->team_buf.p + ring_bytes + 32);
-    st->team.seq0 = 0;
-    st->team.launch = 0;
-    st->team.rows_per_team = (int32_t)rpb;
-    APX_HIP(hipHostMalloc((void**)&st->h_err, sizeof(int32_t), hipHostMallocDefault));
-    *st->h_err = 0;
+    if (pl.P > 1 && team_blocks_per_cu<kTeamFkPd, SlabPdDev>(pl, true) < 1) return APX_OK;      // (it does not fit a CU: the generic kernels)
+    APX_TRY(team_alloc(ctx, &st->team, (int)B, pl.P, rpb));
   }
   st->B = (int)B;
   SlabPdDev d{};
@@ -344,8 +335,8 @@ int32_t slab_pd_setup(apx_solver* s) {
 }
 
 template <typename T>
-static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x, void* aty, apx_record* recs, int64_t rec_cap,
-                             hipStream_t q) {
+static void slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev& d, const void* x, void* aty, apx_record* recs,
+                             int64_t rec_cap, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   constexpr bool f32 = sizeof(T) == 4;
   if (st->cpt == 27) {                             // k_multi_rows: H rows per step, the dual steps of a step in the row wave's lanes
@@ -359,7 +350,7 @@ static void slab_pd_launch_t(SlabPdState* st, const SlabPdDev& d, const void* x,
   }
   if (st->team_kv != 0) {
     if constexpr (!f32) {
-      team_launch<kTeamFkPd, SlabPdDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, d, st->team, x, q);
+      team_launch<kTeamFkPd, SlabPdDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, cooperative, d, st->team.dev, x, q);
       hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
                          d, st->B, (T*)aty, recs, rec_cap);
     }
@@ -408,32 +399,53 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   SlabPdDev d = st->dev;
   d.AT = p->A_lin->dT;
   d.ldT = p->A_lin->ldT;
-  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)p->A_lin->m * (double)p->A_lin->n * (double)p->es()));
-  if (p->dtype == APX_F32) slab_pd_launch_t<float>(st, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
-  else slab_pd_launch_t<double>(st, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
+  if (st->kname.empty()) {
+    char b[256];
+    if (st->team_kv != 0)
+      snprintf(b, sizeof b, "k_team_rows<primal_dual, %d member%s, %d vectors per thread, %d row slots, %d row%s of slack> + k_slabpd_close", st->team_p,
+               st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), (st->team_big || st->team_p == 1) ? 3 : 4,
+               (st->team_big || st->team_p == 1) ? 1 : 2, (st->team_big || st->team_p == 1) ? "" : "s");
+    else if (st->cpt == 27)
+      snprintf(b, sizeof b, "k_multi_rows<primal_dual, %d vectors per thread, %d row group(s)> + k_slabpd_close", (int)((((int64_t)d.n + 1) / 2 + 703) / 704),
+               multi_groups(d.n));
+    else
+      snprintf(b, sizeof b, "k_slabpd_rows<%s, %d columns per thread, %d threads> + k_slabpd_close", p->dtype == APX_F32 ? "float" : "double", st->cpt, st->bs);
+    st->kname = b;
+  }
+  ctx->kname[APX_KSTAT_ONE_PASS] = st->kname;
+  APX_TRY(prof_begin(ctx, APX_KSTAT_ONE_PASS, (double)p->A_lin->m * (double)p->A_lin->n * (double)p->es()));
+  if (p->dtype == APX_F32) slab_pd_launch_t<float>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
+  else slab_pd_launch_t<double>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
   *done_here = true;
   return APX_OK;
 }
 
-bool slab_pd_uses_teams(const apx_solver* s) { return s->slab_pd != nullptr && s->slab_pd->team_kv != 0; }
+bool slab_pd_uses_teams(const apx_solver* s) { return s->slab_pd != nullptr && s->slab_pd->team_p > 1; }
 
-// the error word of the team hand-off (0: fine), read with the convergence flag and with the result
+// the error word of the team hand-off (0: fine), read with the convergence flag and with the result ; the message carries the
+// diagnostic record of the wave that gave up (csrc/team_rows.h team_describe)
 int32_t slab_pd_check(apx_solver* s) {
   SlabPdState* st = s->slab_pd;
-  if (st == nullptr || st->team_kv == 0) return APX_OK;
-  apx_ctx* ctx = s->p->ctx;
-  APX_HIP(hipMemcpyAsync(st->h_err, st->team.err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  APX_HIP(hipStreamSynchronize(ctx->stream));
-  if (*st->h_err == 0) return APX_OK;
+  if (st == nullptr || st->team_p <= 1) return APX_OK;
+  int32_t err = 0;
+  APX_TRY(team_read_err(s->p->ctx, &st->team, &err));
+  if (err == 0) return APX_OK;
   s->p->team_failed = true;
-  return fail(APX_ERR_HIP, *st->h_err == 2
-                               ? "one-pass primal-dual kernel: an XCD received more than 32 workgroups of a launch (the GPU is "
-                                 "shared or partitioned); the result is invalid — switch the policy off (apx_ctx_fused_small(ctx, 0))"
-                               : "one-pass primal-dual kernel: a workgroup waited 20 ms for its team partner (the GPU is shared with "
-                                 "other work, so the 256 workgroups were not resident together); the result is invalid — "
-                                 "switch the policy off (apx_ctx_fused_small(ctx, 0))");
+  const std::string what = team_describe(st->team.pinned->diag, "one-pass primal-dual kernel (teams)");
+  note_incident(what);
+  return fail(APX_ERR_HIP, what);
+}
+
+int32_t slab_pd_team_waits(apx_solver* s, int64_t out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0;
+  SlabPdState* st = s->slab_pd;
+  if (st == nullptr || st->team_p <= 1) return APX_OK;
+  APX_TRY(team_read_waits(s->p->ctx, &st->team, out));
+  out[2] *= 10;                                    // ticks of 10 ns
+  out[3] = st->team.dev.launch;
+  return APX_OK;
 }
 
 }  // namespace apx

@@ -73,6 +73,19 @@ static int32_t do_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dt
   return APX_OK;
 }
 
+int32_t ranks_sum(apx_problem* p, double local, double* total) {
+  *total = local;
+  if (!p->sharded()) return APX_OK;
+  apx_ctx* ctx = p->ctx;
+  ctx->h_scal[56] = local;
+  APX_HIP(hipMemcpyAsync(ctx->scal + 15, &ctx->h_scal[56], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  APX_TRY(do_allreduce(p, ctx->scal + 15, 1, APX_F64));
+  APX_HIP(hipMemcpyAsync(&ctx->h_scal[57], ctx->scal + 15, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  *total = ctx->h_scal[57];
+  return APX_OK;
+}
+
 // `f_x, pb = eval_with_pullback(f, x)` on a device x.  need_f: f_x must be final in Ctrl
 // when this returns to the stream (backtracking); otherwise a row-sharded f may defer the
 // scalar all-reduce to the pullback, where it rides along with the gradient.
@@ -356,6 +369,7 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   r.t = 1.0;
   APX_TRY(init_ctrl(p.get(), &r, 0.0));
   ctx_retain(ctx);
+  comm_retain(p->comm);
   *out = p.release();
   return APX_OK;
 }
@@ -366,7 +380,9 @@ int32_t apx_problem_destroy(apx_problem* p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     apx_ctx* ctx = p->ctx;
+    apx_comm* comm = p->comm;
     delete p;
+    comm_release(comm);
     ctx_release(ctx);
   } catch (...) {
   }
@@ -378,10 +394,24 @@ int32_t apx_eval(apx_problem* p, const void* x, double* f_x) {
   APX_REQUIRE(p->active == nullptr, "apx_eval: a solver is active on this problem");
   APX_HIP(hipSetDevice(p->ctx->device));
   APX_TRY(h2d(p->ctx, p->xtmp.p, x, (size_t)p->n * p->es()));
-  APX_TRY(eval_f(p, p->xtmp.p, true));
+  // (a failed team hand-off: the evaluation is repeated on the two passes, and the problem stays on them)
+  APX_TRY(with_team_fallback(p, nullptr, [&] { return eval_f(p, p->xtmp.p, true); }));
   Ctrl c;
   APX_TRY(read_ctrl(p, &c));
   *f_x = c.f_x;
+  return APX_OK;
+}
+
+int32_t apx_problem_team_waits(apx_problem* p, int64_t* out) {
+  APX_REQUIRE(p != nullptr && out != nullptr, "apx_problem_team_waits: NULL argument");
+  APX_HIP(hipSetDevice(p->ctx->device));
+  int64_t pd[4] = {0, 0, 0, 0};
+  APX_TRY(slab_team_waits(p, out));
+  if (p->active != nullptr) APX_TRY(slab_pd_team_waits(p->active, pd));
+  out[0] += pd[0];
+  out[1] = std::max(out[1], pd[1]);
+  out[2] = std::max(out[2], pd[2]);
+  out[3] += pd[3];
   return APX_OK;
 }
 
@@ -534,11 +564,19 @@ static int32_t enqueue_iteration(apx_solver* s) {
     APX_TRY(launch_gemv_n(ctx, p->A_lin, s->x.p, &splits, p->done_ptr()));
     APX_TRY(launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, s->ax.p, p->done_ptr()));
   }
-  APX_TRY(eval_f(p, s->x.p, false));                                           // :336 (one pass over A where csrc/slab.hip applies)
+  // (no linear operator: where f and its gradient come from one pass over A, the closing kernel of that pass may take the
+  //  residual / step-size reductions and the rule along — csrc/slab.hip SlabTail ; it says so in tail_done)
+  SlabTailReq tail{s->x.p, s->xprev.p, s->gprev.p, s->v.p, p->gd, (apx_record*)s->recs.p, s->rec_cap};
+  p->tail_req = lin ? nullptr : &tail;
+  p->tail_done = false;
+  const int32_t rc_f = eval_f(p, s->x.p, false);                               // :336 (one pass over A where csrc/slab.hip applies)
+  p->tail_req = nullptr;
+  APX_TRY(rc_f);
   APX_TRY(pullback_f(p));
-  APX_TRY(vo_reduce_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p,
-                         lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
-                         s->rec_cap));                                         // :338-342
+  if (!p->tail_done)
+    APX_TRY(vo_reduce_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p,
+                           lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
+                           s->rec_cap));                                       // :338-342
   if (lin_one_pass) {
     bool done_here = false;
     APX_TRY(slab_pd_iteration(s, &done_here));                                 // :335, :344-358
@@ -568,7 +606,7 @@ static int32_t capture_iteration(apx_solver* s) {
   apx_ctx* ctx = s->p->ctx;
   if (slab_uses_teams(s->p) || slab_pd_uses_teams(s))
     return fail(APX_ERR_UNSUPPORTED, "hipGraph replay: not with the team kernels of long rows (their launches carry host-side "
-                                     "ticket and sequence counters); use eager launches, or apx_ctx_fused_small(ctx, 0)");
+                                     "ticket and sequence counters); use eager launches, or apx_ctx_one_pass(ctx, 2)");
   const bool prof = ctx->profile;
   ctx->profile = false;                          // event records would become graph nodes
   hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
@@ -591,6 +629,17 @@ static int32_t capture_iteration(apx_solver* s) {
   return APX_OK;
 }
 
+// the error word of the team kernels this solver's iterations ran on ; a failure invalidates the solver for good
+static int32_t solver_team_check(apx_solver* s) {
+  if (s->poisoned)
+    return fail(APX_ERR_HIP, "this solver's iterate was invalidated by a failed team hand-off (apx_last_incident() has the record); "
+                             "destroy it — a new solver on the same problem runs on the two GEMV passes");
+  int32_t rc = slab_check(s->p);
+  if (rc == APX_OK) rc = slab_pd_check(s);
+  if (rc != APX_OK) s->poisoned = true;
+  return rc;
+}
+
 static int32_t poll_done(apx_solver* s, bool* done) {
   apx_ctx* ctx = s->p->ctx;
   int32_t* h = (int32_t*)&ctx->h_scal[40];
@@ -600,13 +649,13 @@ static int32_t poll_done(apx_solver* s, bool* done) {
   APX_HIP(hipMemcpyAsync(h, dp, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   APX_HIP(hipStreamSynchronize(ctx->stream));
   *done = *h != 0;
-  APX_TRY(slab_check(s->p));
-  return slab_pd_check(s);
+  return solver_team_check(s);
 }
 
 int32_t apx_solver_step(apx_solver* s, int64_t iters, int32_t sync) {
   APX_REQUIRE(s != nullptr && iters >= 0, "apx_solver_step: bad argument");
   APX_HIP(hipSetDevice(s->p->ctx->device));
+  if (s->poisoned) return solver_team_check(s);
   const bool cb = s->p->f_kind == APX_F_CALLBACK;
   if (s->use_graph && s->graph_exec == nullptr && iters > 0 && !s->stopped) APX_TRY(capture_iteration(s));
   for (int64_t k = 0; k < iters && !s->stopped; ++k) {
@@ -628,8 +677,7 @@ int32_t apx_solver_result(apx_solver* s, void* x_out, void* y_out, apx_result* r
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
   APX_HIP(hipSetDevice(ctx->device));
-  APX_TRY(slab_pd_check(s));                       // (a timed-out team hand-off invalidates the iterate)
-  APX_TRY(slab_check(p));
+  APX_TRY(solver_team_check(s));                   // (a failed team hand-off invalidates the iterate)
   Ctrl c;
   if (s->small != nullptr) APX_TRY(d2h(ctx, &c, s->small->cb.p, sizeof(Ctrl)));
   else if (s->small_pd != nullptr) APX_TRY(d2h(ctx, &c, small_pd_ctrl(s), sizeof(Ctrl)));
@@ -698,22 +746,18 @@ int32_t apx_adaptive_primal_dual(apx_problem* p, const apx_rule* rule, const voi
                                  int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out,
                                  apx_result* res) {
   APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
-  for (int attempt = 0;; ++attempt) {
+  APX_REQUIRE(p != nullptr, "apx_adaptive_primal_dual: problem is NULL");
+  // (a team hand-off that failed — the GPU is shared with other work: the 256 workgroups of a launch were not resident
+  //  together — discards that run: the solve is repeated from x0 on the two GEMV passes, which need no co-residency, the
+  //  problem stays on them and the result carries APX_FLAG_TEAM_FALLBACK ; solver_internal.h with_team_fallback)
+  return with_team_fallback(p, res, [&]() -> int32_t {
     apx_solver* s = nullptr;
     APX_TRY(apx_solver_create(p, rule, x0, y0, tol, opts, &s));
     int32_t rc = apx_solver_step(s, maxit, 1);
     if (rc == APX_OK) rc = apx_solver_result(s, x_out, y_out, res);
     apx_solver_destroy(s);
-    // a team hand-off timed out (the GPU is shared with other work: the 256 workgroups of a launch were not resident
-    // together): nothing of that run is used — the solve is repeated from x0 on the two GEMV passes, which need no
-    // co-residency, and the problem stays on them.  Not for a row shard: a rank that started again alone would leave the
-    // sequence of collectives its peers are in — there the error is returned (every rank: apx_ctx_fused_small(ctx, 0)).
-    if (rc == APX_ERR_HIP && p->team_failed && !p->teams_off && attempt == 0 && !p->sharded()) {
-      p->teams_off = true;
-      continue;
-    }
     return rc;
-  }
+  });
 }
 
 int32_t apx_adaptive_proxgrad(apx_problem* p, const apx_rule* rule, const void* x0, double tol, int64_t maxit,
@@ -928,9 +972,16 @@ int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch
 }
 
 // backtracking_proxgrad — src/AdaProx.jl:34-64
+static int32_t backtracking_proxgrad_run(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol,
+                                         int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res);
 int32_t apx_backtracking_proxgrad(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol,
                                   int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_REQUIRE(p != nullptr && x0 != nullptr && x_out != nullptr, "apx_backtracking_proxgrad: NULL argument");
+  // (a failed team hand-off: the call runs again on the two passes — solver_internal.h with_team_fallback)
+  return with_team_fallback(p, res, [&] { return backtracking_proxgrad_run(p, x0, gamma0, xi, shrink, tol, maxit, opts, x_out, res); });
+}
+static int32_t backtracking_proxgrad_run(apx_problem* p, const void* x0, double gamma0, double xi, double shrink, double tol,
+                                         int64_t maxit, const apx_solve_opts* opts, void* x_out, apx_result* res) {
   APX_REQUIRE(p->A_lin == nullptr, "backtracking_proxgrad: the problem must have no linear operator");
   APX_REQUIRE(p->active == nullptr, "a solver is active on this problem");
   APX_REQUIRE(maxit >= 0, "maxit must be non-negative");

@@ -10,6 +10,14 @@
 namespace apx {
 struct SlabState;          // (slab.hip: f and grad f in one pass over A)
 void slab_destroy(SlabState* st);
+// what the generic loop hands to an evaluation of f so that the closing kernel of a one-pass launch can take the end of the
+// iteration along (csrc/slab.hip SlabTail): the solver's n-vectors, g, the record sink
+struct SlabTailReq {
+  const void *x, *xprev, *gprev, *v;
+  ProxDev g;
+  apx_record* recs;
+  int64_t rec_cap;
+};
 }
 
 struct apx_problem {
@@ -38,9 +46,15 @@ struct apx_problem {
   // evaluation at hand already left the gradient in `grad`, the pullback has nothing to do
   apx::SlabState* slab = nullptr;
   bool slab_checked = false, grad_ready = false;
-  // set when a team hand-off timed out on this problem (the GPU is shared): from then on the two GEMV passes run, and the
-  // one-shot entry point re-runs the solve on them instead of failing
+  // team_failed: a team hand-off failed on this problem (the GPU is shared with other work) ; teams_off: it runs on the two
+  // GEMV passes from now on.  The one-shot entry points set the second when they see the first and run their call again
+  // (with_team_fallback below) ; the stepping interface returns the error and sets it for the next solver.
   bool teams_off = false, team_failed = false;
+  bool teams_dead() const { return teams_off || team_failed; }     // (no team launch on this problem any more)
+  // the end of a proximal-gradient iteration riding in the closing kernel of the one-pass launch (csrc/slab.hip SlabTail): the
+  // generic loop asks for it around its eval_f ; tail_done: that evaluation took it — k_reduce_n / k_rule are not launched
+  const void* tail_req = nullptr;
+  bool tail_done = false;
   ~apx_problem() { apx::slab_destroy(slab); }
 
   apx::Ctrl* ctrl() const { return (apx::Ctrl*)ctrl_buf.p; }
@@ -186,6 +200,7 @@ struct apx_solver {
   apx_record* host_recs = nullptr;
   int64_t iters = 0;        // iterations enqueued so far
   bool stopped = false;     // the host has seen done == 1
+  bool poisoned = false;    // a team hand-off failed under this solver: its iterate is invalid, every later call says so
   bool use_graph = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -204,6 +219,21 @@ struct apx_solver {
 };
 
 namespace apx {
+
+// A one-shot entry point whose run ended in a failed team hand-off runs again, from the same starting point, with the
+// problem taken off the team kernels — and says so (APX_FLAG_TEAM_FALLBACK, apx_last_incident()).  On a row shard every rank
+// sees the failure at the same point (slab_check sums the error word over the ranks), so all of them come through here
+// together and their collectives stay matched.
+template <class F>
+inline int32_t with_team_fallback(apx_problem* p, apx_result* res, F&& run) {
+  int32_t rc = run();
+  if (rc == APX_ERR_HIP && p != nullptr && p->team_failed && !p->teams_off) {
+    p->teams_off = true;
+    rc = run();
+    if (rc == APX_OK && res != nullptr) res->flags |= APX_FLAG_TEAM_FALLBACK;
+  }
+  return rc;
+}
 
 int32_t h2d(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t d2h(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
@@ -231,11 +261,15 @@ bool slab_pd_eligible(const apx_problem* p);
 int32_t slab_pd_setup(apx_solver* s);
 int32_t slab_pd_iteration(apx_solver* s, bool* done_here);
 int32_t slab_pd_check(apx_solver* s);
+int32_t slab_pd_team_waits(apx_solver* s, int64_t out[4]);
 bool slab_pd_uses_teams(const apx_solver* s);
 bool slab_uses_teams(const apx_problem* p);   // (team kernels: host-side launch counters — no hipGraph replay)      // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP
 // slab.hip: true when f and grad f at x_dev were formed in one pass over A (f -> Ctrl, grad -> p->grad)
 int32_t slab_eval_with_gradient(apx_problem* p, const void* x_dev, bool* done_here);
 int32_t slab_check(apx_problem* p);        // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP
+int32_t slab_team_waits(apx_problem* p, int64_t out[4]);
+// sum of a scalar over the ranks of a row-sharded problem (the value itself otherwise): what the ranks agree on paths with
+int32_t ranks_sum(apx_problem* p, double local, double* total);
 bool skinny_pg_eligible(const apx_problem* p);
 int32_t skinny_pg_setup(apx_solver* s);
 int32_t skinny_pg_enqueue(apx_solver* s);

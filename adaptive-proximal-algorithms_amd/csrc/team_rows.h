@@ -3,8 +3,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstring>
 #include <cstdlib>
+#include <string>
 
 #include "skinny_dev.h"
 #include "solver_internal.h"
@@ -92,7 +96,10 @@ __device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowCon
 //     them in a fixed tree — the same `A x` on every member, no atomics on data —, evaluates the residual / the logistic
 //     link ONCE and leaves it in LDS; member 0's accumulates the loss sums.  Two rows of slack absorb the hand-off
 //     (1 - 3 us) and the slowest member.
-// Every wait is bounded by the wall clock (20 ms) and ends in an error word the host reads: the grid always drains.
+// Every wait is bounded (TeamDev::wait_ticks of wall clock — one second by default — AND 4096 polls) and ends in an error
+// word the host reads: the grid always drains.  The word is STICKY: a launch that finds it set returns at once, a wave that
+// finds it set while it polls stops waiting — one failure costs one bound, not one per launch — and the wave that set it
+// leaves a TeamDiag record (csrc/team_dev.h) from which the host's message is built.
 // tools/split_probe.hip, tools/pattern_probe.hip (profiles/r02_team_probe_*.log, r02_team_handoff_traffic.log): 6.6 - 6.7
 // TB/s on rows of C2's length — A read once per evaluation of f and its gradient instead of twice at 7.1 TB/s.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   extern __shared__ double team_x[];               // the member's slice of x: KV * 704 * 2 doubles
   __shared__ double wsum[2][CW];
   __shared__ double res_s[4];
-  __shared__ int ident[2];
+  __shared__ int ident[5];                         // team, member, the sticky error word, XCC_ID, ticket
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (P > 1 && tid == 0) {                         // (every launch takes its 32 tickets per XCD, a finished loop's too)
@@ -142,15 +149,34 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     const unsigned k = atomicAdd(t.tickets + xcc, 1u) - t.launch * 32u;
     ident[0] = k < (unsigned)(TPX * P) ? (int)(xcc * TPX + k / P) : -1;
     ident[1] = (int)(k % P);
-    if (k >= 32u) atomicCAS(t.err, 0, 2);
+    ident[3] = (int)xcc;
+    ident[4] = (int)k;
+    if (k >= 32u && atomicCAS(t.err, 0, kTeamErrTickets) == 0) {      // an XCD with more than 32 workgroups of a launch
+      TeamDiag* g = t.diag;
+      g->code = kTeamErrTickets;
+      g->members = P;
+      g->team = g->member = -1;
+      g->xcc = (int)xcc;
+      g->ticket = (int)k;
+      g->block = (int)blockIdx.x;
+      g->depth = DEPTH;
+      g->launch = t.launch;
+      g->seq0 = t.seq0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g->tickets[c] = __hip_atomic_load(t.tickets + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the error word of an EARLIER launch (or of a workgroup of this one that has given up already): nothing is waited for
+    // any more — the host reads the word with its next poll and the result is discarded
+    ident[2] = __hip_atomic_load(t.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (P == 1 && tid == 0) {                        // P = 1: a workgroup on its own — no team to form, nothing to hand over
     ident[0] = (int)blockIdx.x;
     ident[1] = 0;
+    ident[2] = 0;
   }
   __syncthreads();
   const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
-  if (team < 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
+  if (team < 0 || ident[2] != 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
   const int nvec = (d.ncols + 1) / 2;
   const int nvs = (nvec + P - 1) / P;              // 16-byte vectors per member
   const int v0 = s * nvs;
@@ -175,6 +201,8 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     const TeamRowConsts<FK> kc(d, xv);
     double e0 = 0.0, e1 = 0.0;
     bool dead = false;
+    [[maybe_unused]] unsigned w_waits = 0, w_polls = 0;              // hand-offs that were not there at the first look ; the longest
+    [[maybe_unused]] unsigned long long w_ticks = 0;                 // of them, in polls and in 10 ns ticks (TeamWait: statistics)
     [[maybe_unused]] double own_prev = 0.0;        // P = 1: the workgroup's own row sum, one step later
     // The P records of a row are taken on the SCALAR path: P / 4 loads of 64 bytes (`s_load_dwordx16 ... glc`: past the
     // scalar cache, from the XCD's L2 — the teams are formed inside an XCD, and the members' agent-scope stores pass
@@ -214,21 +242,57 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         } else {
           const unsigned long long want = t.seq0 + (unsigned long long)r + 1;
           if (!all_there(want) && !dead) {         // not all there yet (or half written): poll, bounded
-            // Bounded twice over: 20 ms of wall clock AND 4096 polls.  The clock alone would also expire in a wave that was
-            // merely descheduled in the middle of a poll — a queue preempted for another process's work has all its waves saved
-            // and restored, the clock running on — and a partner that is only late would pass for a missing one.
+            // Bounded twice over: t.wait_ticks of wall clock (one second unless the host set another bound) AND 4096 polls.
+            // The clock alone would also expire in a wave that was merely descheduled in the middle of a poll — a queue
+            // preempted for another process's work has all its waves saved and restored, the clock running on — and a
+            // partner that is only late would pass for a missing one ; a partner that IS late (the same preemption, seen from
+            // the other side) gets the whole bound, three orders of magnitude above a step.  Every 64 polls the wave also looks
+            // at the error word: once any wave of the problem has given up the launch is lost, and waiting on is pointless.
             const long long t0 = wall_clock64();
             int polls = 0;
             for (;;) {
               fetch(r);
               if (all_there(want)) break;
-              if (++polls > 4096 && wall_clock64() - t0 > 2000000) {      // (20 ms at 100 MHz: give up — the grid must drain)
-                dead = true;
-                if (lane == 0) atomicCAS(t.err, 0, 1);
-                break;
+              if ((++polls & 63) == 0) {
+                if (__hip_atomic_load(t.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                  dead = true;
+                  break;
+                }
+                const long long waited = wall_clock64() - t0;
+                if (polls > 4096 && waited > (long long)t.wait_ticks) {       // give up — the grid must drain
+                  dead = true;
+                  if (lane == 0 && atomicCAS(t.err, 0, kTeamErrTimeout) == 0) {
+                    TeamDiag* g = t.diag;                                       // (the first failure of the problem: what this wave saw)
+                    g->code = kTeamErrTimeout;
+                    g->members = P;
+                    g->team = team;
+                    g->member = s;
+                    g->xcc = ident[3];
+                    g->ticket = ident[4];
+                    g->block = (int)blockIdx.x;
+                    g->depth = DEPTH;
+                    g->launch = t.launch;
+                    g->polls = polls;
+                    g->row = r;
+                    g->nsteps = nsteps;
+                    g->want = want;
+                    g->seq0 = t.seq0;
+                    g->ticks = (unsigned long long)waited;
+                    g->limit = t.wait_ticks;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) g->tickets[c] = __hip_atomic_load(t.tickets + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int m = 0; m < P; ++m) g->seen[m] = TeamRec{rec_word(m, 0), rec_word(m, 1)};
+                  }
+                  break;
+                }
               }
               __builtin_amdgcn_s_sleep(1);
             }
+            const unsigned long long waited = (unsigned long long)(wall_clock64() - t0);
+            w_waits += 1;
+            w_polls = max(w_polls, (unsigned)polls);
+            w_ticks = waited > w_ticks ? waited : w_ticks;
           }
           // the P partials added in a fixed pairwise tree, from the same P records on every member: the same `A x` bit for bit
           double part[P];
@@ -281,6 +345,14 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
       out[d.ncols] = e0;
       out[d.ncols + 1] = e1;
+    }
+    if constexpr (P > 1) {
+      if (lane == 0 && w_waits != 0) {             // (this launch's only writer of the slot ; launches are serialised)
+        TeamWait* w = t.wait + blockIdx.x;
+        w->waits += w_waits;
+        w->max_polls = max(w->max_polls, w_polls);
+        w->max_ticks = w_ticks > w->max_ticks ? w_ticks : w->max_ticks;
+      }
     }
     return;
   }
@@ -600,40 +672,66 @@ inline void team_allow_lds() {
     done_devs.fetch_or(bit, std::memory_order_relaxed);
   }
 }
-// (APX_TEAM_FAULT_GRID: a TEST hook — launches that many workgroups instead of all of them, so that some teams miss members:
+// One launch of a plan, or — `query` — the question whether it CAN run: the scheme needs all of a launch's workgroups resident
+// together, one per CU, and that is a property of the kernel's registers and LDS that the runtime can be asked about before
+// anything is launched (hipOccupancyMaxActiveBlocksPerMultiprocessor).  What it cannot answer is whether the CUs are FREE — a
+// GPU shared with another process's kernels: that is what the bounded waits and the error word remain for.
+struct TeamCall {
+  bool query = false;       // do not launch: fill blocks_per_cu
+  bool cooperative = false; // hipLaunchCooperativeKernel (APX_OPT_TEAM_COOPERATIVE: the runtime refuses a grid that cannot be co-resident)
+  int blocks_per_cu = -1;
+  hipError_t launch_error = hipSuccess;
+};
+// (TeamDev::fault_grid: a TEST hook — launches that many workgroups instead of all of them, so that some teams miss members:
 //  what a GPU shared with other work does to this scheme.  tests/test_gpu_team_fault.py checks that the waits time out,
 //  the grid drains and the error comes back)
-inline unsigned team_grid(int nteams, int P) {
-  static const int fault_grid = getenv("APX_TEAM_FAULT_GRID") ? atoi(getenv("APX_TEAM_FAULT_GRID")) : 0;
-  return (unsigned)(fault_grid > 0 && P > 1 ? fault_grid : nteams * P);
-}
+inline unsigned team_grid(const TeamDev& t, int nteams, int P) { return (unsigned)(t.fault_grid > 0 && P > 1 ? t.fault_grid : nteams * P); }
 template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV>
-inline void team_launch_one(int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+inline void team_launch_one(TeamCall& call, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);      // the slice of x
+  auto kernel = k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>;
   if constexpr (lds > 64 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>>();
-  hipLaunchKernelGGL((k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>), dim3(team_grid(nteams, P)), dim3(768), lds, q, d, t, x);
+  if (call.query) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 768, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      nb = 0;
+    }
+    call.blocks_per_cu = nb;
+    return;
+  }
+  const dim3 grid(team_grid(t, nteams, P)), block(768);
+  if (call.cooperative && P > 1) {
+    DEV dd = d;
+    TeamDev tt = t;
+    const void* xx = x;
+    void* args[3] = {&dd, &tt, &xx};
+    call.launch_error = hipLaunchCooperativeKernel((const void*)kernel, grid, block, args, (unsigned)lds, q);
+    return;
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, q, d, t, x);
 }
 // four row slots, two rows of slack: 2 ... 6 vectors
 // (measured and dropped at C2, interleaved runs of bench.py: five and six slots, two or three rows of slack, one to three rows
 //  really in flight — nothing ; profiles/r02_team_handoff_traffic.log has what the gap to the streaming rate was instead)
 template <int FK, int P, class DEV>
-inline bool team_launch_d2(int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+inline bool team_launch_d2(TeamCall& call, int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   switch (kv) {
     case 1:
-    case 2: team_launch_one<FK, P, 2, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
-    case 3: team_launch_one<FK, P, 3, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
-    case 4: team_launch_one<FK, P, 4, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
-    case 5: team_launch_one<FK, P, 5, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
-    case 6: team_launch_one<FK, P, 6, true, 4, 2, DEV>(nteams, d, t, x, q); return true;
+    case 2: team_launch_one<FK, P, 2, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
+    case 3: team_launch_one<FK, P, 3, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
+    case 4: team_launch_one<FK, P, 4, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
+    case 5: team_launch_one<FK, P, 5, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
+    case 6: team_launch_one<FK, P, 6, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
     default: return false;
   }
 }
 // three row slots, one row of slack: 7 or 8 vectors (a workgroup on its own: 4 ... 8, non-temporal loads by the matrix size)
 template <int FK, int P, bool NT, class DEV>
-inline bool team_launch_d1(int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+inline bool team_launch_d1(TeamCall& call, int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   switch (kv) {
-    case 7: team_launch_one<FK, P, 7, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
-    case 8: team_launch_one<FK, P, 8, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
+    case 7: team_launch_one<FK, P, 7, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
+    case 8: team_launch_one<FK, P, 8, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
     default: break;
   }
   if constexpr (P == 1) {
@@ -641,30 +739,136 @@ inline bool team_launch_d1(int kv, int nteams, const DEV& d, const TeamDev& t, c
       case 1:
       case 2:
       case 3:
-      case 4: team_launch_one<FK, 1, 4, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
-      case 5: team_launch_one<FK, 1, 5, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
-      case 6: team_launch_one<FK, 1, 6, NT, 3, 1, DEV>(nteams, d, t, x, q); return true;
+      case 4: team_launch_one<FK, 1, 4, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
+      case 5: team_launch_one<FK, 1, 5, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
+      case 6: team_launch_one<FK, 1, 6, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
       default: break;
     }
   }
   return false;
 }
-// the launch of a plan ; advances the launch's ranges of tickets and sequence numbers (never reset)
+// the launch of a plan (or the query whether it can be resident: TeamCall) ; a launch advances the ranges of tickets and
+// sequence numbers (never reset)
 template <int FK, class DEV>
-inline bool team_launch(const TeamPlan& pl, int nteams, bool nt, const DEV& d, TeamDev& t, const void* x, hipStream_t q) {
+inline bool team_dispatch(TeamCall& call, const TeamPlan& pl, int nteams, bool nt, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   bool ok = false;
-  if (pl.P == 1) ok = nt ? team_launch_d1<FK, 1, true, DEV>(pl.kv, nteams, d, t, x, q) : team_launch_d1<FK, 1, false, DEV>(pl.kv, nteams, d, t, x, q);
+  if (pl.P == 1) ok = nt ? team_launch_d1<FK, 1, true, DEV>(call, pl.kv, nteams, d, t, x, q) : team_launch_d1<FK, 1, false, DEV>(call, pl.kv, nteams, d, t, x, q);
   else if (pl.big) {
-    if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV>(pl.kv, nteams, d, t, x, q);
-    else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV>(pl.kv, nteams, d, t, x, q);
-    else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV>(pl.kv, nteams, d, t, x, q);
-  } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV>(pl.kv, nteams, d, t, x, q);
-  else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV>(pl.kv, nteams, d, t, x, q);
-  else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV>(pl.kv, nteams, d, t, x, q);
-  else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV>(pl.kv, nteams, d, t, x, q);
+    if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV>(call, pl.kv, nteams, d, t, x, q);
+    else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV>(call, pl.kv, nteams, d, t, x, q);
+    else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV>(call, pl.kv, nteams, d, t, x, q);
+  } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV>(call, pl.kv, nteams, d, t, x, q);
+  else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV>(call, pl.kv, nteams, d, t, x, q);
+  else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV>(call, pl.kv, nteams, d, t, x, q);
+  else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV>(call, pl.kv, nteams, d, t, x, q);
+  return ok;
+}
+template <int FK, class DEV>
+inline bool team_launch(const TeamPlan& pl, int nteams, bool nt, bool cooperative, const DEV& d, TeamDev& t, const void* x, hipStream_t q) {
+  TeamCall call;
+  call.cooperative = cooperative;
+  const bool ok = team_dispatch<FK, DEV>(call, pl, nteams, nt, d, t, x, q) && call.launch_error == hipSuccess;
   t.launch += 1;
   t.seq0 += (unsigned long long)t.rows_per_team + 16;
   return ok;
+}
+// workgroups of this plan's kernel that fit one CU at once (0: the runtime could not say, or none)
+template <int FK, class DEV>
+inline int team_blocks_per_cu(const TeamPlan& pl, bool nt) {
+  TeamCall call;
+  call.query = true;
+  const DEV d{};
+  const TeamDev t{};
+  if (!team_dispatch<FK, DEV>(call, pl, 1, nt, d, t, nullptr, nullptr)) return 0;
+  return call.blocks_per_cu;
+}
+
+// ---- host side: the hand-off state of a problem's teams, and what a failure looked like --------------------------------------
+struct TeamHost {
+  DBuf buf;                 // ring | tickets | err | diag | wait
+  TeamDev dev{};
+  struct Pinned { int32_t err; int32_t _pad; TeamDiag diag; TeamWait wait[256]; }* pinned = nullptr;
+  ~TeamHost() { if (pinned) (void)hipHostFree(pinned); }
+};
+inline int32_t team_alloc(apx_ctx* ctx, TeamHost* th, int nteams, int P, int64_t rows_per_team) {
+  const size_t ring_bytes = (size_t)nteams * kTeamSlots * P * sizeof(TeamRec);
+  const size_t off_tickets = ring_bytes, off_err = off_tickets + 32, off_diag = off_err + 32;
+  const size_t off_wait = off_diag + (sizeof(TeamDiag) + 63) / 64 * 64;
+  APX_TRY(th->buf.alloc_zero(off_wait + 256 * sizeof(TeamWait), ctx->stream));
+  char* base = (char*)th->buf.p;
+  th->dev.ring = (TeamRec*)base;
+  th->dev.tickets = (unsigned*)(base + off_tickets);
+  th->dev.err = (int*)(base + off_err);
+  th->dev.diag = (TeamDiag*)(base + off_diag);
+  th->dev.wait = (TeamWait*)(base + off_wait);
+  th->dev.seq0 = 0;
+  th->dev.launch = 0;
+  th->dev.rows_per_team = (int32_t)rows_per_team;
+  th->dev.wait_ticks = (unsigned long long)ctx->team_wait_ms * 100000ull;      // (s_memrealtime: 100 MHz)
+  th->dev.fault_grid = ctx->team_fault_grid;
+  APX_HIP(hipHostMalloc((void**)&th->pinned, sizeof(TeamHost::Pinned), hipHostMallocDefault));
+  memset(th->pinned, 0, sizeof(TeamHost::Pinned));
+  return APX_OK;
+}
+// the error word (0: fine) ; on a failure the diagnostic record comes with it
+inline int32_t team_read_err(apx_ctx* ctx, TeamHost* th, int32_t* err) {
+  APX_HIP(hipMemcpyAsync(&th->pinned->err, th->dev.err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  *err = th->pinned->err;
+  if (*err != 0) {
+    APX_HIP(hipMemcpyAsync(&th->pinned->diag, th->dev.diag, sizeof(TeamDiag), hipMemcpyDeviceToHost, ctx->stream));
+    APX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return APX_OK;
+}
+// the longest hand-off wait any workgroup slot has seen so far (polls, 10 ns ticks) and the number of waits
+inline int32_t team_read_waits(apx_ctx* ctx, TeamHost* th, int64_t out[3]) {
+  APX_HIP(hipMemcpyAsync(th->pinned->wait, th->dev.wait, sizeof(th->pinned->wait), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  out[0] = out[1] = out[2] = 0;
+  for (const TeamWait& w : th->pinned->wait) {
+    out[0] += w.waits;
+    out[1] = std::max<int64_t>(out[1], w.max_polls);
+    out[2] = std::max<int64_t>(out[2], (int64_t)w.max_ticks);
+  }
+  return APX_OK;
+}
+// the failure in words: which wave gave up, on what, and what it saw
+inline std::string team_describe(const TeamDiag& g, const char* which) {
+  char b[512];
+  std::string s = std::string(which) + ": ";
+  if (g.code == kTeamErrTickets) {
+    snprintf(b, sizeof b, "XCD %d handed out ticket %d of launch %u (workgroup %d): more than 32 workgroups of one launch on an XCD — the "
+             "GPU is partitioned, or an earlier launch of this problem did not run all its workgroups. Tickets per XCD now:",
+             g.xcc, g.ticket, g.launch, g.block);
+    s += b;
+  } else {
+    snprintf(b, sizeof b, "a hand-off wait expired after %.1f ms and %d polls (bound %.0f ms): launch %u, team %d member %d of %d "
+             "(workgroup %d, XCD %d, ticket %d), row %lld of its slab (step %lld of %lld, %d rows of slack), expected sequence word %llu. "
+             "Records of that row as last read — member:state —",
+             (double)g.ticks * 1e-5, g.polls, (double)g.limit * 1e-5, g.launch, g.team, g.member, g.members, g.block, g.xcc, g.ticket,
+             g.row, g.row + g.depth, g.nsteps, g.depth, g.want);
+    s += b;
+    for (int m = 0; m < g.members && m < kTeamMaxMembers; ++m) {
+      const unsigned long long tag = g.seen[m].v ^ g.seen[m].chk;
+      if (tag == g.want) snprintf(b, sizeof b, " %d:ok", m);
+      else if (tag > g.seq0 && tag <= g.seq0 + (unsigned long long)g.nsteps) snprintf(b, sizeof b, " %d:row %lld", m, (long long)(tag - g.seq0 - 1));
+      else snprintf(b, sizeof b, " %d:none(tag %llx)", m, tag);
+      s += b;
+    }
+    s += ". Tickets per XCD:";
+  }
+  for (int c = 0; c < 8; ++c) {
+    snprintf(b, sizeof b, " %u", g.tickets[c] - g.launch * 32u);
+    s += b;
+  }
+  s += g.code == kTeamErrTickets
+           ? " (32 each is a complete launch)."
+           : " (32 each: every workgroup of the launch had started ; fewer: some never became resident — the GPU is shared with other "
+             "work, or partitioned).";
+  s += " The result of this launch is invalid and was discarded ; the problem now runs on the two GEMV passes (apx_ctx_one_pass(ctx, 2) "
+       "keeps every new problem off the team kernels).";
+  return s;
 }
 
 }  // namespace apx

@@ -7,7 +7,8 @@ HBM), plus the fraction of the HBM roofline of the dominant GEMV kernel.
 
 A "step" = ONE iteration of src/AdaProx.jl:334-362 = GEMV-N (A x - b, ||r||^2) + GEMV-T
 (A' r) + the fused residual / step-size / soft-threshold kernels, on data already resident
-in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every
+in HBM.  N > 1 (one rank per GPU — launched by torch.distributed.run, or by THIS script: `python bench.py --gpus N`
+without a launcher's environment starts the N ranks itself, before anything has touched a GPU): weak scaling — every
 rank holds a 50 000-row shard of the (50 000 N) x 100 000 matrix (BASELINE config C4 at
 N = 8) and the partial gradient A_k' r_k is all-reduced with RCCL over xGMI each iteration: ONE
 ncclAllReduce(n + 2 fp64) per iteration, enqueued by the native loop itself on its stream through the communicator
@@ -62,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0: 10000, or 4000 on a small host)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="time budget of each CPU-baseline leg")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 legs of the N = 1 run")
+    ap.add_argument("--two-pass", action="store_true", help="NOT the default product path: the two GEMV passes of round 1 (apx_ctx_one_pass(ctx, 0))")
+    ap.add_argument("--gemv-t-variant", type=int, default=-1, help="tile shape of the column-streaming kernel of the two-pass iteration (tools/bench_variants.sh)")
     return ap.parse_args()
 
 
@@ -160,6 +163,38 @@ def cpu_baseline(n: int, m_full: int, rows: int, seconds: float, seed: int) -> d
     }
 
 
+def relaunch_command(argv: list, gpus: int, port: int) -> list:
+    """`python bench.py --gpus N` outside a launcher: the command that starts the N ranks (one per GPU, RCCL between them)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def maybe_relaunch(args, argv: list, run=None) -> bool:
+    """With --gpus N > 1 and no launcher's environment (WORLD_SIZE unset) this process becomes the LAUNCHER: it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, passes its output through and exits with its
+    code.  It happens before torch is imported and before any HIP call — a process that has initialised the GPU must neither
+    fork ranks nor be replaced by another program on this pool — and the children find WORLD_SIZE set, so they do not come
+    through here again.  Returns False when there is nothing to launch (this process is a rank, or N = 1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return False
+    assert "torch" not in sys.modules, "bench.py: the launcher must not have imported torch"
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: RCCL between processes needs it on this pool)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = relaunch_command(argv, args.gpus, free_port())
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    rc = (run or subprocess.call)(cmd, env=env)
+    sys.exit(int(rc))
+
+
 class _StdoutToStderr:
     """Rank 0 prints ONE JSON line on stdout.  Gloo and RCCL announce themselves from C (`[Gloo] Rank 0 is connected ...`,
     `RCCL version : ...`) on file descriptor 1 when their groups are created: while that happens, descriptor 1 points at
@@ -210,7 +245,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     (2 m n sizeof(T) per iteration: above 1 where one pass over A serves both products)."""
     out = {}
 
-    def report(m, n, es, steps, dt, stats, res, one_pass_note, one_pass_kernel):
+    def report(m, n, es, steps, dt, stats, res, one_pass_note):
         k = kernel_table(stats)
         dom = max(k, key=lambda q: k[q]["avg_ms"] * k[q]["launches"])
         its = steps / dt
@@ -225,7 +260,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
              "objective": res.objective, "norm_res": res.norm_res}
         if passes < 1.5:
             r["note"] = one_pass_note
-            r["roofline"]["kernel"] = one_pass_kernel + " (HIP events booked under the library's gemv_n slot)"
+        r["roofline"]["kernel"] = ctx.kernel_name(dom)           # (the kernels as the library launched them)
         return r
 
     # C3: sparse_logreg, dense synthetic X 100 000 x 10 000 fp32, logistic gradient + NormL1 prox
@@ -244,9 +279,8 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
         raise RuntimeError("C3 leg: the loop stopped after %d iterations or left the finite numbers: the timed steps were not all real"
                            % int(res.numit))
     out["C3"] = report(m, n, 4, 150, dt, st, res,
-                       "f and grad f in ONE pass over X per iteration (csrc/slab.hip, booked under gemv_n): "
-                       "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read",
-                       "k_slab_rows + k_slab_close")
+                       "f and grad f in ONE pass over X per iteration (csrc/slab.hip): "
+                       "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read")
     out["C3"]["workload"] = "sparse_logreg, dense synthetic A 100000x10000 fp32, logistic grad + NormL1 prox, adaptive_proxgrad (OurRule)"
     s.close()
     p.X.free()
@@ -264,8 +298,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     if not np.all(np.isfinite(x)) or int(res.numit) != 210 or res.converged:
         raise RuntimeError("C5 leg: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
     out["C5"] = report(m, n, 8, 200, dt, st, res,
-                       "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip)",
-                       "k_team_rows (the primal-dual form: csrc/team_rows.h) + k_slabpd_close")
+                       "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip, csrc/team_rows.h)")
     out["C5"]["workload"] = "least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50000x20000 fp64 (Ax / A'y pair + conj-prox)"
     s.close()
     p.A.free()
@@ -274,12 +307,11 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
 
 def main():
     args = parse()
+    maybe_relaunch(args, sys.argv[1:])               # (--gpus N > 1 outside a launcher: this process starts the ranks and exits)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     # ---- the transport of the row-sharded run: decided from the environment alone, BEFORE anything touches the GPU ----
     #   "rccl"   (default with more than one rank; APX_BENCH_FORCE_DIST=1 runs it with a single rank — the 1-GPU box
@@ -383,6 +415,10 @@ def main():
 
         if args.exploit_sparsity:
             ctx.exploit_sparsity(True)
+        if args.two_pass:
+            ctx.one_pass(0)
+        if args.gemv_t_variant >= 0:
+            ctx.set_gemv_config(t_variant=args.gemv_t_variant)
         g = apx.NormL1(prob.lam)
 
         def make_solver():
@@ -396,59 +432,60 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # The W warm-up steps, and a look at the error word of the team kernels behind them.  The one-pass kernels for rows
-        # of this length need the GPU to themselves (all 256 workgroups of a launch resident together); if a hand-off
-        # timed out on ANY rank, every rank falls back to the two GEMV passes — loudly: the JSON line says so — instead
-        # of the job dying.  (Every rank has enqueued the same collectives either way.)
-        solver = make_solver()
-        team_failure = 0
-        try:
-            solver.step(args.warmup, sync=True)
-            solver.result()
-        except apx.ApxError as e:
-            if "one-pass kernel (teams)" not in str(e):
-                raise
-            team_failure = 1
-            print(f"bench.py rank {rank}: {e}", file=sys.stderr)
-        if use_dist:
-            tf = torch.tensor([team_failure], dtype=torch.int32,
-                              device=f"cuda:{dev}" if transport == "torch-nccl" else "cpu")
-            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-            team_failure = int(tf.item())
-        if team_failure:
+        # W warm-up steps, then the K timed ones.  The one-pass kernels for rows of this length (teams of workgroups) need the GPU
+        # to themselves — all 256 workgroups of a launch resident together ; a hand-off that fails (a GPU shared with other
+        # work) invalidates the run.  On a row shard the library sums the error word over the ranks wherever it reads it, so
+        # every rank gets the failure from the same call ; the ranks then agree ONCE MORE over the launcher's group (any kind
+        # of failure, on any rank) before anybody raises or moves on: nobody is left inside a collective.  After a team
+        # failure every rank repeats warm-up and timed steps on the two GEMV passes, and the JSON line says so
+        # (`note_team_kernels`, with the diagnostic record of the wave that gave up) instead of the job dying without a number.
+        def agree(flag: int) -> int:
+            if not use_dist:
+                return flag
+            t = torch.tensor([flag], dtype=torch.int32, device=f"cuda:{dev}" if transport == "torch-nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t.item())
+
+        def attempt():
+            """-> (status, payload): 0 = timed (dt, stats, x, res) ; 1 = a team hand-off failed (message) ; 2 = another error"""
+            solver = None
             try:
-                solver.close()
-            except apx.ApxError:
-                pass
-            ctx.fused_small(False)
-            solver = make_solver()
-            solver.step(args.warmup, sync=True)
-        try:
-            dt, stats = timed_steps(ctx, solver, args.steps, 0, barrier)
-            x, _, res = solver.result()
-        except apx.ApxError as e:
-            # a hand-off that timed out INSIDE the timed steps (the warm-up was clean): with one rank the steps are run again
-            # on the two GEMV passes and the line says so ; with several ranks the peers are inside a collective this rank has
-            # left, and nothing can be done from here
-            if "one-pass kernel (teams)" not in str(e) or use_dist:
-                raise
-            print(f"bench.py: {e}", file=sys.stderr)
+                solver = make_solver()
+                solver.step(args.warmup, sync=True)
+                solver.result()                              # (reads the error word behind the warm-up)
+                dt_, stats_ = timed_steps(ctx, solver, args.steps, 0, barrier)
+                x_, _, res_ = solver.result()
+                return 0, (dt_, stats_, x_, res_)
+            except apx.ApxError as e:
+                return (1 if "one-pass kernel (teams)" in str(e) or "failed team hand-off" in str(e) else 2), str(e)
+            finally:
+                if solver is not None:
+                    try:
+                        solver.close()
+                    except apx.ApxError:
+                        pass
+
+        team_failure, team_incident = 0, ""
+        status, payload = attempt()
+        worst = agree(status)
+        if worst == 1:
             team_failure = 1
-            try:
-                solver.close()
-            except apx.ApxError:
-                pass
-            ctx.fused_small(False)
-            solver = make_solver()
-            solver.step(args.warmup, sync=True)
-            dt, stats = timed_steps(ctx, solver, args.steps, 0, barrier)
-            x, _, res = solver.result()
+            team_incident = payload if status == 1 else apx.last_incident()
+            print(f"bench.py rank {rank}: {team_incident or 'a team hand-off failed on another rank'}", file=sys.stderr)
+            # (every rank is at the same point: the library's own agreement made the failure surface from the same call on all
+            #  of them — after the warm-up, before the first barrier, or after the timed steps, behind the second)
+            ctx.one_pass(0)                                  # every rank: the two GEMV passes
+            status, payload = attempt()
+            worst = agree(status)
+        if worst != 0:
+            sys.exit(f"bench.py rank {rank}: {payload if status != 0 else 'another rank failed'}")
+        dt, stats, x, res = payload
         if not np.all(np.isfinite(x)):
             sys.exit("bench.py: non-finite iterate")
         if int(res.numit) != args.warmup + args.steps or res.converged:
             sys.exit("bench.py: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
-        solver.close()
         dual_layout = prob.dual_layout
+        kernel_names = {k: ctx.kernel_name(k) for k in ("gemv_n", "gemv_t", "one_pass")}
         final_objective, optimum = res.objective, prob.optimum
         if world == 1 and not use_dist and not args.no_other_configs and (args.m, args.n) == (50_000, 100_000):
             prob.A.free()                                  # give the 80 GB back before the other configs
@@ -483,7 +520,7 @@ def main():
             try:
                 # with the dual layout both passes run the column-streaming kernel (the "gemv_t" entry)
                 tj = json.load(open(tpath))
-                tkey = "k_team_rows" if one_pass else ("gemv_t" if dual_layout else dom)
+                tkey = "k_team_rows" if one_pass else ("gemv_t" if dual_layout else dom)      # (keys of profiles/pmc_traffic.json)
                 traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
                 traffic_source = tj.get("source", "profiles/pmc_traffic.json") + f" [{tkey}]"
             except Exception:
@@ -502,7 +539,7 @@ def main():
                                   + (", the iteration reads the transposed copy ONCE (40 GB)" if one_pass
                                      else ", each pass still reads 40 GB")),
                        "parallelism": "single" if world == 1 else f"row-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": ("k_team_rows + k_slab_close (booked under gemv_n)" if one_pass else dom),
+            "roofline": {"bound": "hbm", "kernel": kernel_names.get(dom) or dom,      # (as the library launched it: apx_ctx_kernel_name)
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
                          "frac_of_measured_read_ceiling": achieved / HBM_READ_GBS,
@@ -516,8 +553,8 @@ def main():
             "lib_srchash": __graft_entry__.source_hash()[:16],
         }
         if team_failure:
-            out["note_team_kernels"] = ("a hand-off of the one-pass team kernels timed out (during the warm-up on at least one rank, or with one rank inside the "
-                                        "timed steps: the GPU was shared with other work): the timed steps ran on the two GEMV passes instead")
+            out["note_team_kernels"] = ("a hand-off of the one-pass team kernels failed on at least one rank (the GPU was shared with other work): warm-up "
+                                        "and timed steps were repeated on the two GEMV passes by every rank. " + team_incident)
         if one_pass:
             out["roofline"]["note"] = (
                 "one launch forms A x, the residual AND A' r from ONE read of A (teams of 16 workgroups per slab of rows): "

@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define APX_ABI_VERSION 2   /* 2: apx_problem_desc.comm, apx_comm_*, APX_ERR_COMM */
+#define APX_ABI_VERSION 3   /* 2: apx_problem_desc.comm, apx_comm_*, APX_ERR_COMM
+                               3: apx_ctx_one_pass, apx_ctx_set_option / get_option, APX_KSTAT_ONE_PASS + apx_ctx_kernel_name,
+                                  APX_FLAG_TEAM_FALLBACK, apx_last_incident, apx_problem_team_waits ; apx_ctx_fused_small no
+                                  longer switches the one-pass kernels ; no environment variables are read any more */
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -50,7 +53,10 @@ enum {
 enum {
   APX_FLAG_TINY_GAMMA = 1,  /* backtracking gamma < 1e-12: `@error` logged, src/AdaProx.jl:40-42 */
   APX_FLAG_NAN_GAMMA = 2,   /* the rule produced a NaN step (Julia `min` propagates NaN)         */
-  APX_FLAG_DOMAIN = 4       /* sqrt of a negative number inside a rule (Julia: DomainError)      */
+  APX_FLAG_DOMAIN = 4,      /* sqrt of a negative number inside a rule (Julia: DomainError)      */
+  APX_FLAG_TEAM_FALLBACK = 8 /* (no reference counterpart) a hand-off of the one-pass TEAM kernels failed during this call: the
+                                result returned is that of a second run of the same call, from the same starting point, on the
+                                two GEMV passes ; what the failure looked like: apx_last_incident()                            */
 };
 
 enum { APX_F64 = 0, APX_F32 = 1 };
@@ -138,7 +144,8 @@ typedef struct {
   int32_t _pad2;
   apx_comm* comm;          /* row-sharded problem: the communicator whose ranks hold the other row blocks; the loop
                               enqueues ncclAllReduce on the context's stream where the callback above would be called
-                              (shard_mask as above).  Must outlive the problem.  NULL = single device / callback.       */
+                              (shard_mask as above).  The problem keeps it alive: apx_comm_destroy on a communicator
+                              that still has problems is deferred to the last of them.  NULL = single device / callback. */
 } apx_problem_desc;
 
 typedef struct {
@@ -193,7 +200,9 @@ typedef struct {
   double bytes;            /* algorithmic bytes moved by those launches (m*n*sizeof(T) each) */
 } apx_kernel_stat;
 
-enum { APX_KSTAT_GEMV_N = 0, APX_KSTAT_GEMV_T = 1, APX_KSTAT_COUNT = 2 };
+/* timing slots: the two GEMV passes, and the ONE-pass launches (row kernel + its closing kernel: f and grad f, or A x, the
+ * dual step and A' y, from one read of A — csrc/slab.hip, csrc/slab_pd.hip, csrc/team_rows.h) */
+enum { APX_KSTAT_GEMV_N = 0, APX_KSTAT_GEMV_T = 1, APX_KSTAT_ONE_PASS = 2, APX_KSTAT_COUNT = 3 };
 
 /* ---- library / context ----------------------------------------------------- */
 int32_t apx_abi_version(void);
@@ -206,6 +215,9 @@ int32_t apx_ctx_stream(apx_ctx* ctx, void** stream_out);
 /* enable/disable per-launch HIP-event timing of the GEMV kernels; read / reset the totals */
 int32_t apx_ctx_profile(apx_ctx* ctx, int32_t enable);
 int32_t apx_ctx_kernel_stats(apx_ctx* ctx, apx_kernel_stat* stats /* [APX_KSTAT_COUNT] */, int32_t reset);
+/* the kernels last booked under a timing slot, as the library launched them — e.g.
+ * "k_team_rows<least_squares, 16 members, 5 vectors, 4 slots, 2 rows of slack> + k_slab_close" ; "" before the first launch */
+const char* apx_ctx_kernel_name(apx_ctx* ctx, int32_t slot);
 
 /* tuning hooks (no reference counterpart): pick one of the compiled GEMV variants and the
  * target grid size; negative / zero arguments leave a field unchanged.  Defaults are the
@@ -232,26 +244,53 @@ int32_t apx_ctx_exploit_sparsity(apx_ctx* ctx, int32_t enable);
  *   - a problem built on a SPARSE matrix that is small as a dense one (m x n within the limits above, <= 256 MB:
  *     the three LIBSVM datasets of experiments/sparse_logreg/runme.jl:177-204) runs on a dense copy of it, which the
  *     matrix keeps (products through apx_gemv_n/t stay on the compressed storage).
- *   - dense LinearLeastSquares / LogisticLoss with rows of at most 10752 entries and >= 192 MB of A: f and
- *     grad f in ONE pass over A per iteration instead of two (csrc/slab.hip); it reads the transposed copy of A, which
- *     a matrix of up to 16 GB is given when a solver is created on it (as by apx_matrix_build_transpose).
- *     The primal-dual loop likewise for a separable h (A x, the dual step and A' y in one pass: csrc/slab_pd.hip).
- *   - the same one pass for Float64 rows too long for one workgroup's registers, by TEAMS of workgroups that split the
- *     columns of a slab of rows and hand their partial dot products over through L2: f and grad f for rows of
- *     10 753 ... 180 224 entries (teams of 2 / 4 / 8 / 16: BASELINE config C2's 100 000 — csrc/slab.hip k_team_rows), the
- *     primal-dual loop for the same lengths with the dual step in the kernel's communication wave (C5's 20 000: teams of
- *     two — csrc/team_rows.h).  The teams need
- *     the part's 8 XCDs x 32 CUs to themselves (all 256 workgroups of a launch resident together): every hand-off wait is
- *     bounded (20 ms); after a timed-out one the one-shot solver entry points repeat the solve on the two GEMV passes and
- *     keep the problem on them (not for a row shard: a rank restarting alone would leave its peers' sequence of
- *     collectives — the error is returned), the stepping interface and apx_eval return APX_ERR_HIP — on a GPU shared
- *     with other work switch the policy off.  Not replayable as a hipGraph (APX_ERR_UNSUPPORTED).
- *     (Float64 logistic rows of 5121 ... 11 264 columns take the same kernel with a "team" of ONE workgroup — its
- *     communication wave evaluates the link function; nothing is handed over and no co-residency is needed.)
- *     A row shard of f (apx_problem_desc.comm / .allreduce) takes the same one-pass kernels; the block sums are all-reduced.
  * Same arithmetic, different summation order than the generic path; 0 switches back to the generic kernels and
- * the host-driven loops. */
+ * the host-driven loops.  (ABI 2 also switched the one-pass kernels of large matrices with this call: they have their own
+ * switch now, apx_ctx_one_pass.) */
 int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
+/* Default 1: execution policy for LARGE dense matrices (>= apx_ctx_one_pass_threshold bytes, rows of 128 ... 180 224 entries):
+ * ONE pass over A per iteration instead of the two GEMV passes of the reference's cost model (experiments/lasso/runme.jl:179-180).
+ *   - LinearLeastSquares / LogisticLoss: f and grad f from one read of A (csrc/slab.hip) ; the primal-dual loop with a
+ *     separable h: A x, the dual step and A' y from one read (csrc/slab_pd.hip).  The kernels read the transposed copy of A,
+ *     which a matrix of up to 16 GB is given when a solver is created on it (apx_ctx_auto_transpose).
+ *   - rows short enough for one workgroup's registers (<= 10 752 entries ; Float64 <= 11 264) need nothing else.
+ *   - Float64 rows beyond that (BASELINE config C2's 100 000, C5's 20 000) are split over TEAMS of 2 / 4 / 8 / 16 workgroups that
+ *     hand their partial dot products over through the XCD's L2 (csrc/team_rows.h).  The teams need the part's 8 XCDs x 32 CUs
+ *     to themselves: all 256 workgroups of a launch resident together.  That the kernel FITS (one workgroup per CU) is asked of
+ *     the runtime when the problem is set up ; that the CUs are FREE cannot be known in advance, so every hand-off wait is
+ *     bounded (APX_OPT_TEAM_WAIT_MS, default 1000 ms, and 4096 polls), a failure is sticky (later launches return at once),
+ *     leaves a diagnostic record (in the error message, and in apx_last_incident()) and takes the PROBLEM off the team
+ *     kernels for good.  The one-shot entry points (apx_adaptive_primal_dual and its wrappers, apx_backtracking_proxgrad,
+ *     apx_backtracking_nesterov, apx_fixed_nesterov, apx_agraal) then run the same call again on the two GEMV passes and set
+ *     APX_FLAG_TEAM_FALLBACK ; apx_eval re-evaluates ; the stepping interface returns APX_ERR_HIP (its solver's iterate is
+ *     invalid: destroy it — a new solver on the same problem takes the two passes).  A row-sharded problem behaves the same on
+ *     every rank: the error word is summed over the ranks wherever it is read, so all ranks see a failure of any of them at the
+ *     same iteration and fall back together.  Team launches cannot be replayed as a hipGraph (APX_ERR_UNSUPPORTED).
+ *   mode 0: off — the two GEMV passes ; 1: on ; 2: on, but never the team kernels (a GPU shared with other work). */
+int32_t apx_ctx_one_pass(apx_ctx* ctx, int32_t mode);
+/* Options by key (no reference counterpart).  A/B switches of measured alternatives and the hooks the tests use — the library
+ * reads NO environment variables. */
+enum {
+  APX_OPT_MULTI_ROWS_MASK = 1,   /* default 7: short Float64 rows on k_multi_rows — bit 0 least squares, 1 logistic, 2 the
+                                    primal-dual loop ; a cleared bit runs the first-generation row shapes (A/B)              */
+  APX_OPT_SLAB_GENERATION = 2,   /* default 0 = by measurement ; 1 / 2 force the first / second generation of the
+                                    single-workgroup kernel for rows of 5121 ... 10 752 entries (A/B)                       */
+  APX_OPT_TEAM_WAIT_MS = 3,      /* default 1000: wall-clock bound of a team hand-off wait                                  */
+  APX_OPT_TEAM_COOPERATIVE = 4,  /* default 0 ; 1: team kernels through hipLaunchCooperativeKernel (the runtime refuses a grid
+                                    that cannot be co-resident ; measured no faster and not needed: DESIGN.md section 9)     */
+  APX_OPT_TEAM_FAULT_GRID = 5,   /* TEST hook, default 0: launch this many of a team launch's 256 workgroups, so that teams
+                                    miss members (tests/test_gpu_team_fault.py)                                            */
+  APX_OPT_GEMV_N_VARIANT = 6, APX_OPT_GEMV_T_VARIANT = 7, APX_OPT_GEMV_N_BLOCKS = 8, APX_OPT_GEMV_T_BLOCKS = 9,
+                                 /* = apx_ctx_set_gemv_config, one field at a time (tools/gemv_sweep.py)                    */
+  APX_OPT_FUSED_TAIL = 10        /* default 1: the residual / step-size reductions and the rule ride in the closing kernel of a
+                                    one-pass launch (two kernels between consecutive passes over A instead of four) ; 0: the
+                                    separate kernels (A/B ; bit-identical results)                                          */
+};
+int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
+int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);
+/* the diagnostic text of the last team-kernel failure on the calling thread — also when the call recovered by itself
+ * (APX_FLAG_TEAM_FALLBACK) and apx_last_error() was never set ; "" if there was none */
+const char* apx_last_incident(void);
 /* Tuning hook: the matrix size in bytes from which the one-pass kernels (csrc/slab.hip, csrc/slab_pd.hip) replace the two
  * GEMV passes.  Default 192 MB — the measured break-even on MI355X; the parity tests lower it to reach the kernels
  * with small matrices. */
@@ -344,6 +383,11 @@ int32_t apx_problem_destroy(apx_problem* p);
 int32_t apx_eval(apx_problem* p, const void* x, double* f_x);
 /* `pb()`: gradient at the x of the latest apx_eval (one GEMV-T on the saved residual) */
 int32_t apx_pullback(apx_problem* p, void* grad);
+/* Statistics of the team hand-offs of this problem's one-pass kernels since it was set up: out[0] = hand-offs that were
+ * not complete at the first look, out[1] = the most polls one of them took, out[2] = the longest one in nanoseconds ;
+ * out[3] = team launches ; all 0 for a problem that runs no team kernels.  (tools/soak.py: how close normal operation comes to
+ * the bound of APX_OPT_TEAM_WAIT_MS.) */
+int32_t apx_problem_team_waits(apx_problem* p, int64_t* out /* [4] */);
 /* `y, g_y = prox(g, v, gamma)` (ProximalCore.prox); conj != 0 applies convex_conjugate(desc) */
 int32_t apx_prox(apx_ctx* ctx, const apx_prox_desc* desc, int32_t conj, int32_t dtype,
                  const void* v, int64_t n, double gamma, void* y, double* g_y);

@@ -96,6 +96,16 @@ end
 
 "Execution policy: the two-kernel iteration for small dense problems (default on) and the opt-in sparse-iterate product."
 fused_small!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_fused_small, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
+"Execution policy for large dense matrices: 0 = the two GEMV passes, 1 = one pass over A per iteration (default), 2 = one pass
+ without the team kernels (a GPU shared with other work)."
+one_pass!(c::Context, mode::Integer = 1) = check(ccall((:apx_ctx_one_pass, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, mode))
+"Options by key (include/adaprox_hip.h APX_OPT_*): A/B switches and test hooks; the library reads no environment variables."
+set_option!(c::Context, key::Integer, value::Integer) = check(ccall((:apx_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Int32, Int64), c.h, key, value))
+"What the last failure of the one-pass team kernels on this thread looked like (\"\" if none) — also after a call that recovered
+ by itself on the two GEMV passes (bit 8 of `Result.flags`, APX_FLAG_TEAM_FALLBACK)."
+last_incident() = unsafe_string(ccall((:apx_last_incident, LIB), Cstring, ()))
+"warns when a one-shot call recovered from a failed team hand-off by running again on the two GEMV passes"
+warn_team_fallback(res::Result) = (res.flags & 8) != 0 && @warn "adaprox_hip: a hand-off of the one-pass team kernels failed; the call was run again on the two GEMV passes (its result is valid)" incident = last_incident()
 one_pass_threshold!(c::Context, min_bytes::Integer) = check(ccall((:apx_ctx_one_pass_threshold, LIB), Int32, (Ptr{Cvoid}, Int64), c.h, min_bytes))
 exploit_sparsity!(c::Context, on::Bool = true) = check(ccall((:apx_ctx_exploit_sparsity, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on))
 
@@ -253,6 +263,7 @@ function with_problem(body, f, g, h, A, ::Type{T}) where {T}
 end
 
 function bump!(f, g, h, A, res::Result)
+    warn_team_fallback(res)      # (every one-shot wrapper comes through here with its apx_result)
     f isa AdaProx.Counting && (f.eval_count += res.f_evals; f.grad_count += res.grad_f_evals)
     g isa AdaProx.Counting && (g.prox_count += res.prox_g_evals)
     h isa AdaProx.Counting && res.prox_h_evals >= 0 && (h.prox_count += res.prox_h_evals)

@@ -116,7 +116,7 @@ def test_one_pass_kernels_on_a_row_shard(apx, sharded):
                                           record=recs.append)
             st = ctx.kernel_stats(reset=True)
             ctx.profile(False)
-            assert st["gemv_t"]["launches"] == 0 and st["gemv_n"]["launches"] == 16, (m, n, st)      # one pass over A per evaluation
+            assert st["gemv_t"]["launches"] == 0 and st["gemv_n"]["launches"] == 0 and st["one_pass"]["launches"] == 16, (m, n, st)      # one pass over A per evaluation
             out.append((x, [r["objective"] for r in recs], [r["gamma"] for r in recs]))
         assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2], (m, n)
         dA.free()

@@ -15,6 +15,29 @@ def apx():
     return apx
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _multi_mask_hook():
+    """test_first_generation_shapes re-runs parity cases of this file in a child process with APX_TEST_MULTI_MASK set: every
+    context that child creates gets the option APX_OPT_MULTI_ROWS_MASK (the library itself reads no environment)."""
+    import os
+    mask = os.environ.get("APX_TEST_MULTI_MASK")
+    if mask is None:
+        yield
+        return
+    import adaprox_amd as apx
+    from importlib import import_module
+    L = import_module("adaptive-proximal-algorithms_amd._lib")
+    orig = apx.Context.__init__
+
+    def patched(self, *a, **kw):
+        orig(self, *a, **kw)
+        self.set_option(L.APX_OPT_MULTI_ROWS_MASK, int(mask))
+
+    apx.Context.__init__ = patched
+    yield
+    apx.Context.__init__ = orig
+
+
 def _rel(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)))) / \
         max(float(np.max(np.abs(b))), 1e-300)
@@ -372,7 +395,7 @@ def test_transposed_copy_is_opt_out(apx):
     dA.build_transpose()
     x, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(dA, b, ctx=ctx), **kw)
     st = ctx.kernel_stats(reset=True)
-    assert st["gemv_t"]["launches"] == 0 and st["gemv_n"]["launches"] == 11 and _rel(x, xo) <= 1e-10      # one pass
+    assert st["gemv_t"]["launches"] == 0 and st["gemv_n"]["launches"] == 0 and st["one_pass"]["launches"] == 11 and _rel(x, xo) <= 1e-10      # one pass
     dA.drop_transpose()
     x, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(dA, b, ctx=ctx), **kw)
     st = ctx.kernel_stats(reset=True)
@@ -403,7 +426,7 @@ def test_team_kernel_is_reproducible_steps_and_terminates(apx):
     x1, y1, _ = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=0.0, maxit=24, record=recs.append, **t)
     st = ctx.kernel_stats(reset=True)
     ctx.profile(False)
-    assert st["gemv_t"]["launches"] == 1 and st["gemv_n"]["launches"] == 1 + 24       # the pre-loop products, then one pass each
+    assert st["gemv_t"]["launches"] == 1 and st["gemv_n"]["launches"] == 1 and st["one_pass"]["launches"] == 24       # the pre-loop products, then one pass each
     x2, y2, _ = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=0.0, maxit=24, **t)
     assert np.array_equal(x1, x2) and np.array_equal(y1, y2)
     s = apx.Solver(x0, y0, rule=rule, tol=0.0, **t)
@@ -472,14 +495,14 @@ def test_team_kernel_proximal_gradient_stepping_termination_replay(apx):
 
 def test_first_generation_shapes():
     """The Float64 rows of up to 5632 entries run on k_multi_rows by default ; the first-generation shapes they replaced (one
-    element per lane and load, 1 ... 5 columns per thread, the link next to the rows) remain behind APX_MULTI=0 — the A/B
-    switch — and are what Float32 runs: the same parity cases once more with the switch off, in a process of its own (the
-    switch is read once)."""
+    element per lane and load, 1 ... 5 columns per thread, the link next to the rows) remain behind the option APX_OPT_MULTI_ROWS_MASK = 0
+    — the A/B switch — and are what Float32 runs: the same parity cases once more with the switch off, in a process of its own
+    whose contexts are all created with it (APX_TEST_MULTI_MASK: read by THIS test file, not by the library — _multi_mask_hook)."""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, APX_MULTI="0")
+    env = dict(os.environ, APX_TEST_MULTI_MASK="0")
     ids = "8500-1000-False-float64 or 8600-1024-True-float64 or 8500-1300-False-float64 or 4097-2049-True-float64 or " \
           "4100-3000-False-float64 or 4101-4096-True-float64 or 4200-5120-False-float64 or 9000-1000-tl1-float64 or " \
           "9100-1300-tl1-float64 or 4099-2100-tbox-float64 or 4098-5000-tl1-float64"
@@ -487,3 +510,55 @@ def test_first_generation_shapes():
                          env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert " passed" in out.stdout and "11 passed" in out.stdout, out.stdout[-500:]
+
+
+@pytest.mark.parametrize("m,n,logistic,dtype", [(9000, 1000, False, np.float64),      # k_multi_rows
+                                                (8600, 1024, True, np.float32),       # first-generation shapes, the bias entry in a block of its own (1025 entries)
+                                                (8300, 10000, True, np.float32),      # C3's kernel
+                                                (4200, 9000, False, np.float64),      # k_slab2_rows
+                                                (4400, 7000, True, np.float64),       # k_team_rows, one workgroup
+                                                (4300, 30000, False, np.float64)])    # k_team_rows, teams of four
+def test_fused_tail_is_bit_identical(apx, m, n, logistic, dtype):
+    """The residual / step-size reductions and the rule ride in the closing kernel of the one-pass launch (csrc/slab.hip SlabTail:
+    two kernels between consecutive passes over A instead of four).  They are summed in exactly the order of the separate
+    kernels (k_reduce_n + k_rule), so switching the fusion off (APX_OPT_FUSED_TAIL = 0) must not change one bit: iterates,
+    records, termination."""
+    from importlib import import_module
+    L = import_module("adaptive-proximal-algorithms_amd._lib")
+    rng = np.random.default_rng(31)
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
+    b = (rng.uniform(size=m) < 0.5).astype(dtype) if logistic else rng.standard_normal(m).astype(dtype)
+    nx = n + 1 if logistic else n
+    gam = 4.0 / (n / 3.0 + 1.0) if logistic else 1.0 / (m * n / 3.0)
+    x0 = (0.01 * rng.standard_normal(nx)).astype(dtype)
+    runs = []
+    for fused in (1, 0):
+        ctx = apx.Context(0)
+        ctx.one_pass_threshold(16 << 20)
+        ctx.set_option(L.APX_OPT_FUSED_TAIL, fused)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        f = apx.LogisticLoss(dA, b, ctx=ctx) if logistic else apx.LinearLeastSquares(dA, b, ctx=ctx)
+        recs = []
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        x, it = apx.adaptive_proxgrad(x0, f=f, g=apx.NormL1(1e-3 if logistic else 1.0), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=12,
+                                      ctx=ctx, record=recs.append)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        assert st["one_pass"]["launches"] == 13 and st["gemv_t"]["launches"] == 0, st
+        runs.append((x, [(r["gamma"], r["norm_res"], r["objective"]) for r in recs]))
+        dA.free()
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    # ... and the termination test runs in the closing kernel too: the same iteration, the same iterate
+    tol = runs[0][1][7][1] * 1.0000001
+    outs = []
+    for fused in (1, 0):
+        ctx = apx.Context(0)
+        ctx.one_pass_threshold(16 << 20)
+        ctx.set_option(L.APX_OPT_FUSED_TAIL, fused)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        f = apx.LogisticLoss(dA, b, ctx=ctx) if logistic else apx.LinearLeastSquares(dA, b, ctx=ctx)
+        outs.append(apx.adaptive_proxgrad(x0, f=f, g=apx.NormL1(1e-3 if logistic else 1.0), rule=apx.OurRule(gamma=gam), tol=tol, maxit=50,
+                                          ctx=ctx, poll_every=3))
+        dA.free()
+    assert outs[0][1] == outs[1][1] <= 8 and np.array_equal(outs[0][0], outs[1][0])

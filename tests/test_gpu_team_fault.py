@@ -1,8 +1,11 @@
-"""The team kernels need all 256 workgroups of a launch resident together (csrc/slab.hip k_team_rows).  When they are not —
-a GPU shared with other work — some teams miss members.  The design's promise: every wait is bounded (20 ms of wall clock),
-the grid DRAINS, and the host never gets a wrong iterate: the stepping interface returns APX_ERR_HIP, the one-shot entry point
-repeats the solve on the two GEMV passes (and keeps the problem on them).  APX_TEAM_FAULT_GRID launches 248 of the 256
-workgroups (31 per XCD: one team of each XCD is a member short); one fresh child process, which must finish in seconds."""
+"""The team kernels need all 256 workgroups of a launch resident together (csrc/team_rows.h k_team_rows).  When they are not —
+a GPU shared with other work — some teams miss members.  The design's promise: every wait is bounded, the grid DRAINS, a
+failure is sticky (one bound per failure, not one per launch), self-describing (the message names the team, the member, the
+row and what the wave saw) and never yields a wrong iterate: the stepping interface returns APX_ERR_HIP, the one-shot entry
+points repeat the call on the two GEMV passes, keep the problem on them and say so (APX_FLAG_TEAM_FALLBACK -> a
+RuntimeWarning of the Python mirror, apx.last_incident()).  The option APX_OPT_TEAM_FAULT_GRID launches 248 of the 256
+workgroups (31 per XCD: one team of each XCD is a member short), APX_OPT_TEAM_WAIT_MS shortens the bound ; one fresh child
+process, which must finish in seconds."""
 import os
 import subprocess
 import sys
@@ -15,12 +18,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r"""
-import sys, time
+import sys, time, warnings
 sys.path.insert(0, %r)
+FAULT = %d
 import numpy as np
 import adaprox_amd as apx
+from importlib import import_module
+L = import_module("adaptive-proximal-algorithms_amd._lib")
 ctx = apx.Context(0)
 ctx.one_pass_threshold(16 << 20)
+if FAULT:
+    ctx.set_option(L.APX_OPT_TEAM_FAULT_GRID, FAULT)
+    ctx.set_option(L.APX_OPT_TEAM_WAIT_MS, 50)
 m, n = 4300, 12000
 A = apx.DeviceMatrix.uniform(m, n, seed=5, ctx=ctx).build_transpose()
 b = np.random.default_rng(0).standard_normal(m)
@@ -28,32 +37,60 @@ f = apx.LinearLeastSquares(A, b, ctx=ctx)
 t0 = time.perf_counter()
 try:
     s = apx.Solver(np.zeros(n), f=f, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, ctx=ctx)
-    s.step(3, sync=True)
+    s.step(40, sync=True)          # (sticky: the launches behind the failed one return at once)
     s.result()
-    print("STEPPING: NO ERROR")
+    print("STEPPING: NO ERROR", s.team_waits())
 except apx.ApxError as e:
     print("STEPPING ERROR:", e)
+print("stepping seconds %%.2f" %% (time.perf_counter() - t0))
+# the same problem object again: it is off the team kernels now, a new solver on it runs (two passes)
+try:
+    s.restart(np.zeros(n))
+    s.step(3, sync=True)
+    xs, _, _ = s.result()
+    print("SECOND SOLVER: OK")
+except apx.ApxError as e:
+    print("SECOND SOLVER ERROR:", e)
 # the one-shot entry point on a fresh problem: falls back to the two passes by itself
 f2 = apx.LinearLeastSquares(A, b, ctx=ctx)
 ctx.kernel_stats(reset=True); ctx.profile(True)
-x, it = apx.adaptive_proxgrad(np.zeros(n), f=f2, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=3, ctx=ctx)
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter("always")
+    x, it = apx.adaptive_proxgrad(np.zeros(n), f=f2, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=3, ctx=ctx)
+print("WARNINGS", len([w for w in caught if "APX_FLAG_TEAM_FALLBACK" in str(w.message)]))
+print("INCIDENT:", apx.last_incident())
 st = ctx.kernel_stats(reset=True); ctx.profile(False)
+# (the stepping solvers above share f's problem: f2 is a fresh one and fails / falls back on its own)
+zb, _ = apx.backtracking_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A, b, ctx=ctx), g=apx.NormL1(1.0), gamma0=1e-7, xi=1.2, tol=0.0, maxit=3, ctx=ctx)
+print("BACKTRACKING finite", bool(np.all(np.isfinite(zb))))
 ctx2 = apx.Context(0); ctx2.fused_small(False)
 A2 = apx.DeviceMatrix.uniform(m, n, seed=5, ctx=ctx2)
 xr, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A2, b, ctx=ctx2), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7),
                               tol=0.0, maxit=3, ctx=ctx2)
+if FAULT:
+    print("SECOND SOLVER diff", float(np.max(np.abs(xs - xr))))
 print("ONE-SHOT it", it, "gemv_t launches", st["gemv_t"]["launches"], "max diff vs two-pass context", float(np.max(np.abs(x - xr))))
 print("seconds %%.2f" %% (time.perf_counter() - t0))
 """
 
 
 def test_missing_team_members_time_out_and_report():
-    env = dict(os.environ, APX_TEAM_FAULT_GRID="248")
     t0 = time.perf_counter()
-    out = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=120)
+    out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, 248)], env=dict(os.environ), capture_output=True, text=True, timeout=120)
     dt = time.perf_counter() - t0
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "STEPPING ERROR:" in out.stdout and "waited 20 ms" in out.stdout, out.stdout
+    assert "STEPPING ERROR:" in out.stdout and "a hand-off wait expired" in out.stdout, out.stdout
+    # self-describing: the team, the member, the row, the records it saw (the missing member's among them), the tickets (31 per XCD)
+    msg = [l for l in out.stdout.splitlines() if l.startswith("STEPPING ERROR:")][0]
+    for word in ("team ", "member ", "row ", "expected sequence word", ":none(", "Tickets per XCD: 31 31 31 31 31 31 31 31", "bound 50 ms"):
+        assert word in msg, (word, msg)
+    # sticky: forty launches behind the failure cost ONE bound, not forty
+    st_s = float([l for l in out.stdout.splitlines() if l.startswith("stepping seconds")][0].split()[-1])
+    assert st_s < 5.0, out.stdout
+    assert "SECOND SOLVER: OK" in out.stdout, out.stdout             # the problem is off the team kernels: a new solver runs
+    assert float([l for l in out.stdout.splitlines() if l.startswith("SECOND SOLVER diff")][0].split()[-1]) <= 1e-12, out.stdout
+    assert "WARNINGS 1" in out.stdout and "INCIDENT: one-pass kernel (teams): a hand-off wait expired" in out.stdout, out.stdout
+    assert "BACKTRACKING finite True" in out.stdout, out.stdout
     line = [l for l in out.stdout.splitlines() if l.startswith("ONE-SHOT")][0].split()
     assert line[2] == "3" and int(line[5]) >= 4, out.stdout          # the repeat ran on the two passes (gemv_t launched)
     assert float(line[-1]) <= 1e-12, out.stdout                      # ... and gives the two-pass context's iterate
@@ -61,7 +98,8 @@ def test_missing_team_members_time_out_and_report():
 
 
 def test_the_same_child_without_the_fault_is_fine():
-    out = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=dict(os.environ), capture_output=True, text=True, timeout=120)
+    out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, 0)], env=dict(os.environ), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "STEPPING: NO ERROR" in out.stdout, out.stdout + out.stderr[-1500:]
+    assert "WARNINGS 0" in out.stdout, out.stdout
     line = [l for l in out.stdout.splitlines() if l.startswith("ONE-SHOT")][0].split()
     assert line[2] == "3" and int(line[5]) == 0, out.stdout           # one pass over A per evaluation: no gemv_t

@@ -64,3 +64,40 @@ def test_row_sharded_primal_dual():
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert out.stdout.count("PD-SHARDED") == 2
+
+
+def test_bench_starts_its_own_ranks_and_survives_the_team_kernels_on_a_shared_gpu():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command): the script starts its two
+    ranks itself, before anything has touched the GPU, and rank 0 prints ONE JSON line with n_gpus = 2.  The shards (4200 x 12000
+    fp64) are on the team kernels' path, and two processes that share one GPU are exactly what those kernels cannot have:
+    their launches interleave on the CUs and hand-offs may fail.  Whatever happens — clean, or a failure that the library
+    makes visible on BOTH ranks at the same call, after which both repeat the steps on the two GEMV passes — the job ends with
+    a number, the same 13 iterations as one rank on the whole matrix, and says which path it timed."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APX_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--cols", "12000", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", "4200"] + common, cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "row-shard x2"
+    assert "launching 2 ranks" in out.stderr
+    passes = two["roofline"]["passes_over_A_per_iter"]
+    assert (passes == 1.0) != ("note_team_kernels" in two), two          # one pass, or the two passes WITH the note
+    one = _bench(["--rows", "8400"] + common, {}, 1)
+    assert two["lasso_optimum"] == pytest.approx(one["lasso_optimum"], rel=1e-12)
+    assert two["final_objective"] == pytest.approx(one["final_objective"], rel=1e-10)
+
+
+def test_ranks_agree_on_the_path_when_only_one_shard_is_eligible():
+    """8191 rows over two ranks = 4096 + 4095: the first shard is eligible for the one-pass kernels (>= 4096 rows), the second is
+    not.  The two paths enqueue different collectives, so each rank deciding for itself would hang or corrupt the run: the
+    ranks agree on the first evaluation (csrc/slab.hip slab_eval_with_gradient) and both take the two passes."""
+    common = ["--rows", "8191", "--cols", "12000", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    one = _bench(common, {}, 1)
+    two = _bench(common + ["--strong"], {"APX_BENCH_SHARE_GPU": "1"}, 2)
+    assert two["n_gpus"] == 2 and two["roofline"]["passes_over_A_per_iter"] == 2.0, two["roofline"]
+    assert two["final_objective"] == pytest.approx(one["final_objective"], rel=1e-10)

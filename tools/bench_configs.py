@@ -1,7 +1,7 @@
 """Times the non-headline BASELINE configs at full size on one MI355X (C3 logreg fp32,
 C5 LAD via Condat-Vu, C2 backtracking, C1 small lasso).  Same protocol as bench.py: data
 resident, warm-up, K timed iterations, HIP-event kernel times from the library.
-(C3 runs f and grad f in one pass over A, csrc/slab.hip, booked under gemv_n; APX_SINGLE_LAYOUT=1 no longer gives a
+(C3 runs f and grad f in one pass over A, csrc/slab.hip, booked under the one_pass slot; APX_SINGLE_LAYOUT=1 no longer gives a
 single-layout C3: the one-pass kernel builds the transposed copy it reads.)"""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,10 +27,11 @@ def timed(solver, steps, warm, bytes_per_iter):
     assert np.all(np.isfinite(x))
     r = dict(iters_per_s=steps / dt, ms_per_iter=dt / steps * 1e3, frac_of_8TBs=bytes_per_iter * steps / dt / 8e12, kernels=k,
              objective=res.objective, norm_res=res.norm_res)
-    if "gemv_t" not in k and "gemv_n" in k:      # csrc/slab.hip: f and grad f in ONE pass over A (booked under gemv_n)
+    if "one_pass" in k:      # csrc/slab.hip / slab_pd.hip: ONE pass over A per iteration
         r["note"] = ("one pass over A per iteration: frac_of_8TBs is of the TWO-pass algorithmic bytes (SURVEY 8d) and can "
-                     "exceed 1; the bytes actually read per iteration are half, at kernels.gemv_n.GBps")
-        r["frac_of_8TBs_bytes_read"] = k["gemv_n"]["GBps"] / 8e3
+                     "exceed 1; the bytes actually read per iteration are half, at kernels.one_pass.GBps")
+        r["frac_of_8TBs_bytes_read"] = k["one_pass"]["GBps"] / 8e3
+        r["one_pass_kernel"] = ctx.kernel_name("one_pass")
     return r
 
 which = sys.argv[1:] or ["c3", "c5", "c2bt", "c1"]

@@ -14,7 +14,9 @@ import adaprox_amd as apx  # noqa: E402
 
 
 def make(ctx, A, y, logistic, dtype, n, m, v1):
-    os.environ["APX_SLAB_V1"] = "1" if v1 else "0"
+    from importlib import import_module
+    L = import_module("adaptive-proximal-algorithms_amd._lib")
+    ctx.set_option(L.APX_OPT_SLAB_GENERATION, 1 if v1 else 2)      # (read when the problem is set up: its first evaluation)
     if logistic:
         f, nx, gam = apx.LogisticLoss(A, y, ctx=ctx), n + 1, 4.0 / (n / 3.0 + 1.0)
     else:

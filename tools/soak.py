@@ -31,11 +31,18 @@ def leg_c2(iters):
         x, _, res = s.result()
         assert np.all(np.isfinite(x)) and int(res.numit) == 2000
         obj.append(res.objective)
+        w = s.team_waits()            # (every Solver is a problem of its own: summed / maximised over the solves below)
+        waits = w if rep == 0 else dict(waits=waits["waits"] + w["waits"], max_polls=max(waits["max_polls"], w["max_polls"]),
+                                        max_wait_ns=max(waits["max_wait_ns"], w["max_wait_ns"]),
+                                        team_launches=waits["team_launches"] + w["team_launches"])
         s.close()
     dt = time.perf_counter() - t0
     assert len(set(obj)) == 1, obj
     print(json.dumps({"leg": "C2 k_team_rows", "solves": len(obj), "iterations_each": 2000, "seconds": dt, "it_per_s": iters / dt,
-                      "objective_after_2000": obj[0], "optimum": p.optimum, "identical_objectives": True}), flush=True)
+                      "objective_after_2000": obj[0], "optimum": p.optimum, "identical_objectives": True,
+                      # hand-offs that were not complete at the first look, the most polls / the longest any of them took: how
+                      # close normal operation comes to the bound of a wait (APX_OPT_TEAM_WAIT_MS: 1000 ms AND 4096 polls)
+                      "team_hand_off_waits": waits}), flush=True)
     p.A.free()
 
 
@@ -59,7 +66,7 @@ def leg_c5(iters):
     dt = time.perf_counter() - t0
     assert np.all(np.isfinite(x)) and np.all(np.isfinite(y))
     print(json.dumps({"leg": "C5 k_team_rows (primal-dual)", "iterations": int(res.numit), "seconds": dt, "it_per_s": iters / dt,
-                      "objective_norm_res_every_5000": res_hist}), flush=True)
+                      "objective_norm_res_every_5000": res_hist, "team_hand_off_waits": s.team_waits()}), flush=True)
     s.close()
     p.A.free()
 
