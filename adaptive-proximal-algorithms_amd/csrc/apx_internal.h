@@ -98,7 +98,10 @@ struct apx_ctx {
   bool one_pass = true;          // large dense matrices: one pass over A per iteration (apx_ctx_one_pass: slab.hip, slab_pd.hip)
   bool teams = true;             // ... and its team kernels for rows too long for one workgroup (team_rows.h ; mode 2 switches them off)
   // options by key (apx_ctx_set_option)
-  int multi_mask = 7;            // APX_OPT_MULTI_ROWS_MASK
+  int multi_mask = 15;           // APX_OPT_MULTI_ROWS_MASK
+  int multi_waves = 0;           // APX_OPT_MULTI_WAVES
+  int team_members = 0;          // APX_OPT_TEAM_MEMBERS
+  int team_slots = 0;            // APX_OPT_TEAM_SLOTS
   int slab_generation = 0;       // APX_OPT_SLAB_GENERATION
   int team_wait_ms = 1000;       // APX_OPT_TEAM_WAIT_MS
   bool team_cooperative = false; // APX_OPT_TEAM_COOPERATIVE

@@ -307,7 +307,7 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
   APX_REQUIRE(ctx != nullptr, "apx_ctx_set_option: ctx is NULL");
   switch (key) {
     case APX_OPT_MULTI_ROWS_MASK:
-      APX_REQUIRE(value >= 0 && value <= 7, "APX_OPT_MULTI_ROWS_MASK: a mask of three bits");
+      APX_REQUIRE(value >= 0 && value <= 15, "APX_OPT_MULTI_ROWS_MASK: a mask of four bits");
       ctx->multi_mask = (int)value;
       return APX_OK;
     case APX_OPT_SLAB_GENERATION:
@@ -332,6 +332,18 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
     case APX_OPT_FUSED_TAIL:
       ctx->fused_tail = value != 0;
       return APX_OK;
+    case APX_OPT_MULTI_WAVES:
+      APX_REQUIRE(value == 0 || value == 10 || value == 11, "APX_OPT_MULTI_WAVES: 0 (by fit), 10 or 11");
+      ctx->multi_waves = (int)value;
+      return APX_OK;
+    case APX_OPT_TEAM_MEMBERS:
+      APX_REQUIRE(value == 0 || value == 2 || value == 4 || value == 8 || value == 16, "APX_OPT_TEAM_MEMBERS: 0 (by the row length), 2, 4, 8 or 16");
+      ctx->team_members = (int)value;
+      return APX_OK;
+    case APX_OPT_TEAM_SLOTS:
+      APX_REQUIRE(value == 0 || value == 52 || value == 62 || value == 53 || value == 63, "APX_OPT_TEAM_SLOTS: 0, 52, 62, 53 or 63");
+      ctx->team_slots = (int)value;
+      return APX_OK;
     default:
       return fail(APX_ERR_INVALID, "apx_ctx_set_option: unknown key");
   }
@@ -350,6 +362,9 @@ int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
     case APX_OPT_GEMV_N_BLOCKS: *value = ctx->cfg.n_target_blocks; return APX_OK;
     case APX_OPT_GEMV_T_BLOCKS: *value = ctx->cfg.t_target_blocks; return APX_OK;
     case APX_OPT_FUSED_TAIL: *value = ctx->fused_tail ? 1 : 0; return APX_OK;
+    case APX_OPT_MULTI_WAVES: *value = ctx->multi_waves; return APX_OK;
+    case APX_OPT_TEAM_MEMBERS: *value = ctx->team_members; return APX_OK;
+    case APX_OPT_TEAM_SLOTS: *value = ctx->team_slots; return APX_OK;
     default:
       return fail(APX_ERR_INVALID, "apx_ctx_get_option: unknown key");
   }

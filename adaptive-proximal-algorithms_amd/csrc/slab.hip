@@ -66,12 +66,14 @@ struct SlabState {
   DBuf part;
   SlabDev dev{};
   int B = 0, cpt = 0, bs = 0;     // blocks ; columns per thread ; threads per block
+  int multi_waves = 0;            // k_multi_rows: 0 = by fit, 10 / 11 compute waves forced (APX_OPT_MULTI_WAVES)
   int kv = 0, bs2 = 768;          // long rows: 16-byte vectors per thread and row of k_slab2_rows (0: k_slab_rows), its block size
   bool v2 = true;                 // (APX_SLAB_V1=1 in the environment: the first-generation kernel for long rows too — A/B runs)
   bool pipe = true, nt = true;    // two row groups in flight ; non-temporal loads of A
   // rows of more than 10 752 Float64 entries: teams of team_p workgroups (k_team_rows), team_kv vectors per thread
   int team_p = 0, team_kv = 0;
   bool team_big = false;          // slices of 6 ... 8 vectors per thread: three row slots, ONE row of slack (k_team_rows<..., 3, 1>)
+  TeamPlan plan;                  // (the three fields above, and the number of compute waves)
   TeamHost team;                  // ring, tickets, the error word and its diagnostic record, wait statistics (csrc/team_rows.h)
   DBuf tail_buf;                  // the fused end of the iteration (SlabTail): wave partials of the five reductions + the arrival counter
   std::string kname;              // the row kernel as launched (apx_ctx_kernel_name)
@@ -570,6 +572,9 @@ static SlabShape slab_shape(const apx_problem* p) {
   // switch — 0 runs the first-generation shapes, which stay for Float32 ; tests/test_gpu_slab.py::test_first_generation_shapes)
   const int multi = p->ctx->multi_mask;
   if (p->dtype == APX_F64 && cols <= 2 * 4 * 704 && ((p->f_kind == APX_F_LOGISTIC ? 2 : 1) & multi)) return {768, kSlabMultiCpt, 1};
+  // Float32 rows of up to 11 264 entries likewise (round 3, bit 3 of the mask): four columns per 16-byte vector, partial sums
+  // in Float32, the link in Float32 in the row wave — BASELINE config C3's 10 000 columns run here
+  if (p->dtype == APX_F32 && cols <= 4 * 4 * 704 && (multi & 8)) return {768, kSlabMultiCpt, 1};
   if (cols <= 1024) return {1024, 1, kSlabRows};      // (one column per thread, 32 rows per step: with two, half the loads of such a row are clamped away)
   if (cols <= 2 * 768) return {768, 2, kSlabRows};    // (1025 ... 1536 entries: two columns of 768 threads keep more lanes busy than of 1024)
   if (cols <= 2 * 1024) return {1024, 2, kSlabRows};
@@ -631,6 +636,7 @@ static int32_t slab_setup(apx_problem* p) {
   const SlabShape sh = slab_shape(p);
   st->cpt = sh.cpt;
   st->bs = sh.bs;
+  st->multi_waves = ctx->multi_waves;
   // as many blocks as fit the chip at once — one per CU, two of the two-columns-per-thread kind (~58 VGPRs): rows in
   // contiguous slabs, a multiple of the step ; fewer blocks = fewer partial vectors for the closing kernel
   int64_t B = (int64_t)ctx->num_cu * (st->cpt <= 2 ? 2 : 1);      // (kSlabMultiCpt, kSlabTeamCpt > 2: one block per CU)
@@ -641,8 +647,9 @@ static int32_t slab_setup(apx_problem* p) {
   st->B = (int)B;
   int64_t rpb_team = 0;
   if (st->cpt == kSlabTeamCpt) {           // teams: the fewest members whose slice fits 5 vectors per compute thread
-    const TeamPlan pl = team_plan(A->n);      // (csrc/team_rows.h)
+    const TeamPlan pl = team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, 0});      // (csrc/team_rows.h)
     const int P = pl.P;
+    st->plan = pl;
     st->team_big = pl.big;
     st->team_p = pl.P;
     st->team_kv = pl.kv;
@@ -680,7 +687,7 @@ static int32_t slab_setup(apx_problem* p) {
   d.b = p->b.p;
   d.ldpart = round_up(d.ncols + 2, 8);
   // (k_multi_rows on very short rows leaves multi_groups(n) partial vectors per workgroup)
-  const int64_t nparts = B * (st->cpt == kSlabMultiCpt ? multi_groups(A->n) : 1);
+  const int64_t nparts = B * (st->cpt == kSlabMultiCpt ? multi_groups(A->n, p->dtype == APX_F32 ? 4 : 2) : 1);
   APX_TRY(st->part.alloc_zero((size_t)nparts * d.ldpart * sizeof(double), ctx->stream));
   d.part = (double*)st->part.p;
   d.c = p->ctrl();
@@ -762,17 +769,15 @@ static bool slab_launch_t(SlabState* st, bool cooperative, const SlabDev& d, con
   if (st->team_p != 0) {
     bool ok = true;
     if constexpr (sizeof(T) == 8) {
-      ok = team_launch<FK, SlabDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+      ok = team_launch<FK, SlabDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
       slab_close_launch<T, FK>(d, st->B, grad, tl, q);
     }
     return ok;
   }
   if (st->cpt == kSlabMultiCpt) {
-    if constexpr (sizeof(T) == 8) {
-      if (st->nt) multi_launch<FK, true, SlabDev>(d.ncols, st->B, d, x, q);
-      else multi_launch<FK, false, SlabDev>(d.ncols, st->B, d, x, q);
-      slab_close_launch<T, FK>(d, st->B * multi_groups(d.ncols), grad, tl, q);
-    }
+    if (st->nt) multi_launch<T, FK, true, SlabDev>(d.ncols, st->B, st->multi_waves, d, x, q);
+    else multi_launch<T, FK, false, SlabDev>(d.ncols, st->B, st->multi_waves, d, x, q);
+    slab_close_launch<T, FK>(d, st->B * multi_groups(d.ncols, 16 / (int)sizeof(T)), grad, tl, q);
     return true;
   }
   constexpr int R14 = sizeof(T) == 4 ? kSlabRows : (FK == APX_F_LOGISTIC ? 1 : kSlabRows / 2);
@@ -795,12 +800,16 @@ static std::string slab_kernel_name(const SlabState* st, const apx_problem* p) {
   const char* fk = p->f_kind == APX_F_LOGISTIC ? "logistic" : "least_squares";
   const char* ty = p->dtype == APX_F32 ? "float" : "double";
   if (st->team_p != 0)
-    snprintf(b, sizeof b, "k_team_rows<%s, %d member%s, %d vectors per thread, %d row slots, %d row%s of slack>", fk, st->team_p,
-             st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), (st->team_big || st->team_p == 1) ? 3 : 4,
+    snprintf(b, sizeof b, "k_team_rows<%s, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack>", fk, st->team_p,
+             st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), st->plan.waves, (st->team_big || st->team_p == 1) ? 3 : 4,
              (st->team_big || st->team_p == 1) ? 1 : 2, (st->team_big || st->team_p == 1) ? "" : "s");
-  else if (st->cpt == kSlabMultiCpt)
-    snprintf(b, sizeof b, "k_multi_rows<%s, %d vectors per thread, %d row group%s>", fk, (int)((((int64_t)st->dev.ncols + 1) / 2 + 703) / 704),
-             multi_groups(st->dev.ncols), multi_groups(st->dev.ncols) == 1 ? "" : "s");
+  else if (st->cpt == kSlabMultiCpt) {
+    const int vw = p->dtype == APX_F32 ? 4 : 2;
+    const int64_t nvec = ((int64_t)st->dev.ncols + vw - 1) / vw;
+    const int gr = multi_groups(st->dev.ncols, vw), w = gr > 1 ? 0 : multi_waves(nvec, st->multi_waves);
+    if (gr > 1) snprintf(b, sizeof b, "k_multi_rows<%s, %s, 1 vector per thread, %d row groups>", ty, fk, gr);
+    else snprintf(b, sizeof b, "k_multi_rows<%s, %s, %d vectors per thread, %d compute waves>", ty, fk, (int)((nvec + w * 64 - 1) / (w * 64)), w);
+  }
   else if (st->cpt == 14 && st->kv != 0 && st->v2 && !(p->dtype == APX_F64 && p->f_kind == APX_F_LOGISTIC))
     snprintf(b, sizeof b, "k_slab2_rows<%s, %s, %d vectors per thread>", ty, fk, st->kv);
   else

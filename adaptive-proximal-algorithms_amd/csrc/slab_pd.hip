@@ -39,6 +39,8 @@ struct SlabPdState {
   // rows of more than 10 752 Float64 entries: k_team_rows (csrc/team_rows.h) — one workgroup, or teams of 2 ... 16
   int team_p = 0, team_kv = 0;      // members ; 16-byte vectors per thread and row of a member's slice (0: not this scheme)
   bool team_big = false;
+  TeamPlan plan;          // (the three fields above, the number of compute waves, an experimental slot shape)
+  int multi_waves = 0;    // k_multi_rows: 0 = by fit, 10 / 11 compute waves forced (APX_OPT_MULTI_WAVES)
   TeamHost team;          // ring, tickets, the error word and its diagnostic record, wait statistics (csrc/team_rows.h)
   std::string kname;      // the row kernel as launched (apx_ctx_kernel_name)
 };
@@ -246,6 +248,7 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   // slab_shape) — against the shapes below, TB/s of the bytes read at 6 GB: 600: 4.0 -> 5.7, 1000: 5.8 -> 6.3, 2100: 4.2 -> 6.3, 5632: 6.0 -> 6.9
   const int multi = p->ctx->multi_mask;
   if (!f32 && cols <= 2 * 4 * 704 && (multi & 4)) return {768, 27, 1};
+  if (f32 && cols <= 4 * 4 * 704 && (multi & 4) && (multi & 8)) return {768, 27, 1};      // (Float32, round 3: bit 3 of the mask — csrc/slab.hip slab_shape)
   if (cols <= 1024) return {1024, 1, 4};           // (one column per thread, sixteen rows per step — 32 spill here: csrc/slab.hip slab_shape)
   if (cols <= 2 * 768) return {768, 2, 4};         // (1025 ... 1536 entries: csrc/slab.hip slab_shape)
   if (cols <= 2 * 1024) return {1024, 2, 4};
@@ -299,11 +302,13 @@ int32_t slab_pd_setup(apx_solver* s) {
   st->cpt = sh.cpt;
   st->bs = sh.bs;
   st->rows = sh.rows;
+  st->multi_waves = ctx->multi_waves;
   int64_t B = (int64_t)ctx->num_cu * (st->cpt <= 2 ? 2 : 1);
   int64_t rpb = (A->m + B - 1) / B;                // dealt evenly, nothing rounded up: a block's last step may be partial
   B = (A->m + rpb - 1) / rpb;                      // (csrc/slab.hip: rounding to 16 left CUs without a block)
   if (st->cpt == 28) {                             // k_team_rows: slabs = teams, ALL P x B workgroups launched
-    const TeamPlan pl = team_plan(A->n);
+    const TeamPlan pl = team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, ctx->team_slots});
+    st->plan = pl;
     st->team_p = pl.P;
     st->team_kv = pl.kv;
     st->team_big = pl.big;
@@ -323,7 +328,7 @@ int32_t slab_pd_setup(apx_solver* s) {
   d.Y = s->y.p;
   d.AXP = s->axprev.p;
   d.ldpart = round_up(d.n + 2, 8);
-  const int64_t nparts = B * (st->cpt == 27 ? multi_groups(A->n) : 1);      // (k_multi_rows on very short rows: csrc/team_rows.h)
+  const int64_t nparts = B * (st->cpt == 27 ? multi_groups(A->n, p->dtype == APX_F32 ? 4 : 2) : 1);      // (k_multi_rows on very short rows: csrc/team_rows.h)
   APX_TRY(st->part.alloc_zero((size_t)nparts * d.ldpart * sizeof(double), ctx->stream));
   d.part = (double*)st->part.p;
   d.c = p->ctrl();
@@ -340,17 +345,15 @@ static void slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
   const dim3 grid((unsigned)st->B);
   constexpr bool f32 = sizeof(T) == 4;
   if (st->cpt == 27) {                             // k_multi_rows: H rows per step, the dual steps of a step in the row wave's lanes
-    if constexpr (!f32) {
-      if (st->nt) multi_launch<kTeamFkPd, true, SlabPdDev>(d.n, st->B, d, x, q);
-      else multi_launch<kTeamFkPd, false, SlabPdDev>(d.n, st->B, d, x, q);
-      hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
-                         d, st->B * multi_groups(d.n), (T*)aty, recs, rec_cap);
-    }
+    if (st->nt) multi_launch<T, kTeamFkPd, true, SlabPdDev>(d.n, st->B, st->multi_waves, d, x, q);
+    else multi_launch<T, kTeamFkPd, false, SlabPdDev>(d.n, st->B, st->multi_waves, d, x, q);
+    hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
+                       d, st->B * multi_groups(d.n, 16 / (int)sizeof(T)), (T*)aty, recs, rec_cap);
     return;
   }
   if (st->team_kv != 0) {
     if constexpr (!f32) {
-      team_launch<kTeamFkPd, SlabPdDev>(TeamPlan{st->team_p, st->team_kv, st->team_big}, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+      team_launch<kTeamFkPd, SlabPdDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
       hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
                          d, st->B, (T*)aty, recs, rec_cap);
     }
@@ -402,12 +405,13 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   if (st->kname.empty()) {
     char b[256];
     if (st->team_kv != 0)
-      snprintf(b, sizeof b, "k_team_rows<primal_dual, %d member%s, %d vectors per thread, %d row slots, %d row%s of slack> + k_slabpd_close", st->team_p,
-               st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), (st->team_big || st->team_p == 1) ? 3 : 4,
-               (st->team_big || st->team_p == 1) ? 1 : 2, (st->team_big || st->team_p == 1) ? "" : "s");
+      snprintf(b, sizeof b, "k_team_rows<primal_dual, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack> + k_slabpd_close",
+               st->team_p, st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), st->plan.waves,
+               st->plan.alt ? st->plan.alt / 10 : ((st->team_big || st->team_p == 1) ? 3 : 4),
+               st->plan.alt ? st->plan.alt % 10 : ((st->team_big || st->team_p == 1) ? 1 : 2), (st->team_big || st->team_p == 1) ? "" : "s");
     else if (st->cpt == 27)
-      snprintf(b, sizeof b, "k_multi_rows<primal_dual, %d vectors per thread, %d row group(s)> + k_slabpd_close", (int)((((int64_t)d.n + 1) / 2 + 703) / 704),
-               multi_groups(d.n));
+      snprintf(b, sizeof b, "k_multi_rows<%s, primal_dual, %d row group(s)> + k_slabpd_close", p->dtype == APX_F32 ? "float" : "double",
+               multi_groups(d.n, p->dtype == APX_F32 ? 4 : 2));
     else
       snprintf(b, sizeof b, "k_slabpd_rows<%s, %d columns per thread, %d threads> + k_slabpd_close", p->dtype == APX_F32 ? "float" : "double", st->cpt, st->bs);
     st->kname = b;

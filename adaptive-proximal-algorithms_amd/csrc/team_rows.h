@@ -28,23 +28,23 @@ template <int FK>
 struct TeamRowConsts {
   double bias = 0.0, sigma = 0.0, rho = 0.0;
   template <class DEV>
-  __device__ TeamRowConsts(const DEV& d, const void* xv) {
-    if constexpr (FK == APX_F_LOGISTIC) bias = ((const double*)xv)[d.n - 1];
+  __device__ TeamRowConsts(const DEV& d, const void* xv, bool f32 = false) {
+    if constexpr (FK == APX_F_LOGISTIC) bias = f32 ? (double)((const float*)xv)[d.n - 1] : ((const double*)xv)[d.n - 1];
     if constexpr (FK == kTeamFkPd) {
       sigma = d.c->sigma;             // this iteration's, set by the rule kernel before this launch
       rho = d.c->rho;
     }
   }
 };
-template <int FK, class DEV>
+template <int FK, class DEV, typename T = double>
 __device__ __forceinline__ TeamRowState team_row_state(const DEV& d, int i) {
   TeamRowState s;
   if constexpr (FK == kTeamFkPd) {
-    s.a = ((const double*)d.Y)[i];
-    s.b = ((const double*)d.AXP)[i];
-    s.c = d.h.has_shift ? ((const double*)d.h.shift)[i] : 0.0;
+    s.a = (double)((const T*)d.Y)[i];
+    s.b = (double)((const T*)d.AXP)[i];
+    s.c = d.h.has_shift ? (double)((const T*)d.h.shift)[i] : 0.0;
   } else {
-    s.a = ((const double*)d.b)[i];
+    s.a = (double)((const T*)d.b)[i];
   }
   return s;
 }
@@ -52,30 +52,43 @@ template <int FK>
 __device__ __forceinline__ void team_row_state_landed(TeamRowState& s) {
   if constexpr (FK == kTeamFkPd) asm volatile("" : "+v"(s.a), "+v"(s.b), "+v"(s.c));      // (a use: the compiler waits for the loads)
 }
-// the value the compute waves multiply row i by ; the loss sums (every member forms them — member 0's are the ones stored)
-template <int FK, class DEV>
-__device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowConsts<FK>& kc, const TeamRowState& st, double ax, int i,
+// the value the compute waves multiply row i by ; the loss sums (every member forms them — member 0's are the ones stored).
+// `dot` is the row's <A[i, :], x> in Float64 ; T is the storage type: A x is rounded to T like every stored A x, and for Float32
+// data the logistic link runs in Float32, as Julia does on Float32 arrays (csrc/slab.hip slab_group) — for T = double nothing
+// is rounded.
+template <int FK, class DEV, typename T = double>
+__device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowConsts<FK>& kc, const TeamRowState& st, double dot, int i,
                                                   bool writer, double& e0, double& e1) {
+  const double ax = (double)(T)dot;
   if constexpr (FK == APX_F_LEAST_SQUARES) {
-    const double res = ax - st.a;                                     // experiments/lasso/runme.jl:22
+    const double res = (double)(T)(ax - st.a);                        // experiments/lasso/runme.jl:22
     e0 += res * res;
     return res;
   } else if constexpr (FK == APX_F_LOGISTIC) {
     const double logit = ax + kc.bias;                                // experiments/sparse_logreg/runme.jl:24-36
-    const double e = 1.0 + exp(-logit);
-    e0 += (st.a - 1.0) * logit - log(e);
-    const double res = 1.0 / e - st.a;
+    double res;
+    if constexpr (sizeof(T) == 4) {
+      const float lf = (float)logit;
+      const float ef = 1.0f + expf(-lf);
+      e0 += (double)(((float)st.a - 1.0f) * lf - logf(ef));
+      res = (double)(1.0f / ef - (float)st.a);
+    } else {
+      const double e = 1.0 + exp(-logit);
+      e0 += (st.a - 1.0) * logit - log(e);
+      res = 1.0 / e - st.a;
+    }
     e1 += res;
     return res;
   } else {
     const double w = st.a + kc.sigma * ((1.0 + kc.rho) * ax - kc.rho * st.b);      // src/AdaProx.jl:344
-    const double yn = prox_conj_elem_s<double>(d.h, w, kc.sigma, i, 0.0, st.c);    // :345
+    const T ynt = (T)prox_conj_elem_s<T>(d.h, w, kc.sigma, i, 0.0, st.c);          // :345
+    const double yn = (double)ynt;
     const double dr = (w - yn) / kc.sigma - ax;                                    // :347
     e0 += dr * dr;
-    e1 += gval_elem_s<double>(d.h, ax, i, st.c);
+    e1 += gval_elem_s<T>(d.h, ax, i, st.c);
     if (writer) {
-      ((double*)d.Y)[i] = yn;
-      ((double*)d.AXP)[i] = ax;                                                    // :360
+      ((T*)d.Y)[i] = ynt;
+      ((T*)d.AXP)[i] = (T)ax;                                                      // :360
     }
     return yn;
   }
@@ -131,14 +144,17 @@ __device__ __forceinline__ void team_fetch(const TeamRec* row, raw16_t (&q)[(P +
                  : "memory");
 }
 
-template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2, class DEV = SlabDev>
+// CW: compute waves (11, or 10 where ten waves take no more vectors per thread than eleven: fewer idle lanes for the same
+// registers — C2's slice of 3125 vectors is 5 x 640 x 0.98 or 5 x 704 x 0.89) ; the wave behind them is the communication wave
+template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2, class DEV = SlabDev, int CW = 11>
 __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void* xv) {
-  constexpr int CW = 11, BSC = CW * 64, TPX = 32 / P;
+  constexpr int BSC = CW * 64, TPX = 32 / P;
+  static_assert(CW == 10 || CW == 11, "ten or eleven compute waves and the communication wave");
   static_assert(G >= DEPTH + 2 && DEPTH <= 3, "slots: DEPTH rows awaiting their residuals, one computing, one loading ; res_s has 4 entries");
   static_assert(P > 1 || DEPTH == 1, "a workgroup on its own has its row sum one step later");
   typedef double vec_t __attribute__((ext_vector_type(2)));
   typedef unsigned raw_t __attribute__((ext_vector_type(4)));
-  extern __shared__ double team_x[];               // the member's slice of x: KV * 704 * 2 doubles
+  extern __shared__ double team_x[];               // the member's slice of x: KV * BSC * 2 doubles
   __shared__ double wsum[2][CW];
   __shared__ double res_s[4];
   __shared__ int ident[5];                         // team, member, the sticky error word, XCC_ID, ticket
@@ -454,15 +470,32 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 // ---------------------------------------------------------------------------------------------------------------------
 // GR > 1 (rows of fewer than ~700 entries, KV = 1): the compute waves form GR groups of WG waves, each group its own H rows of
 // a step — GR H rows per step, one lane of the row wave each — and its own column accumulator, stored as a block partial of
-// its own (the closing kernel sums GR partials per workgroup).
-template <int FK, int KV, int H, bool NT, class DEV = SlabDev, int GR = 1, int WG = 11>
+// its own (the closing kernel sums GR partials per workgroup).  GR = 1 with WG < 11: the row is dealt to WG waves only (a row of
+// 2500 vectors — C3's — fills four vectors of 640 threads to 98 %, of 704 to 89 %) ; the waves beyond keep the barriers.
+//
+// T = float (round 3): the same kernel for Float32 data — four columns per 16-byte vector ; a thread's share of a dot product
+// (<= 16 products per row) and the H products a column receives per step are summed in Float32, everything across threads and
+// steps in Float64 (csrc/slab.hip k_slab2_rows has the error analysis: 5e-10 on f, 4e-8 on the gradient, relative — the size of
+// the rounding of `A x` and of the gradient to Float32 that follows anyway) ; the row wave evaluates the logistic link in
+// Float32, as Julia does on Float32 arrays.  What it buys over the first-generation Float32 shapes is what it bought Float64:
+// the residual / the link of a row is evaluated where no row of A is held and OFF the compute waves' critical path — one
+// barrier per step instead of two with a serial section between them.
+template <typename T> struct TeamVec;
+template <> struct TeamVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct TeamVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <typename T, int FK, int KV, int H, bool NT, class DEV = SlabDev, int GR = 1, int WG = 11>
 __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
   constexpr int CW = 11, BSC = WG * 64, G = 3, RS = GR * H;          // (BSC: threads of a group ; RS: rows per step)
+  constexpr int VW = 16 / (int)sizeof(T);                            // columns per 16-byte vector
+  constexpr bool kF32 = sizeof(T) == 4;
   static_assert(H * KV <= 8 && (H == 1 || H == 2 || H == 4 || H == 8), "rows per step x vectors per row: the registers of three steps");
   static_assert(GR * WG <= CW && RS <= 64 && (GR == 1 || KV == 1), "groups of whole waves ; a lane of the row wave per row");
-  typedef double vec_t __attribute__((ext_vector_type(2)));
+  typedef typename TeamVec<T>::type vec_t;
   typedef unsigned raw_t __attribute__((ext_vector_type(4)));
-  extern __shared__ double multi_x[];              // x: KV * BSC * 2 doubles
+  constexpr int HP = H < 2 ? 2 : H;                // (the multi-value wave sum wants at least two)
+  extern __shared__ double multi_x_raw[];          // x: KV * BSC vectors of 16 bytes
+  T* multi_x = (T*)multi_x_raw;
   __shared__ double wsum[2][CW][H];
   __shared__ double res_s[4][RS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -474,7 +507,7 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
   const int nsteps = 1 + ((nrows + RS - 1) / RS + G - 1) / G * G;    // one step of prologue, then whole rounds of G steps
   if (wv == CW) {
     // ---- the row wave: lane L < RS is row L of a step (group L / H, its row L % H) ---------------------------------------
-    const TeamRowConsts<FK> kc(d, xv);
+    const TeamRowConsts<FK> kc(d, xv, kF32);
     double e0 = 0.0, e1 = 0.0, own_prev = 0.0;
     TeamRowState st_prev{};
     const int ll = min(lane, RS - 1), lg = ll / H, lh = ll % H;
@@ -482,12 +515,12 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
       // (the state of THIS step's rows, taken before the barrier behind which their dots complete ; the same wave writes
       //  y+ and A_x a step later: no other reader)
       const int inew = row_begin + step * RS + ll;
-      const TeamRowState snew = team_row_state<FK>(d, max(min(inew, row_end - 1), 0));
+      const TeamRowState snew = team_row_state<FK, DEV, T>(d, max(min(inew, row_end - 1), 0));
       const int r = step - 1;
       if (r >= 0) {
         const int i = row_begin + r * RS + ll;
         double res = 0.0;
-        if (lane < RS && i < row_end) res = team_row_finish<FK>(d, kc, st_prev, own_prev, i, true, e0, e1);
+        if (lane < RS && i < row_end) res = team_row_finish<FK, DEV, T>(d, kc, st_prev, own_prev, i, true, e0, e1);
         if (lane < RS) res_s[r & 3][lane] = res;
       }
       __syncthreads();                             // the barrier of the step
@@ -511,27 +544,27 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
     return;
   }
   // ---- the compute waves ----------------------------------------------------------------------------------------------
-  const int grp = __builtin_amdgcn_readfirstlane(GR == 1 ? 0 : wv / WG);      // (waves beyond GR WG: no group — they only keep the barriers)
-  const bool idle = GR > 1 && grp >= GR;
-  const int gt = GR == 1 ? tid : tid - grp * BSC;  // the thread within its group
-  const double* __restrict__ X = (const double*)xv;
-  const int nvec = (d.ncols + 1) / 2;
-  double acc[KV][2];
+  const int grp = __builtin_amdgcn_readfirstlane(GR * WG == CW && GR == 1 ? 0 : wv / WG);      // (waves beyond GR WG: no group — they only keep the barriers)
+  const bool idle = grp >= GR;
+  const int gt = tid - grp * BSC;                  // the thread within its group (an idle wave: a valid index too)
+  const T* __restrict__ X = (const T*)xv;
+  const int nvec = (d.ncols + VW - 1) / VW;
+  double acc[KV][VW];
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
     const int lv = gt + k * BSC;
-    const int j = lv * 2;
+    const int j = lv * VW;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < VW; ++e) {
       // (each thread reads back only the entries it wrote — with GR > 1 the same thread of every group writes them, the same
-      //  values: no barrier)
-      if (!idle) multi_x[lv * 2 + e] = (lv < nvec && j + e < d.ncols) ? X[j + e] : 0.0;
+      //  values: no barrier ; logistic: X[ncols] is the bias, not a column weight)
+      if (!idle) multi_x[lv * VW + e] = (lv < nvec && j + e < d.ncols) ? X[j + e] : (T)0;
       acc[k][e] = 0.0;
     }
   }
   const int voff = gt * 16;
-  const int row_bytes = idle ? 0 : (int)min((int64_t)nvec * 16, d.ldT * 8);      // (rows are zero-padded to whole vectors ; idle waves load nothing)
-  const double* __restrict__ AT = (const double*)d.AT;
+  const int row_bytes = idle ? 0 : (int)min((int64_t)nvec * 16, d.ldT * (int64_t)sizeof(T));      // (rows are zero-padded to whole vectors ; idle waves load nothing)
+  const T* __restrict__ AT = (const T*)d.AT;
   vec_t a[G][H][KV];
   auto load = [&](int g, int step) {
 #pragma unroll
@@ -552,19 +585,35 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
     __builtin_amdgcn_sched_barrier(0);
   }
   auto dots = [&](int g, int step) {
-    double p[H];
+    double p[HP];
 #pragma unroll
-    for (int h = 0; h < H; ++h) p[h] = 0.0;
+    for (int h = 0; h < HP; ++h) p[h] = 0.0;
+    if constexpr (kF32) {
+      float q[H];
 #pragma unroll
-    for (int k = 0; k < KV; ++k)
+      for (int h = 0; h < H; ++h) q[h] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const double xe = multi_x[(gt + k * BSC) * 2 + e];
+      for (int k = 0; k < KV; ++k)
 #pragma unroll
-        for (int h = 0; h < H; ++h) p[h] = fma(a[g][h][k][e], xe, p[h]);
-      }
-    wave_sum_multi<H>(p);                          // lane l: the wave's sum for row l / (64 / H), the same in all its lanes
-    wsum[step & 1][wv][lane / (64 / H)] = p[0];    // (every lane stores: no branch in the loop body)
+        for (int e = 0; e < VW; ++e) {
+          const float xe = multi_x[(gt + k * BSC) * VW + e];
+#pragma unroll
+          for (int h = 0; h < H; ++h) q[h] = fmaf(a[g][h][k][e], xe, q[h]);
+        }
+#pragma unroll
+      for (int h = 0; h < H; ++h) p[h] = (double)q[h];
+    } else {
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          const double xe = multi_x[(gt + k * BSC) * VW + e];
+#pragma unroll
+          for (int h = 0; h < H; ++h) p[h] = fma(a[g][h][k][e], xe, p[h]);
+        }
+    }
+    wave_sum_multi<HP>(p);                         // lane l: the wave's sum for row l / (64 / HP), the same in all its lanes
+    if (H > 1 || lane < 32) wsum[step & 1][wv][H > 1 ? lane / (64 / H) : 0] = p[0];      // (H = 1: the first half of the lanes hold the row's sum)
     __syncthreads();
   };
   dots(0, 0);                                      // step 0: nothing to accumulate yet ; fills the slot the prologue left empty
@@ -577,18 +626,33 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
     for (int u = 0; u < G; ++u) {
       const int step = q + u, r = step - 1;
       dots((1 + u) % G, step);
+      if constexpr (kF32) {
+        float rf[H];
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const double rr = res_s[r & 3][(idle ? 0 : grp) * H + h];
+        for (int h = 0; h < H; ++h) rf[h] = (float)res_s[r & 3][(idle ? 0 : grp) * H + h];      // (the residuals ARE Float32 values)
 #pragma unroll
         for (int k = 0; k < KV; ++k)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[u][h][k][e], rr, acc[k][e]);      // (slot of step r: (step - 1) % G = u)
+          for (int e = 0; e < VW; ++e) {
+            float t = a[u][0][k][e] * rf[0];       // (slot of step r: (step - 1) % G = u)
+#pragma unroll
+            for (int h = 1; h < H; ++h) t = fmaf(a[u][h][k][e], rf[h], t);
+            acc[k][e] += (double)t;
+          }
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const double rr = res_s[r & 3][(idle ? 0 : grp) * H + h];
+#pragma unroll
+          for (int k = 0; k < KV; ++k)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) acc[k][e] = fma(a[u][h][k][e], rr, acc[k][e]);      // (slot of step r: (step - 1) % G = u)
+        }
       }
 #pragma unroll
       for (int k = 0; k < KV; ++k)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+        for (int e = 0; e < VW; ++e) asm volatile("" : "+v"(acc[k][e]));
       __builtin_amdgcn_sched_barrier(0);
       load(u, r + G);
       __builtin_amdgcn_sched_barrier(0);
@@ -599,33 +663,49 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
     const int lv = gt + k * BSC;
-    const int j = lv * 2;
+    const int j = lv * VW;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < VW; ++e)
       if (lv < nvec && j + e < d.ncols) out[j + e] = acc[k][e];
   }
 }
 
 // the launch for a row length: KV = vectors per compute thread and row, H = 8 / KV rows per step (H KV <= 8)
 // rows per workgroup partial: the workgroup's GR groups each leave one (the closing kernels sum nblocks * multi_groups(ncols))
-inline int multi_groups(int64_t ncols) {
-  const int64_t nvec = (ncols + 1) / 2;
+inline int multi_groups(int64_t ncols, int vw = 2) {
+  const int64_t nvec = (ncols + vw - 1) / vw;
   return nvec <= 128 ? 5 : nvec <= 192 ? 3 : nvec <= 320 ? 2 : 1;
 }
-template <int FK, bool NT, class DEV>
-inline bool multi_launch(int64_t ncols, int nblocks, const DEV& d, const void* x, hipStream_t q) {
-  const int64_t nvec = (ncols + 1) / 2;
-  const int kv = (int)((nvec + 703) / 704);
+// ten compute waves instead of eleven where that takes no more vectors per thread: fewer idle lanes for the same registers
+// (C3: 2500 vectors per row = 4 x 640 x 0.98 against 4 x 704 x 0.89) ; `waves` = 10 / 11 forces one (APX_OPT_MULTI_WAVES: A/B)
+inline int multi_waves(int64_t nvec, int waves) {
+  if (waves == 10 || waves == 11) return waves;
+  const int64_t kv11 = (nvec + 703) / 704, kv10 = (nvec + 639) / 640;
+  return kv10 == kv11 && kv11 >= 2 ? 10 : 11;
+}
+constexpr int64_t kMultiMaxVec = 4 * 704;          // rows per step >= 2: up to four vectors per thread
+template <typename T, int FK, bool NT, class DEV>
+inline bool multi_launch(int64_t ncols, int nblocks, int waves, const DEV& d, const void* x, hipStream_t q) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int64_t nvec = (ncols + VW - 1) / VW;
   const dim3 grid((unsigned)nblocks), block(768);
   // very short rows: GR groups of WG waves, eight rows each per step (40 / 24 / 16 rows per step)
-  if (nvec <= 128) { hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV, 5, 2>), grid, block, (size_t)128 * 16, q, d, x); return true; }
-  if (nvec <= 192) { hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV, 3, 3>), grid, block, (size_t)192 * 16, q, d, x); return true; }
-  if (nvec <= 320) { hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV, 2, 5>), grid, block, (size_t)320 * 16, q, d, x); return true; }
-  switch (kv) {
-    case 1: hipLaunchKernelGGL((k_multi_rows<FK, 1, 8, NT, DEV>), grid, block, (size_t)1 * 704 * 16, q, d, x); return true;
-    case 2: hipLaunchKernelGGL((k_multi_rows<FK, 2, 4, NT, DEV>), grid, block, (size_t)2 * 704 * 16, q, d, x); return true;
-    case 3: hipLaunchKernelGGL((k_multi_rows<FK, 3, 2, NT, DEV>), grid, block, (size_t)3 * 704 * 16, q, d, x); return true;
-    case 4: hipLaunchKernelGGL((k_multi_rows<FK, 4, 2, NT, DEV>), grid, block, (size_t)4 * 704 * 16, q, d, x); return true;
+  if (nvec <= 128) { hipLaunchKernelGGL((k_multi_rows<T, FK, 1, 8, NT, DEV, 5, 2>), grid, block, (size_t)128 * 16, q, d, x); return true; }
+  if (nvec <= 192) { hipLaunchKernelGGL((k_multi_rows<T, FK, 1, 8, NT, DEV, 3, 3>), grid, block, (size_t)192 * 16, q, d, x); return true; }
+  if (nvec <= 320) { hipLaunchKernelGGL((k_multi_rows<T, FK, 1, 8, NT, DEV, 2, 5>), grid, block, (size_t)320 * 16, q, d, x); return true; }
+  if (multi_waves(nvec, waves) == 10) {
+    switch ((int)((nvec + 639) / 640)) {
+      case 2: hipLaunchKernelGGL((k_multi_rows<T, FK, 2, 4, NT, DEV, 1, 10>), grid, block, (size_t)2 * 640 * 16, q, d, x); return true;
+      case 3: hipLaunchKernelGGL((k_multi_rows<T, FK, 3, 2, NT, DEV, 1, 10>), grid, block, (size_t)3 * 640 * 16, q, d, x); return true;
+      case 4: hipLaunchKernelGGL((k_multi_rows<T, FK, 4, 2, NT, DEV, 1, 10>), grid, block, (size_t)4 * 640 * 16, q, d, x); return true;
+      default: break;
+    }
+  }
+  switch ((int)((nvec + 703) / 704)) {
+    case 1: hipLaunchKernelGGL((k_multi_rows<T, FK, 1, 8, NT, DEV>), grid, block, (size_t)1 * 704 * 16, q, d, x); return true;
+    case 2: hipLaunchKernelGGL((k_multi_rows<T, FK, 2, 4, NT, DEV>), grid, block, (size_t)2 * 704 * 16, q, d, x); return true;
+    case 3: hipLaunchKernelGGL((k_multi_rows<T, FK, 3, 2, NT, DEV>), grid, block, (size_t)3 * 704 * 16, q, d, x); return true;
+    case 4: hipLaunchKernelGGL((k_multi_rows<T, FK, 4, 2, NT, DEV>), grid, block, (size_t)4 * 704 * 16, q, d, x); return true;
     default: return false;
   }
 }
@@ -637,6 +717,11 @@ constexpr int64_t kTeamMaxCols = (int64_t)16 * kTeamSingleKv * 704 * 2;      // 
 struct TeamPlan {
   int P = 0, kv = 0;                  // members ; 16-byte vectors per compute thread and row of a member's slice
   bool big = false;                   // seven or eight vectors: three row slots, ONE row of slack
+  int waves = 11;                     // compute waves: 10 where that takes no more vectors per thread (k_team_rows CW)
+  int alt = 0;                        // experimental slot shapes, G * 10 + DEPTH (APX_OPT_TEAM_SLOTS ; teams of four, KV = 4, the primal-dual form only)
+};
+struct TeamTune {                     // A/B overrides (apx_ctx_set_option): 0 = the plan below decides
+  int members = 0, waves = 0, alt = 0;
 };
 // One workgroup where the row fits its eight vectors per thread (three row slots, nothing to hand over).  Else the members'
 // slices as large as the registers allow, because a step costs a barrier and a hand-off whatever its bytes:
@@ -644,7 +729,7 @@ struct TeamPlan {
 //   seven or eight with three slots and ONE row of slack — which teams of two and four absorb (a step is 60 - 90 KB per
 //   member: tools/pattern_probe.hip, 6.6 and 6.9 TB/s) but teams of eight and sixteen do not (6.2 and 5.5 against 6.6 with
 //   two rows of slack) ; sixteen members take it only beyond 135 168 columns, where the alternative is two passes.
-inline TeamPlan team_plan(int64_t ncols) {
+inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}) {
   const int64_t nvec = (ncols + 1) / 2, v6 = 6 * 704, v8 = (int64_t)kTeamSingleKv * 704;
   TeamPlan pl;
   pl.P = 16;
@@ -656,7 +741,20 @@ inline TeamPlan team_plan(int64_t ncols) {
   else if (nvec <= 8 * v6) pl.P = 8;
   else if (nvec <= 16 * v6) pl.P = 16;
   else pl.big = true;
-  pl.kv = (int)(((nvec + pl.P - 1) / pl.P + 703) / 704);
+  // (A/B: a forced team size, where the row still fits its eight vectors per thread and is long enough to be split)
+  if (pl.P > 1 && (tune.members == 2 || tune.members == 4 || tune.members == 8 || tune.members == 16) && nvec <= tune.members * v8 &&
+      nvec > (int64_t)tune.members * 704) {
+    pl.P = tune.members;
+    pl.big = nvec > (int64_t)tune.members * v6;
+    if (pl.big && pl.P == 8) pl.P = 16, pl.big = nvec > 16 * v6;      // (no three-slot instance for teams of eight)
+  }
+  const int64_t nvs = (nvec + pl.P - 1) / pl.P;
+  pl.kv = (int)((nvs + 703) / 704);
+  const int kv10 = (int)((nvs + 639) / 640);
+  pl.waves = tune.waves == 10 || tune.waves == 11 ? tune.waves : (kv10 == pl.kv ? 10 : 11);
+  if (pl.waves == 10 && kv10 > (pl.big || pl.P == 1 ? 8 : 6)) pl.waves = 11;      // (a forced 10 that would not fit the shape)
+  if (pl.waves == 10) pl.kv = kv10;
+  if (pl.P == 4 && pl.kv == 4 && !pl.big) pl.alt = tune.alt;
   return pl;
 }
 
@@ -686,21 +784,22 @@ struct TeamCall {
 //  what a GPU shared with other work does to this scheme.  tests/test_gpu_team_fault.py checks that the waits time out,
 //  the grid drains and the error comes back)
 inline unsigned team_grid(const TeamDev& t, int nteams, int P) { return (unsigned)(t.fault_grid > 0 && P > 1 ? t.fault_grid : nteams * P); }
-template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV>
+template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV, int CW>
 inline void team_launch_one(TeamCall& call, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
-  constexpr size_t lds = (size_t)KV * 704 * 2 * sizeof(double);      // the slice of x
-  auto kernel = k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>;
-  if constexpr (lds > 64 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV>>();
+  constexpr size_t lds = (size_t)KV * CW * 64 * 2 * sizeof(double);      // the slice of x
+  constexpr int kThreads = (CW + 1) * 64;
+  auto kernel = k_team_rows<FK, P, KV, NT, G, DEPTH, DEV, CW>;
+  if constexpr (lds > 64 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV, CW>>();
   if (call.query) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 768, lds) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kThreads, lds) != hipSuccess) {
       (void)hipGetLastError();
       nb = 0;
     }
     call.blocks_per_cu = nb;
     return;
   }
-  const dim3 grid(team_grid(t, nteams, P)), block(768);
+  const dim3 grid(team_grid(t, nteams, P)), block(kThreads);
   if (call.cooperative && P > 1) {
     DEV dd = d;
     TeamDev tt = t;
@@ -714,24 +813,36 @@ inline void team_launch_one(TeamCall& call, int nteams, const DEV& d, const Team
 // four row slots, two rows of slack: 2 ... 6 vectors
 // (measured and dropped at C2, interleaved runs of bench.py: five and six slots, two or three rows of slack, one to three rows
 //  really in flight — nothing ; profiles/r02_team_handoff_traffic.log has what the gap to the streaming rate was instead)
-template <int FK, int P, class DEV>
-inline bool team_launch_d2(TeamCall& call, int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+template <int FK, int P, class DEV, int CW>
+inline bool team_launch_d2(TeamCall& call, int kv, int alt, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+  // (APX_OPT_TEAM_SLOTS: more row slots / rows of slack for C5's length as teams of four — an A/B hook, the primal-dual form only)
+  if constexpr (P == 4 && FK == kTeamFkPd) {
+    if (kv == 4) {
+      switch (alt) {
+        case 52: team_launch_one<FK, P, 4, true, 5, 2, DEV, CW>(call, nteams, d, t, x, q); return true;
+        case 62: team_launch_one<FK, P, 4, true, 6, 2, DEV, CW>(call, nteams, d, t, x, q); return true;
+        case 53: team_launch_one<FK, P, 4, true, 5, 3, DEV, CW>(call, nteams, d, t, x, q); return true;
+        case 63: team_launch_one<FK, P, 4, true, 6, 3, DEV, CW>(call, nteams, d, t, x, q); return true;
+        default: break;
+      }
+    }
+  }
   switch (kv) {
     case 1:
-    case 2: team_launch_one<FK, P, 2, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
-    case 3: team_launch_one<FK, P, 3, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
-    case 4: team_launch_one<FK, P, 4, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
-    case 5: team_launch_one<FK, P, 5, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
-    case 6: team_launch_one<FK, P, 6, true, 4, 2, DEV>(call, nteams, d, t, x, q); return true;
+    case 2: team_launch_one<FK, P, 2, true, 4, 2, DEV, CW>(call, nteams, d, t, x, q); return true;
+    case 3: team_launch_one<FK, P, 3, true, 4, 2, DEV, CW>(call, nteams, d, t, x, q); return true;
+    case 4: team_launch_one<FK, P, 4, true, 4, 2, DEV, CW>(call, nteams, d, t, x, q); return true;
+    case 5: team_launch_one<FK, P, 5, true, 4, 2, DEV, CW>(call, nteams, d, t, x, q); return true;
+    case 6: team_launch_one<FK, P, 6, true, 4, 2, DEV, CW>(call, nteams, d, t, x, q); return true;
     default: return false;
   }
 }
 // three row slots, one row of slack: 7 or 8 vectors (a workgroup on its own: 4 ... 8, non-temporal loads by the matrix size)
-template <int FK, int P, bool NT, class DEV>
+template <int FK, int P, bool NT, class DEV, int CW>
 inline bool team_launch_d1(TeamCall& call, int kv, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   switch (kv) {
-    case 7: team_launch_one<FK, P, 7, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
-    case 8: team_launch_one<FK, P, 8, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
+    case 7: team_launch_one<FK, P, 7, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
+    case 8: team_launch_one<FK, P, 8, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
     default: break;
   }
   if constexpr (P == 1) {
@@ -739,9 +850,9 @@ inline bool team_launch_d1(TeamCall& call, int kv, int nteams, const DEV& d, con
       case 1:
       case 2:
       case 3:
-      case 4: team_launch_one<FK, 1, 4, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
-      case 5: team_launch_one<FK, 1, 5, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
-      case 6: team_launch_one<FK, 1, 6, NT, 3, 1, DEV>(call, nteams, d, t, x, q); return true;
+      case 4: team_launch_one<FK, 1, 4, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
+      case 5: team_launch_one<FK, 1, 5, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
+      case 6: team_launch_one<FK, 1, 6, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
       default: break;
     }
   }
@@ -749,19 +860,23 @@ inline bool team_launch_d1(TeamCall& call, int kv, int nteams, const DEV& d, con
 }
 // the launch of a plan (or the query whether it can be resident: TeamCall) ; a launch advances the ranges of tickets and
 // sequence numbers (never reset)
+template <int FK, class DEV, int CW>
+inline bool team_dispatch_w(TeamCall& call, const TeamPlan& pl, int nteams, bool nt, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+  bool ok = false;
+  if (pl.P == 1) ok = nt ? team_launch_d1<FK, 1, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q) : team_launch_d1<FK, 1, false, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+  else if (pl.big) {
+    if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+    else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+    else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+  } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+  else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+  else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+  else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+  return ok;
+}
 template <int FK, class DEV>
 inline bool team_dispatch(TeamCall& call, const TeamPlan& pl, int nteams, bool nt, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
-  bool ok = false;
-  if (pl.P == 1) ok = nt ? team_launch_d1<FK, 1, true, DEV>(call, pl.kv, nteams, d, t, x, q) : team_launch_d1<FK, 1, false, DEV>(call, pl.kv, nteams, d, t, x, q);
-  else if (pl.big) {
-    if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV>(call, pl.kv, nteams, d, t, x, q);
-    else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV>(call, pl.kv, nteams, d, t, x, q);
-    else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV>(call, pl.kv, nteams, d, t, x, q);
-  } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV>(call, pl.kv, nteams, d, t, x, q);
-  else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV>(call, pl.kv, nteams, d, t, x, q);
-  else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV>(call, pl.kv, nteams, d, t, x, q);
-  else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV>(call, pl.kv, nteams, d, t, x, q);
-  return ok;
+  return pl.waves == 10 ? team_dispatch_w<FK, DEV, 10>(call, pl, nteams, nt, d, t, x, q) : team_dispatch_w<FK, DEV, 11>(call, pl, nteams, nt, d, t, x, q);
 }
 template <int FK, class DEV>
 inline bool team_launch(const TeamPlan& pl, int nteams, bool nt, bool cooperative, const DEV& d, TeamDev& t, const void* x, hipStream_t q) {

@@ -271,8 +271,9 @@ int32_t apx_ctx_one_pass(apx_ctx* ctx, int32_t mode);
 /* Options by key (no reference counterpart).  A/B switches of measured alternatives and the hooks the tests use — the library
  * reads NO environment variables. */
 enum {
-  APX_OPT_MULTI_ROWS_MASK = 1,   /* default 7: short Float64 rows on k_multi_rows — bit 0 least squares, 1 logistic, 2 the
-                                    primal-dual loop ; a cleared bit runs the first-generation row shapes (A/B)              */
+  APX_OPT_MULTI_ROWS_MASK = 1,   /* default 15: short rows (Float64 <= 5632 entries, Float32 <= 11 264) on k_multi_rows — bit 0
+                                    least squares, 1 logistic, 2 the primal-dual loop, 3 Float32 data at all ; a cleared bit
+                                    runs the first-generation row shapes (A/B)                                               */
   APX_OPT_SLAB_GENERATION = 2,   /* default 0 = by measurement ; 1 / 2 force the first / second generation of the
                                     single-workgroup kernel for rows of 5121 ... 10 752 entries (A/B)                       */
   APX_OPT_TEAM_WAIT_MS = 3,      /* default 1000: wall-clock bound of a team hand-off wait                                  */
@@ -282,9 +283,14 @@ enum {
                                     miss members (tests/test_gpu_team_fault.py)                                            */
   APX_OPT_GEMV_N_VARIANT = 6, APX_OPT_GEMV_T_VARIANT = 7, APX_OPT_GEMV_N_BLOCKS = 8, APX_OPT_GEMV_T_BLOCKS = 9,
                                  /* = apx_ctx_set_gemv_config, one field at a time (tools/gemv_sweep.py)                    */
-  APX_OPT_FUSED_TAIL = 10        /* default 1: the residual / step-size reductions and the rule ride in the closing kernel of a
+  APX_OPT_FUSED_TAIL = 10,       /* default 1: the residual / step-size reductions and the rule ride in the closing kernel of a
                                     one-pass launch (two kernels between consecutive passes over A instead of four) ; 0: the
                                     separate kernels (A/B ; bit-identical results)                                          */
+  APX_OPT_MULTI_WAVES = 11,      /* default 0 = by fit ; 10 / 11: compute waves a row (k_multi_rows) or a member's slice of it
+                                    (k_team_rows) is dealt to (A/B)                                                          */
+  APX_OPT_TEAM_MEMBERS = 12,     /* default 0 = by the row length ; 2 / 4 / 8 / 16: workgroups per team where the row allows (A/B) */
+  APX_OPT_TEAM_SLOTS = 13        /* default 0 ; 52 / 62 / 53 / 63: row slots x 10 + rows of slack, teams of four with four vectors
+                                    per thread in the primal-dual loop only (C5's length as teams of four: A/B)              */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);

@@ -110,7 +110,19 @@ def _rel(a, b):
                                                 (4098, 8448, True, np.float64),
                                                 (4097, 9857, True, np.float64),
                                                 (4101, 10000, True, np.float64),       # C3's shape in the reference's precision
-                                                (4100, 11264, True, np.float64)])
+                                                (4100, 11264, True, np.float64),
+                                                # Float32 on k_multi_rows (round 3): four columns per 16-byte vector, ragged row
+                                                # lengths around the shape boundaries — five / three / two row groups, one vector
+                                                # per thread, 10 or 11 compute waves, the longest row (4 x 704 vectors)
+                                                (60000, 130, False, np.float32),
+                                                (50000, 601, True, np.float32),
+                                                (30000, 1279, False, np.float32),
+                                                (4099, 2563, True, np.float32),
+                                                (4098, 5000, True, np.float32),
+                                                (4100, 5130, False, np.float32),
+                                                (4097, 7677, True, np.float32),
+                                                (4101, 11264, True, np.float32),
+                                                (4100, 11263, False, np.float32)])
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
@@ -247,7 +259,11 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              # ... and beyond, since the loop shares k_team_rows with f's gradient: teams of 4, 8, 16
                                              (4100, 30000, "tl1", np.float64),
                                              (4099, 60001, "tbox", np.float64),
-                                             (4098, 150000, "tl1", np.float64)])
+                                             (4098, 150000, "tl1", np.float64),
+                                             # Float32 on k_multi_rows (round 3)
+                                             (70000, 300, "tl1", np.float32),
+                                             (4099, 5001, "tbox", np.float32),
+                                             (4100, 11264, "tl1", np.float32)])
 def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))
@@ -505,11 +521,13 @@ def test_first_generation_shapes():
     env = dict(os.environ, APX_TEST_MULTI_MASK="0")
     ids = "8500-1000-False-float64 or 8600-1024-True-float64 or 8500-1300-False-float64 or 4097-2049-True-float64 or " \
           "4100-3000-False-float64 or 4101-4096-True-float64 or 4200-5120-False-float64 or 9000-1000-tl1-float64 or " \
-          "9100-1300-tl1-float64 or 4099-2100-tbox-float64 or 4098-5000-tl1-float64"
+          "9100-1300-tl1-float64 or 4099-2100-tbox-float64 or 4098-5000-tl1-float64 or 8700-600-False-float32 or " \
+          "9000-900-True-float32 or 8600-1536-True-float32 or 4200-3072-True-float32 or 4099-3500-False-float32 or " \
+          "9800-10000-True-float32 or 4099-10239-True-float32 or 9000-700-tbox-float32 or 4100-4000-tl1-float32 or 4100-10752-tl1-float32"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", ids],
                          env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
-    assert " passed" in out.stdout and "11 passed" in out.stdout, out.stdout[-500:]
+    assert " passed" in out.stdout and "21 passed" in out.stdout, out.stdout[-500:]
 
 
 @pytest.mark.parametrize("m,n,logistic,dtype", [(9000, 1000, False, np.float64),      # k_multi_rows
