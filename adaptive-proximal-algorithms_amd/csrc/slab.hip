@@ -574,7 +574,12 @@ static SlabShape slab_shape(const apx_problem* p) {
   if (p->dtype == APX_F64 && cols <= 2 * 4 * 704 && ((p->f_kind == APX_F_LOGISTIC ? 2 : 1) & multi)) return {768, kSlabMultiCpt, 1};
   // Float32 rows of up to 11 264 entries likewise (round 3, bit 3 of the mask): four columns per 16-byte vector, partial sums
   // in Float32, the link in Float32 in the row wave — BASELINE config C3's 10 000 columns run here
-  if (p->dtype == APX_F32 && cols <= 4 * 4 * 704 && (multi & 8)) return {768, kSlabMultiCpt, 1};
+  // Measured against the first-generation shapes (tools/shape_sweep.py f32, 4 GB, profiles/r03_row_length_sweep_f32.log), TB/s of the
+  // bytes read: 130: 0.8 -> 3.4, 300: 1.8 -> 5.6, 600: 3.4 -> 6.0, 2100: 3.8 -> 6.2, 3100: 5.0 -> 6.4, 5000 ... 8200: the same ;
+  // 8500 ... 10 752 the fourteen-column first-generation kernel is as fast (least squares) or 1 - 4 % faster (logistic ; C3
+  // itself, interleaved in one process: 0.5915 against 0.5994 ms) and stays ; beyond it the one pass is new: up to 22 528
+  // entries (eight vectors per thread, one row per step)
+  if (p->dtype == APX_F32 && (multi & 8) && (cols <= 8192 || (cols > 14 * 768 && cols <= 4 * 8 * 640))) return {768, kSlabMultiCpt, 1};
   if (cols <= 1024) return {1024, 1, kSlabRows};      // (one column per thread, 32 rows per step: with two, half the loads of such a row are clamped away)
   if (cols <= 2 * 768) return {768, 2, kSlabRows};    // (1025 ... 1536 entries: two columns of 768 threads keep more lanes busy than of 1024)
   if (cols <= 2 * 1024) return {1024, 2, kSlabRows};

@@ -373,17 +373,17 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     return;
   }
   // ---- the compute waves ----------------------------------------------------------------------------------------------
-  double acc[KV][2];
+  // The member's slice of x goes to LDS — its KV 16-byte loads per thread all in flight at once, issued AHEAD of the first rows of
+  // A and written behind them.  (Round 2 took it entry by entry, every entry behind a branch of its own with a wait for the
+  // load in it: sixteen dependent trips to L2 before the first row of A was asked for — 10 us of every launch, 1.5 % of C3's.)
+  vec_t xin[KV];
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BSC;
-    const int j = (v0 + lv) * 2;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      team_x[lv * 2 + e] = (lv < nvs && j + e < d.ncols) ? X[j + e] : 0.0;     // (each thread reads back only what it wrote)
-      acc[k][e] = 0.0;
-    }
+    const int src = max(min(v0 + tid + k * BSC, nvec - 1), 0);       // (a valid address ; what lies past the slice or the row is zeroed below)
+    xin[k] = *(const vec_t*)(X + (int64_t)src * 2);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  double acc[KV][2];
   const int voff = tid * 16;
   const int64_t cbase = (int64_t)v0 * 16;
   const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * 8 - cbase));      // (rows are zero-padded to whole vectors)
@@ -391,8 +391,12 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   vec_t a[G][KV];
   auto load = [&](int g, int row) {
     const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+    // (a dummy row past the slab — the steps that fill the last round — gets a descriptor of ZERO bytes: every lane is out of
+    //  range and reads 0 without a memory request ; clamped to the slab's last row these steps re-read it from HBM, the loads
+    //  being non-temporal: 3 of C3's 199 steps)
+    const int nb = __builtin_amdgcn_readfirstlane(row < row_end ? slice_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, slice_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, nb, 0x00020000);
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
       const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
@@ -405,6 +409,17 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     load(g, row_begin + g);
     __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = tid + k * BSC;
+    const int j = (v0 + lv) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      team_x[lv * 2 + e] = (lv < nvs && j + e < d.ncols) ? xin[k][e] : 0.0;     // (each thread reads back only what it wrote)
+      acc[k][e] = 0.0;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   // the dots of the row in slot g (step seq) and the barrier behind them
   auto dots = [&](int g, long long seq) {
     double p = 0.0;
@@ -484,9 +499,10 @@ template <typename T> struct TeamVec;
 template <> struct TeamVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct TeamVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
 
-template <typename T, int FK, int KV, int H, bool NT, class DEV = SlabDev, int GR = 1, int WG = 11>
+template <typename T, int FK, int KV, int H, bool NT, class DEV = SlabDev, int GR = 1, int WG = 11, int G = 3>
 __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
-  constexpr int CW = 11, BSC = WG * 64, G = 3, RS = GR * H;          // (BSC: threads of a group ; RS: rows per step)
+  constexpr int CW = 11, BSC = WG * 64, RS = GR * H;                 // (BSC: threads of a group ; RS: rows per step ; G: steps held in registers)
+  static_assert(G == 2 || G == 3, "two or three steps in registers");
   constexpr int VW = 16 / (int)sizeof(T);                            // columns per 16-byte vector
   constexpr bool kF32 = sizeof(T) == 4;
   static_assert(H * KV <= 8 && (H == 1 || H == 2 || H == 4 || H == 8), "rows per step x vectors per row: the registers of three steps");
@@ -549,19 +565,16 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
   const int gt = tid - grp * BSC;                  // the thread within its group (an idle wave: a valid index too)
   const T* __restrict__ X = (const T*)xv;
   const int nvec = (d.ncols + VW - 1) / VW;
-  double acc[KV][VW];
+  // x to LDS: all of a thread's 16-byte loads in flight at once, issued ahead of the first rows of A, written behind them
+  // (see k_team_rows ; logistic: X[ncols] is the bias, not a column weight — zeroed with everything past the row)
+  vec_t xin[KV];
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
-    const int lv = gt + k * BSC;
-    const int j = lv * VW;
-#pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      // (each thread reads back only the entries it wrote — with GR > 1 the same thread of every group writes them, the same
-      //  values: no barrier ; logistic: X[ncols] is the bias, not a column weight)
-      if (!idle) multi_x[lv * VW + e] = (lv < nvec && j + e < d.ncols) ? X[j + e] : (T)0;
-      acc[k][e] = 0.0;
-    }
+    const int src = max(min(gt + k * BSC, nvec - 1), 0);
+    xin[k] = *(const vec_t*)(X + (int64_t)src * VW);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  double acc[KV][VW];
   const int voff = gt * 16;
   const int row_bytes = idle ? 0 : (int)min((int64_t)nvec * 16, d.ldT * (int64_t)sizeof(T));      // (rows are zero-padded to whole vectors ; idle waves load nothing)
   const T* __restrict__ AT = (const T*)d.AT;
@@ -569,8 +582,10 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
   auto load = [&](int g, int step) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      const int ri = __builtin_amdgcn_readfirstlane(max(min(row_begin + step * RS + (idle ? 0 : grp) * H + h, row_end - 1), 0));
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, row_bytes, 0x00020000);
+      const int row = row_begin + step * RS + (idle ? 0 : grp) * H + h;
+      const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+      const int nb = __builtin_amdgcn_readfirstlane(row < row_end ? row_bytes : 0);      // (a dummy row: zero bytes, no memory request — see k_team_rows)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, nb, 0x00020000);
 #pragma unroll
       for (int k = 0; k < KV; ++k) {
         const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
@@ -584,6 +599,20 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
     load(g, g);
     __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int lv = gt + k * BSC;
+    const int j = lv * VW;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      // (each thread reads back only the entries it wrote — with GR > 1 the same thread of every group writes them, the same
+      //  values: no barrier)
+      const T xe = (lv < nvec && j + e < d.ncols) ? xin[k][e] : (T)0;
+      if (!idle) multi_x[lv * VW + e] = xe;
+      acc[k][e] = 0.0;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   auto dots = [&](int g, int step) {
     double p[HP];
 #pragma unroll
@@ -612,8 +641,14 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
           for (int h = 0; h < H; ++h) p[h] = fma(a[g][h][k][e], xe, p[h]);
         }
     }
-    wave_sum_multi<HP>(p);                         // lane l: the wave's sum for row l / (64 / HP), the same in all its lanes
-    if (H > 1 || lane < 32) wsum[step & 1][wv][H > 1 ? lane / (64 / H) : 0] = p[0];      // (H = 1: the first half of the lanes hold the row's sum)
+    if constexpr (H == 1) {
+#pragma unroll                                     // (a butterfly: every lane ends with the wave's sum and stores it — no branch)
+      for (int off = 32; off > 0; off >>= 1) p[0] += __shfl_xor(p[0], off, 64);
+      wsum[step & 1][wv][0] = p[0];
+    } else {
+      wave_sum_multi<HP>(p);                       // lane l: the wave's sum for row l / (64 / HP), the same in all its lanes
+      wsum[step & 1][wv][lane / (64 / H)] = p[0];  // (every lane stores: no branch in the loop body)
+    }
     __syncthreads();
   };
   dots(0, 0);                                      // step 0: nothing to accumulate yet ; fills the slot the prologue left empty
@@ -706,8 +741,30 @@ inline bool multi_launch(int64_t ncols, int nblocks, int waves, const DEV& d, co
     case 2: hipLaunchKernelGGL((k_multi_rows<T, FK, 2, 4, NT, DEV>), grid, block, (size_t)2 * 704 * 16, q, d, x); return true;
     case 3: hipLaunchKernelGGL((k_multi_rows<T, FK, 3, 2, NT, DEV>), grid, block, (size_t)3 * 704 * 16, q, d, x); return true;
     case 4: hipLaunchKernelGGL((k_multi_rows<T, FK, 4, 2, NT, DEV>), grid, block, (size_t)4 * 704 * 16, q, d, x); return true;
-    default: return false;
+    default: break;
   }
+  // one row per step, five to eight vectors per thread — Float32 rows of 11 265 ... 22 528 entries (Float64 rows of this many
+  // vectors take k_team_rows with one workgroup, the same structure) ; seven and eight vectors hold TWO steps in registers (three
+  // spill: the Float64 accumulator of a Float32 row is twice the row)
+  if constexpr (sizeof(T) == 4) {
+    if (multi_waves(nvec, waves) == 10) {
+      switch ((int)((nvec + 639) / 640)) {
+        case 5: hipLaunchKernelGGL((k_multi_rows<T, FK, 5, 1, NT, DEV, 1, 10>), grid, block, (size_t)5 * 640 * 16, q, d, x); return true;
+        case 6: hipLaunchKernelGGL((k_multi_rows<T, FK, 6, 1, NT, DEV, 1, 10>), grid, block, (size_t)6 * 640 * 16, q, d, x); return true;
+        case 7: hipLaunchKernelGGL((k_multi_rows<T, FK, 7, 1, NT, DEV, 1, 10, 2>), grid, block, (size_t)7 * 640 * 16, q, d, x); return true;
+        case 8: hipLaunchKernelGGL((k_multi_rows<T, FK, 8, 1, NT, DEV, 1, 10, 2>), grid, block, (size_t)8 * 640 * 16, q, d, x); return true;
+        default: break;
+      }
+    }
+    switch ((int)((nvec + 703) / 704)) {
+      case 5: hipLaunchKernelGGL((k_multi_rows<T, FK, 5, 1, NT, DEV>), grid, block, (size_t)5 * 704 * 16, q, d, x); return true;
+      case 6: hipLaunchKernelGGL((k_multi_rows<T, FK, 6, 1, NT, DEV>), grid, block, (size_t)6 * 704 * 16, q, d, x); return true;
+      case 7: hipLaunchKernelGGL((k_multi_rows<T, FK, 7, 1, NT, DEV, 1, 11, 2>), grid, block, (size_t)7 * 704 * 16, q, d, x); return true;
+      case 8: hipLaunchKernelGGL((k_multi_rows<T, FK, 8, 1, NT, DEV, 1, 11, 2>), grid, block, (size_t)8 * 704 * 16, q, d, x); return true;
+      default: break;
+    }
+  }
+  return false;
 }
 
 // ---- host side: the plan for a row length, and the launch ----------------------------------------------------------------
@@ -751,7 +808,12 @@ inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}) {
   const int64_t nvs = (nvec + pl.P - 1) / pl.P;
   pl.kv = (int)((nvs + 703) / 704);
   const int kv10 = (int)((nvs + 639) / 640);
-  pl.waves = tune.waves == 10 || tune.waves == 11 ? tune.waves : (kv10 == pl.kv ? 10 : 11);
+  // Ten compute waves where they take no more vectors per thread than eleven (fewer idle lanes, the same registers) — measured,
+  // interleaved in one process (tools/ab.py, profiles/r03_ab_*.jsonl): C2 (sixteen members, five vectors) 6.134 against 6.168 ms,
+  // Float64 logistic 100 000 x 10 000 (one workgroup, eight vectors) 1.199 against 1.252, C5's length as teams of four 1.197 against
+  // 1.235 — but NOT the three-slot shape of real teams, where the hand-off sits a single row behind: C5 (two members, eight
+  // vectors) 1.194 ms with eleven waves against 1.221 with ten.
+  pl.waves = tune.waves == 10 || tune.waves == 11 ? tune.waves : (kv10 == pl.kv && !(pl.P > 1 && pl.big) ? 10 : 11);
   if (pl.waves == 10 && kv10 > (pl.big || pl.P == 1 ? 8 : 6)) pl.waves = 11;      // (a forced 10 that would not fit the shape)
   if (pl.waves == 10) pl.kv = kv10;
   if (pl.P == 4 && pl.kv == 4 && !pl.big) pl.alt = tune.alt;

@@ -122,7 +122,13 @@ def _rel(a, b):
                                                 (4100, 5130, False, np.float32),
                                                 (4097, 7677, True, np.float32),
                                                 (4101, 11264, True, np.float32),
-                                                (4100, 11263, False, np.float32)])
+                                                (4100, 11263, False, np.float32),
+                                                # ... and one row per step, five to eight vectors per thread: Float32 rows beyond the
+                                                # first-generation kernels' 10 752 entries read A once too, up to 22 528
+                                                (4100, 12000, False, np.float32),
+                                                (4099, 16001, True, np.float32),
+                                                (4100, 20000, False, np.float32),
+                                                (4101, 22528, True, np.float32)])
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))

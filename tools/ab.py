@@ -74,7 +74,7 @@ def main():
         p.X.build_transpose()
         mk = lambda: apx.Solver(np.zeros(n + 1, dtype=dt), f=apx.LogisticLoss(p.X, p.y), g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0),      # noqa: E731
                                 tol=0.0, ctx=ctx, poll_every=1 << 30)
-        restart_every = 120 if dt == np.float32 else 40        # (the loop runs past its fixed point: DESIGN.md section 9)
+        restart_every = 36 if dt == np.float32 else 40        # (the loop runs past its fixed point: DESIGN.md section 9)
     else:
         dt = np.float64 if args.config == "c5" else np.float32
         m, n, es = args.rows or 50_000, (20_000 if args.config == "c5" else 10_000), np.dtype(dt).itemsize
@@ -117,15 +117,17 @@ def main():
             ms = sum(k["total_ms"] for k in st.values()) / args.steps
             kern[v].append(ms)
             wall[v].append(dtw / args.steps * 1e3)
+    finals = {}
     for v, _ in variants:
         x, _, res = solvers[v].result()
-        assert np.all(np.isfinite(x)), v
+        finals[v] = (int(res.numit), float(res.objective), bool(np.all(np.isfinite(x))))
     base = statistics.median(kern[variants[0][0]])
     for v, _ in variants:
         k, w = statistics.median(kern[v]), statistics.median(wall[v])
         print(json.dumps({"config": args.config, "variant": v, "kernel": names[v], "pass_ms_median": round(k, 4), "pass_ms_min": round(min(kern[v]), 4),
                           "pass_ms_max": round(max(kern[v]), 4), "iter_ms_median": round(w, 4), "TBps_of_bytes_read": round(m * n * es / k / 1e9, 3),
-                          "vs_first": round(k / base, 4), "rounds": args.rounds, "steps": args.steps}), flush=True)
+                          "vs_first": round(k / base, 4), "rounds": args.rounds, "steps": args.steps,
+                          "last_solver": {"iterations": finals[v][0], "objective": finals[v][1], "finite": finals[v][2]}}), flush=True)
 
 
 if __name__ == "__main__":

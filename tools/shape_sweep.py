@@ -14,14 +14,18 @@ dtype = np.float32 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else np.float
 kind = sys.argv[2] if len(sys.argv) > 2 else "ls"
 gb = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0
 two_pass = len(sys.argv) > 4 and sys.argv[4] == "two"
-only = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else None
+only = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+mask = int(sys.argv[6]) if len(sys.argv) > 6 else None       # APX_OPT_MULTI_ROWS_MASK (A/B: 7 = Float32 on the first-generation shapes)
 es = np.dtype(dtype).itemsize
-NS = [600, 1000, 1500, 2000, 2048, 2100, 2600, 3072, 3100, 3600, 4096, 4200, 5000, 5120, 5200, 6000, 6144, 6200, 7000, 7680, 7700,
+NS = [130, 200, 300, 450, 600, 1000, 1500, 2000, 2048, 2100, 2600, 3072, 3100, 3600, 4096, 4200, 5000, 5120, 5200, 6000, 6144, 6200, 7000, 7680, 7700,
       8500, 9216, 9300, 10000, 10752, 10800, 11264, 11300, 12000, 14000, 16000, 20000, 24000, 28160, 28200, 33000, 40000, 50000,
       56320, 56400, 70000, 85000, 100000, 112640, 113000, 130000]
 ctx = apx.Context(0)
 if two_pass:
     ctx.fused_small(False)
+if mask is not None:
+    from importlib import import_module
+    ctx.set_option(import_module("adaptive-proximal-algorithms_amd._lib").APX_OPT_MULTI_ROWS_MASK, mask)
 if only:
     NS = only
 rng = np.random.default_rng(0)
