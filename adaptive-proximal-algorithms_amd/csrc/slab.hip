@@ -49,16 +49,22 @@ struct SlabDev {
   double* fsc_out;        // row-sharded f: the closing kernel leaves the two LOCAL loss sums here (they are all-reduced with the
 };                        // gradient, then k_f_final closes f) ; NULL: it closes f itself
 
-// The end of a proximal-gradient iteration riding in the closing kernel (no linear operator, no row shard): the primal
-// residual and the step-size reductions (src/AdaProx.jl:338, :260-261 — k_reduce_n) over the 64 columns whose gradient a
-// block has just formed, and — by the block that arrives LAST — their totals, the rule and the end of the iteration
-// (:340-342, :348-354 — k_rule).  Two kernels between consecutive passes over A (this one and k_step) instead of four.
-// The sums are formed in exactly the order of k_reduce_n + k_rule (a block's 64 columns are one wave of k_reduce_n's
-// 256-element block: wave partials here, the same two-level tree there), so the iterates are bit-identical to the
-// separate kernels (tests/test_gpu_slab.py::test_fused_tail_is_bit_identical).
+// The end of a proximal-gradient iteration in TWO kernels behind the pass over A instead of four (no linear operator, no row
+// shard).  The closing kernel, which has just formed the gradient of its 64 columns, also forms k_reduce_n's terms of those 64
+// entries — the primal residual and the step-size sums, src/AdaProx.jl:338, :260-261 — and leaves them as wave partials, and
+// block 0 leaves a SNAPSHOT of the control block behind f's value.  The step kernel (csrc/vecops.hip k_step_rule) then adds the
+// partials up in EVERY block — the same totals everywhere, no grid-wide synchronisation — runs the rule and the end of the
+// iteration (:340-342, :348-354) on a private copy of the snapshot, and takes the step with the new gamma ; block 0 writes the
+// control block back.  Nobody reads the control block while it is written: the blocks work from the snapshot.
+// The sums are formed in exactly the order of k_reduce_n + k_rule (a closing block's 64 columns are one wave of k_reduce_n's
+// 256-entry block: wave partials here, the same two-level tree there), so the iterates are bit-identical to the separate kernels
+// (tests/test_gpu_slab.py::test_fused_tail_is_bit_identical).
+// (Round 3's first form let the LAST-ARRIVING closing block run the rule behind a fence and an arrival counter: one kernel fewer
+// still, and slower than the four it replaced — the 1563 device-scope fences of C2's closing grid, an L2 write-back each, took
+// the kernel from 7.4 to 53 us ; profiles/r03_tail_fence.md.)
 struct SlabTail : SlabTailReq {          // (the solver's n-vectors, g, the record sink: solver_internal.h)
   double* wred;                          // [5][ldw] wave partials (entries beyond the last wave stay zero)
-  unsigned* arrive;                      // blocks that have stored theirs (reset by the last one)
+  Ctrl* snap;                            // the control block as the closing kernel left it (f_x final, the rule not yet run)
   int32_t ldw, enabled;
 };
 
@@ -441,8 +447,6 @@ __global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B
   constexpr int S = kSlabCloseBlock / kSlabCloseCols;
   __shared__ double fs[2];
   __shared__ double sub[S][kSlabCloseCols];
-  __shared__ double tsh[kBlock / 64][5];
-  __shared__ unsigned last_s;
   if (d.c->done != 0) return;
   const int tid = threadIdx.x;
   const int c = tid % kSlabCloseCols, sl = tid / kSlabCloseCols;
@@ -516,43 +520,11 @@ __global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B
         if (tid == 0) tl.wred[(int64_t)k * tl.ldw + blockIdx.x] = w;
       }
     }
-    // ---- the block that arrives last closes the iteration ----------------------------------------------------------------
-    if (tid == 0) {
-      __threadfence();                                                       // (this block's partials before its arrival)
-      last_s = atomicAdd(tl.arrive, 1u);
+    // ---- f's value, and the control block as the step kernel's blocks will read it ------------------------------------------
+    if (blockIdx.x == 0 && tid == 0) {
+      f_finalize(d.c, FK, fs);
+      *tl.snap = *d.c;
     }
-    __syncthreads();
-    if (last_s != gridDim.x - 1) return;
-    __threadfence();                                                         // (the others' partials after theirs)
-    if (tid == 0) *tl.arrive = 0u;                                           // (everybody has arrived: the next launch starts at 0)
-    // k_rule's totals: blocks of four waves ((W0 + W1) + W2) + W3 — block_partials_store —, thread t the blocks t, t + 256,
-    // ..., wave sums, the four waves in order — reduce_partials
-    const int nblk = (d.n + kBlock - 1) / kBlock;
-    double tot[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (tid < kBlock) {
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const double* __restrict__ w = tl.wred + (int64_t)k * tl.ldw;
-        double s = 0.0;
-        for (int b = tid; b < nblk; b += kBlock) s += ((w[4 * b] + w[4 * b + 1]) + w[4 * b + 2]) + w[4 * b + 3];
-        s = wave_sum(s);
-        if ((tid & 63) == 0) tsh[tid >> 6][k] = s;
-      }
-    }
-    __syncthreads();
-    if (tid != 0) return;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) tot[k] = ((tsh[0][k] + tsh[1][k]) + tsh[2][k]) + tsh[3][k];
-    Ctrl* cc = d.c;
-    f_finalize(cc, FK, fs);
-    cc->it += 1;
-    const double npr = sqrt(tot[0]);
-    cc->npr2 = npr * npr;
-    cc->g_x = gval_final(tl.g, tot[4]);
-    rule_update(cc, tot[1], tot[2], tot[3]);
-    cc->ndr2 = 0.0;
-    cc->h_Ax = 0.0;
-    finish_iteration(cc, tl.recs, tl.rec_cap);
   }
 }
 
@@ -705,9 +677,9 @@ static int32_t slab_setup(apx_problem* p) {
   st->pipe = rpb / rows_per_step >= 16;
   st->dev = d;
   // the fused end of the iteration (SlabTail): five rows of wave partials (one per closing block, the entries beyond the last
-  // wave of k_reduce_n's last block stay zero) and the arrival counter
+  // wave of k_reduce_n's last block stay zero) and the snapshot of the control block
   const int64_t ldw = round_up(4 * ((p->n + kBlock - 1) / kBlock), 64) + 64;
-  APX_TRY(st->tail_buf.alloc_zero((size_t)(5 * ldw) * sizeof(double) + 64, ctx->stream));
+  APX_TRY(st->tail_buf.alloc_zero((size_t)(5 * ldw) * sizeof(double) + sizeof(Ctrl) + 64, ctx->stream));
   p->slab = st.release();
   return APX_OK;
 }
@@ -861,11 +833,15 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   // enqueue_iteration ; not for a row shard: the all-reduce of the gradient sits between the two)
   SlabTail tl{};
   if (p->tail_req != nullptr && !p->f_sharded && ctx->fused_tail && p->n <= (int64_t)kMaxRedBlocks * kBlock) {
-    static_cast<SlabTailReq&>(tl) = *(const SlabTailReq*)p->tail_req;
+    static_cast<SlabTailReq&>(tl) = *p->tail_req;
     tl.ldw = (int32_t)(round_up(4 * ((p->n + kBlock - 1) / kBlock), 64) + 64);
     tl.wred = (double*)st->tail_buf.p;
-    tl.arrive = (unsigned*)((char*)st->tail_buf.p + (size_t)5 * tl.ldw * sizeof(double));
+    tl.snap = (Ctrl*)((char*)st->tail_buf.p + (size_t)5 * tl.ldw * sizeof(double));
     tl.enabled = 1;
+    SlabTailReq* rq = (SlabTailReq*)p->tail_req;      // (what the step kernel needs of it)
+    rq->wred = tl.wred;
+    rq->ldw = tl.ldw;
+    rq->snap = tl.snap;
     p->tail_done = true;
   }
   const bool ls = p->f_kind == APX_F_LEAST_SQUARES;

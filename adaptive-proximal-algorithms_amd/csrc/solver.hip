@@ -162,8 +162,7 @@ int32_t pullback_f(apx_problem* p) {
   apx_ctx* ctx = p->ctx;
   APX_REQUIRE(p->have_eval, "pullback before eval_with_pullback");
   switch (p->f_kind) {
-    case APX_F_ZERO:
-      APX_HIP(hipMemsetAsync(p->grad.p, 0, (size_t)p->n_pad * p->es(), ctx->stream));
+    case APX_F_ZERO:      // `pb() = zero(x)`: the buffer was allocated zeroed and nothing of an f = Zero problem ever writes it
       break;
     case APX_F_LEAST_SQUARES:
     case APX_F_LOGISTIC: {
@@ -566,7 +565,7 @@ static int32_t enqueue_iteration(apx_solver* s) {
   }
   // (no linear operator: where f and its gradient come from one pass over A, the closing kernel of that pass may take the
   //  residual / step-size reductions and the rule along — csrc/slab.hip SlabTail ; it says so in tail_done)
-  SlabTailReq tail{s->x.p, s->xprev.p, s->gprev.p, s->v.p, p->gd, (apx_record*)s->recs.p, s->rec_cap};
+  SlabTailReq tail{s->x.p, s->xprev.p, s->gprev.p, s->v.p, p->gd, (apx_record*)s->recs.p, s->rec_cap, nullptr, nullptr, 0};
   p->tail_req = lin ? nullptr : &tail;
   p->tail_done = false;
   const int32_t rc_f = eval_f(p, s->x.p, false);                               // :336 (one pass over A where csrc/slab.hip applies)
@@ -593,6 +592,9 @@ static int32_t enqueue_iteration(apx_solver* s) {
     APX_TRY(launch_gemv_t(ctx, p->A_lin, s->y.p, s->aty.p, p->done_ptr()));    // :358
     if (p->lin_sharded) APX_TRY(do_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));   // A'y = sum_k A_k' y_k
   }
+  if (p->tail_done)      // (the totals of the closing kernel's partials, the rule, the end of the iteration and the step: one kernel)
+    return vo_step_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, p->n, p->gd, p->ctrl(), tail.snap, tail.wred,
+                        tail.ldw, (apx_record*)s->recs.p, s->rec_cap);       // :338-342, :348-361
   APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
                   p->gd, p->ctrl()));                                          // :359-361
   return APX_OK;

@@ -17,6 +17,11 @@ struct SlabTailReq {
   ProxDev g;
   apx_record* recs;
   int64_t rec_cap;
+  // filled in by the evaluation that took the request: where the closing kernel left the wave partials of the reductions and
+  // the snapshot of the control block — the step kernel's inputs (csrc/vecops.hip k_step_rule)
+  const double* wred = nullptr;
+  const Ctrl* snap = nullptr;
+  int32_t ldw = 0;
 };
 }
 
@@ -53,7 +58,7 @@ struct apx_problem {
   bool teams_dead() const { return teams_off || team_failed; }     // (no team launch on this problem any more)
   // the end of a proximal-gradient iteration riding in the closing kernel of the one-pass launch (csrc/slab.hip SlabTail): the
   // generic loop asks for it around its eval_f ; tail_done: that evaluation took it — k_reduce_n / k_rule are not launched
-  const void* tail_req = nullptr;
+  apx::SlabTailReq* tail_req = nullptr;
   bool tail_done = false;
   ~apx_problem() { apx::slab_destroy(slab); }
 

@@ -23,6 +23,9 @@ int32_t vo_dual_sharded(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, vo
                         const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap,
                         const std::function<int32_t(double*, int64_t)>& reduce);
 // K5+K6
+// the totals of the one-pass closing kernel's partials + the rule + the end of the iteration + the step (csrc/slab.hip SlabTail)
+int32_t vo_step_rule(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v, int64_t n,
+                     const ProxDev& g, Ctrl* c, const Ctrl* snap, const double* wred, int32_t ldw, apx_record* recs, int64_t rec_cap);
 int32_t vo_step(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v,
                 const void* aty, int64_t n, const ProxDev& g, const Ctrl* c);
 // K10: out3 (device) = { <grad, z-x>, sum (z-x)^2, raw g(z) accumulator }

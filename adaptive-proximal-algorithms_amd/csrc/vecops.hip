@@ -221,6 +221,60 @@ __global__ __launch_bounds__(kBlock) void k_step(T* __restrict__ x, T* __restric
   }
 }
 
+// K5 + K6 behind the one-pass kernels (csrc/slab.hip SlabTail): the totals of the closing kernel's wave partials — in k_rule's
+// order, by EVERY block: the same bits everywhere, no grid-wide synchronisation —, the rule and the end of the iteration
+// (:340-342, :348-354) on a private copy of the control block's snapshot, then the step (:359-361) with the new gamma.  Block 0
+// writes the control block back ; nobody reads it here except for `done`, which only ever goes from 0 to 1 with the same
+// outcome (no step) for a block that sees it early.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_step_rule(T* __restrict__ x, T* __restrict__ xprev, const T* __restrict__ grad,
+                                                      T* __restrict__ gprev, T* __restrict__ v, int64_t n, ProxDev g, Ctrl* c,
+                                                      const Ctrl* __restrict__ snap, const double* __restrict__ wred, int ldw,
+                                                      apx_record* recs, int64_t rec_cap) {
+  __shared__ Ctrl lc;
+  __shared__ double tsh[kBlock / 64][5];
+  if (c->done != 0) return;
+  const int tid = threadIdx.x;
+  const int nblk = (int)((n + kBlock - 1) / kBlock);
+  // blocks of four waves ((W0 + W1) + W2) + W3 — block_partials_store —, thread t the blocks t, t + 256, ..., wave sums, the
+  // four waves in order — reduce_partials
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double* __restrict__ w = wred + (int64_t)k * ldw;
+    double s = 0.0;
+    for (int b = tid; b < nblk; b += kBlock) s += ((w[4 * b] + w[4 * b + 1]) + w[4 * b + 2]) + w[4 * b + 3];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) tsh[tid >> 6][k] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) tot[k] = ((tsh[0][k] + tsh[1][k]) + tsh[2][k]) + tsh[3][k];
+    lc = *snap;
+    lc.it += 1;
+    const double npr = sqrt(tot[0]);
+    lc.npr2 = npr * npr;
+    lc.g_x = gval_final(g, tot[4]);
+    rule_update(&lc, tot[1], tot[2], tot[3]);
+    lc.ndr2 = 0.0;
+    lc.h_Ax = 0.0;
+    finish_iteration(&lc, blockIdx.x == 0 ? recs : nullptr, rec_cap);
+    if (blockIdx.x == 0) *c = lc;
+  }
+  __syncthreads();
+  if (lc.done != 0) return;                        // (the test passed: x stays the tested iterate)
+  const double gamma = lc.gamma;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + tid; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xi = (double)x[i], gi = (double)grad[i];
+    const T vi = (T)(xi - gamma * gi);
+    v[i] = vi;
+    xprev[i] = (T)xi;
+    gprev[i] = (T)gi;
+    x[i] = (T)prox_elem<T>(g, (double)vi, gamma, i, 0.0);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // K10: backtracking trial  z = prox_{gamma g}(x - gamma*grad) ; <grad, z-x> ; ||z-x||^2 ; g(z)
 // (src/AdaProx.jl:35-36, :26)
@@ -571,6 +625,18 @@ int32_t vo_step(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* g
                                 (const double*)grad, (double*)gprev, (double*)v, (const double*)aty, n, g, c),
              hipLaunchKernelGGL(k_step<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)x, (float*)xprev,
                                 (const float*)grad, (float*)gprev, (float*)v, (const float*)aty, n, g, c));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_step_rule(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v, int64_t n,
+                     const ProxDev& g, Ctrl* c, const Ctrl* snap, const double* wred, int32_t ldw, apx_record* recs, int64_t rec_cap) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_step_rule<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)x, (double*)xprev,
+                                (const double*)grad, (double*)gprev, (double*)v, n, g, c, snap, wred, (int)ldw, recs, rec_cap),
+             hipLaunchKernelGGL(k_step_rule<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)x, (float*)xprev,
+                                (const float*)grad, (float*)gprev, (float*)v, n, g, c, snap, wred, (int)ldw, recs, rec_cap));
   APX_HIP(hipGetLastError());
   return APX_OK;
 }

@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 legs of the N = 1 run")
     ap.add_argument("--two-pass", action="store_true", help="NOT the default product path: the two GEMV passes of round 1 (apx_ctx_one_pass(ctx, 0))")
     ap.add_argument("--gemv-t-variant", type=int, default=-1, help="tile shape of the column-streaming kernel of the two-pass iteration (tools/bench_variants.sh)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="NOT the default product path: a context option by name (include/adaprox_hip.h APX_OPT_*, e.g. FUSED_TAIL=0) — A/B runs ; flagged in the JSON line")
     return ap.parse_args()
 
 
@@ -419,6 +421,9 @@ def main():
             ctx.one_pass(0)
         if args.gemv_t_variant >= 0:
             ctx.set_gemv_config(t_variant=args.gemv_t_variant)
+        for kv in args.option:
+            key, val = kv.split("=")
+            ctx.set_option(getattr(import_module("adaptive-proximal-algorithms_amd._lib"), "APX_OPT_" + key), int(val))
         g = apx.NormL1(prob.lam)
 
         def make_solver():
@@ -571,6 +576,8 @@ def main():
                          if transport == "gloo-fallback" else
                          "all-reduce callback of the test transport (not RCCL inside the library)")}
             out["rccl_ranks"] = rccl_ranks
+        if args.option or args.two_pass or args.gemv_t_variant >= 0:
+            out["non_default_options"] = {"option": args.option, "two_pass": args.two_pass, "gemv_t_variant": args.gemv_t_variant}
         if args.exploit_sparsity:
             out["note"] = ("x-sparsity exploited (A*x skips columns with x_j == 0; nnz(x) = %d of %d at the end): this "
                            "is NOT the BASELINE dense metric; roofline figures assume the dense byte count"

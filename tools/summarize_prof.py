@@ -46,6 +46,35 @@ def main():
                  "median_us": v_sorted[len(v) // 2] / 1e3, "min_us": v_sorted[0] / 1e3, "max_us": v_sorted[-1] / 1e3,
                  "pct": 100.0 * sum(v) / total}
     summary["kernel_trace"] = kt
+    # ---- what lies between two consecutive passes over A: from the end of a row kernel to the start of the next launch of the
+    # same kernel (the closing kernel, the reductions, the rule, the step, the launch gaps) — pauses of more than 1 ms (set-up
+    # between legs, host read-backs) are not iterations and are left out
+    ROWK = ("k_team_rows", "k_team_rows (primal-dual)", "k_multi_rows", "k_slab_rows", "k_slab2_rows", "k_slabpd_rows")
+    ev = []
+    for f in find(os.path.join(prof, "trace"), "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    ev.sort()
+    gaps, between = defaultdict(list), defaultdict(lambda: defaultdict(list))
+    last = {}
+    for i, (t0, t1, name) in enumerate(ev):
+        k = short(name)
+        if k not in ROWK:
+            continue
+        if name in last:
+            j, e_prev = last[name]
+            g = t0 - e_prev
+            if 0 <= g < 1_000_000:
+                gaps[name].append(g)
+                for (a0, a1, an) in ev[j + 1:i]:
+                    between[name][short(an)].append(a1 - a0)
+        last[name] = (i, t1)
+    gp = {}
+    for name, v in gaps.items():
+        v.sort()
+        gp[name] = {"launches": len(v) + 1, "median_gap_us": v[len(v) // 2] / 1e3, "mean_gap_us": sum(v) / len(v) / 1e3,
+                    "kernels_in_the_gap_avg_us": {k: sum(d) / len(d) / 1e3 for k, d in between[name].items()}}
+    summary["between_consecutive_row_kernels"] = gp
     # ---- PMC passes
     pmc = defaultdict(lambda: defaultdict(list))
     for sub in ("pmc_fetch", "pmc_write"):
@@ -78,6 +107,10 @@ def main():
             fh.write(f"| {k} | {e.get('FETCH_SIZE_KiB_median', float('nan')):.0f} | "
                      f"{e.get('fetch_bytes_corrected', float('nan')):.4g} | "
                      f"{e.get('WRITE_SIZE_KiB_median', float('nan')):.0f} | {e['hbm_bytes_per_launch']:.4g} |\n")
+        fh.write("\n| row kernel | launches | median time to the NEXT launch of it (us) | kernels in between, average us |\n|---|---|---|---|\n")
+        for name, e in gp.items():
+            fh.write(f"| {name[:150]} | {e['launches']} | {e['median_gap_us']:.1f} | " +
+                     ", ".join(f"{k} {u:.1f}" for k, u in e["kernels_in_the_gap_avg_us"].items()) + " |\n")
     # what bench.py reads for roofline.traffic
     # with the dual layout (bench default) A*x runs the column-streaming kernel on the transposed copy,
     # so both passes appear as gemv_t_kernel in the trace
