@@ -101,6 +101,7 @@ struct apx_ctx {
   int multi_mask = 15;           // APX_OPT_MULTI_ROWS_MASK
   int multi_waves = 0;           // APX_OPT_MULTI_WAVES
   int team_members = 0;          // APX_OPT_TEAM_MEMBERS
+  int row_deal = -1;             // APX_OPT_ROW_DEAL: -1 chunks by the row length, 0 slabs of consecutive rows, R chunks of R rows
   int team_slots = 0;            // APX_OPT_TEAM_SLOTS
   int slab_generation = 0;       // APX_OPT_SLAB_GENERATION
   int team_wait_ms = 1000;       // APX_OPT_TEAM_WAIT_MS

@@ -340,6 +340,11 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       APX_REQUIRE(value == 0 || value == 2 || value == 4 || value == 8 || value == 16, "APX_OPT_TEAM_MEMBERS: 0 (by the row length), 2, 4, 8 or 16");
       ctx->team_members = (int)value;
       return APX_OK;
+    case APX_OPT_ROW_DEAL:
+      APX_REQUIRE(value >= -1 && value <= 1024 && (value <= 0 || (value & (value - 1)) == 0),
+                  "APX_OPT_ROW_DEAL: -1 (chunks by the row length), 0 (slabs of consecutive rows) or a power of two (rows per chunk of the cyclic deal)");
+      ctx->row_deal = (int)value;
+      return APX_OK;
     case APX_OPT_TEAM_SLOTS:
       APX_REQUIRE(value == 0 || value == 52 || value == 62 || value == 53 || value == 63, "APX_OPT_TEAM_SLOTS: 0, 52, 62, 53 or 63");
       ctx->team_slots = (int)value;
@@ -365,6 +370,7 @@ int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
     case APX_OPT_MULTI_WAVES: *value = ctx->multi_waves; return APX_OK;
     case APX_OPT_TEAM_MEMBERS: *value = ctx->team_members; return APX_OK;
     case APX_OPT_TEAM_SLOTS: *value = ctx->team_slots; return APX_OK;
+    case APX_OPT_ROW_DEAL: *value = ctx->row_deal; return APX_OK;
     default:
       return fail(APX_ERR_INVALID, "apx_ctx_get_option: unknown key");
   }

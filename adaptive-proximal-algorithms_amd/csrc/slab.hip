@@ -42,6 +42,7 @@ struct SlabDev {
   const void* AT;         // A' column-major: row i of A at AT + i * ldT, contiguous
   int64_t ldT;
   int32_t m, ncols, n, rows_per_block;
+  int32_t deal_stride, deal_log;      // how the rows are dealt to the blocks: csrc/team_dev.h deal_rows / deal_row (stride 1: slabs)
   const void* b;
   double* part;           // [blocks][ldpart]: ncols column partials, then the loss sum(s)
   int64_t ldpart;
@@ -95,14 +96,15 @@ __device__ __forceinline__ void slab_load(T (&a)[H][C], T& b_in, const SlabDev& 
   const T* __restrict__ bv = (const T*)d.b;
 #pragma unroll
   for (int r = 0; r < H; ++r) {
-    const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, row_end - 1));   // (uniform: keep it scalar)
+    // (r0, row_end: the block's OWN row numbers — deal_row gives the matrix row, clamped into the block's rows ; uniform: scalar)
+    const int ri = __builtin_amdgcn_readfirstlane(deal_row(r0 + r, row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log));
     const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
     for (int k = 0; k < C; ++k)                  // scalar row base + 32-bit BYTE offset: one address register per load
       a[r][k] = NT ? __builtin_nontemporal_load((const T*)((const char*)row + off[k]))   // (read once: past the caches,
                    : *(const T*)((const char*)row + off[k]);                             //  unless A fits the Infinity Cache)
   }
-  b_in = bv[min(r0 + min(tid, H - 1), row_end - 1)];      // (goes out with the loads of A ; every thread, unconverted: a
+  b_in = bv[deal_row(r0 + min(tid, H - 1), row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log)];      // (goes out with the loads of A ; every thread, unconverted: a
                                                           //  branch or a conversion here would wait for all of them)
 }
 
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(BS) void k_slab_rows(SlabDev d, const void* xv) {
   double bias = 0.0;
   if constexpr (FK == APX_F_LOGISTIC) bias = (double)X[d.n - 1];
   double e0 = 0.0, e1 = 0.0;                     // loss sums of the rows this thread finishes (tid < H)
-  const int row_begin = blockIdx.x * d.rows_per_block;
-  const int row_end = min(row_begin + d.rows_per_block, d.m);
+  const int row_begin = 0;                        // (the block's own row numbers 0 .. row_end - 1 ; slab_load maps them: deal_row)
+  const int row_end = deal_rows(d.m, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log);
   if constexpr (!PIPE) {
     for (int r0 = row_begin; r0 < row_end; r0 += R) {
       T a[H][C];
@@ -299,8 +301,8 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
   const int voff = tid * 16;                       // the one per-lane address register
   const int row_bytes = (int)(d.ldT * (int64_t)sizeof(T));
   double e0 = 0.0, e1 = 0.0;                       // loss sums of the rows this thread finishes (tid < H)
-  const int row_begin = blockIdx.x * d.rows_per_block;
-  const int row_end = min(row_begin + d.rows_per_block, d.m);
+  const int row_begin = 0;                         // (the block's own row numbers ; the loads map them: deal_row)
+  const int row_end = deal_rows(d.m, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log);
   vec_t a[G][H][KV];
   T b_in[G];
   const T* __restrict__ AT = (const T*)d.AT;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
   auto load = [&](int g, int r0) {                 // rows past the slab: its last row again (a valid address ; residual 0)
 #pragma unroll
     for (int r = 0; r < H; ++r) {
-      const int ri = __builtin_amdgcn_readfirstlane(min(r0 + r, row_end - 1));
+      const int ri = __builtin_amdgcn_readfirstlane(deal_row(r0 + r, row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log));
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, row_bytes, 0x00020000);
 #pragma unroll
       for (int k = 0; k < KV; ++k) {
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
         a[g][r][k] = __builtin_bit_cast(vec_t, raw);
       }
     }
-    b_in[g] = bv[min(r0 + min(tid, H - 1), row_end - 1)];
+    b_in[g] = bv[deal_row(r0 + min(tid, H - 1), row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log)];
   };
   auto group = [&](int g, int r0) {
     double p[H];
@@ -640,7 +642,7 @@ static int32_t slab_setup(apx_problem* p) {
                                                      : team_blocks_per_cu<APX_F_LEAST_SQUARES, SlabDev>(pl, nt_q);
       if (per_cu < 1) return APX_OK;         // (it does not fit: no state, the two passes run)
     }
-    APX_TRY(team_alloc(ctx, &st->team, (int)B, P, rpb_team));
+    APX_TRY(team_alloc(ctx, &st->team, (int)B, P, rpb_team, A->n * (int64_t)sizeof(double)));
   }
   if (st->cpt == 14) {                     // long rows: k_slab2_rows, KV 16-byte vectors per thread and row
     const int64_t vw = 16 / (int64_t)dtype_size(p->dtype);
@@ -661,6 +663,11 @@ static int32_t slab_setup(apx_problem* p) {
   d.ncols = (int32_t)A->n;
   d.n = (int32_t)p->n;
   d.rows_per_block = (int32_t)(rpb_team > 0 ? rpb_team : rpb);
+  // rows dealt in chunks, the chunks cyclically over the blocks (csrc/team_dev.h ; the team kernels carry theirs in TeamDev)
+  d.deal_stride = ctx->row_deal != 0 ? (int32_t)B : 1;
+  d.deal_log = 0;
+  if (ctx->row_deal < 0) d.deal_log = deal_chunk_log(A->n * (int64_t)dtype_size(p->dtype), d.rows_per_block);
+  for (int r = ctx->row_deal; r > 1; r >>= 1) d.deal_log += 1;
   d.b = p->b.p;
   d.ldpart = round_up(d.ncols + 2, 8);
   // (k_multi_rows on very short rows leaves multi_groups(n) partial vectors per workgroup)

@@ -23,6 +23,7 @@ struct SlabPdDev {
   const void* AT;         // A' column-major: row i of A at AT + i * ldT, contiguous
   int64_t ldT;
   int32_t m, n, rows_per_block, ncols;      // (ncols = n: the name csrc/team_rows.h reads)
+  int32_t deal_stride, deal_log;            // k_multi_rows: the rows dealt in chunks (csrc/team_dev.h) ; k_slabpd_rows keeps its slabs
   void* Y;                // y (T), updated in place
   void* AXP;              // A_x_prev (T), updated in place (:360)
   double* part;           // [blocks][ldpart]: n column partials of A' y, then sum dual_res^2, raw h(A_x)
@@ -315,7 +316,7 @@ int32_t slab_pd_setup(apx_solver* s) {
     B = ctx->num_cu / pl.P;
     rpb = (A->m + B - 1) / B;
     if (pl.P > 1 && team_blocks_per_cu<kTeamFkPd, SlabPdDev>(pl, true) < 1) return APX_OK;      // (it does not fit a CU: the generic kernels)
-    APX_TRY(team_alloc(ctx, &st->team, (int)B, pl.P, rpb));
+    APX_TRY(team_alloc(ctx, &st->team, (int)B, pl.P, rpb, A->n * (int64_t)sizeof(double)));
   }
   st->B = (int)B;
   SlabPdDev d{};
@@ -325,6 +326,13 @@ int32_t slab_pd_setup(apx_solver* s) {
   d.n = (int32_t)p->n;
   d.ncols = d.n;
   d.rows_per_block = (int32_t)rpb;
+  d.deal_stride = 1;
+  d.deal_log = 0;
+  if (st->cpt == 27 && ctx->row_deal != 0) {      // (k_multi_rows ; the team kernels carry their deal in TeamDev)
+    d.deal_stride = (int32_t)B;
+    if (ctx->row_deal < 0) d.deal_log = deal_chunk_log(A->n * (int64_t)dtype_size(p->dtype), rpb);
+    for (int r = ctx->row_deal; r > 1; r >>= 1) d.deal_log += 1;
+  }
   d.Y = s->y.p;
   d.AXP = s->axprev.p;
   d.ldpart = round_up(d.n + 2, 8);

@@ -47,6 +47,42 @@ struct TeamWait {
   unsigned max_polls, waits;    // waits: hand-offs that were not there at the first look
 };
 
+// How the rows of A are dealt to the workgroups (teams) of a one-pass launch.  Round 2 gave each a SLAB of consecutive rows: the
+// 256 workgroups then stream 256 places of the matrix a fixed distance apart for the whole launch, and how those fall on the HBM
+// channels depends on where the allocation landed — the same binary on the same box ran C5's kernel at 1.20 or at 1.31 ms from
+// one process to the next, C2's at 6.13 or 6.32 (profiles/r03_row_deal.md).  Dealing single rows cyclically (the chip reads one
+// window of consecutive rows) cured that and cost C2 5 %: every step of a team then starts on new pages.  CHUNKS of 2^chunk_log
+// consecutive rows dealt cyclically have both — a team stays on its pages for a chunk, the teams stay within one window of the
+// matrix: C2 6.09 ms in every process.  deal_rows / deal_row: the number of rows of a block, and the matrix row of its k-th.
+__host__ __device__ inline int deal_rows(int m, int block, int rows_per_block, int stride, int lr) {
+  if (stride == 1) {
+    const int b = block * rows_per_block;
+    const int e = b + rows_per_block < m ? b + rows_per_block : m;
+    return e > b ? e - b : 0;
+  }
+  const int R = 1 << lr, chunks = (m + R - 1) >> lr;
+  const int mine = block < chunks ? (chunks - block + stride - 1) / stride : 0;
+  if (mine <= 0) return 0;
+  const int last = (mine - 1) * stride + block;                      // its last chunk (the matrix's last one may be short)
+  const int tail = m - (last << lr);
+  return ((mine - 1) << lr) + (tail < R ? tail : R);
+}
+__host__ __device__ inline int deal_row(int k, int nrows, int block, int rows_per_block, int stride, int lr) {
+  const int kk = k < nrows ? (k > 0 ? k : 0) : (nrows > 0 ? nrows - 1 : 0);      // (clamped into the block's rows)
+  if (stride == 1) return block * rows_per_block + kk;
+  return (block << lr) + (((kk >> lr) * stride) << lr) + (kk & ((1 << lr) - 1));
+}
+// The chunk for a row length: about 4 MB of consecutive rows (a 2 MB page and some), but at least 48 chunks per block — the blocks'
+// row counts differ by up to one chunk, and that imbalance is paid in full: C3's kernel (391 rows per block) 0.580 - 0.594 ms with
+// chunks of 8 rows, 0.598 - 0.600 with slabs, 0.608 - 0.628 with chunks of 32, 0.643 - 0.657 with 64 ; C5's (391 rows per team)
+// 1.22 with 4 or 8, 1.34 with 32 on the box where slabs gave 1.28 - 1.31 ; C2's (3125 rows per team) 6.06 - 6.10 ms with 4, 8,
+// 16 or 64 against 6.13 - 6.36 for slabs and 6.53 for single rows (tools/ab.py, profiles/r03_row_deal.md).
+inline int deal_chunk_log(int64_t row_bytes, int64_t rows_per_block) {
+  int lr = 0;
+  while (((int64_t)1 << lr) * row_bytes < ((int64_t)4 << 20) && ((int64_t)1 << (lr + 1)) * 48 <= rows_per_block) lr += 1;
+  return lr;
+}
+
 struct TeamDev {
   TeamRec* ring;          // [teams][kTeamSlots][members]
   unsigned* tickets;      // [8] one counter per XCD, monotonic over the launches
@@ -57,6 +93,8 @@ struct TeamDev {
   unsigned long long wait_ticks;   // bound of a hand-off wait, wall-clock ticks of 10 ns
   unsigned launch;        // launches so far: the ticket base is launch * 32
   int32_t rows_per_team;
+  int32_t row_stride;     // 1: a team's rows are a slab of rows_per_team consecutive rows ; T (= teams): chunks dealt cyclically,
+  int32_t chunk_log;      //    2^chunk_log consecutive rows each (0: every T-th row)
   int32_t fault_grid;     // TEST hook (APX_OPT_TEAM_FAULT_GRID): launch this many workgroups instead of all 256
 };
 

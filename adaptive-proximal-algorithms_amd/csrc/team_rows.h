@@ -196,9 +196,15 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   const int nvec = (d.ncols + 1) / 2;
   const int nvs = (nvec + P - 1) / P;              // 16-byte vectors per member
   const int v0 = s * nvs;
-  const int row_begin = team * t.rows_per_team;
-  const int row_end = min(row_begin + t.rows_per_team, d.m);
-  const int nrows = max(row_end - row_begin, 0);
+  // The team's rows: a SLAB of consecutive rows (row_stride 1), or every T-th row of the matrix (the cyclic deal, row_stride = T
+  // teams): with slabs the 256 workgroups stream 256 places of the matrix a fixed 60 MB apart for the whole launch, and how those
+  // fall on the HBM channels is a matter of the allocation — the same binary on the same box ran C5 at 1.20 or at 1.28 ms from
+  // one process to the next ; dealt cyclically the chip reads ONE window of T consecutive rows at a time, spread over the channels
+  // like any contiguous stream.  rowi(k): the matrix row of the team's k-th row, clamped into its rows.
+  // In between: CHUNKS of 2^chunk_log consecutive rows dealt cyclically (consecutive rows keep a team on the same pages, the
+  // cyclic deal of the chunks keeps the chip on one window).
+  const int nrows = deal_rows(d.m, team, t.rows_per_team, t.row_stride, t.chunk_log);
+  auto rowi = [&](long long k) { return deal_row((int)max(min(k, (long long)nrows), -1LL), nrows, team, t.rows_per_team, t.row_stride, t.chunk_log); };
   // rows past the slab are dummy rows (clamped loads, residual 0) that every member runs alike: DEPTH steps of prologue,
   // then whole rounds of G steps — the loop body of the compute waves has no branch between a load and its use, so the
   // waits the compiler places are counted ones and the rows in the loading slots really stay in flight
@@ -246,10 +252,10 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     };
     for (long long seq = 0; seq < nsteps; ++seq) {
       TeamRowState snew{};
-      if constexpr (FK == kTeamFkPd) snew = team_row_state<FK>(d, max(min(row_begin + (int)seq, row_end - 1), 0));
+      if constexpr (FK == kTeamFkPd) snew = team_row_state<FK>(d, rowi(seq));
       const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
       if (r >= 0) {
-        const int i = row_begin + (int)r;
+        const int i = rowi(r);
         double ax;
         if constexpr (P == 1) {
           // a workgroup on its own: the sum of its eleven waves IS `A x` of the row — formed after the barrier of step
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         }
         // the residual / the logistic link / the dual step, ONCE per row, where no row of A is held (exp and log in Float64
         // take ~50 registers: next to the rows they cost the row kernels two of their three rows in flight)
-        const double res = i < row_end ? team_row_finish<FK>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
+        const double res = r < nrows ? team_row_finish<FK>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
         if (lane == 0) res_s[r & 3] = res;
       }
       __syncthreads();                             // the barrier of step seq
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         // cost C2 3 % of its iterations, measured three times over against the build before: the wait for it, which the
         // in-order return per wave extends to the acknowledgement of the stores in front of it, then falls between a
         // step's records and its barrier.)
-        if (r + 1 >= 0) h[0] = team_row_state<FK>(d, max(min(row_begin + (int)(r + 1), row_end - 1), 0));
+        if (r + 1 >= 0) h[0] = team_row_state<FK>(d, rowi(r + 1));
       }
       if constexpr (P > 1) {
         if (r + 1 >= 0) fetch(r + 1);
@@ -389,12 +395,12 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * 8 - cbase));      // (rows are zero-padded to whole vectors)
   const double* __restrict__ AT = (const double*)d.AT;
   vec_t a[G][KV];
-  auto load = [&](int g, int row) {
-    const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
+  auto load = [&](int g, long long k) {            // (k: the team's k-th row)
+    const int ri = __builtin_amdgcn_readfirstlane(rowi(k));
     // (a dummy row past the slab — the steps that fill the last round — gets a descriptor of ZERO bytes: every lane is out of
     //  range and reads 0 without a memory request ; clamped to the slab's last row these steps re-read it from HBM, the loads
     //  being non-temporal: 3 of C3's 199 steps)
-    const int nb = __builtin_amdgcn_readfirstlane(row < row_end ? slice_bytes : 0);
+    const int nb = __builtin_amdgcn_readfirstlane(k < nrows ? slice_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, nb, 0x00020000);
 #pragma unroll
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int g = 0; g < G - 1; ++g) {
-    load(g, row_begin + g);
+    load(g, g);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   for (int u = 0; u < DEPTH; ++u) {
     dots(u, u);
     __builtin_amdgcn_sched_barrier(0);
-    if (u == DEPTH - 1) load(G - 1, row_begin + G - 1);
+    if (u == DEPTH - 1) load(G - 1, G - 1);
     __builtin_amdgcn_sched_barrier(0);
   }
   // step seq >= DEPTH: the dots of row seq (slot seq % G) ; the barrier ; row seq - DEPTH (slot (seq - DEPTH) % G)
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 #pragma unroll
         for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
       __builtin_amdgcn_sched_barrier(0);
-      load(u, row_begin + (int)(r + G));
+      load(u, r + G);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -517,9 +523,9 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (d.c->done != 0) return;                      // (written by an earlier launch: uniform over the grid)
-  const int row_begin = (int)blockIdx.x * d.rows_per_block;
-  const int row_end = min(row_begin + d.rows_per_block, d.m);
-  const int nrows = max(row_end - row_begin, 0);
+  // (the block's rows: dealt in chunks, csrc/team_dev.h ; k = its own row number, rowi(k) the matrix row, clamped into its rows)
+  const int nrows = deal_rows(d.m, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log);
+  auto rowi = [&](int k) { return deal_row(k, nrows, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log); };
   const int nsteps = 1 + ((nrows + RS - 1) / RS + G - 1) / G * G;    // one step of prologue, then whole rounds of G steps
   if (wv == CW) {
     // ---- the row wave: lane L < RS is row L of a step (group L / H, its row L % H) ---------------------------------------
@@ -530,13 +536,12 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
     for (int step = 0; step < nsteps; ++step) {
       // (the state of THIS step's rows, taken before the barrier behind which their dots complete ; the same wave writes
       //  y+ and A_x a step later: no other reader)
-      const int inew = row_begin + step * RS + ll;
-      const TeamRowState snew = team_row_state<FK, DEV, T>(d, max(min(inew, row_end - 1), 0));
+      const TeamRowState snew = team_row_state<FK, DEV, T>(d, rowi(step * RS + ll));
       const int r = step - 1;
       if (r >= 0) {
-        const int i = row_begin + r * RS + ll;
+        const int k = r * RS + ll;
         double res = 0.0;
-        if (lane < RS && i < row_end) res = team_row_finish<FK, DEV, T>(d, kc, st_prev, own_prev, i, true, e0, e1);
+        if (lane < RS && k < nrows) res = team_row_finish<FK, DEV, T>(d, kc, st_prev, own_prev, rowi(k), true, e0, e1);
         if (lane < RS) res_s[r & 3][lane] = res;
       }
       __syncthreads();                             // the barrier of the step
@@ -582,9 +587,9 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
   auto load = [&](int g, int step) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      const int row = row_begin + step * RS + (idle ? 0 : grp) * H + h;
-      const int ri = __builtin_amdgcn_readfirstlane(max(min(row, row_end - 1), 0));
-      const int nb = __builtin_amdgcn_readfirstlane(row < row_end ? row_bytes : 0);      // (a dummy row: zero bytes, no memory request — see k_team_rows)
+      const int k = step * RS + (idle ? 0 : grp) * H + h;
+      const int ri = __builtin_amdgcn_readfirstlane(rowi(k));
+      const int nb = __builtin_amdgcn_readfirstlane(k < nrows ? row_bytes : 0);          // (a dummy row: zero bytes, no memory request — see k_team_rows)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, nb, 0x00020000);
 #pragma unroll
       for (int k = 0; k < KV; ++k) {
@@ -946,7 +951,7 @@ inline bool team_launch(const TeamPlan& pl, int nteams, bool nt, bool cooperativ
   call.cooperative = cooperative;
   const bool ok = team_dispatch<FK, DEV>(call, pl, nteams, nt, d, t, x, q) && call.launch_error == hipSuccess;
   t.launch += 1;
-  t.seq0 += (unsigned long long)t.rows_per_team + 16;
+  t.seq0 += (unsigned long long)t.rows_per_team + (1u << t.chunk_log) + 16;      // (> the steps of a launch: the sequence words never repeat)
   return ok;
 }
 // workgroups of this plan's kernel that fit one CU at once (0: the runtime could not say, or none)
@@ -967,7 +972,7 @@ struct TeamHost {
   struct Pinned { int32_t err; int32_t _pad; TeamDiag diag; TeamWait wait[256]; }* pinned = nullptr;
   ~TeamHost() { if (pinned) (void)hipHostFree(pinned); }
 };
-inline int32_t team_alloc(apx_ctx* ctx, TeamHost* th, int nteams, int P, int64_t rows_per_team) {
+inline int32_t team_alloc(apx_ctx* ctx, TeamHost* th, int nteams, int P, int64_t rows_per_team, int64_t row_bytes) {
   const size_t ring_bytes = (size_t)nteams * kTeamSlots * P * sizeof(TeamRec);
   const size_t off_tickets = ring_bytes, off_err = off_tickets + 32, off_diag = off_err + 32;
   const size_t off_wait = off_diag + (sizeof(TeamDiag) + 63) / 64 * 64;
@@ -981,6 +986,11 @@ inline int32_t team_alloc(apx_ctx* ctx, TeamHost* th, int nteams, int P, int64_t
   th->dev.seq0 = 0;
   th->dev.launch = 0;
   th->dev.rows_per_team = (int32_t)rows_per_team;
+  // APX_OPT_ROW_DEAL: -1 = chunks by the row length (default) ; 0 = slabs ; R = 1, 2, 4, ... = chunks of R consecutive rows
+  th->dev.row_stride = ctx->row_deal != 0 ? nteams : 1;
+  th->dev.chunk_log = 0;
+  if (ctx->row_deal < 0) th->dev.chunk_log = deal_chunk_log(row_bytes, rows_per_team);
+  for (int r = ctx->row_deal; r > 1; r >>= 1) th->dev.chunk_log += 1;
   th->dev.wait_ticks = (unsigned long long)ctx->team_wait_ms * 100000ull;      // (s_memrealtime: 100 MHz)
   th->dev.fault_grid = ctx->team_fault_grid;
   APX_HIP(hipHostMalloc((void**)&th->pinned, sizeof(TeamHost::Pinned), hipHostMallocDefault));

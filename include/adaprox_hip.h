@@ -289,8 +289,12 @@ enum {
   APX_OPT_MULTI_WAVES = 11,      /* default 0 = by fit ; 10 / 11: compute waves a row (k_multi_rows) or a member's slice of it
                                     (k_team_rows) is dealt to (A/B)                                                          */
   APX_OPT_TEAM_MEMBERS = 12,     /* default 0 = by the row length ; 2 / 4 / 8 / 16: workgroups per team where the row allows (A/B) */
-  APX_OPT_TEAM_SLOTS = 13        /* default 0 ; 52 / 62 / 53 / 63: row slots x 10 + rows of slack, teams of four with four vectors
+  APX_OPT_TEAM_SLOTS = 13,       /* default 0 ; 52 / 62 / 53 / 63: row slots x 10 + rows of slack, teams of four with four vectors
                                     per thread in the primal-dual loop only (C5's length as teams of four: A/B)              */
+  APX_OPT_ROW_DEAL = 14          /* default -1: the rows of A are dealt to the workgroups (teams) of a one-pass launch in CHUNKS of
+                                    consecutive rows (about 4 MB), the chunks cyclically — the chip streams one window of the
+                                    matrix at a time, whatever the allocation ; 0: one slab of consecutive rows each (round 2) ;
+                                    a power of two: that many rows per chunk (A/B: profiles/r03_row_deal.md)                */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);

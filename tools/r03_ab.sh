@@ -1,19 +1,16 @@
 #!/bin/bash
 set -o pipefail
-O=gpurun_out/r03e
+O=gpurun_out/r03l
 mkdir -p $O
-N=130,200,300,450,600,1000,1500,2000,2100,2600,3100,4096,5000,5200,6000,7000,7700,8500,9300,10000,10752,11264
-for k in ls log; do
-  for mask in 15 7; do
-    timeout -k 10 240 python tools/shape_sweep.py f32 $k 4 one $N $mask > $O/sweep_f32_${k}_mask$mask.jsonl 2>> $O/sweep.err; echo "$k $mask rc $?"
-  done
+for i in 1 2 3; do
+timeout -k 10 300 python tools/ab.py c3 base "ROW_DEAL=0" --rounds 6 --steps 30 > $O/ab_c3_$i.jsonl 2> $O/ab_c3.err; echo "c3 rc $?"
+timeout -k 10 300 python tools/ab.py c5 base "ROW_DEAL=0" --rounds 4 --steps 40 > $O/ab_c5_$i.jsonl 2> $O/ab_c5.err; echo "c5 rc $?"
 done
+timeout -k 10 300 python tools/ab.py c3f64 base "ROW_DEAL=0" --rounds 4 --steps 30 > $O/ab_c3f64.jsonl 2> $O/ab_c3f64.err; echo "c3f64 rc $?"
 python3 - <<'PY'
-import json
-O="gpurun_out/r03e"
-for k in ("ls","log"):
-    a={json.loads(l)["n"]:json.loads(l) for l in open(f"{O}/sweep_f32_{k}_mask15.jsonl") if l.startswith("{")}
-    b={json.loads(l)["n"]:json.loads(l) for l in open(f"{O}/sweep_f32_{k}_mask7.jsonl") if l.startswith("{")}
-    for n in sorted(a):
-        if n in b: print(k, n, "multi", a[n]["GBps_of_bytes_read"], a[n]["passes_per_iter"], "gen1", b[n]["GBps_of_bytes_read"], b[n]["passes_per_iter"])
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r03l/ab_*.jsonl")):
+    print(f)
+    for l in open(f):
+        d=json.loads(l); print("   ", d["variant"], d["pass_ms_median"], d["pass_ms_min"], d["pass_ms_max"], d["TBps_of_bytes_read"], d["kernel"][:40])
 PY
