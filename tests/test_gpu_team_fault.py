@@ -82,6 +82,11 @@ def test_missing_team_members_time_out_and_report():
     assert "STEPPING ERROR:" in out.stdout and "a hand-off wait expired" in out.stdout, out.stdout
     # self-describing: the team, the member, the row, the records it saw (the missing member's among them), the tickets (31 per XCD)
     msg = [l for l in out.stdout.splitlines() if l.startswith("STEPPING ERROR:")][0]
+    try:      # (kept as an example of what a failure looks like: profiles/incidents/)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "team_fault_record.txt"), "w").write(out.stdout)
+    except OSError:
+        pass
     for word in ("team ", "member ", "row ", "expected sequence word", ":none(", "Tickets per XCD: 31 31 31 31 31 31 31 31", "bound 50 ms"):
         assert word in msg, (word, msg)
     # sticky: forty launches behind the failure cost ONE bound, not forty
