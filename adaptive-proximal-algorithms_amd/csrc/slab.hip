@@ -553,7 +553,7 @@ static SlabShape slab_shape(const apx_problem* p) {
   // 8500 ... 10 752 the fourteen-column first-generation kernel is as fast (least squares) or 1 - 4 % faster (logistic ; C3
   // itself, interleaved in one process: 0.5915 against 0.5994 ms) and stays ; beyond it the one pass is new: up to 22 528
   // entries (eight vectors per thread, one row per step)
-  if (p->dtype == APX_F32 && (multi & 8) && (cols <= 8192 || (cols > 14 * 768 && cols <= 4 * 8 * 640))) return {768, kSlabMultiCpt, 1};
+  if (p->dtype == APX_F32 && (multi & 8) && (cols <= 8192 || (cols > 14 * 768 && cols <= 4 * 8 * 704))) return {768, kSlabMultiCpt, 1};
   if (cols <= 1024) return {1024, 1, kSlabRows};      // (one column per thread, 32 rows per step: with two, half the loads of such a row are clamped away)
   if (cols <= 2 * 768) return {768, 2, kSlabRows};    // (1025 ... 1536 entries: two columns of 768 threads keep more lanes busy than of 1024)
   if (cols <= 2 * 1024) return {1024, 2, kSlabRows};
@@ -574,6 +574,9 @@ static SlabShape slab_shape(const apx_problem* p) {
   // longer rows (BASELINE config C2: 100 000): teams of 2 / 4 / 8 / 16 workgroups, a slice of every row each (k_team_rows) —
   // Float64, on a part of 8 XCDs x 32 CUs
   if (p->dtype == APX_F64 && cols <= kTeamMaxCols && p->ctx->num_cu == 256 && p->ctx->teams && !p->teams_dead()) return {768, kSlabTeamCpt, 1};
+  // Float32 rows beyond one workgroup's eight vectors (22 529 ... 225 280 entries): teams too (round 3)
+  if (p->dtype == APX_F32 && cols > 4 * 8 * 704 && cols <= kTeamMaxColsF32 && p->ctx->num_cu == 256 && p->ctx->teams && !p->teams_dead() && (multi & 8))
+    return {768, kSlabTeamCpt, 1};
   return {0, 0, 0};
 }
 
@@ -626,7 +629,10 @@ static int32_t slab_setup(apx_problem* p) {
   st->B = (int)B;
   int64_t rpb_team = 0;
   if (st->cpt == kSlabTeamCpt) {           // teams: the fewest members whose slice fits 5 vectors per compute thread
-    const TeamPlan pl = team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, 0});      // (csrc/team_rows.h)
+    const bool f32 = p->dtype == APX_F32;
+    const TeamPlan pl = f32 ? team_plan(A->n, TeamTune{0, ctx->multi_waves, 0}, 4)
+                            : team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, 0});      // (csrc/team_rows.h)
+    if (pl.P == 0) return APX_OK;
     const int P = pl.P;
     st->plan = pl;
     st->team_big = pl.big;
@@ -638,11 +644,12 @@ static int32_t slab_setup(apx_problem* p) {
     if (P > 1) {
       // the scheme's precondition, as far as it can be known up front: one workgroup of THIS kernel per CU, 256 of them
       const bool nt_q = true;
-      const int per_cu = p->f_kind == APX_F_LOGISTIC ? team_blocks_per_cu<APX_F_LOGISTIC, SlabDev>(pl, nt_q)
-                                                     : team_blocks_per_cu<APX_F_LEAST_SQUARES, SlabDev>(pl, nt_q);
+      const bool lg = p->f_kind == APX_F_LOGISTIC;
+      const int per_cu = f32 ? (lg ? team_blocks_per_cu<APX_F_LOGISTIC, SlabDev, float>(pl, nt_q) : team_blocks_per_cu<APX_F_LEAST_SQUARES, SlabDev, float>(pl, nt_q))
+                             : (lg ? team_blocks_per_cu<APX_F_LOGISTIC, SlabDev>(pl, nt_q) : team_blocks_per_cu<APX_F_LEAST_SQUARES, SlabDev>(pl, nt_q));
       if (per_cu < 1) return APX_OK;         // (it does not fit: no state, the two passes run)
     }
-    APX_TRY(team_alloc(ctx, &st->team, (int)B, P, rpb_team, A->n * (int64_t)sizeof(double)));
+    APX_TRY(team_alloc(ctx, &st->team, (int)B, P, rpb_team, A->n * (int64_t)dtype_size(p->dtype)));
   }
   if (st->cpt == 14) {                     // long rows: k_slab2_rows, KV 16-byte vectors per thread and row
     const int64_t vw = 16 / (int64_t)dtype_size(p->dtype);
@@ -751,11 +758,8 @@ template <typename T, int FK>
 static bool slab_launch_t(SlabState* st, bool cooperative, const SlabDev& d, const void* x, void* grad, const SlabTail& tl, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   if (st->team_p != 0) {
-    bool ok = true;
-    if constexpr (sizeof(T) == 8) {
-      ok = team_launch<FK, SlabDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
-      slab_close_launch<T, FK>(d, st->B, grad, tl, q);
-    }
+    const bool ok = team_launch<FK, SlabDev, T>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+    slab_close_launch<T, FK>(d, st->B, grad, tl, q);
     return ok;
   }
   if (st->cpt == kSlabMultiCpt) {
@@ -784,7 +788,7 @@ static std::string slab_kernel_name(const SlabState* st, const apx_problem* p) {
   const char* fk = p->f_kind == APX_F_LOGISTIC ? "logistic" : "least_squares";
   const char* ty = p->dtype == APX_F32 ? "float" : "double";
   if (st->team_p != 0)
-    snprintf(b, sizeof b, "k_team_rows<%s, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack>", fk, st->team_p,
+    snprintf(b, sizeof b, "k_team_rows<%s%s, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack>", p->dtype == APX_F32 ? "float, " : "", fk, st->team_p,
              st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), st->plan.waves, (st->team_big || st->team_p == 1) ? 3 : 4,
              (st->team_big || st->team_p == 1) ? 1 : 2, (st->team_big || st->team_p == 1) ? "" : "s");
   else if (st->cpt == kSlabMultiCpt) {

@@ -144,17 +144,28 @@ __device__ __forceinline__ void team_fetch(const TeamRec* row, raw16_t (&q)[(P +
                  : "memory");
 }
 
+template <typename T> struct TeamVec;
+template <> struct TeamVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct TeamVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
 // CW: compute waves (11, or 10 where ten waves take no more vectors per thread than eleven: fewer idle lanes for the same
 // registers — C2's slice of 3125 vectors is 5 x 640 x 0.98 or 5 x 704 x 0.89) ; the wave behind them is the communication wave
-template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2, class DEV = SlabDev, int CW = 11>
+// T: the storage type.  Float32 (round 3: rows of 22 529 ... 225 280 entries as teams of 2 ... 16, two to five vectors per thread)
+// is k_multi_rows' Float32 arithmetic on this kernel's structure: four columns per vector, a thread's share of a dot product and
+// its products with the residual in Float32, the sums across threads, members and rows in Float64 — the hand-off carries Float64
+// partials exactly as for Float64 data.
+template <int FK, int P, int KV, bool NT, int G = 4, int DEPTH = 2, class DEV = SlabDev, int CW = 11, typename T = double>
 __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void* xv) {
   constexpr int BSC = CW * 64, TPX = 32 / P;
+  constexpr int VW = 16 / (int)sizeof(T);          // columns per 16-byte vector
+  constexpr bool kF32 = sizeof(T) == 4;
   static_assert(CW == 10 || CW == 11, "ten or eleven compute waves and the communication wave");
   static_assert(G >= DEPTH + 2 && DEPTH <= 3, "slots: DEPTH rows awaiting their residuals, one computing, one loading ; res_s has 4 entries");
   static_assert(P > 1 || DEPTH == 1, "a workgroup on its own has its row sum one step later");
-  typedef double vec_t __attribute__((ext_vector_type(2)));
+  typedef typename TeamVec<T>::type vec_t;
   typedef unsigned raw_t __attribute__((ext_vector_type(4)));
-  extern __shared__ double team_x[];               // the member's slice of x: KV * BSC * 2 doubles
+  extern __shared__ double team_x_raw[];           // the member's slice of x: KV * BSC vectors of 16 bytes
+  T* team_x = (T*)team_x_raw;
   __shared__ double wsum[2][CW];
   __shared__ double res_s[4];
   __shared__ int ident[5];                         // team, member, the sticky error word, XCC_ID, ticket
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   __syncthreads();
   const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
   if (team < 0 || ident[2] != 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
-  const int nvec = (d.ncols + 1) / 2;
+  const int nvec = (d.ncols + VW - 1) / VW;
   const int nvs = (nvec + P - 1) / P;              // 16-byte vectors per member
   const int v0 = s * nvs;
   // The team's rows: a SLAB of consecutive rows (row_stride 1), or every T-th row of the matrix (the cyclic deal, row_stride = T
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   // waits the compiler places are counted ones and the rows in the loading slots really stay in flight
   const int nsteps = DEPTH + (nrows + G - 1) / G * G;
   TeamRec* ring = t.ring + (int64_t)team * kTeamSlots * P;
-  const double* __restrict__ X = (const double*)xv;
+  const T* __restrict__ X = (const T*)xv;
   if (wv == CW) {
     // ---- the communication wave -------------------------------------------------------------------------------------
     // What it needs of a row besides `A x` — b[i] (least squares, logistic) or y[i], A_x_prev[i] and the shift of h (the
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     TeamRowState h[DEPTH];
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) h[j] = TeamRowState{};
-    const TeamRowConsts<FK> kc(d, xv);
+    const TeamRowConsts<FK> kc(d, xv, kF32);
     double e0 = 0.0, e1 = 0.0;
     bool dead = false;
     [[maybe_unused]] unsigned w_waits = 0, w_polls = 0;              // hand-offs that were not there at the first look ; the longest
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     };
     for (long long seq = 0; seq < nsteps; ++seq) {
       TeamRowState snew{};
-      if constexpr (FK == kTeamFkPd) snew = team_row_state<FK>(d, rowi(seq));
+      if constexpr (FK == kTeamFkPd) snew = team_row_state<FK, DEV, T>(d, rowi(seq));
       const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
       if (r >= 0) {
         const int i = rowi(r);
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         }
         // the residual / the logistic link / the dual step, ONCE per row, where no row of A is held (exp and log in Float64
         // take ~50 registers: next to the rows they cost the row kernels two of their three rows in flight)
-        const double res = r < nrows ? team_row_finish<FK>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
+        const double res = r < nrows ? team_row_finish<FK, DEV, T>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
         if (lane == 0) res_s[r & 3] = res;
       }
       __syncthreads();                             // the barrier of step seq
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         // cost C2 3 % of its iterations, measured three times over against the build before: the wait for it, which the
         // in-order return per wave extends to the acknowledgement of the stores in front of it, then falls between a
         // step's records and its barrier.)
-        if (r + 1 >= 0) h[0] = team_row_state<FK>(d, rowi(r + 1));
+        if (r + 1 >= 0) h[0] = team_row_state<FK, DEV, T>(d, rowi(r + 1));
       }
       if constexpr (P > 1) {
         if (r + 1 >= 0) fetch(r + 1);
@@ -386,14 +397,14 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
     const int src = max(min(v0 + tid + k * BSC, nvec - 1), 0);       // (a valid address ; what lies past the slice or the row is zeroed below)
-    xin[k] = *(const vec_t*)(X + (int64_t)src * 2);
+    xin[k] = *(const vec_t*)(X + (int64_t)src * VW);
   }
   __builtin_amdgcn_sched_barrier(0);
-  double acc[KV][2];
+  double acc[KV][VW];
   const int voff = tid * 16;
   const int64_t cbase = (int64_t)v0 * 16;
-  const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * 8 - cbase));      // (rows are zero-padded to whole vectors)
-  const double* __restrict__ AT = (const double*)d.AT;
+  const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * (int64_t)sizeof(T) - cbase));      // (rows are zero-padded to whole vectors)
+  const T* __restrict__ AT = (const T*)d.AT;
   vec_t a[G][KV];
   auto load = [&](int g, long long k) {            // (k: the team's k-th row)
     const int ri = __builtin_amdgcn_readfirstlane(rowi(k));
@@ -418,10 +429,10 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
     const int lv = tid + k * BSC;
-    const int j = (v0 + lv) * 2;
+    const int j = (v0 + lv) * VW;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      team_x[lv * 2 + e] = (lv < nvs && j + e < d.ncols) ? xin[k][e] : 0.0;     // (each thread reads back only what it wrote)
+    for (int e = 0; e < VW; ++e) {
+      team_x[lv * VW + e] = (lv < nvs && j + e < d.ncols) ? xin[k][e] : (T)0;     // (each thread reads back only what it wrote)
       acc[k][e] = 0.0;
     }
   }
@@ -429,10 +440,19 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   // the dots of the row in slot g (step seq) and the barrier behind them
   auto dots = [&](int g, long long seq) {
     double p = 0.0;
+    if constexpr (kF32) {
+      float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < KV; ++k)
+      for (int k = 0; k < KV; ++k)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) p = fma(a[g][k][e], team_x[(tid + k * BSC) * 2 + e], p);
+        for (int e = 0; e < VW; ++e) q = fmaf(a[g][k][e], team_x[(tid + k * BSC) * VW + e], q);
+      p = (double)q;
+    } else {
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) p = fma(a[g][k][e], team_x[(tid + k * BSC) * VW + e], p);
+    }
 #pragma unroll                                     // (a butterfly: EVERY lane ends with the wave's sum, so all of them store
     for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);      //  it and the loop body has no branch)
     wsum[seq & 1][wv] = p;                         // (double-buffered by row parity: one barrier per row)
@@ -456,14 +476,22 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       const long long r = seq - DEPTH;
       dots((DEPTH + u) % G, seq);
       const double rr = res_s[r & 3];
+      if constexpr (kF32) {
+        const float rf = (float)rr;                // (the residual IS a Float32 value)
 #pragma unroll
-      for (int k = 0; k < KV; ++k)
+        for (int k = 0; k < KV; ++k)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) acc[k][e] = fma(a[u][k][e], rr, acc[k][e]);      // (slot of row r: (seq - DEPTH) % G = u)
+          for (int e = 0; e < VW; ++e) acc[k][e] += (double)(a[u][k][e] * rf);      // (slot of row r: (seq - DEPTH) % G = u)
+      } else {
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) acc[k][e] = fma(a[u][k][e], rr, acc[k][e]);
+      }
 #pragma unroll                                     // (the sums are complete HERE: see k_slab_rows)
       for (int k = 0; k < KV; ++k)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(acc[k][e]));
+        for (int e = 0; e < VW; ++e) asm volatile("" : "+v"(acc[k][e]));
       __builtin_amdgcn_sched_barrier(0);
       load(u, r + G);
       __builtin_amdgcn_sched_barrier(0);
@@ -473,9 +501,9 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
     const int lv = tid + k * BSC;
-    const int j = (v0 + lv) * 2;
+    const int j = (v0 + lv) * VW;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < VW; ++e)
       if (lv < nvs && j + e < d.ncols) out[j + e] = acc[k][e];
   }
 }
@@ -501,9 +529,6 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 // Float32, as Julia does on Float32 arrays.  What it buys over the first-generation Float32 shapes is what it bought Float64:
 // the residual / the link of a row is evaluated where no row of A is held and OFF the compute waves' critical path — one
 // barrier per step instead of two with a serial section between them.
-template <typename T> struct TeamVec;
-template <> struct TeamVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct TeamVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
 
 template <typename T, int FK, int KV, int H, bool NT, class DEV = SlabDev, int GR = 1, int WG = 11, int G = 3>
 __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
@@ -775,6 +800,7 @@ inline bool multi_launch(int64_t ncols, int nblocks, int waves, const DEV& d, co
 // ---- host side: the plan for a row length, and the launch ----------------------------------------------------------------
 constexpr int kTeamSingleKv = 8;      // one workgroup / the three-slot shape: up to 8 vectors per compute thread
 constexpr int64_t kTeamMaxCols = (int64_t)16 * kTeamSingleKv * 704 * 2;      // 180 224 Float64 columns
+constexpr int64_t kTeamMaxColsF32 = (int64_t)16 * 5 * 704 * 4;               // 225 280 Float32 columns (teams of sixteen, five vectors)
 
 struct TeamPlan {
   int P = 0, kv = 0;                  // members ; 16-byte vectors per compute thread and row of a member's slice
@@ -791,9 +817,21 @@ struct TeamTune {                     // A/B overrides (apx_ctx_set_option): 0 =
 //   seven or eight with three slots and ONE row of slack — which teams of two and four absorb (a step is 60 - 90 KB per
 //   member: tools/pattern_probe.hip, 6.6 and 6.9 TB/s) but teams of eight and sixteen do not (6.2 and 5.5 against 6.6 with
 //   two rows of slack) ; sixteen members take it only beyond 135 168 columns, where the alternative is two passes.
-inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}) {
-  const int64_t nvec = (ncols + 1) / 2, v6 = 6 * 704, v8 = (int64_t)kTeamSingleKv * 704;
+inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}, int vw = 2) {
+  const int64_t nvec = (ncols + vw - 1) / vw, v6 = 6 * 704, v8 = (int64_t)kTeamSingleKv * 704;
   TeamPlan pl;
+  if (vw == 4) {      // Float32: the four-slot shapes of real teams only, two to FIVE vectors (the Float64 accumulator of a Float32 row
+    const int64_t v5 = 5 * 704;      // is twice the row: six vectors spill 44 bytes)
+    pl.P = nvec <= 2 * v5 ? 2 : nvec <= 4 * v5 ? 4 : nvec <= 8 * v5 ? 8 : nvec <= 16 * v5 ? 16 : 0;
+    if (pl.P == 0) return pl;
+    const int64_t nvs = (nvec + pl.P - 1) / pl.P;
+    pl.kv = (int)((nvs + 703) / 704);
+    const int kv10 = (int)((nvs + 639) / 640);
+    pl.waves = tune.waves == 10 || tune.waves == 11 ? tune.waves : (kv10 == pl.kv ? 10 : 11);
+    if (pl.waves == 10 && kv10 > 5) pl.waves = 11;
+    if (pl.waves == 10) pl.kv = kv10;
+    return pl;
+  }
   pl.P = 16;
   if (nvec <= v8) pl.P = 1;
   else if (nvec <= 2 * v6) pl.P = 2;
@@ -851,12 +889,12 @@ struct TeamCall {
 //  what a GPU shared with other work does to this scheme.  tests/test_gpu_team_fault.py checks that the waits time out,
 //  the grid drains and the error comes back)
 inline unsigned team_grid(const TeamDev& t, int nteams, int P) { return (unsigned)(t.fault_grid > 0 && P > 1 ? t.fault_grid : nteams * P); }
-template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV, int CW>
+template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV, int CW, typename T = double>
 inline void team_launch_one(TeamCall& call, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   constexpr size_t lds = (size_t)KV * CW * 64 * 2 * sizeof(double);      // the slice of x
   constexpr int kThreads = (CW + 1) * 64;
-  auto kernel = k_team_rows<FK, P, KV, NT, G, DEPTH, DEV, CW>;
-  if constexpr (lds > 64 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV, CW>>();
+  auto kernel = k_team_rows<FK, P, KV, NT, G, DEPTH, DEV, CW, T>;
+  if constexpr (lds > 64 * 1024) team_allow_lds<k_team_rows<FK, P, KV, NT, G, DEPTH, DEV, CW, T>>();
   if (call.query) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kThreads, lds) != hipSuccess) {
@@ -880,8 +918,18 @@ inline void team_launch_one(TeamCall& call, int nteams, const DEV& d, const Team
 // four row slots, two rows of slack: 2 ... 6 vectors
 // (measured and dropped at C2, interleaved runs of bench.py: five and six slots, two or three rows of slack, one to three rows
 //  really in flight — nothing ; profiles/r02_team_handoff_traffic.log has what the gap to the streaming rate was instead)
-template <int FK, int P, class DEV, int CW>
+template <int FK, int P, class DEV, int CW, typename T = double>
 inline bool team_launch_d2(TeamCall& call, int kv, int alt, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
+  if constexpr (sizeof(T) == 4) {                  // Float32: two to six vectors, four slots, two rows of slack
+    switch (kv) {
+      case 1:
+      case 2: team_launch_one<FK, P, 2, true, 4, 2, DEV, CW, T>(call, nteams, d, t, x, q); return true;
+      case 3: team_launch_one<FK, P, 3, true, 4, 2, DEV, CW, T>(call, nteams, d, t, x, q); return true;
+      case 4: team_launch_one<FK, P, 4, true, 4, 2, DEV, CW, T>(call, nteams, d, t, x, q); return true;
+      case 5: team_launch_one<FK, P, 5, true, 4, 2, DEV, CW, T>(call, nteams, d, t, x, q); return true;
+      default: return false;
+    }
+  }
   // (APX_OPT_TEAM_SLOTS: more row slots / rows of slack for C5's length as teams of four — an A/B hook, the primal-dual form only)
   if constexpr (P == 4 && FK == kTeamFkPd) {
     if (kv == 4) {
@@ -927,41 +975,50 @@ inline bool team_launch_d1(TeamCall& call, int kv, int nteams, const DEV& d, con
 }
 // the launch of a plan (or the query whether it can be resident: TeamCall) ; a launch advances the ranges of tickets and
 // sequence numbers (never reset)
-template <int FK, class DEV, int CW>
+template <int FK, class DEV, int CW, typename T = double>
 inline bool team_dispatch_w(TeamCall& call, const TeamPlan& pl, int nteams, bool nt, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   bool ok = false;
-  if (pl.P == 1) ok = nt ? team_launch_d1<FK, 1, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q) : team_launch_d1<FK, 1, false, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
-  else if (pl.big) {
-    if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
-    else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
-    else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
-  } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
-  else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
-  else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
-  else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
-  return ok;
+  if constexpr (sizeof(T) == 4) {
+    if (pl.big || pl.P < 2) return false;
+    if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV, CW, T>(call, pl.kv, 0, nteams, d, t, x, q);
+    else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV, CW, T>(call, pl.kv, 0, nteams, d, t, x, q);
+    else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV, CW, T>(call, pl.kv, 0, nteams, d, t, x, q);
+    else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV, CW, T>(call, pl.kv, 0, nteams, d, t, x, q);
+    return ok;
+  } else {
+    if (pl.P == 1) ok = nt ? team_launch_d1<FK, 1, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q) : team_launch_d1<FK, 1, false, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+    else if (pl.big) {
+      if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+      else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+      else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+    } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+    else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+    else if (pl.P == 8) ok = team_launch_d2<FK, 8, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+    else if (pl.P == 16) ok = team_launch_d2<FK, 16, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
+    return ok;
+  }
 }
-template <int FK, class DEV>
+template <int FK, class DEV, typename T = double>
 inline bool team_dispatch(TeamCall& call, const TeamPlan& pl, int nteams, bool nt, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
-  return pl.waves == 10 ? team_dispatch_w<FK, DEV, 10>(call, pl, nteams, nt, d, t, x, q) : team_dispatch_w<FK, DEV, 11>(call, pl, nteams, nt, d, t, x, q);
+  return pl.waves == 10 ? team_dispatch_w<FK, DEV, 10, T>(call, pl, nteams, nt, d, t, x, q) : team_dispatch_w<FK, DEV, 11, T>(call, pl, nteams, nt, d, t, x, q);
 }
-template <int FK, class DEV>
+template <int FK, class DEV, typename T = double>
 inline bool team_launch(const TeamPlan& pl, int nteams, bool nt, bool cooperative, const DEV& d, TeamDev& t, const void* x, hipStream_t q) {
   TeamCall call;
   call.cooperative = cooperative;
-  const bool ok = team_dispatch<FK, DEV>(call, pl, nteams, nt, d, t, x, q) && call.launch_error == hipSuccess;
+  const bool ok = team_dispatch<FK, DEV, T>(call, pl, nteams, nt, d, t, x, q) && call.launch_error == hipSuccess;
   t.launch += 1;
   t.seq0 += (unsigned long long)t.rows_per_team + (1u << t.chunk_log) + 16;      // (> the steps of a launch: the sequence words never repeat)
   return ok;
 }
 // workgroups of this plan's kernel that fit one CU at once (0: the runtime could not say, or none)
-template <int FK, class DEV>
+template <int FK, class DEV, typename T = double>
 inline int team_blocks_per_cu(const TeamPlan& pl, bool nt) {
   TeamCall call;
   call.query = true;
   const DEV d{};
   const TeamDev t{};
-  if (!team_dispatch<FK, DEV>(call, pl, 1, nt, d, t, nullptr, nullptr)) return 0;
+  if (!team_dispatch<FK, DEV, T>(call, pl, 1, nt, d, t, nullptr, nullptr)) return 0;
   return call.blocks_per_cu;
 }
 

@@ -128,7 +128,14 @@ def _rel(a, b):
                                                 (4100, 12000, False, np.float32),
                                                 (4099, 16001, True, np.float32),
                                                 (4100, 20000, False, np.float32),
-                                                (4101, 22528, True, np.float32)])
+                                                (4101, 22528, True, np.float32),
+                                                # ... and beyond one workgroup: Float32 TEAMS of 2 / 4 / 8 / 16 (two to five vectors per
+                                                # thread, four slots) — rows up to 225 280 entries read A once
+                                                (4100, 22529, False, np.float32),      # teams of two, five vectors
+                                                (4099, 28160, True, np.float32),       # teams of two, the longest row of two members
+                                                (4100, 50001, False, np.float32),      # teams of four
+                                                (4098, 90112, True, np.float32),       # teams of eight, four vectors
+                                                (4097, 200000, False, np.float32)])    # teams of sixteen
 def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
