@@ -1088,7 +1088,7 @@ inline std::string team_describe(const TeamDiag& g, const char* which) {
     s += b;
   } else {
     snprintf(b, sizeof b, "a hand-off wait expired after %.1f ms and %d polls (bound %.0f ms): launch %u, team %d member %d of %d "
-             "(workgroup %d, XCD %d, ticket %d), row %lld of its slab (step %lld of %lld, %d rows of slack), expected sequence word %llu. "
+             "(workgroup %d, XCD %d, ticket %d), its row number %lld (step %lld of %lld, %d rows of slack), expected sequence word %llu. "
              "Records of that row as last read — member:state —",
              (double)g.ticks * 1e-5, g.polls, (double)g.limit * 1e-5, g.launch, g.team, g.member, g.members, g.block, g.xcc, g.ticket,
              g.row, g.row + g.depth, g.nsteps, g.depth, g.want);

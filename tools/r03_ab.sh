@@ -1,16 +1,18 @@
 #!/bin/bash
 set -o pipefail
-O=gpurun_out/r03l
+O=gpurun_out/r03o
 mkdir -p $O
-for i in 1 2 3; do
-timeout -k 10 300 python tools/ab.py c3 base "ROW_DEAL=0" --rounds 6 --steps 30 > $O/ab_c3_$i.jsonl 2> $O/ab_c3.err; echo "c3 rc $?"
-timeout -k 10 300 python tools/ab.py c5 base "ROW_DEAL=0" --rounds 4 --steps 40 > $O/ab_c5_$i.jsonl 2> $O/ab_c5.err; echo "c5 rc $?"
+N=12000,16000,20000,22528,23000,28000,40000,56000,80000,112000,160000,225280
+for k in ls log; do
+  timeout -k 10 300 python tools/shape_sweep.py f32 $k 6 one $N > $O/sweep_f32_long_${k}_one.jsonl 2>> $O/sweep.err; echo "$k one rc $?"
+  timeout -k 10 300 python tools/shape_sweep.py f32 $k 6 two $N > $O/sweep_f32_long_${k}_two.jsonl 2>> $O/sweep.err; echo "$k two rc $?"
 done
-timeout -k 10 300 python tools/ab.py c3f64 base "ROW_DEAL=0" --rounds 4 --steps 30 > $O/ab_c3f64.jsonl 2> $O/ab_c3f64.err; echo "c3f64 rc $?"
 python3 - <<'PY'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/r03l/ab_*.jsonl")):
-    print(f)
-    for l in open(f):
-        d=json.loads(l); print("   ", d["variant"], d["pass_ms_median"], d["pass_ms_min"], d["pass_ms_max"], d["TBps_of_bytes_read"], d["kernel"][:40])
+import json
+O="gpurun_out/r03o"
+for k in ("ls","log"):
+    a={json.loads(l)["n"]:json.loads(l) for l in open(f"{O}/sweep_f32_long_{k}_one.jsonl") if l.startswith("{")}
+    b={json.loads(l)["n"]:json.loads(l) for l in open(f"{O}/sweep_f32_long_{k}_two.jsonl") if l.startswith("{")}
+    for n in sorted(a):
+        if n in b: print(k, n, "one pass:", a[n]["passes_per_iter"], a[n]["ms_per_iter"], "ms", a[n]["GBps_of_bytes_read"], "GB/s   two passes:", b[n]["ms_per_iter"], "ms", b[n]["GBps_of_bytes_read"], "GB/s each")
 PY
