@@ -78,9 +78,7 @@ struct SlabState {
   bool v2 = true;                 // (APX_SLAB_V1=1 in the environment: the first-generation kernel for long rows too — A/B runs)
   bool pipe = true, nt = true;    // two row groups in flight ; non-temporal loads of A
   // rows of more than 10 752 Float64 entries: teams of team_p workgroups (k_team_rows), team_kv vectors per thread
-  int team_p = 0, team_kv = 0;
-  bool team_big = false;          // slices of 6 ... 8 vectors per thread: three row slots, ONE row of slack (k_team_rows<..., 3, 1>)
-  TeamPlan plan;                  // (the three fields above, and the number of compute waves)
+  TeamPlan plan;                  // P = 0: no team kernel ; members, vectors per thread, the three-slot shape, compute waves (csrc/team_rows.h)
   TeamHost team;                  // ring, tickets, the error word and its diagnostic record, wait statistics (csrc/team_rows.h)
   DBuf tail_buf;                  // the fused end of the iteration (SlabTail): wave partials of the five reductions + the arrival counter
   std::string kname;              // the row kernel as launched (apx_ctx_kernel_name)
@@ -635,9 +633,6 @@ static int32_t slab_setup(apx_problem* p) {
     if (pl.P == 0) return APX_OK;
     const int P = pl.P;
     st->plan = pl;
-    st->team_big = pl.big;
-    st->team_p = pl.P;
-    st->team_kv = pl.kv;
     B = ctx->num_cu / P;                   // slabs = teams ; ALL 256 workgroups are launched (32 / P teams per XCD)
     rpb_team = (A->m + B - 1) / B;
     st->B = (int)B;
@@ -757,7 +752,7 @@ static void slab_close_launch(const SlabDev& d, int nparts, void* grad, const Sl
 template <typename T, int FK>
 static bool slab_launch_t(SlabState* st, bool cooperative, const SlabDev& d, const void* x, void* grad, const SlabTail& tl, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
-  if (st->team_p != 0) {
+  if (st->plan.P != 0) {
     const bool ok = team_launch<FK, SlabDev, T>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
     slab_close_launch<T, FK>(d, st->B, grad, tl, q);
     return ok;
@@ -787,10 +782,10 @@ static std::string slab_kernel_name(const SlabState* st, const apx_problem* p) {
   char b[256];
   const char* fk = p->f_kind == APX_F_LOGISTIC ? "logistic" : "least_squares";
   const char* ty = p->dtype == APX_F32 ? "float" : "double";
-  if (st->team_p != 0)
-    snprintf(b, sizeof b, "k_team_rows<%s%s, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack>", p->dtype == APX_F32 ? "float, " : "", fk, st->team_p,
-             st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), st->plan.waves, (st->team_big || st->team_p == 1) ? 3 : 4,
-             (st->team_big || st->team_p == 1) ? 1 : 2, (st->team_big || st->team_p == 1) ? "" : "s");
+  if (st->plan.P != 0)
+    snprintf(b, sizeof b, "k_team_rows<%s%s, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack>", p->dtype == APX_F32 ? "float, " : "", fk, st->plan.P,
+             st->plan.P == 1 ? "" : "s", std::max(st->plan.kv, st->plan.P == 1 ? 4 : 2), st->plan.waves, (st->plan.big || st->plan.P == 1) ? 3 : 4,
+             (st->plan.big || st->plan.P == 1) ? 1 : 2, (st->plan.big || st->plan.P == 1) ? "" : "s");
   else if (st->cpt == kSlabMultiCpt) {
     const int vw = p->dtype == APX_F32 ? 4 : 2;
     const int64_t nvec = ((int64_t)st->dev.ncols + vw - 1) / vw;
@@ -834,7 +829,7 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   }
   SlabState* st = p->slab;
   if (st == nullptr || p->A_f->dT == nullptr) return APX_OK;      // (dropped copy: A edited in place — every rank's, if any's)
-  if (st->team_p > 1 && p->teams_dead()) return APX_OK;           // (a hand-off failed earlier: the two passes from now on)
+  if (st->plan.P > 1 && p->teams_dead()) return APX_OK;           // (a hand-off failed earlier: the two passes from now on)
   apx_ctx* ctx = p->ctx;
   SlabDev d = st->dev;
   d.AT = p->A_f->dT;                             // (rebuilt copies may live elsewhere)
@@ -875,7 +870,7 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
 }
 
 // (their launches carry a ticket base and a sequence base that advance on the host: not replayable as a captured graph)
-bool slab_uses_teams(const apx_problem* p) { return p->slab != nullptr && p->slab->team_p > 1 && !p->teams_dead(); }
+bool slab_uses_teams(const apx_problem* p) { return p->slab != nullptr && p->slab->plan.P > 1 && !p->teams_dead(); }
 
 // The error word of the team hand-off (0: fine), read wherever a result is about to be used.  On a row shard the word is
 // SUMMED over the ranks: every rank reads it at the same points of the same control flow (the convergence poll at fixed
@@ -883,7 +878,7 @@ bool slab_uses_teams(const apx_problem* p) { return p->slab != nullptr && p->sla
 // the same iteration — nobody is left inside a collective its peers have abandoned, and all of them fall back together.
 int32_t slab_check(apx_problem* p) {
   SlabState* st = p->slab;
-  if (st == nullptr || st->team_p <= 1 || p->teams_dead()) return APX_OK;      // (reported once: the failure is the problem's state now)
+  if (st == nullptr || st->plan.P <= 1 || p->teams_dead()) return APX_OK;      // (reported once: the failure is the problem's state now)
   apx_ctx* ctx = p->ctx;
   int32_t err = 0;
   APX_TRY(team_read_err(ctx, &st->team, &err));
@@ -902,7 +897,7 @@ int32_t slab_check(apx_problem* p) {
 int32_t slab_team_waits(apx_problem* p, int64_t out[4]) {
   out[0] = out[1] = out[2] = out[3] = 0;
   SlabState* st = p->slab;
-  if (st == nullptr || st->team_p <= 1) return APX_OK;
+  if (st == nullptr || st->plan.P <= 1) return APX_OK;
   APX_TRY(team_read_waits(p->ctx, &st->team, out));
   out[2] *= 10;                                  // ticks of 10 ns
   out[3] = st->team.dev.launch;

@@ -38,9 +38,7 @@ struct SlabPdState {
   int B = 0, cpt = 0, bs = 0, rows = 0;
   bool nt = true;         // non-temporal loads of A (a matrix beyond the Infinity Cache)
   // rows of more than 10 752 Float64 entries: k_team_rows (csrc/team_rows.h) — one workgroup, or teams of 2 ... 16
-  int team_p = 0, team_kv = 0;      // members ; 16-byte vectors per thread and row of a member's slice (0: not this scheme)
-  bool team_big = false;
-  TeamPlan plan;          // (the three fields above, the number of compute waves, an experimental slot shape)
+  TeamPlan plan;          // kv = 0: not k_team_rows ; members, vectors per thread, the three-slot shape, compute waves, an experimental slot shape
   int multi_waves = 0;    // k_multi_rows: 0 = by fit, 10 / 11 compute waves forced (APX_OPT_MULTI_WAVES)
   TeamHost team;          // ring, tickets, the error word and its diagnostic record, wait statistics (csrc/team_rows.h)
   std::string kname;      // the row kernel as launched (apx_ctx_kernel_name)
@@ -310,9 +308,6 @@ int32_t slab_pd_setup(apx_solver* s) {
   if (st->cpt == 28) {                             // k_team_rows: slabs = teams, ALL P x B workgroups launched
     const TeamPlan pl = team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, ctx->team_slots});
     st->plan = pl;
-    st->team_p = pl.P;
-    st->team_kv = pl.kv;
-    st->team_big = pl.big;
     B = ctx->num_cu / pl.P;
     rpb = (A->m + B - 1) / B;
     if (pl.P > 1 && team_blocks_per_cu<kTeamFkPd, SlabPdDev>(pl, true) < 1) return APX_OK;      // (it does not fit a CU: the generic kernels)
@@ -359,7 +354,7 @@ static void slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
                        d, st->B * multi_groups(d.n, 16 / (int)sizeof(T)), (T*)aty, recs, rec_cap);
     return;
   }
-  if (st->team_kv != 0) {
+  if (st->plan.kv != 0) {
     if constexpr (!f32) {
       team_launch<kTeamFkPd, SlabPdDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
       hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
@@ -412,11 +407,11 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   d.ldT = p->A_lin->ldT;
   if (st->kname.empty()) {
     char b[256];
-    if (st->team_kv != 0)
+    if (st->plan.kv != 0)
       snprintf(b, sizeof b, "k_team_rows<primal_dual, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack> + k_slabpd_close",
-               st->team_p, st->team_p == 1 ? "" : "s", std::max(st->team_kv, st->team_p == 1 ? 4 : 2), st->plan.waves,
-               st->plan.alt ? st->plan.alt / 10 : ((st->team_big || st->team_p == 1) ? 3 : 4),
-               st->plan.alt ? st->plan.alt % 10 : ((st->team_big || st->team_p == 1) ? 1 : 2), (st->team_big || st->team_p == 1) ? "" : "s");
+               st->plan.P, st->plan.P == 1 ? "" : "s", std::max(st->plan.kv, st->plan.P == 1 ? 4 : 2), st->plan.waves,
+               st->plan.alt ? st->plan.alt / 10 : ((st->plan.big || st->plan.P == 1) ? 3 : 4),
+               st->plan.alt ? st->plan.alt % 10 : ((st->plan.big || st->plan.P == 1) ? 1 : 2), (st->plan.big || st->plan.P == 1) ? "" : "s");
     else if (st->cpt == 27)
       snprintf(b, sizeof b, "k_multi_rows<%s, primal_dual, %d row group(s)> + k_slabpd_close", p->dtype == APX_F32 ? "float" : "double",
                multi_groups(d.n, p->dtype == APX_F32 ? 4 : 2));
@@ -434,13 +429,13 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   return APX_OK;
 }
 
-bool slab_pd_uses_teams(const apx_solver* s) { return s->slab_pd != nullptr && s->slab_pd->team_p > 1; }
+bool slab_pd_uses_teams(const apx_solver* s) { return s->slab_pd != nullptr && s->slab_pd->plan.P > 1; }
 
 // the error word of the team hand-off (0: fine), read with the convergence flag and with the result ; the message carries the
 // diagnostic record of the wave that gave up (csrc/team_rows.h team_describe)
 int32_t slab_pd_check(apx_solver* s) {
   SlabPdState* st = s->slab_pd;
-  if (st == nullptr || st->team_p <= 1) return APX_OK;
+  if (st == nullptr || st->plan.P <= 1) return APX_OK;
   int32_t err = 0;
   APX_TRY(team_read_err(s->p->ctx, &st->team, &err));
   if (err == 0) return APX_OK;
@@ -453,7 +448,7 @@ int32_t slab_pd_check(apx_solver* s) {
 int32_t slab_pd_team_waits(apx_solver* s, int64_t out[4]) {
   out[0] = out[1] = out[2] = out[3] = 0;
   SlabPdState* st = s->slab_pd;
-  if (st == nullptr || st->team_p <= 1) return APX_OK;
+  if (st == nullptr || st->plan.P <= 1) return APX_OK;
   APX_TRY(team_read_waits(s->p->ctx, &st->team, out));
   out[2] *= 10;                                    // ticks of 10 ns
   out[3] = st->team.dev.launch;
