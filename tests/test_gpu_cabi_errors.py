@@ -179,3 +179,42 @@ def test_prox_entry_points_validate(lib, ctx):
     assert lib.apx_prox(ctx, C.byref(pd), 0, L.APX_F64, pv, 5, 1.0, py, C.byref(val)) == L.APX_OK
     assert np.allclose(y, 0.5) and val.value == pytest.approx(0.5 * 2.5)
     assert lib.apx_prox_value(ctx, C.byref(pd), L.APX_F64, pv, 5, None) == L.APX_ERR_INVALID
+
+
+def test_options_one_pass_switch_and_names(lib, ctx):
+    """ABI 3: options by key instead of environment variables, the switch of the one-pass kernels, the timing slot's kernel name,
+    the incident text and the hand-off statistics — all through the raw C-ABI."""
+    v = C.c_int64(-7)
+    for key, default in ((L.APX_OPT_MULTI_ROWS_MASK, 15), (L.APX_OPT_SLAB_GENERATION, 0), (L.APX_OPT_TEAM_WAIT_MS, 1000),
+                         (L.APX_OPT_TEAM_COOPERATIVE, 0), (L.APX_OPT_TEAM_FAULT_GRID, 0), (L.APX_OPT_FUSED_TAIL, 1),
+                         (L.APX_OPT_MULTI_WAVES, 0), (L.APX_OPT_TEAM_MEMBERS, 0), (L.APX_OPT_TEAM_SLOTS, 0), (L.APX_OPT_ROW_DEAL, -1)):
+        assert lib.apx_ctx_get_option(ctx, key, C.byref(v)) == L.APX_OK and v.value == default, (key, v.value)
+    assert lib.apx_ctx_set_option(ctx, L.APX_OPT_TEAM_WAIT_MS, 250) == L.APX_OK
+    assert lib.apx_ctx_get_option(ctx, L.APX_OPT_TEAM_WAIT_MS, C.byref(v)) == L.APX_OK and v.value == 250
+    assert lib.apx_ctx_set_option(ctx, L.APX_OPT_TEAM_WAIT_MS, 1000) == L.APX_OK
+    for key, bad in ((999, 1), (L.APX_OPT_MULTI_ROWS_MASK, 16), (L.APX_OPT_TEAM_WAIT_MS, 0), (L.APX_OPT_TEAM_MEMBERS, 3),
+                     (L.APX_OPT_ROW_DEAL, 3), (L.APX_OPT_MULTI_WAVES, 9), (L.APX_OPT_TEAM_SLOTS, 42), (L.APX_OPT_TEAM_FAULT_GRID, 257)):
+        assert lib.apx_ctx_set_option(ctx, key, bad) == L.APX_ERR_INVALID and _err(lib), (key, bad)
+    assert lib.apx_ctx_get_option(ctx, 999, C.byref(v)) == L.APX_ERR_INVALID
+    assert lib.apx_ctx_get_option(ctx, L.APX_OPT_ROW_DEAL, None) == L.APX_ERR_INVALID
+    assert lib.apx_ctx_set_option(None, L.APX_OPT_ROW_DEAL, 0) == L.APX_ERR_INVALID
+    for mode in (0, 2, 1):
+        assert lib.apx_ctx_one_pass(ctx, mode) == L.APX_OK
+    assert lib.apx_ctx_one_pass(ctx, 3) == L.APX_ERR_INVALID and "mode" in _err(lib)
+    assert lib.apx_ctx_one_pass(None, 1) == L.APX_ERR_INVALID
+    assert lib.apx_ctx_kernel_name(ctx, 99) == b"" and lib.apx_ctx_kernel_name(None, 0) == b""
+    assert isinstance(lib.apx_last_incident(), bytes)
+    # a problem that runs no team kernels: all-zero statistics ; NULL arguments are refused
+    A = _matrix(lib, ctx, np.random.default_rng(0).standard_normal((40, 30)))
+    b = np.zeros(40)
+    d = L.ProblemDesc()
+    d.f_kind, d.dtype, d.n, d.A_f, d.b = L.APX_F_LEAST_SQUARES, L.APX_F64, 30, A, b.ctypes.data_as(C.c_void_p)
+    d.g.kind = L.APX_G_L1
+    d.g.lam = 1.0
+    p = C.c_void_p()
+    assert lib.apx_problem_create(ctx, C.byref(d), C.byref(p)) == L.APX_OK, _err(lib)
+    out = (C.c_int64 * 4)(1, 2, 3, 4)
+    assert lib.apx_problem_team_waits(p, out) == L.APX_OK and list(out) == [0, 0, 0, 0]
+    assert lib.apx_problem_team_waits(None, out) == L.APX_ERR_INVALID and lib.apx_problem_team_waits(p, None) == L.APX_ERR_INVALID
+    lib.apx_problem_destroy(p)
+    lib.apx_matrix_free(A)
