@@ -42,13 +42,14 @@ __global__ __launch_bounds__(768) void reader(const dvec2* __restrict__ v, int m
   if (s0 + s1 == 123.456) out[0] = s0;
 }
 
+template <int U = 5>
 static double run(const dvec2* buf, int m, int rowv, int P, int R, int mode, int threads, double* out, hipStream_t s, int grid = 256) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL((reader<5>), dim3(grid), dim3(threads), 0, s, buf, m, rowv, P, R, mode, out);
+    hipLaunchKernelGGL((reader<U>), dim3(grid), dim3(threads), 0, s, buf, m, rowv, P, R, mode, out);
     CK(hipEventRecord(e1, s));
     CK(hipStreamSynchronize(s));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -78,6 +79,11 @@ int main(int argc, char** argv) {
       printf("  chunk8, workgroups x threads (members per team): 256 x 640 (%d) %5.0f | 512 x 320 (%d) %5.0f | 1024 x 192 (%d) %5.0f | 512 x 640 (%d) %5.0f\n", c.P,
              run(buf, c.m, c.rowv, c.P, 8, 1, 640, out, s, 256), 2 * c.P, run(buf, c.m, c.rowv, 2 * c.P, 8, 1, 320, out, s, 512), 4 * c.P,
              run(buf, c.m, c.rowv, 4 * c.P, 8, 1, 192, out, s, 1024), 2 * c.P, run(buf, c.m, c.rowv, 2 * c.P, 8, 1, 640, out, s, 512));
+      // more loads in flight per thread (the product keeps two to three rows = 10 ... 16 vectors per thread in flight)
+      printf("  chunk8 / blocked8 with U vectors per thread in flight: U5 %5.0f / %5.0f | U10 %5.0f / %5.0f | U16 %5.0f / %5.0f | slab U10 %5.0f U16 %5.0f\n",
+             run<5>(buf, c.m, c.rowv, c.P, 8, 1, 640, out, s), run<5>(buf, c.m, c.rowv, c.P, 8, 2, 640, out, s), run<10>(buf, c.m, c.rowv, c.P, 8, 1, 640, out, s),
+             run<10>(buf, c.m, c.rowv, c.P, 8, 2, 640, out, s), run<16>(buf, c.m, c.rowv, c.P, 8, 1, 640, out, s), run<16>(buf, c.m, c.rowv, c.P, 8, 2, 640, out, s),
+             run<10>(buf, c.m, c.rowv, c.P, 1, 0, 640, out, s), run<16>(buf, c.m, c.rowv, c.P, 1, 0, 640, out, s));
       fflush(stdout);
       CK(hipFree(buf));
     }
