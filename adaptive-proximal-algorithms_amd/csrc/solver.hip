@@ -572,7 +572,9 @@ static int32_t enqueue_iteration(apx_solver* s) {
   p->tail_req = nullptr;
   APX_TRY(rc_f);
   APX_TRY(pullback_f(p));
-  if (!p->tail_done)
+  if (s->red_ready)      // (the previous iteration's step kernel left k_reduce_n's partials: k_step_red)
+    APX_TRY(vo_rule_only(ctx, (const double*)s->red_own.p, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p, s->rec_cap));
+  else if (!p->tail_done)
     APX_TRY(vo_reduce_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p,
                            lin ? s->aty.p : nullptr, p->n, p->gd, p->ctrl(), lin, (apx_record*)s->recs.p,
                            s->rec_cap));                                       // :338-342
@@ -595,6 +597,15 @@ static int32_t enqueue_iteration(apx_solver* s) {
   if (p->tail_done)      // (the totals of the closing kernel's partials, the rule, the end of the iteration and the step: one kernel)
     return vo_step_rule(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, p->n, p->gd, p->ctrl(), tail.snap, tail.wred,
                         tail.ldw, (apx_record*)s->recs.p, s->rec_cap);       // :338-342, :348-361
+  // f = Zero with a linear operator (the least-absolute-deviation loops): the step also leaves the next iteration's reduction
+  // partials (the gradient is zero there as here) — not under hipGraph replay, whose captured iteration must be self-contained
+  if (lin && p->f_kind == APX_F_ZERO && !s->use_graph && p->ctx->fused_tail) {
+    if (s->red_own.p == nullptr) APX_TRY(s->red_own.alloc_zero(sizeof(double) * kRedQ * kMaxRedBlocks, ctx->stream));
+    APX_TRY(vo_step_red(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, s->aty.p, p->n, p->gd, p->ctrl(),
+                        (double*)s->red_own.p));                               // :359-361, and :338, :260-261 of the next iteration
+    s->red_ready = true;
+    return APX_OK;
+  }
   APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
                   p->gd, p->ctrl()));                                          // :359-361
   return APX_OK;

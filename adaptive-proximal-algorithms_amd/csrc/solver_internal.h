@@ -201,6 +201,9 @@ struct apx_solver {
   double tol = 0.0;
   int32_t poll_every = 16;
   apx::DBuf x, xprev, gprev, v, aty, y, ax, axprev, recs;
+  // f = Zero with a linear operator: the step kernel leaves the next iteration's reduction partials here (vecops.hip k_step_red)
+  apx::DBuf red_own;
+  bool red_ready = false;
   int64_t rec_cap = 0;
   apx_record* host_recs = nullptr;
   int64_t iters = 0;        // iterations enqueued so far

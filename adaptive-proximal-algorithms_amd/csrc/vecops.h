@@ -23,6 +23,11 @@ int32_t vo_dual_sharded(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, vo
                         const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap,
                         const std::function<int32_t(double*, int64_t)>& reduce);
 // K5+K6
+// the step of a primal-dual iteration with f = Zero that also leaves k_reduce_n's block partials of the NEXT iteration in `red`
+// ([kRedQ][kMaxRedBlocks]) ; vo_rule_only: k_rule on them
+int32_t vo_step_red(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v, const void* aty,
+                    int64_t n, const ProxDev& g, const Ctrl* c, double* red);
+int32_t vo_rule_only(apx_ctx* ctx, const double* red, int64_t n, const ProxDev& g, Ctrl* c, bool has_lin, apx_record* recs, int64_t rec_cap);
 // the totals of the one-pass closing kernel's partials + the rule + the end of the iteration + the step (csrc/slab.hip SlabTail)
 int32_t vo_step_rule(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v, int64_t n,
                      const ProxDev& g, Ctrl* c, const Ctrl* snap, const double* wred, int32_t ldw, apx_record* recs, int64_t rec_cap);

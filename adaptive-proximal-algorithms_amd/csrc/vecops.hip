@@ -221,6 +221,42 @@ __global__ __launch_bounds__(kBlock) void k_step(T* __restrict__ x, T* __restric
   }
 }
 
+// K5 + K6 of the primal-dual loop with f = Zero, and K7 + K8's sums of the NEXT iteration with them: everything k_reduce_n
+// reads at the top of iteration k + 1 — x, x_prev, v, A'y, and a gradient that is identically zero — is in this kernel's hands at
+// the end of iteration k, so it leaves k_reduce_n's block partials itself (the same grid, the same thread-to-entry mapping, the
+// same order: bit-identical sums) and the next iteration starts at k_rule.  One launch fewer per iteration of the loop C5 runs.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_step_red(T* __restrict__ x, T* __restrict__ xprev, const T* __restrict__ grad,
+                                                     T* __restrict__ gprev, T* __restrict__ v, const T* __restrict__ aty, int64_t n,
+                                                     ProxDev g, const Ctrl* c, double* __restrict__ red) {
+  if (c->done != 0) return;
+  const double gamma = c->gamma;
+  double q[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xi = (double)x[i], gi = (double)grad[i];
+    double gs = gi;
+    if (aty != nullptr) gs = gi + (double)aty[i];
+    const T vi = (T)(xi - gamma * gs);
+    const T xn = (T)prox_elem<T>(g, (double)vi, gamma, i, 0.0);
+    v[i] = vi;
+    xprev[i] = (T)xi;
+    gprev[i] = (T)gi;
+    x[i] = xn;
+    // k_reduce_n at the new point (its gamma is still this one: the rule runs behind it ; grad f = 0 there as here)
+    const double xn_d = (double)xn;
+    double pr = ((double)vi - xn_d) / gamma + gi;
+    if (aty != nullptr) pr = pr + (double)aty[i];
+    const double dg = gi - (double)(T)gi;
+    const double dx = xn_d - (double)(T)xi;
+    q[0] = fma(pr, pr, q[0]);
+    q[1] = fma(dg, dg, q[1]);
+    q[2] = fma(dg, dx, q[2]);
+    q[3] = fma(dx, dx, q[3]);
+    q[4] += gval_elem<T>(g, xn_d, i);
+  }
+  block_partials_store<5>(q, red);
+}
+
 // K5 + K6 behind the one-pass kernels (csrc/slab.hip SlabTail): the totals of the closing kernel's wave partials — in k_rule's
 // order, by EVERY block: the same bits everywhere, no grid-wide synchronisation —, the rule and the end of the iteration
 // (:340-342, :348-354) on a private copy of the control block's snapshot, then the step (:359-361) with the new gamma.  Block 0
@@ -625,6 +661,25 @@ int32_t vo_step(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* g
                                 (const double*)grad, (double*)gprev, (double*)v, (const double*)aty, n, g, c),
              hipLaunchKernelGGL(k_step<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)x, (float*)xprev,
                                 (const float*)grad, (float*)gprev, (float*)v, (const float*)aty, n, g, c));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_step_red(apx_ctx* ctx, int32_t dtype, void* x, void* xprev, const void* grad, void* gprev, void* v, const void* aty,
+                    int64_t n, const ProxDev& g, const Ctrl* c, double* red) {
+  const unsigned gr = vgrid(n);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_step_red<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)x, (double*)xprev,
+                                (const double*)grad, (double*)gprev, (double*)v, (const double*)aty, n, g, c, red),
+             hipLaunchKernelGGL(k_step_red<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)x, (float*)xprev,
+                                (const float*)grad, (float*)gprev, (float*)v, (const float*)aty, n, g, c, red));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+// k_rule on block partials that k_step_red left (the grid of both is vgrid(n))
+int32_t vo_rule_only(apx_ctx* ctx, const double* red, int64_t n, const ProxDev& g, Ctrl* c, bool has_lin, apx_record* recs, int64_t rec_cap) {
+  hipLaunchKernelGGL(k_rule, dim3(1), dim3(kBlock), 0, ctx->stream, red, (int)vgrid(n), g, c, has_lin ? 1 : 0, recs, rec_cap);
   APX_HIP(hipGetLastError());
   return APX_OK;
 }

@@ -593,3 +593,42 @@ def test_fused_tail_is_bit_identical(apx, m, n, logistic, dtype):
                                           ctx=ctx, poll_every=3))
         dA.free()
     assert outs[0][1] == outs[1][1] <= 8 and np.array_equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("m,n,one_pass", [(9000, 1000, True), (4100, 6000, True), (4100, 20000, True), (6000, 3000, False)])
+def test_primal_dual_step_leaves_the_next_reductions_bit_identical(apx, m, n, one_pass):
+    """f = Zero with a linear operator: the step kernel also leaves k_reduce_n's block partials of the NEXT iteration
+    (csrc/vecops.hip k_step_red — one launch fewer per iteration of the least-absolute-deviation loops), summed in k_reduce_n's
+    own order: switching it off (APX_OPT_FUSED_TAIL = 0) must not change one bit — iterates, records, termination, stepping in
+    pieces — on the one-pass kernels and on the two GEMV passes."""
+    from importlib import import_module
+    L = import_module("adaptive-proximal-algorithms_amd._lib")
+    rng = np.random.default_rng(m + n)
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+    yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+    nA = float(np.linalg.norm(A))
+    x0, y0 = np.zeros(n), np.zeros(m)
+    runs = []
+    for fused in (1, 0):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        ctx.one_pass_threshold(16 << 20)
+        ctx.set_option(L.APX_OPT_FUSED_TAIL, fused)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        t = dict(f=apx.Zero(), g=apx.NormL1(5.0), h=apx.Translate(apx.NormL1(1.0), -yv), A=dA, ctx=ctx)
+        recs = []
+        x, y, it = apx.adaptive_primal_dual(x0, y0, rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=14, record=recs.append, **t)
+        s = apx.Solver(x0, y0, rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, **t)
+        for k in (1, 5, 8):
+            s.step(k)
+            s.result()
+        xs, ys, _ = s.result()
+        s.close()
+        tol = recs[9]["norm_res"] * 1.0000001
+        xt, yt, itt = apx.adaptive_primal_dual(x0, y0, rule=apx.OurRule(t=1.0, norm_A=nA), tol=tol, maxit=60, poll_every=3, **t)
+        runs.append((x, y, [(r["gamma"], r["sigma"], r["norm_res"], r["objective"]) for r in recs], xs, ys, xt, yt, itt))
+        dA.free()
+    a, b = runs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(a[3], a[0]) and np.array_equal(b[3], b[0]) and np.array_equal(a[4], b[4])      # stepping in pieces = one call
+    assert a[7] == b[7] <= 10 and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
