@@ -345,6 +345,10 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
                   "APX_OPT_ROW_DEAL: -1 (chunks by the row length), 0 (slabs of consecutive rows) or a power of two (rows per chunk of the cyclic deal)");
       ctx->row_deal = (int)value;
       return APX_OK;
+    case APX_OPT_TEAM_INTERLEAVE:
+      APX_REQUIRE(value >= 0 && value <= 2, "APX_OPT_TEAM_INTERLEAVE: 0 (off), 1 (teams of four or more members) or 2 (every team)");
+      ctx->team_interleave = (int)value;
+      return APX_OK;
     case APX_OPT_TEAM_SLOTS:
       APX_REQUIRE(value == 0 || value == 52 || value == 62 || value == 53 || value == 63, "APX_OPT_TEAM_SLOTS: 0, 52, 62, 53 or 63");
       ctx->team_slots = (int)value;
@@ -371,6 +375,7 @@ int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
     case APX_OPT_TEAM_MEMBERS: *value = ctx->team_members; return APX_OK;
     case APX_OPT_TEAM_SLOTS: *value = ctx->team_slots; return APX_OK;
     case APX_OPT_ROW_DEAL: *value = ctx->row_deal; return APX_OK;
+    case APX_OPT_TEAM_INTERLEAVE: *value = ctx->team_interleave; return APX_OK;
     default:
       return fail(APX_ERR_INVALID, "apx_ctx_get_option: unknown key");
   }

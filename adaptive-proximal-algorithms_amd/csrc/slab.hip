@@ -783,8 +783,8 @@ static std::string slab_kernel_name(const SlabState* st, const apx_problem* p) {
   const char* fk = p->f_kind == APX_F_LOGISTIC ? "logistic" : "least_squares";
   const char* ty = p->dtype == APX_F32 ? "float" : "double";
   if (st->plan.P != 0)
-    snprintf(b, sizeof b, "k_team_rows<%s%s, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack>", p->dtype == APX_F32 ? "float, " : "", fk, st->plan.P,
-             st->plan.P == 1 ? "" : "s", std::max(st->plan.kv, st->plan.P == 1 ? 4 : 2), st->plan.waves, (st->plan.big || st->plan.P == 1) ? 3 : 4,
+    snprintf(b, sizeof b, "k_team_rows<%s%s, %d member%s%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack>", p->dtype == APX_F32 ? "float, " : "", fk, st->plan.P,
+             st->plan.P == 1 ? "" : "s", st->team.dev.interleave ? " (shares interleaved)" : "", std::max(st->plan.kv, st->plan.P == 1 ? 4 : 2), st->plan.waves, (st->plan.big || st->plan.P == 1) ? 3 : 4,
              (st->plan.big || st->plan.P == 1) ? 1 : 2, (st->plan.big || st->plan.P == 1) ? "" : "s");
   else if (st->cpt == kSlabMultiCpt) {
     const int vw = p->dtype == APX_F32 ? 4 : 2;

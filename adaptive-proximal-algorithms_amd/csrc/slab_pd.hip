@@ -408,8 +408,8 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   if (st->kname.empty()) {
     char b[256];
     if (st->plan.kv != 0)
-      snprintf(b, sizeof b, "k_team_rows<primal_dual, %d member%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack> + k_slabpd_close",
-               st->plan.P, st->plan.P == 1 ? "" : "s", std::max(st->plan.kv, st->plan.P == 1 ? 4 : 2), st->plan.waves,
+      snprintf(b, sizeof b, "k_team_rows<primal_dual, %d member%s%s, %d vectors per thread, %d compute waves, %d row slots, %d row%s of slack> + k_slabpd_close",
+               st->plan.P, st->plan.P == 1 ? "" : "s", st->team.dev.interleave ? " (shares interleaved)" : "", std::max(st->plan.kv, st->plan.P == 1 ? 4 : 2), st->plan.waves,
                st->plan.alt ? st->plan.alt / 10 : ((st->plan.big || st->plan.P == 1) ? 3 : 4),
                st->plan.alt ? st->plan.alt % 10 : ((st->plan.big || st->plan.P == 1) ? 1 : 2), (st->plan.big || st->plan.P == 1) ? "" : "s");
     else if (st->cpt == 27)

@@ -95,6 +95,8 @@ struct TeamDev {
   int32_t rows_per_team;
   int32_t row_stride;     // 1: a team's rows are a slab of rows_per_team consecutive rows ; T (= teams): chunks dealt cyclically,
   int32_t chunk_log;      //    2^chunk_log consecutive rows each (0: every T-th row)
+  int32_t interleave;     // 1: the members' slices of a row are INTERLEAVED in pieces of one workgroup's load (member s holds pieces
+                          //    s, s + P, s + 2 P, ... of BSC vectors) ; 0: member s holds the s-th contiguous P-th of the row (round 2)
   int32_t fault_grid;     // TEST hook (APX_OPT_TEAM_FAULT_GRID): launch this many workgroups instead of all 256
 };
 

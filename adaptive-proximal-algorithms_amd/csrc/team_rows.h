@@ -205,8 +205,16 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   const int team = __builtin_amdgcn_readfirstlane(ident[0]), s = __builtin_amdgcn_readfirstlane(ident[1]);
   if (team < 0 || ident[2] != 0 || d.c->done != 0) return;          // (done: written by an earlier launch, uniform over the grid)
   const int nvec = (d.ncols + VW - 1) / VW;
-  const int nvs = (nvec + P - 1) / P;              // 16-byte vectors per member
-  const int v0 = s * nvs;
+  // The member's share of a row (and of x, and of the column accumulator): piece k of a thread is vector v0 + k * kstep + tid.
+  // Round 2 gave member s the s-th contiguous P-th of the row (v0 = s nvs, kstep = BSC): the sixteen members of C2's teams then
+  // stream sixteen places of a row 50 KB apart.  INTERLEAVED (round 3, t.interleave): the pieces of BSC vectors — one load
+  // instruction of a workgroup, 10 KB — are dealt to the members in turn (v0 = s BSC, kstep = P BSC): with every load instruction
+  // a team covers P x 10 KB CONTIGUOUS bytes of the row.  Pure reads of C2's rows in the two patterns: 6.37 against 6.78 TB/s
+  // (tools/stream_pattern_probe.hip, profiles/r03_stream_pattern_probe2.log) ; teams of two: no difference.
+  const bool il = t.interleave != 0;
+  const int nvs = il ? nvec : (nvec + P - 1) / P;  // 16-byte vectors a member's share may reach (contiguous: its length)
+  const int v0 = il ? s * BSC : s * nvs;
+  const int kstep = il ? P * BSC : BSC;
   // The team's rows: a SLAB of consecutive rows (row_stride 1), or every T-th row of the matrix (the cyclic deal, row_stride = T
   // teams): with slabs the 256 workgroups stream 256 places of the matrix a fixed 60 MB apart for the whole launch, and how those
   // fall on the HBM channels is a matter of the allocation — the same binary on the same box ran C5 at 1.20 or at 1.28 ms from
@@ -396,14 +404,17 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   vec_t xin[KV];
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
-    const int src = max(min(v0 + tid + k * BSC, nvec - 1), 0);       // (a valid address ; what lies past the slice or the row is zeroed below)
+    const int src = max(min(v0 + tid + k * kstep, nvec - 1), 0);     // (a valid address ; what lies past the slice or the row is zeroed below)
     xin[k] = *(const vec_t*)(X + (int64_t)src * VW);
   }
   __builtin_amdgcn_sched_barrier(0);
   double acc[KV][VW];
   const int voff = tid * 16;
+  const int kstep16 = __builtin_amdgcn_readfirstlane(kstep * 16);
   const int64_t cbase = (int64_t)v0 * 16;
-  const int slice_bytes = (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * (int64_t)sizeof(T) - cbase));      // (rows are zero-padded to whole vectors)
+  // (rows are zero-padded to whole vectors ; interleaved, the descriptor runs from the member's first piece to the END OF THE ROW)
+  const int slice_bytes = il ? (int)max((int64_t)0, min((int64_t)nvec * 16, d.ldT * (int64_t)sizeof(T)) - cbase)
+                             : (int)max((int64_t)0, min((int64_t)nvs * 16, d.ldT * (int64_t)sizeof(T) - cbase));
   const T* __restrict__ AT = (const T*)d.AT;
   vec_t a[G][KV];
   auto load = [&](int g, long long k) {            // (k: the team's k-th row)
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(AT + (int64_t)ri * d.ldT) + cbase), 0, nb, 0x00020000);
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
-      const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * BSC * 16, NT ? 2 : 0);
+      const raw_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k * kstep16, NT ? 2 : 0);
       a[g][k] = __builtin_bit_cast(vec_t, raw);
     }
   };
@@ -429,10 +440,11 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
     const int lv = tid + k * BSC;
-    const int j = (v0 + lv) * VW;
+    const int gv = tid + k * kstep;                // (its place in the member's share of the row)
+    const int j = (v0 + gv) * VW;
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
-      team_x[lv * VW + e] = (lv < nvs && j + e < d.ncols) ? xin[k][e] : (T)0;     // (each thread reads back only what it wrote)
+      team_x[lv * VW + e] = (gv < nvs && j + e < d.ncols) ? xin[k][e] : (T)0;     // (each thread reads back only what it wrote)
       acc[k][e] = 0.0;
     }
   }
@@ -500,11 +512,11 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   double* __restrict__ out = d.part + (int64_t)team * d.ldpart;
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
-    const int lv = tid + k * BSC;
-    const int j = (v0 + lv) * VW;
+    const int gv = tid + k * kstep;
+    const int j = (v0 + gv) * VW;
 #pragma unroll
     for (int e = 0; e < VW; ++e)
-      if (lv < nvs && j + e < d.ncols) out[j + e] = acc[k][e];
+      if (gv < nvs && j + e < d.ncols) out[j + e] = acc[k][e];
   }
 }
 
@@ -1050,6 +1062,8 @@ inline int32_t team_alloc(apx_ctx* ctx, TeamHost* th, int nteams, int P, int64_t
   for (int r = ctx->row_deal; r > 1; r >>= 1) th->dev.chunk_log += 1;
   th->dev.wait_ticks = (unsigned long long)ctx->team_wait_ms * 100000ull;      // (s_memrealtime: 100 MHz)
   th->dev.fault_grid = ctx->team_fault_grid;
+  // (teams of two gain nothing in the pure-read probe and LOSE 1.7 % in the product — C5: 1.289 -> 1.312 ms — : from four members on)
+  th->dev.interleave = (ctx->team_interleave == 2 && P > 1) || (ctx->team_interleave == 1 && P >= 4) ? 1 : 0;
   APX_HIP(hipHostMalloc((void**)&th->pinned, sizeof(TeamHost::Pinned), hipHostMallocDefault));
   memset(th->pinned, 0, sizeof(TeamHost::Pinned));
   return APX_OK;

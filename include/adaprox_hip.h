@@ -292,10 +292,13 @@ enum {
   APX_OPT_TEAM_MEMBERS = 12,     /* default 0 = by the row length ; 2 / 4 / 8 / 16: workgroups per team where the row allows (A/B) */
   APX_OPT_TEAM_SLOTS = 13,       /* default 0 ; 52 / 62 / 53 / 63: row slots x 10 + rows of slack, teams of four with four vectors
                                     per thread in the primal-dual loop only (C5's length as teams of four: A/B)              */
-  APX_OPT_ROW_DEAL = 14          /* default -1: the rows of A are dealt to the workgroups (teams) of a one-pass launch in CHUNKS of
+  APX_OPT_ROW_DEAL = 14,         /* default -1: the rows of A are dealt to the workgroups (teams) of a one-pass launch in CHUNKS of
                                     consecutive rows (about 4 MB), the chunks cyclically — the chip streams one window of the
                                     matrix at a time, whatever the allocation ; 0: one slab of consecutive rows each (round 2) ;
                                     a power of two: that many rows per chunk (A/B: profiles/r03_row_deal.md)                */
+  APX_OPT_TEAM_INTERLEAVE = 15   /* default 1: the members of a team of FOUR OR MORE take a row's 10 KB pieces in turn (with every
+                                    load instruction a team covers one contiguous stretch of the row) ; 2: teams of two as well ;
+                                    0: each member its contiguous P-th of the row (round 2 ; A/B: profiles/r03_ab_interleave.jsonl) */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);

@@ -632,3 +632,59 @@ def test_primal_dual_step_leaves_the_next_reductions_bit_identical(apx, m, n, on
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
     assert np.array_equal(a[3], a[0]) and np.array_equal(b[3], b[0]) and np.array_equal(a[4], b[4])      # stepping in pieces = one call
     assert a[7] == b[7] <= 10 and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+
+
+@pytest.mark.parametrize("m,n,kind,dtype", [(4100, 12001, "ls", np.float64),        # teams of two (contiguous shares by default)
+                                            (4099, 30001, "ls", np.float64),        # teams of four: the last 10 KB piece is partial
+                                            (4098, 44803, "logistic", np.float64),  # teams of eight, the bias entry in a piece of its own
+                                            (4097, 100000, "ls", np.float64),       # C2's row: sixteen members, pieces 78 and 79 of 80 short / empty
+                                            (4100, 20000, "pd", np.float64),        # C5's row
+                                            (4099, 30001, "pd", np.float64),
+                                            (4100, 40002, "logistic", np.float32),  # Float32 teams
+                                            (4098, 90001, "ls", np.float32)])
+def test_team_members_shares_contiguous_or_interleaved(apx, m, n, kind, dtype):
+    """A team's members divide a row either into P contiguous shares (round 2) or — teams of four or more, by default — take its
+    10 KB pieces in turn (csrc/team_rows.h, APX_OPT_TEAM_INTERLEAVE: with every load instruction a team covers one contiguous
+    stretch of the row ; C2's kernel 6.07 -> 5.87 ms).  Which columns a thread holds changes, so the sums associate differently:
+    the three settings agree to rounding with each other and with the oracle, on rows whose last pieces are partial or empty."""
+    from importlib import import_module
+    L = import_module("adaptive-proximal-algorithms_amd._lib")
+    rng = np.random.default_rng(m + n)
+    K = 6
+    x0 = (0.01 * rng.standard_normal(n + (kind == "logistic"))).astype(dtype)
+    if kind == "pd":
+        A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))
+        yv = (A.astype(np.float64) @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)).astype(dtype)
+        nA = float(np.linalg.norm(A.astype(np.float64)))
+        xo, yo, _ = O.adaptive_primal_dual(np.zeros(n), np.zeros(m), f=O.Zero(), g=O.NormL1(5.0), h=O.Translate(O.NormL1(1.0), -yv.astype(np.float64)),
+                                           A=A.astype(np.float64), rule=O.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K)
+    else:
+        A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
+        b = (rng.uniform(size=m) < 0.5).astype(dtype) if kind == "logistic" else rng.standard_normal(m).astype(dtype)
+        gam = 4.0 / (n / 3.0 + 1.0) if kind == "logistic" else 1.0 / (m * n / 3.0)
+        fo = O.LogisticLoss(A.astype(np.float64), b.astype(np.float64)) if kind == "logistic" else O.LinearLeastSquares(A.astype(np.float64), b.astype(np.float64))
+        xo, _ = O.adaptive_proxgrad(x0.astype(np.float64), f=fo, g=O.NormL1(1e-3 if kind == "logistic" else 1.0), rule=O.OurRule(gamma=gam), tol=0.0, maxit=K)
+    xs = []
+    for mode in (1, 0, 2):
+        ctx = apx.Context(0)
+        ctx.one_pass_threshold(16 << 20)
+        ctx.set_option(L.APX_OPT_TEAM_INTERLEAVE, mode)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        if kind == "pd":
+            x, y, it = apx.adaptive_primal_dual(np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype), f=apx.Zero(), g=apx.NormL1(5.0),
+                                                h=apx.Translate(apx.NormL1(1.0), -yv), A=dA, rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx)
+        else:
+            f = apx.LogisticLoss(dA, b, ctx=ctx) if kind == "logistic" else apx.LinearLeastSquares(dA, b, ctx=ctx)
+            x, it = apx.adaptive_proxgrad(x0, f=f, g=apx.NormL1(1e-3 if kind == "logistic" else 1.0), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=K, ctx=ctx)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        assert it == K and st["one_pass"]["launches"] >= K and st["gemv_t"]["launches"] <= (1 if kind == "pd" else 0), st     # (pd: A' y0 once)
+        assert "k_team_rows" in ctx.kernel_name("one_pass"), ctx.kernel_name("one_pass")
+        xs.append(np.asarray(x, dtype=np.float64))
+        dA.free()
+    tol = 1e-10 if dtype == np.float64 else 2e-3
+    for x in xs:
+        assert _rel(x, xo) <= tol
+    assert _rel(xs[1], xs[0]) <= tol and _rel(xs[2], xs[0]) <= tol

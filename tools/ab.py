@@ -28,7 +28,7 @@ L = import_module("adaptive-proximal-algorithms_amd._lib")
 problems = import_module("adaptive-proximal-algorithms_amd.problems")
 
 DEFAULTS = {"MULTI_ROWS_MASK": 15, "SLAB_GENERATION": 0, "TEAM_COOPERATIVE": 0, "FUSED_TAIL": 1, "MULTI_WAVES": 0, "TEAM_MEMBERS": 0,
-            "TEAM_SLOTS": 0, "ROW_DEAL": -1}
+            "TEAM_SLOTS": 0, "ROW_DEAL": -1, "TEAM_INTERLEAVE": 1}
 
 
 def parse_variant(text):
@@ -58,11 +58,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--cols", type=int, default=0)
     args = ap.parse_args()
     ctx = apx.Context(0)
     apx.set_default_context(ctx)
     if args.config == "c2":
-        m, n, es = args.rows or 50_000, 100_000, 8
+        m, n, es = args.rows or 50_000, args.cols or 100_000, 8
         p = problems.device_lasso(m, n, pfactor=10, seed=0, power_iters=20, ctx=ctx, dual_layout=True)
         mk = lambda: apx.Solver(np.zeros(n), f=apx.LinearLeastSquares(p.A, p.b), g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=1.0 / p.Lf),      # noqa: E731
                                 tol=0.0, ctx=ctx, poll_every=1 << 30)
@@ -77,7 +78,7 @@ def main():
         restart_every = 36 if dt == np.float32 else 40        # (the loop runs past its fixed point: DESIGN.md section 9)
     else:
         dt = np.float64 if args.config == "c5" else np.float32
-        m, n, es = args.rows or 50_000, (20_000 if args.config == "c5" else 10_000), np.dtype(dt).itemsize
+        m, n, es = args.rows or 50_000, args.cols or (20_000 if args.config == "c5" else 10_000), np.dtype(dt).itemsize
         p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx) if dt == np.float64 else None
         if p is None:
             raise SystemExit("c5f32: not wired")

@@ -29,7 +29,18 @@ __global__ __launch_bounds__(768) void reader(const dvec2* __restrict__ v, int m
       const int c = (k / R) * T + team, rin = k % R;
       const int row = min(c * R + rin, m - 1);
       if (mode == 1) p = v + (size_t)row * rowv + (size_t)s * nvs;
-      else p = v + ((size_t)c * P + s) * (size_t)R * nvs + (size_t)rin * nvs;      // [chunk][member][row in chunk][slice]
+      else if (mode == 2) p = v + ((size_t)c * P + s) * (size_t)R * nvs + (size_t)rin * nvs;      // [chunk][member][row in chunk][slice]
+      else p = v + (size_t)row * rowv;               // 3: the members' slices INTERLEAVED in pieces of one workgroup's load (BS vectors)
+    }
+    if (mode == 3) {          // piece j of the row goes to member j % P: per load instruction the team covers P * BS contiguous vectors
+      for (int j = s; j * BS < rowv; j += U * P) {
+        dvec2 a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = (j + u * P) * BS + threadIdx.x; a[u] = (i < rowv) ? __builtin_nontemporal_load(p + i) : dvec2{0, 0}; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s0 += a[u][0]; s1 += a[u][1]; }
+      }
+      continue;
     }
     for (int i = threadIdx.x; i < nvs; i += U * BS) {
       dvec2 a[U];
@@ -65,6 +76,27 @@ int main(int argc, char** argv) {
                                                             {"C3 rows 40 KB (fp32), one workgroup", 100000, 2500, 1}};
   hipStream_t s; CK(hipStreamCreate(&s));
   double* out; CK(hipMalloc(&out, 64));
+  if (argc > 1) {      // second set (round 3): would FEWER, wider members or interleaved slices read C2's rows faster ?  and the harness's ceiling
+    for (int rep = 0; rep < 2; ++rep) {
+      const Cfg c = cfgs[0];
+      dvec2* buf;
+      const size_t bytes = (size_t)c.m * c.rowv * 16 + (64 << 20);
+      CK(hipMalloc(&buf, bytes));
+      CK(hipMemset(buf, 0, bytes));
+      printf("%s (allocation %d), chunk8, members per team:", c.name, rep);
+      for (int P : {1, 2, 4, 8, 16, 32}) printf(" P%-2d %5.0f", P, run(buf, c.m, c.rowv, P, 8, 1, 640, out, s));
+      printf("\n  the members' slices interleaved in pieces of 10 KB (chunk8):");
+      for (int P : {2, 4, 8, 16}) printf(" P%-2d %5.0f", P, run(buf, c.m, c.rowv, P, 8, 3, 640, out, s));
+      printf("\n  ... chunk1:");
+      for (int P : {2, 4, 8, 16}) printf(" P%-2d %5.0f", P, run(buf, c.m, c.rowv, P, 1, 3, 640, out, s));
+      // the ceiling: the whole buffer as ONE row dealt in 10 KB pieces to 256 members (a linear stream of the chip), and 256 contiguous 1/256ths
+      printf("\n  the buffer as one linear stream of the chip (10 KB pieces dealt to 256 workgroups) %5.0f ; as 256 contiguous parts %5.0f\n",
+             run(buf, 2, c.m / 2 * c.rowv, 256, 1, 3, 640, out, s), run(buf, 2, c.m / 2 * c.rowv, 256, 1, 1, 640, out, s));
+      fflush(stdout);
+      CK(hipFree(buf));
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep)
     for (const Cfg& c : cfgs) {
       dvec2* buf;
