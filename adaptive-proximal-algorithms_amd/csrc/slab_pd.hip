@@ -306,7 +306,7 @@ int32_t slab_pd_setup(apx_solver* s) {
   int64_t rpb = (A->m + B - 1) / B;                // dealt evenly, nothing rounded up: a block's last step may be partial
   B = (A->m + rpb - 1) / rpb;                      // (csrc/slab.hip: rounding to 16 left CUs without a block)
   if (st->cpt == 28) {                             // k_team_rows: slabs = teams, ALL P x B workgroups launched
-    const TeamPlan pl = team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, ctx->team_slots});
+    const TeamPlan pl = team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, ctx->team_slots, true});
     st->plan = pl;
     B = ctx->num_cu / pl.P;
     rpb = (A->m + B - 1) / B;

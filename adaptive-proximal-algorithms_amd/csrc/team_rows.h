@@ -51,6 +51,38 @@ __device__ __forceinline__ TeamRowState team_row_state(const DEV& d, int i) {
 template <int FK>
 __device__ __forceinline__ void team_row_state_landed(TeamRowState& s) {
   if constexpr (FK == kTeamFkPd) asm volatile("" : "+v"(s.a), "+v"(s.b), "+v"(s.c));      // (a use: the compiler waits for the loads)
+  else asm volatile("" : "+v"(s.a));
+}
+// lane l's state, on every lane (l uniform)
+__device__ __forceinline__ double team_lane_value(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+template <int FK>
+__device__ __forceinline__ TeamRowState team_row_state_of_lane(const TeamRowState& s, int l) {
+  TeamRowState o;
+  o.a = team_lane_value(s.a, l);
+  if constexpr (FK == kTeamFkPd) {
+    o.b = team_lane_value(s.b, l);
+    o.c = team_lane_value(s.c, l);
+  }
+  return o;
+}
+// The dual step of row i of the primal-dual loop in two parts: y+[i] — what the compute waves wait for — and the row's terms of
+// the residual norm and of h(A x), which nothing waits for (a division and the value of h: k_team_rows forms them BEHIND the
+// publication of its next partial, off the path between two barriers).
+template <class DEV, typename T>
+__device__ __forceinline__ double team_pd_dual(const DEV& d, const TeamRowConsts<kTeamFkPd>& kc, const TeamRowState& st, double dot, int i, double& w) {
+  const double ax = (double)(T)dot;
+  w = st.a + kc.sigma * ((1.0 + kc.rho) * ax - kc.rho * st.b);                     // src/AdaProx.jl:344
+  return (double)(T)prox_conj_elem_s<T>(d.h, w, kc.sigma, i, 0.0, st.c);           // :345
+}
+template <class DEV, typename T>
+__device__ __forceinline__ void team_pd_sums(const DEV& d, const TeamRowConsts<kTeamFkPd>& kc, double shift, double ax, double w, double yn, int i,
+                                             double& e0, double& e1) {
+  const double dr = (w - yn) / kc.sigma - ax;                                      // :347
+  e0 += dr * dr;
+  e1 += gval_elem_s<T>(d.h, ax, i, shift);
 }
 // the value the compute waves multiply row i by ; the loss sums (every member forms them — member 0's are the ones stored).
 // `dot` is the row's <A[i, :], x> in Float64 ; T is the storage type: A x is rounded to T like every stored A x, and for Float32
@@ -80,12 +112,10 @@ __device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowCon
     e1 += res;
     return res;
   } else {
-    const double w = st.a + kc.sigma * ((1.0 + kc.rho) * ax - kc.rho * st.b);      // src/AdaProx.jl:344
-    const T ynt = (T)prox_conj_elem_s<T>(d.h, w, kc.sigma, i, 0.0, st.c);          // :345
-    const double yn = (double)ynt;
-    const double dr = (w - yn) / kc.sigma - ax;                                    // :347
-    e0 += dr * dr;
-    e1 += gval_elem_s<T>(d.h, ax, i, st.c);
+    double w;
+    const double yn = team_pd_dual<DEV, T>(d, kc, st, dot, i, w);
+    const T ynt = (T)yn;
+    team_pd_sums<DEV, T>(d, kc, st.c, ax, w, yn, i, e0, e1);
     if (writer) {
       ((T*)d.Y)[i] = ynt;
       ((T*)d.AXP)[i] = (T)ax;                                                      // :360
@@ -269,9 +299,34 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       for (int m = 0; m < P; ++m) ok &= (rec_word(m, 0) ^ rec_word(m, 1)) == want;
       return ok;
     };
+    constexpr bool late = FK == kTeamFkPd && P > 1;
+    // What the wave needs of a row — b[i], or y[i], A_x_prev[i] and the shift — comes in BATCHES of kBatch rows, lane l of the wave
+    // taking row base + l, a whole batch AHEAD: with the chip's memory pipes full of A a load takes several steps to return (the
+    // compute waves keep two to three rows — 4 to 6 us — in flight for that reason), and a wait for one falls between two barriers
+    // of the workgroup.  (Round 2 took a row's state at the top of its step — the primal-dual loop — or a step ahead: the wait
+    // stood in the critical path of C5's kernel, 6.3 TB/s against 6.95 for least squares on the same matrix.)  Reading y and
+    // A_x_prev early is safe: member 0 overwrites row i's only after every member has published row i's partial.
+    constexpr int kBatch = 16;
+    auto batch = [&](long long base) { return team_row_state<FK, DEV, T>(d, rowi(base + min(lane, kBatch - 1))); };
+    [[maybe_unused]] TeamRowState bcur{}, bnext{};
+    if constexpr (FK == kTeamFkPd) {
+      bcur = batch(0);
+      team_row_state_landed<FK>(bcur);             // (a wait is for everything asked for before it: each batch is waited for BEFORE the next is asked for)
+      bnext = batch(kBatch);
+    }
     for (long long seq = 0; seq < nsteps; ++seq) {
-      TeamRowState snew{};
-      if constexpr (FK == kTeamFkPd) snew = team_row_state<FK, DEV, T>(d, rowi(seq));
+      [[maybe_unused]] double st_y = 0.0, st_ax = 0.0, st_w = 0.0, st_c = 0.0;      // (the primal-dual loop: row r's y+, A x, w and shift, for what
+      [[maybe_unused]] int st_i = -1;                                                //  is done behind the publication of the next partial)
+      [[maybe_unused]] TeamRowState snew{};
+      if constexpr (FK == kTeamFkPd) {
+        const int bl = (int)(seq % kBatch);
+        if (bl == 0 && seq > 0) {
+          team_row_state_landed<FK>(bnext);        // (asked for sixteen steps ago)
+          bcur = bnext;
+          bnext = batch(seq + kBatch);
+        }
+        snew = team_row_state_of_lane<FK>(bcur, bl);
+      }
       const long long r = seq - DEPTH;             // before the barrier of step seq: the residual of row seq - DEPTH
       if (r >= 0) {
         const int i = rowi(r);
@@ -347,7 +402,15 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         }
         // the residual / the logistic link / the dual step, ONCE per row, where no row of A is held (exp and log in Float64
         // take ~50 registers: next to the rows they cost the row kernels two of their three rows in flight)
-        const double res = r < nrows ? team_row_finish<FK, DEV, T>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
+        double res = 0.0;
+        if constexpr (late) {
+          if (r < nrows) {
+            res = team_pd_dual<DEV, T>(d, kc, h[0], ax, i, st_w);
+            st_i = i, st_y = res, st_ax = (double)(T)ax, st_c = h[0].c;
+          }
+        } else {
+          res = r < nrows ? team_row_finish<FK, DEV, T>(d, kc, h[0], ax, i, s == 0 && lane == 0, e0, e1) : 0.0;
+        }
         if (lane == 0) res_s[r & 3] = res;
       }
       __syncthreads();                             // the barrier of step seq
@@ -357,8 +420,6 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       if constexpr (P == 1) {
         own_prev = own;
       } else {
-        // (only the primal-dual loop must have the row's state before it publishes ; for b[i] see below)
-        if constexpr (FK == kTeamFkPd) team_row_state_landed<FK>(snew);
         if (lane == 0) {
           const unsigned long long bits = __builtin_bit_cast(unsigned long long, own);
           TeamRec* rec = ring + (seq % kTeamSlots) * P + s;
@@ -366,17 +427,26 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
           __hip_atomic_store(&rec->chk, bits ^ (t.seq0 + (unsigned long long)seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      if constexpr (late) {
+        if (st_i >= 0) team_pd_sums<DEV, T>(d, kc, st_c, st_ax, st_w, st_y, st_i, e0, e1);
+      }
       if constexpr (FK == kTeamFkPd) {
 #pragma unroll
         for (int j = 0; j + 1 < DEPTH; ++j) h[j] = h[j + 1];
         h[DEPTH - 1] = snew;
       } else {
         // b[i] is read-only: it is taken HERE, behind the publication of the partial and a step ahead of its use, for the row
-        // whose residual is due next.  (Taken at the top of the step — the order the primal-dual loop needs — the same load
-        // cost C2 3 % of its iterations, measured three times over against the build before: the wait for it, which the
-        // in-order return per wave extends to the acknowledgement of the stores in front of it, then falls between a
-        // step's records and its barrier.)
+        // whose residual is due next.  (Taken at the top of the step the same load cost C2 3 % of its iterations, measured three
+        // times over: the wait for it, which the in-order return per wave extends to the acknowledgement of the stores in front
+        // of it, then falls between a step's records and its barrier.  In batches like the primal-dual loop's: least squares
+        // on C5's matrix 1.153 -> 1.169 ms — the lane reads on the path cost more than the wait they replace.)
         if (r + 1 >= 0) h[0] = team_row_state<FK, DEV, T>(d, rowi(r + 1));
+      }
+      if constexpr (late) {
+        if (st_i >= 0 && s == 0 && lane == 0) {
+          ((T*)d.Y)[st_i] = (T)st_y;
+          ((T*)d.AXP)[st_i] = (T)st_ax;                                            // :360
+        }
       }
       if constexpr (P > 1) {
         if (r + 1 >= 0) fetch(r + 1);
@@ -822,6 +892,7 @@ struct TeamPlan {
 };
 struct TeamTune {                     // A/B overrides (apx_ctx_set_option): 0 = the plan below decides
   int members = 0, waves = 0, alt = 0;
+  bool pd = false;                    // the primal-dual form (csrc/slab_pd.hip)
 };
 // One workgroup where the row fits its eight vectors per thread (three row slots, nothing to hand over).  Else the members'
 // slices as large as the registers allow, because a step costs a barrier and a hand-off whatever its bytes:
@@ -853,6 +924,18 @@ inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}, int 
   else if (nvec <= 8 * v6) pl.P = 8;
   else if (nvec <= 16 * v6) pl.P = 16;
   else pl.big = true;
+  // The primal-dual form: the three-slot shape has the whole dual step of a row — a division, the conjugate prox — between two
+  // barriers a single row behind the hand-off, and pays for it (C5's matrix: 6.46 TB/s against 6.95 for least squares in the same
+  // shape).  Twice the members with half the vectors, four slots and two rows of slack absorb it, but cost ~2 % at equal lane fill
+  // (more members per hand-off): taken where they fill their lanes at least 6 % better — 20 000 columns as 4 x 4 x 640 (98 %)
+  // instead of 2 x 8 x 704 (89 %): 1.239 -> 1.202 ms ; 40 000 as teams of eight: 2.545 -> 2.433 ; but 17 000, 18 000, 21 000,
+  // 22 528, 34 000, 45 056 stay (tools/ab.py, profiles/r03_ab_pd_shapes.jsonl).
+  if (tune.pd && pl.big && (pl.P == 2 || pl.P == 4)) {
+    const int64_t nvb = (nvec + pl.P - 1) / pl.P, kvb = (nvb + 703) / 704;
+    const int64_t nvw = (nvec + 2 * pl.P - 1) / (2 * pl.P), kw10 = (nvw + 639) / 640, kw11 = (nvw + 703) / 704;
+    const int64_t slots_b = pl.P * kvb * 704, slots_w = 2 * pl.P * (kw10 == kw11 ? kw10 * 640 : kw11 * 704);
+    if (kw11 <= 6 && 100 * slots_b >= 106 * slots_w) pl.P *= 2, pl.big = false;
+  }
   // (A/B: a forced team size, where the row still fits its eight vectors per thread and is long enough to be split)
   if (pl.P > 1 && (tune.members == 2 || tune.members == 4 || tune.members == 8 || tune.members == 16) && nvec <= tune.members * v8 &&
       nvec > (int64_t)tune.members * 704) {

@@ -38,6 +38,7 @@ def parse_variant(text):
             k, v = kv.split("=")
             if k == "ONE_PASS":
                 opts["ONE_PASS"] = int(v)
+
             else:
                 assert k in DEFAULTS, k
                 opts[k] = int(v)
@@ -118,17 +119,21 @@ def main():
             ms = sum(k["total_ms"] for k in st.values()) / args.steps
             kern[v].append(ms)
             wall[v].append(dtw / args.steps * 1e3)
-    finals = {}
+    finals, tw = {}, {}
     for v, _ in variants:
         x, _, res = solvers[v].result()
         finals[v] = (int(res.numit), float(res.objective), bool(np.all(np.isfinite(x))))
+        try:
+            tw[v] = solvers[v].team_waits()
+        except Exception:      # noqa: BLE001 (not a team kernel)
+            tw[v] = None
     base = statistics.median(kern[variants[0][0]])
     for v, _ in variants:
         k, w = statistics.median(kern[v]), statistics.median(wall[v])
         print(json.dumps({"config": args.config, "variant": v, "kernel": names[v], "pass_ms_median": round(k, 4), "pass_ms_min": round(min(kern[v]), 4),
                           "pass_ms_max": round(max(kern[v]), 4), "iter_ms_median": round(w, 4), "TBps_of_bytes_read": round(m * n * es / k / 1e9, 3),
                           "vs_first": round(k / base, 4), "rounds": args.rounds, "steps": args.steps,
-                          "last_solver": {"iterations": finals[v][0], "objective": finals[v][1], "finite": finals[v][2]}}), flush=True)
+                          "last_solver": {"iterations": finals[v][0], "objective": finals[v][1], "finite": finals[v][2]}, "team_waits": tw[v]}), flush=True)
 
 
 if __name__ == "__main__":
