@@ -307,9 +307,15 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     // stood in the critical path of C5's kernel, 6.3 TB/s against 6.95 for least squares on the same matrix.)  Reading y and
     // A_x_prev early is safe: member 0 overwrites row i's only after every member has published row i's partial.
     constexpr int kBatch = 16;
+    // b[i] of least squares / the logistic loss the same way where the hand-off has two rows of slack: C2's kernel 5.88 -> 5.78 ms,
+    // teams of eight on 100 000 x 50 000 5.91 -> 5.79 (two builds alternated on one box, profiles/r03_ab_state_batches.jsonl) ;
+    // NOT with one row of slack (teams of two with eight vectors, 50 000 x 20 000: 1.153 -> 1.169 — there the lane reads, on
+    // the path between two barriers, cost more than the wait they replace ; nor for a workgroup on its own: Float64 logistic
+    // 100 000 x 10 000 1.171 / 1.180 -> 1.186 / 1.198).
+    constexpr bool kBatched = FK == kTeamFkPd || (P > 1 && DEPTH == 2);
     auto batch = [&](long long base) { return team_row_state<FK, DEV, T>(d, rowi(base + min(lane, kBatch - 1))); };
     [[maybe_unused]] TeamRowState bcur{}, bnext{};
-    if constexpr (FK == kTeamFkPd) {
+    if constexpr (kBatched) {
       bcur = batch(0);
       team_row_state_landed<FK>(bcur);             // (a wait is for everything asked for before it: each batch is waited for BEFORE the next is asked for)
       bnext = batch(kBatch);
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       [[maybe_unused]] double st_y = 0.0, st_ax = 0.0, st_w = 0.0, st_c = 0.0;      // (the primal-dual loop: row r's y+, A x, w and shift, for what
       [[maybe_unused]] int st_i = -1;                                                //  is done behind the publication of the next partial)
       [[maybe_unused]] TeamRowState snew{};
-      if constexpr (FK == kTeamFkPd) {
+      if constexpr (kBatched) {
         const int bl = (int)(seq % kBatch);
         if (bl == 0 && seq > 0) {
           team_row_state_landed<FK>(bnext);        // (asked for sixteen steps ago)
@@ -430,16 +436,15 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       if constexpr (late) {
         if (st_i >= 0) team_pd_sums<DEV, T>(d, kc, st_c, st_ax, st_w, st_y, st_i, e0, e1);
       }
-      if constexpr (FK == kTeamFkPd) {
+      if constexpr (kBatched) {
 #pragma unroll
         for (int j = 0; j + 1 < DEPTH; ++j) h[j] = h[j + 1];
         h[DEPTH - 1] = snew;
       } else {
-        // b[i] is read-only: it is taken HERE, behind the publication of the partial and a step ahead of its use, for the row
-        // whose residual is due next.  (Taken at the top of the step the same load cost C2 3 % of its iterations, measured three
-        // times over: the wait for it, which the in-order return per wave extends to the acknowledgement of the stores in front
-        // of it, then falls between a step's records and its barrier.  In batches like the primal-dual loop's: least squares
-        // on C5's matrix 1.153 -> 1.169 ms — the lane reads on the path cost more than the wait they replace.)
+        // (one row of slack, or a workgroup on its own) b[i] is taken HERE, behind the publication of the partial and a step
+        // ahead of its use, for the row whose residual is due next.  (Taken at the top of the step the same load cost C2 3 % of
+        // its iterations in round 2: the wait for it, which the in-order return per wave extends to the acknowledgement of the
+        // stores in front of it, then falls between a step's records and its barrier.)
         if (r + 1 >= 0) h[0] = team_row_state<FK, DEV, T>(d, rowi(r + 1));
       }
       if constexpr (late) {
