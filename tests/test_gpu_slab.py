@@ -688,3 +688,36 @@ def test_team_members_shares_contiguous_or_interleaved(apx, m, n, kind, dtype):
     for x in xs:
         assert _rel(x, xo) <= tol
     assert _rel(xs[1], xs[0]) <= tol and _rel(xs[2], xs[0]) <= tol
+
+
+@pytest.mark.parametrize("n,members", [(17000, 2), (20000, 4), (21000, 2), (22528, 2), (34000, 4), (40000, 8), (45056, 4)])
+def test_primal_dual_team_shape_by_lane_fill(apx, n, members):
+    """csrc/team_rows.h team_plan: the primal-dual form takes twice the members (four row slots, two rows of slack) instead of the
+    wide three-slot shape where they fill their lanes at least 6 % better — 20 000 columns (C5) as teams of four, 40 000 as teams
+    of eight ; least squares keeps the wide shape ; APX_OPT_TEAM_MEMBERS still overrides.  The shapes only — parity of every one of
+    them is test_one_pass_primal_dual_matches_oracle_and_two_passes / test_team_members_shares_contiguous_or_interleaved."""
+    from importlib import import_module
+    L = import_module("adaptive-proximal-algorithms_amd._lib")
+    m = 4100
+    names = {}
+    for forced in (0, members // 2 if members > 2 else 0):
+        ctx = apx.Context(0)
+        ctx.one_pass_threshold(16 << 20)
+        if forced:
+            ctx.set_option(L.APX_OPT_TEAM_MEMBERS, forced)
+        dA = apx.DeviceMatrix.uniform(m, n, seed=3, ctx=ctx).build_transpose()
+        yv = np.random.default_rng(n).standard_normal(m)
+        x, y, it = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(5.0), h=apx.Translate(apx.NormL1(1.0), -yv), A=dA,
+                                            rule=apx.OurRule(t=1.0, norm_A=float(np.sqrt(m * n / 3.0))), tol=0.0, maxit=3, ctx=ctx)
+        assert it == 3 and np.all(np.isfinite(x))
+        names[forced] = ctx.kernel_name("one_pass")
+        if not forced:
+            b = np.random.default_rng(1).standard_normal(m)
+            apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(dA, b, ctx=ctx), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=2, ctx=ctx)
+            ls_name = ctx.kernel_name("one_pass")
+        dA.free()
+    assert "primal_dual, %d members" % members in names[0], names
+    wide = 2 if n <= 22528 else 4
+    assert "least_squares, %d members" % wide in ls_name and "3 row slots" in ls_name, ls_name
+    if members > wide:
+        assert "primal_dual, %d members" % wide in names[members // 2] and "3 row slots" in names[members // 2], names
