@@ -95,14 +95,14 @@ __device__ __forceinline__ void slab_load(T (&a)[H][C], T& b_in, const SlabDev& 
 #pragma unroll
   for (int r = 0; r < H; ++r) {
     // (r0, row_end: the block's OWN row numbers — deal_row gives the matrix row, clamped into the block's rows ; uniform: scalar)
-    const int ri = __builtin_amdgcn_readfirstlane(deal_row(r0 + r, row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log));
+    const int ri = __builtin_amdgcn_readfirstlane(min(deal_row(r0 + r, row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log), d.m - 1));
     const T* __restrict__ row = AT + (int64_t)ri * d.ldT;
 #pragma unroll
     for (int k = 0; k < C; ++k)                  // scalar row base + 32-bit BYTE offset: one address register per load
       a[r][k] = NT ? __builtin_nontemporal_load((const T*)((const char*)row + off[k]))   // (read once: past the caches,
                    : *(const T*)((const char*)row + off[k]);                             //  unless A fits the Infinity Cache)
   }
-  b_in = bv[deal_row(r0 + min(tid, H - 1), row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log)];      // (goes out with the loads of A ; every thread, unconverted: a
+  b_in = bv[min(deal_row(r0 + min(tid, H - 1), row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log), d.m - 1)];      // (goes out with the loads of A ; every thread, unconverted: a
                                                           //  branch or a conversion here would wait for all of them)
 }
 
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
   auto load = [&](int g, int r0) {                 // rows past the slab: its last row again (a valid address ; residual 0)
 #pragma unroll
     for (int r = 0; r < H; ++r) {
-      const int ri = __builtin_amdgcn_readfirstlane(deal_row(r0 + r, row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log));
+      const int ri = __builtin_amdgcn_readfirstlane(min(deal_row(r0 + r, row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log), d.m - 1));
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(AT + (int64_t)ri * d.ldT), 0, row_bytes, 0x00020000);
 #pragma unroll
       for (int k = 0; k < KV; ++k) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(768) void k_slab2_rows(SlabDev d, const void* xv) {
         a[g][r][k] = __builtin_bit_cast(vec_t, raw);
       }
     }
-    b_in[g] = bv[deal_row(r0 + min(tid, H - 1), row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log)];
+    b_in[g] = bv[min(deal_row(r0 + min(tid, H - 1), row_end, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log), d.m - 1)];
   };
   auto group = [&](int g, int r0) {
     double p[H];

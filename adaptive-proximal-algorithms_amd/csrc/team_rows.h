@@ -253,7 +253,8 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   // In between: CHUNKS of 2^chunk_log consecutive rows dealt cyclically (consecutive rows keep a team on the same pages, the
   // cyclic deal of the chunks keeps the chip on one window).
   const int nrows = deal_rows(d.m, team, t.rows_per_team, t.row_stride, t.chunk_log);
-  auto rowi = [&](long long k) { return deal_row((int)max(min(k, (long long)nrows), -1LL), nrows, team, t.rows_per_team, t.row_stride, t.chunk_log); };
+  // (a block WITHOUT rows — a forced deal on a small matrix — would be pointed past the matrix: the last row then, like every dummy row)
+  auto rowi = [&](long long k) { return min(deal_row((int)max(min(k, (long long)nrows), -1LL), nrows, team, t.rows_per_team, t.row_stride, t.chunk_log), d.m - 1); };
   // rows past the slab are dummy rows (clamped loads, residual 0) that every member runs alike: DEPTH steps of prologue,
   // then whole rounds of G steps — the loop body of the compute waves has no branch between a load and its use, so the
   // waits the compiler places are counted ones and the rows in the loading slots really stay in flight
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(768) void k_multi_rows(DEV d, const void* xv) {
   if (d.c->done != 0) return;                      // (written by an earlier launch: uniform over the grid)
   // (the block's rows: dealt in chunks, csrc/team_dev.h ; k = its own row number, rowi(k) the matrix row, clamped into its rows)
   const int nrows = deal_rows(d.m, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log);
-  auto rowi = [&](int k) { return deal_row(k, nrows, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log); };
+  auto rowi = [&](int k) { return min(deal_row(k, nrows, (int)blockIdx.x, d.rows_per_block, d.deal_stride, d.deal_log), d.m - 1); };
   const int nsteps = 1 + ((nrows + RS - 1) / RS + G - 1) / G * G;    // one step of prologue, then whole rounds of G steps
   if (wv == CW) {
     // ---- the row wave: lane L < RS is row L of a step (group L / H, its row L % H) ---------------------------------------

@@ -721,3 +721,34 @@ def test_primal_dual_team_shape_by_lane_fill(apx, n, members):
     assert "least_squares, %d members" % wide in ls_name and "3 row slots" in ls_name, ls_name
     if members > wide:
         assert "primal_dual, %d members" % wide in names[members // 2] and "3 row slots" in names[members // 2], names
+
+
+@pytest.mark.parametrize("n,dtype", [(3000, np.float64), (9000, np.float32), (12001, np.float64), (40000, np.float64)])
+def test_forced_row_deals_on_a_small_matrix(apx, n, dtype):
+    """APX_OPT_ROW_DEAL is an A/B hook, but any value it accepts must be safe: slabs (0) and chunks far larger than the default
+    (64, 1024 rows) leave some of the 256 workgroups (teams) WITHOUT rows on a matrix of 4097 rows — they run their dummy steps on
+    the matrix's last row (weight 0) instead of pointing past it — and every deal gives the default's iterates to rounding."""
+    from importlib import import_module
+    L = import_module("adaptive-proximal-algorithms_amd._lib")
+    m = 4097
+    rng = np.random.default_rng(n)
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)).astype(dtype))
+    b = rng.standard_normal(m).astype(dtype)
+    xs = []
+    for deal in (-1, 0, 1, 64, 1024):
+        ctx = apx.Context(0)
+        ctx.one_pass_threshold(16 << 20)
+        ctx.set_option(L.APX_OPT_ROW_DEAL, deal)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        x, it = apx.adaptive_proxgrad(np.zeros(n, dtype=dtype), f=apx.LinearLeastSquares(dA, b, ctx=ctx), g=apx.NormL1(1.0),
+                                      rule=apx.OurRule(gamma=1.0 / (m * n / 3.0)), tol=0.0, maxit=6, ctx=ctx)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        assert it == 6 and st["one_pass"]["launches"] >= 6 and st["gemv_t"]["launches"] == 0, st
+        xs.append(np.asarray(x, dtype=np.float64))
+        dA.free()
+    tol = 1e-10 if dtype == np.float64 else 2e-3
+    for x in xs[1:]:
+        assert np.all(np.isfinite(x)) and _rel(x, xs[0]) <= tol
