@@ -264,9 +264,10 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   if (wv == CW) {
     // ---- the communication wave -------------------------------------------------------------------------------------
     // What it needs of a row besides `A x` — b[i] (least squares, logistic) or y[i], A_x_prev[i] and the shift of h (the
-    // primal-dual loop) — is loaded at the top of step i, BEFORE this workgroup's partial of row i is published: in the
-    // primal-dual loop member 0 overwrites y[i] and A_x_prev[i] as soon as it has all partials of row i, so a member that
-    // read them after publishing its own could see the new values.  The rows in between wait in h[0 .. DEPTH - 1].
+    // primal-dual loop) — must be read BEFORE this workgroup's partial of row i is published: in the primal-dual loop member 0
+    // overwrites y[i] and A_x_prev[i] once it has all partials of row i, so a member that read them after publishing its own
+    // could see the new values.  Earlier is always safe, and they are read a batch of rows ahead (below).  The rows between
+    // their step and their residual wait in h[0 .. DEPTH - 1].
     TeamRowState h[DEPTH];
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) h[j] = TeamRowState{};
