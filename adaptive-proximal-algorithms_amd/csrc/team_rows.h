@@ -126,9 +126,10 @@ __device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowCon
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Rows too long for one workgroup's registers (10 753 ... 180 224 Float64 entries — BASELINE config C2: 100 000, a row is
-// 800 KB): TEAMS of P = 2 / 4 / 8 / 16 workgroups, one per CU, formed inside an XCD at run time, share a slab of rows.  Member
-// s keeps columns [s n/P, (s+1) n/P) of x (in LDS) and of the column accumulator (in registers) and streams that slice
-// of every row.  A workgroup is eleven COMPUTE waves and one COMMUNICATION wave:
+// 800 KB): TEAMS of P = 2 / 4 / 8 / 16 workgroups, one per CU, formed inside an XCD at run time, share chunks of rows.  Member
+// s keeps its share of the columns — the s-th contiguous P-th of the row, or (teams of four or more) the row's 10 KB pieces s,
+// s + P, s + 2 P, ... — of x (in LDS) and of the column accumulator (in registers) and streams that share of every row.  A
+// workgroup is ten or eleven COMPUTE waves and one COMMUNICATION wave:
 //   * the compute waves form the partial dot product of a row (one barrier per row) and, DEPTH = 2 rows later, take the
 //     row's residual from LDS and accumulate res[i] * A[i, slice] from the registers the row still sits in;
 //   * the communication wave loads no A, so its vector-memory counter is its own (loads return in order per wave: a
