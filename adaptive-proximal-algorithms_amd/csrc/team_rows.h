@@ -264,6 +264,12 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
   const T* __restrict__ X = (const T*)xv;
   if (wv == CW) {
     // ---- the communication wave -------------------------------------------------------------------------------------
+    // It issues AHEAD of the compute waves of its SIMD: everything it does between two barriers is on the workgroup's path whenever
+    // the workgroup is catching up (DESIGN section 4 "What the communication wave waits for"), and in the arbiter's round-robin every
+    // one of its few hundred dependent instructions stood in line behind two waves of FMAs.  C2's kernel 5.80 / 5.84 -> 5.66 / 5.77
+    // ms, C5's shape of round 2 (teams of two, one row of slack) 1.246 -> 1.167, least squares on that matrix 1.165 -> 1.13 (two
+    // builds alternated on one box, profiles/r03_ab_priority.jsonl) ; a workgroup on its own: no difference.
+    __builtin_amdgcn_s_setprio(3);
     // What it needs of a row besides `A x` — b[i] (least squares, logistic) or y[i], A_x_prev[i] and the shift of h (the
     // primal-dual loop) — must be read BEFORE this workgroup's partial of row i is published: in the primal-dual loop member 0
     // overwrites y[i] and A_x_prev[i] once it has all partials of row i, so a member that read them after publishing its own
@@ -932,18 +938,12 @@ inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}, int 
   else if (nvec <= 8 * v6) pl.P = 8;
   else if (nvec <= 16 * v6) pl.P = 16;
   else pl.big = true;
-  // The primal-dual form: the three-slot shape has the whole dual step of a row — a division, the conjugate prox — between two
-  // barriers a single row behind the hand-off, and pays for it (C5's matrix: 6.46 TB/s against 6.95 for least squares in the same
-  // shape).  Twice the members with half the vectors, four slots and two rows of slack absorb it, but cost ~2 % at equal lane fill
-  // (more members per hand-off): taken where they fill their lanes at least 6 % better — 20 000 columns as 4 x 4 x 640 (98 %)
-  // instead of 2 x 8 x 704 (89 %): 1.239 -> 1.202 ms ; 40 000 as teams of eight: 2.545 -> 2.433 ; but 17 000, 18 000, 21 000,
-  // 22 528, 34 000, 45 056 stay (tools/ab.py, profiles/r03_ab_pd_shapes.jsonl).
-  if (tune.pd && pl.big && (pl.P == 2 || pl.P == 4)) {
-    const int64_t nvb = (nvec + pl.P - 1) / pl.P, kvb = (nvb + 703) / 704;
-    const int64_t nvw = (nvec + 2 * pl.P - 1) / (2 * pl.P), kw10 = (nvw + 639) / 640, kw11 = (nvw + 703) / 704;
-    const int64_t slots_b = pl.P * kvb * 704, slots_w = 2 * pl.P * (kw10 == kw11 ? kw10 * 640 : kw11 * 704);
-    if (kw11 <= 6 && 100 * slots_b >= 106 * slots_w) pl.P *= 2, pl.big = false;
-  }
+  // (The primal-dual form in the three-slot shape has the whole dual step of a row — a division, the conjugate prox — between two
+  // barriers a single row behind the hand-off.  Before the communication wave had its priority, twice the members with half the
+  // vectors and two rows of slack were the better shape wherever they filled their lanes 6 % better — 20 000 columns: 1.239 ->
+  // 1.202 ms — and `team_plan` chose by lane fill ; with the priority the wide shape wins at every length measured: 17 000 columns
+  // 1.000 against 1.130 ms, 20 000: 1.154 against 1.214, 22 528: 1.309 against 1.372, 40 000: 2.298 against 2.439 —
+  // profiles/r03_ab_priority.jsonl.  `tune.pd` is still passed: APX_OPT_TEAM_SLOTS applies to the primal-dual form only.)
   // (A/B: a forced team size, where the row still fits its eight vectors per thread and is long enough to be split)
   if (pl.P > 1 && (tune.members == 2 || tune.members == 4 || tune.members == 8 || tune.members == 16) && nvec <= tune.members * v8 &&
       nvec > (int64_t)tune.members * 704) {
