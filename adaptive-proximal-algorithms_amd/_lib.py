@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libadaprox_hip.so")
 
 # ---- enums (include/adaprox_hip.h) ---------------------------------------------------
 APX_OK, APX_ERR_INVALID, APX_ERR_HIP, APX_ERR_UNSUPPORTED, APX_ERR_DOMAIN, APX_ERR_CALLBACK, APX_ERR_COMM = range(7)
-APX_ABI_VERSION = 3
+APX_ABI_VERSION = 4
 APX_COMM_ID_BYTES = 128
 APX_FLAG_TINY_GAMMA, APX_FLAG_NAN_GAMMA, APX_FLAG_DOMAIN, APX_FLAG_TEAM_FALLBACK = 1, 2, 4, 8
 APX_F64, APX_F32 = 0, 1
@@ -68,6 +68,12 @@ class Result(C.Structure):
                 ("prox_h_evals", c_int64), ("A_evals", c_int64), ("At_evals", c_int64), ("n_records", c_int64)]
 
 
+class TeamWaitSlot(C.Structure):
+    _fields_ = [("waits", c_int64), ("long_waits", c_int64), ("max_polls", c_int64), ("max_wait_ns", c_int64),
+                ("at_launch", c_int64), ("at_step", c_int64), ("at_clock_ns", c_int64),
+                ("block", c_int32), ("team", c_int32), ("member", c_int32), ("xcc", c_int32), ("kind", c_int32), ("_pad", c_int32)]
+
+
 class SolveOpts(C.Structure):
     _fields_ = [("records", C.POINTER(Record)), ("record_cap", c_int64), ("use_graph", c_int32),
                 ("poll_every", c_int32)]
@@ -102,6 +108,7 @@ PROTOTYPES = {
     "apx_ctx_get_option": (c_int32, [c_void_p, c_int32, _P(c_int64)]),
     "apx_last_incident": (C.c_char_p, []),
     "apx_problem_team_waits": (c_int32, [c_void_p, _P(c_int64)]),
+    "apx_problem_team_wait_slots": (c_int32, [c_void_p, _P(TeamWaitSlot), c_int32, _P(c_int32)]),
     "apx_ctx_one_pass_threshold": (c_int32, [c_void_p, c_int64]),
     "apx_ctx_auto_transpose": (c_int32, [c_void_p, c_int32]),
     "apx_comm_unique_id": (c_int32, [c_void_p]),

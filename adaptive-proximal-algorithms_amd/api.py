@@ -96,6 +96,8 @@ class Context:
         """apx_ctx_one_pass: 0 = the two GEMV passes, 1 = one pass over A per iteration for large dense matrices (default),
         2 = one pass, but never the team kernels (a GPU shared with other work)."""
         L.check(self._lib.apx_ctx_one_pass(self._h, int(mode)))
+        if int(mode) != 0:
+            self._one_pass_on = int(mode)       # what "on" means for this context (fused_small switches it back on as it was)
         return self
 
     def set_option(self, key: int, value: int):
@@ -128,7 +130,9 @@ class Context:
         problems as two kernels per iteration, csrc/small.hip and its family) and, unless ``one_pass`` says otherwise,
         apx_ctx_one_pass (large matrices: one pass over A per iteration).  The C-ABI has one switch for each."""
         L.check(self._lib.apx_ctx_fused_small(self._h, 1 if enable else 0))
-        L.check(self._lib.apx_ctx_one_pass(self._h, 1 if (enable if one_pass is None else one_pass) else 0))
+        on = enable if one_pass is None else one_pass
+        # (switching it back ON keeps an earlier one_pass(2) — "never the team kernels" — instead of overriding it: ADVICE r3)
+        self.one_pass(getattr(self, "_one_pass_on", 1) if on else 0)
 
     def exploit_sparsity(self, enable: bool = True):
         """Opt-in: `A*x` streams only the columns with x_j != 0 (dense column-major A)."""
@@ -1173,6 +1177,15 @@ class Solver:
         out = (C.c_int64 * 4)()
         self.prob.check(self.prob.lib.apx_problem_team_waits(self.prob.h, out))
         return dict(waits=int(out[0]), max_polls=int(out[1]), max_wait_ns=int(out[2]), team_launches=int(out[3]))
+
+    def team_wait_slots(self) -> list:
+        """apx_problem_team_wait_slots: per workgroup slot of the team launches, where and when it saw its longest hand-off wait
+        (launch, row, team / member / XCD, the device's wall clock) — tools/soak.py tells a queue that was not running (many
+        slots at one moment) from one late workgroup (one team's partners) by it."""
+        buf = (L.TeamWaitSlot * 512)()
+        cnt = C.c_int32()
+        self.prob.check(self.prob.lib.apx_problem_team_wait_slots(self.prob.h, buf, 512, C.byref(cnt)))
+        return [{k: int(getattr(buf[i], k)) for k, _ in L.TeamWaitSlot._fields_ if k != "_pad"} for i in range(min(cnt.value, 512))]
 
     def close(self):
         if getattr(self, "_h", None):

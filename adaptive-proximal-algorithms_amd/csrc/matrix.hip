@@ -322,7 +322,7 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       ctx->team_cooperative = value != 0;
       return APX_OK;
     case APX_OPT_TEAM_FAULT_GRID:
-      APX_REQUIRE(value >= 0 && value <= 256, "APX_OPT_TEAM_FAULT_GRID: 0 (off) ... 256 workgroups");
+      APX_REQUIRE(value >= 0 && value <= 512, "APX_OPT_TEAM_FAULT_GRID: 0 (off) ... 256 workgroups (257 ... 512: with APX_OPT_TEAM_COOPERATIVE only)");
       ctx->team_fault_grid = (int)value;
       return APX_OK;
     case APX_OPT_GEMV_N_VARIANT: return apx_ctx_set_gemv_config(ctx, (int32_t)value, -1, 0, 0);

@@ -863,8 +863,8 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
                   : slab_launch_t<double, APX_F_LOGISTIC>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream);
   }
   APX_TRY(prof_end(ctx));
+  if (!launched) return team_launch_refused(p, "one-pass kernel (teams)");
   APX_HIP(hipGetLastError());
-  if (!launched) return fail(APX_ERR_HIP, "one-pass kernel (teams): the launch was refused (a cooperative launch whose grid cannot be co-resident)");
   *done_here = true;
   return APX_OK;
 }
@@ -902,6 +902,14 @@ int32_t slab_team_waits(apx_problem* p, int64_t out[4]) {
   out[2] *= 10;                                  // ticks of 10 ns
   out[3] = st->team.dev.launch;
   return APX_OK;
+}
+
+// ... slot by slot (apx_problem_team_wait_slots: where and when each workgroup slot saw its longest wait)
+int32_t slab_team_wait_slots(apx_problem* p, const TeamWait** slots) {
+  *slots = nullptr;
+  SlabState* st = p->slab;
+  if (st == nullptr || st->plan.P <= 1) return APX_OK;
+  return team_read_wait_slots(p->ctx, &st->team, slots);
 }
 
 }  // namespace apx

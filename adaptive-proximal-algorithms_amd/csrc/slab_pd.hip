@@ -343,7 +343,7 @@ int32_t slab_pd_setup(apx_solver* s) {
 }
 
 template <typename T>
-static void slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev& d, const void* x, void* aty, apx_record* recs,
+static bool slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev& d, const void* x, void* aty, apx_record* recs,
                              int64_t rec_cap, hipStream_t q) {
   const dim3 grid((unsigned)st->B);
   constexpr bool f32 = sizeof(T) == 4;
@@ -352,15 +352,16 @@ static void slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
     else multi_launch<T, kTeamFkPd, false, SlabPdDev>(d.n, st->B, st->multi_waves, d, x, q);
     hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
                        d, st->B * multi_groups(d.n, 16 / (int)sizeof(T)), (T*)aty, recs, rec_cap);
-    return;
+    return true;
   }
   if (st->plan.kv != 0) {
+    bool ok = true;
     if constexpr (!f32) {
-      team_launch<kTeamFkPd, SlabPdDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+      ok = team_launch<kTeamFkPd, SlabPdDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
       hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
                          d, st->B, (T*)aty, recs, rec_cap);
     }
-    return;
+    return ok;
   }
   // two row groups in flight only where it measured faster here — Float32 at two columns per thread (400 000 x 2000: 0.572 ->
   // 0.552 ms) ; with the per-row state of y and A_x_prev on top of the rows, the other shapes lose (200 000 x 5000 fp64
@@ -392,6 +393,7 @@ static void slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
   }
   hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q, d,
                      st->B, (T*)aty, recs, rec_cap);
+  return true;
 }
 
 // what gemv_n(A, x) + the dual step + gemv_t(A, y) leave behind: y, A_x_prev updated, At_y in s->aty, the iteration closed.
@@ -421,9 +423,11 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   }
   ctx->kname[APX_KSTAT_ONE_PASS] = st->kname;
   APX_TRY(prof_begin(ctx, APX_KSTAT_ONE_PASS, (double)p->A_lin->m * (double)p->A_lin->n * (double)p->es()));
-  if (p->dtype == APX_F32) slab_pd_launch_t<float>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
-  else slab_pd_launch_t<double>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
+  const bool launched =
+      p->dtype == APX_F32 ? slab_pd_launch_t<float>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream)
+                          : slab_pd_launch_t<double>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
   APX_TRY(prof_end(ctx));
+  if (!launched) return team_launch_refused(p, "one-pass primal-dual kernel (teams)");
   APX_HIP(hipGetLastError());
   *done_here = true;
   return APX_OK;
@@ -453,6 +457,13 @@ int32_t slab_pd_team_waits(apx_solver* s, int64_t out[4]) {
   out[2] *= 10;                                    // ticks of 10 ns
   out[3] = st->team.dev.launch;
   return APX_OK;
+}
+
+int32_t slab_pd_team_wait_slots(apx_solver* s, const TeamWait** slots) {
+  *slots = nullptr;
+  SlabPdState* st = s->slab_pd;
+  if (st == nullptr || st->plan.P <= 1) return APX_OK;
+  return team_read_wait_slots(s->p->ctx, &st->team, slots);
 }
 
 }  // namespace apx

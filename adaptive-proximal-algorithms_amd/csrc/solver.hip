@@ -414,6 +414,39 @@ int32_t apx_problem_team_waits(apx_problem* p, int64_t* out) {
   return APX_OK;
 }
 
+int32_t apx_problem_team_wait_slots(apx_problem* p, apx_team_wait_slot* out, int32_t cap, int32_t* count) {
+  APX_REQUIRE(p != nullptr && count != nullptr && cap >= 0 && (out != nullptr || cap == 0), "apx_problem_team_wait_slots: bad argument");
+  APX_HIP(hipSetDevice(p->ctx->device));
+  *count = 0;
+  for (int kind = 0; kind < 2; ++kind) {
+    const TeamWait* w = nullptr;
+    if (kind == 0) APX_TRY(slab_team_wait_slots(p, &w));
+    else if (p->active != nullptr) APX_TRY(slab_pd_team_wait_slots(p->active, &w));
+    if (w == nullptr) continue;
+    for (int b = 0; b < 256; ++b) {
+      if (w[b].waits == 0) continue;
+      if (*count < cap) {
+        apx_team_wait_slot& o = out[*count];
+        o.waits = w[b].waits;
+        o.long_waits = w[b].long_waits;
+        o.max_polls = w[b].max_polls;
+        o.max_wait_ns = (int64_t)w[b].max_ticks * 10;
+        o.at_launch = w[b].at_launch;
+        o.at_step = w[b].at_step;
+        o.at_clock_ns = (int64_t)w[b].at_clock * 10;
+        o.block = b;
+        o.team = w[b].team;
+        o.member = w[b].member;
+        o.xcc = w[b].xcc;
+        o.kind = kind;
+        o._pad = 0;
+      }
+      *count += 1;       // (the number there is to report, also beyond cap)
+    }
+  }
+  return APX_OK;
+}
+
 int32_t apx_pullback(apx_problem* p, void* grad) {
   APX_REQUIRE(p != nullptr && grad != nullptr, "apx_pullback: NULL argument");
   APX_REQUIRE(p->active == nullptr, "apx_pullback: a solver is active on this problem");
@@ -606,6 +639,9 @@ static int32_t enqueue_iteration(apx_solver* s) {
     s->red_ready = true;
     return APX_OK;
   }
+  // (APX_OPT_FUSED_TAIL is read per iteration: once it is off, nothing refreshes red_own, and the next iteration must take
+  //  its reductions from the vectors again — ADVICE r3)
+  s->red_ready = false;
   APX_TRY(vo_step(ctx, p->dtype, s->x.p, s->xprev.p, p->grad.p, s->gprev.p, s->v.p, lin ? s->aty.p : nullptr, p->n,
                   p->gd, p->ctrl()));                                          // :359-361
   return APX_OK;
@@ -673,7 +709,13 @@ int32_t apx_solver_step(apx_solver* s, int64_t iters, int32_t sync) {
   if (s->use_graph && s->graph_exec == nullptr && iters > 0 && !s->stopped) APX_TRY(capture_iteration(s));
   for (int64_t k = 0; k < iters && !s->stopped; ++k) {
     if (s->graph_exec != nullptr) APX_HIP(hipGraphLaunch(s->graph_exec, s->p->ctx->stream));
-    else APX_TRY(enqueue_iteration(s));
+    else {
+      const int32_t rc = enqueue_iteration(s);
+      if (rc != APX_OK) {
+        if (s->p->team_failed) s->poisoned = true;    // (a refused team launch cut the iteration short: the iterate is not one)
+        return rc;
+      }
+    }
     s->iters += 1;
     if (cb || (s->iters % s->poll_every) == 0) {
       bool done = false;

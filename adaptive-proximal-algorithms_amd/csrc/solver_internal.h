@@ -6,6 +6,7 @@
 
 #include "apx_internal.h"
 #include "vecops.h"
+#include "team_dev.h"
 
 namespace apx {
 struct SlabState;          // (slab.hip: f and grad f in one pass over A)
@@ -243,6 +244,19 @@ inline int32_t with_team_fallback(apx_problem* p, apx_result* res, F&& run) {
   return rc;
 }
 
+// A team launch the runtime refused (a cooperative launch — APX_OPT_TEAM_COOPERATIVE — whose grid cannot be co-resident): nothing
+// ran, the launch and sequence counters stayed where they were (team_launch), and the problem is taken off the team kernels
+// like after a failed hand-off, so the one-shot entry points run again on the two passes instead of asking again.
+inline int32_t team_launch_refused(apx_problem* p, const char* which) {
+  const hipError_t e = hipGetLastError();        // (clears the sticky launch error)
+  p->team_failed = true;
+  const std::string what = std::string(which) + ": the launch was refused (" + (e != hipSuccess ? hipGetErrorString(e) : "no HIP error on record") +
+                           ") — a cooperative launch whose grid cannot be co-resident on this device. Nothing ran ; the problem now runs on "
+                           "the two GEMV passes (apx_ctx_one_pass(ctx, 2) keeps every new problem off the team kernels).";
+  note_incident(what);
+  return fail(APX_ERR_HIP, what);
+}
+
 int32_t h2d(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t d2h(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
 // `f_x, pb = eval_with_pullback(f, x)` on a device x (need_f: f_x final in Ctrl on return to the stream)
@@ -270,12 +284,14 @@ int32_t slab_pd_setup(apx_solver* s);
 int32_t slab_pd_iteration(apx_solver* s, bool* done_here);
 int32_t slab_pd_check(apx_solver* s);
 int32_t slab_pd_team_waits(apx_solver* s, int64_t out[4]);
+int32_t slab_pd_team_wait_slots(apx_solver* s, const TeamWait** slots);
 bool slab_pd_uses_teams(const apx_solver* s);
 bool slab_uses_teams(const apx_problem* p);   // (team kernels: host-side launch counters — no hipGraph replay)      // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP
 // slab.hip: true when f and grad f at x_dev were formed in one pass over A (f -> Ctrl, grad -> p->grad)
 int32_t slab_eval_with_gradient(apx_problem* p, const void* x_dev, bool* done_here);
 int32_t slab_check(apx_problem* p);        // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP
 int32_t slab_team_waits(apx_problem* p, int64_t out[4]);
+int32_t slab_team_wait_slots(apx_problem* p, const TeamWait** slots);
 // sum of a scalar over the ranks of a row-sharded problem (the value itself otherwise): what the ranks agree on paths with
 int32_t ranks_sum(apx_problem* p, double local, double* total);
 bool skinny_pg_eligible(const apx_problem* p);

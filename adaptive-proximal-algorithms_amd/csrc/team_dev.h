@@ -42,9 +42,17 @@ struct TeamDiag {
 };
 
 // Longest hand-off wait a workgroup slot has seen (statistics: how close to the bound normal operation comes)
+// ... and WHERE and WHEN it saw it (round 4): whether the long waits sit at a launch's first rows or in mid-stream, and whether
+// many slots have theirs at the same moment (the whole queue was not running: every polling wave sees the gap) or only the
+// partners of one member (that member's wave was late) is what tells a preempted queue from a slow workgroup — tools/soak.py.
 struct TeamWait {
   unsigned long long max_ticks;
+  unsigned long long at_clock;  // s_memrealtime (10 ns ticks) when the longest wait ended
   unsigned max_polls, waits;    // waits: hand-offs that were not there at the first look
+  unsigned long_waits;          // of them, those that took more than 100 us
+  unsigned at_launch;           // the problem's team launch in which the longest wait happened
+  int32_t at_step;              // ... the row of the team's deal it waited for
+  int32_t team, member, xcc;    // ... and who the slot's workgroup was in that launch
 };
 
 // How the rows of A are dealt to the workgroups (teams) of a one-pass launch.  Round 2 gave each a SLAB of consecutive rows: the

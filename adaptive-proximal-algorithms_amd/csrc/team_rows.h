@@ -283,6 +283,8 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
     bool dead = false;
     [[maybe_unused]] unsigned w_waits = 0, w_polls = 0;              // hand-offs that were not there at the first look ; the longest
     [[maybe_unused]] unsigned long long w_ticks = 0;                 // of them, in polls and in 10 ns ticks (TeamWait: statistics)
+    [[maybe_unused]] unsigned w_long = 0;                            // ... those of more than 100 us
+    [[maybe_unused]] long long w_row = -1, w_clock = 0;              // ... the row the longest one waited for, the clock when it ended
     [[maybe_unused]] double own_prev = 0.0;        // P = 1: the workgroup's own row sum, one step later
     // The P records of a row are taken on the SCALAR path: P / 4 loads of 64 bytes (`s_load_dwordx16 ... glc`: past the
     // scalar cache, from the XCD's L2 — the teams are formed inside an XCD, and the members' agent-scope stores pass
@@ -400,10 +402,12 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
               }
               __builtin_amdgcn_s_sleep(1);
             }
-            const unsigned long long waited = (unsigned long long)(wall_clock64() - t0);
+            const long long t1 = wall_clock64();
+            const unsigned long long waited = (unsigned long long)(t1 - t0);
             w_waits += 1;
+            w_long += waited > 10000ull ? 1u : 0u;
             w_polls = max(w_polls, (unsigned)polls);
-            w_ticks = waited > w_ticks ? waited : w_ticks;
+            if (waited > w_ticks) w_ticks = waited, w_row = r, w_clock = t1;
           }
           // the P partials added in a fixed pairwise tree, from the same P records on every member: the same `A x` bit for bit
           double part[P];
@@ -475,8 +479,17 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       if (lane == 0 && w_waits != 0) {             // (this launch's only writer of the slot ; launches are serialised)
         TeamWait* w = t.wait + blockIdx.x;
         w->waits += w_waits;
+        w->long_waits += w_long;
         w->max_polls = max(w->max_polls, w_polls);
-        w->max_ticks = w_ticks > w->max_ticks ? w_ticks : w->max_ticks;
+        if (w_ticks > w->max_ticks) {
+          w->max_ticks = w_ticks;
+          w->at_clock = (unsigned long long)w_clock;
+          w->at_launch = t.launch;
+          w->at_step = (int32_t)w_row;
+          w->team = team;
+          w->member = s;
+          w->xcc = ident[3];
+        }
       }
     }
     return;
@@ -991,7 +1004,11 @@ struct TeamCall {
 // (TeamDev::fault_grid: a TEST hook — launches that many workgroups instead of all of them, so that some teams miss members:
 //  what a GPU shared with other work does to this scheme.  tests/test_gpu_team_fault.py checks that the waits time out,
 //  the grid drains and the error comes back)
-inline unsigned team_grid(const TeamDev& t, int nteams, int P) { return (unsigned)(t.fault_grid > 0 && P > 1 ? t.fault_grid : nteams * P); }
+//  (more than 256, with APX_OPT_TEAM_COOPERATIVE only: a grid that cannot be co-resident — the runtime refuses the launch)
+inline unsigned team_grid(const TeamDev& t, int nteams, int P, bool cooperative) {
+  const bool hook = t.fault_grid > 0 && P > 1 && (t.fault_grid <= 256 || cooperative);
+  return (unsigned)(hook ? t.fault_grid : nteams * P);
+}
 template <int FK, int P, int KV, bool NT, int G, int DEPTH, class DEV, int CW, typename T = double>
 inline void team_launch_one(TeamCall& call, int nteams, const DEV& d, const TeamDev& t, const void* x, hipStream_t q) {
   constexpr size_t lds = (size_t)KV * CW * 64 * 2 * sizeof(double);      // the slice of x
@@ -1007,7 +1024,7 @@ inline void team_launch_one(TeamCall& call, int nteams, const DEV& d, const Team
     call.blocks_per_cu = nb;
     return;
   }
-  const dim3 grid(team_grid(t, nteams, P)), block(kThreads);
+  const dim3 grid(team_grid(t, nteams, P, call.cooperative)), block(kThreads);
   if (call.cooperative && P > 1) {
     DEV dd = d;
     TeamDev tt = t;
@@ -1110,9 +1127,10 @@ inline bool team_launch(const TeamPlan& pl, int nteams, bool nt, bool cooperativ
   TeamCall call;
   call.cooperative = cooperative;
   const bool ok = team_dispatch<FK, DEV, T>(call, pl, nteams, nt, d, t, x, q) && call.launch_error == hipSuccess;
+  if (!ok) return false;    // (nothing ran: no tickets were drawn, no sequence word used — the ranges stay where they are)
   t.launch += 1;
   t.seq0 += (unsigned long long)t.rows_per_team + (1u << t.chunk_log) + 16;      // (> the steps of a launch: the sequence words never repeat)
-  return ok;
+  return true;
 }
 // workgroups of this plan's kernel that fit one CU at once (0: the runtime could not say, or none)
 template <int FK, class DEV, typename T = double>
@@ -1168,6 +1186,13 @@ inline int32_t team_read_err(apx_ctx* ctx, TeamHost* th, int32_t* err) {
     APX_HIP(hipMemcpyAsync(&th->pinned->diag, th->dev.diag, sizeof(TeamDiag), hipMemcpyDeviceToHost, ctx->stream));
     APX_HIP(hipStreamSynchronize(ctx->stream));
   }
+  return APX_OK;
+}
+// the slots' records as they are (apx_problem_team_wait_slots) ; valid until the next read
+inline int32_t team_read_wait_slots(apx_ctx* ctx, TeamHost* th, const TeamWait** slots) {
+  APX_HIP(hipMemcpyAsync(th->pinned->wait, th->dev.wait, sizeof(th->pinned->wait), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  *slots = th->pinned->wait;
   return APX_OK;
 }
 // the longest hand-off wait any workgroup slot has seen so far (polls, 10 ns ticks) and the number of waits

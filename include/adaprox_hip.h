@@ -33,10 +33,11 @@
 extern "C" {
 #endif
 
-#define APX_ABI_VERSION 3   /* 2: apx_problem_desc.comm, apx_comm_*, APX_ERR_COMM
+#define APX_ABI_VERSION 4   /* 2: apx_problem_desc.comm, apx_comm_*, APX_ERR_COMM
                                3: apx_ctx_one_pass, apx_ctx_set_option / get_option, APX_KSTAT_ONE_PASS + apx_ctx_kernel_name,
                                   APX_FLAG_TEAM_FALLBACK, apx_last_incident, apx_problem_team_waits ; apx_ctx_fused_small no
-                                  longer switches the one-pass kernels ; no environment variables are read any more */
+                                  longer switches the one-pass kernels ; no environment variables are read any more
+                               4: apx_problem_team_wait_slots (additive: everything of version 3 is unchanged) */
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -281,7 +282,8 @@ enum {
   APX_OPT_TEAM_COOPERATIVE = 4,  /* default 0 ; 1: team kernels through hipLaunchCooperativeKernel (the runtime refuses a grid
                                     that cannot be co-resident ; measured no faster and not needed: DESIGN.md section 9)     */
   APX_OPT_TEAM_FAULT_GRID = 5,   /* TEST hook, default 0: launch this many of a team launch's 256 workgroups, so that teams
-                                    miss members (tests/test_gpu_team_fault.py)                                            */
+                                    miss members (tests/test_gpu_team_fault.py) ; 257 ... 512 (with APX_OPT_TEAM_COOPERATIVE
+                                    only): a grid that cannot be co-resident, which the runtime refuses to launch          */
   APX_OPT_GEMV_N_VARIANT = 6, APX_OPT_GEMV_T_VARIANT = 7, APX_OPT_GEMV_N_BLOCKS = 8, APX_OPT_GEMV_T_BLOCKS = 9,
                                  /* = apx_ctx_set_gemv_config, one field at a time (tools/gemv_sweep.py)                    */
   APX_OPT_FUSED_TAIL = 10,       /* default 1: the residual / step-size reductions and the rule ride in the closing kernel of a
@@ -402,6 +404,25 @@ int32_t apx_pullback(apx_problem* p, void* grad);
  * out[3] = team launches ; all 0 for a problem that runs no team kernels.  (tools/soak.py: how close normal operation comes to
  * the bound of APX_OPT_TEAM_WAIT_MS.) */
 int32_t apx_problem_team_waits(apx_problem* p, int64_t* out /* [4] */);
+/* The same statistics per WORKGROUP SLOT of the team launches, with where and when each slot saw its longest wait (ABI 4): up to
+ * `cap` records of the slots that waited at all, *count = how many there are.  Many slots with their longest wait at the same
+ * launch and clock: the whole queue was not running (every polling wave sees the gap) ; only the partners of one member: that
+ * member's workgroup was late.  tools/soak.py prints the clusters ; DESIGN.md section 9. */
+typedef struct apx_team_wait_slot {
+  int64_t waits;          /* hand-offs that were not complete at the first look                              */
+  int64_t long_waits;     /* ... of them, longer than 100 us                                                 */
+  int64_t max_polls;      /* the most polls one of them took                                                  */
+  int64_t max_wait_ns;    /* the longest one                                                                  */
+  int64_t at_launch;      /* the problem's team launch in which the longest one happened (0-based)            */
+  int64_t at_step;        /* ... the row of the team's deal it waited for                                     */
+  int64_t at_clock_ns;    /* ... the device's wall clock (s_memrealtime) when it ended                        */
+  int32_t block;          /* the slot: blockIdx.x                                                             */
+  int32_t team, member;   /* what that workgroup was in that launch (teams form at run time, by XCD)          */
+  int32_t xcc;            /* ... and the XCD it ran on                                                        */
+  int32_t kind;           /* 0: f's one-pass kernel, 1: the primal-dual loop's                                */
+  int32_t _pad;
+} apx_team_wait_slot;
+int32_t apx_problem_team_wait_slots(apx_problem* p, apx_team_wait_slot* out, int32_t cap, int32_t* count);
 /* `y, g_y = prox(g, v, gamma)` (ProximalCore.prox); conj != 0 applies convex_conjugate(desc) */
 int32_t apx_prox(apx_ctx* ctx, const apx_prox_desc* desc, int32_t conj, int32_t dtype,
                  const void* v, int64_t n, double gamma, void* y, double* g_y);

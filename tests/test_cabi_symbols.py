@@ -60,6 +60,8 @@ int main(void) {
          offsetof(apx_problem_desc, A_lin), offsetof(apx_problem_desc, allreduce), offsetof(apx_problem_desc, shard_mask),
          offsetof(apx_problem_desc, comm));
   printf("%zu %zu %zu\n", offsetof(apx_result, f_evals), offsetof(apx_result, n_records), offsetof(apx_rule, xi));
+  printf("%zu %zu %zu %zu\n", sizeof(apx_team_wait_slot), offsetof(apx_team_wait_slot, at_clock_ns), offsetof(apx_team_wait_slot, block),
+         offsetof(apx_team_wait_slot, kind));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -73,6 +75,8 @@ int main(void) {
                     L.ProblemDesc.allreduce.offset, L.ProblemDesc.shard_mask.offset, L.ProblemDesc.comm.offset]
     offs = list(map(int, lines[2].split()))
     assert offs == [L.Result.f_evals.offset, L.Result.n_records.offset, L.Rule.xi.offset]
+    slot = list(map(int, lines[3].split()))
+    assert slot == [C.sizeof(L.TeamWaitSlot), L.TeamWaitSlot.at_clock_ns.offset, L.TeamWaitSlot.block.offset, L.TeamWaitSlot.kind.offset]
 
 
 def test_header_is_plain_c_and_cites_the_reference():

@@ -108,3 +108,64 @@ def test_the_same_child_without_the_fault_is_fine():
     assert "WARNINGS 0" in out.stdout, out.stdout
     line = [l for l in out.stdout.splitlines() if l.startswith("ONE-SHOT")][0].split()
     assert line[2] == "3" and int(line[5]) == 0, out.stdout           # one pass over A per evaluation: no gemv_t
+
+
+REFUSED = r"""
+import sys, warnings
+sys.path.insert(0, %r)
+import numpy as np
+import adaprox_amd as apx
+from importlib import import_module
+L = import_module("adaptive-proximal-algorithms_amd._lib")
+ctx = apx.Context(0)
+ctx.one_pass_threshold(16 << 20)
+ctx.set_option(L.APX_OPT_TEAM_COOPERATIVE, 1)
+ctx.set_option(L.APX_OPT_TEAM_FAULT_GRID, 512)      # twice what can be co-resident: hipLaunchCooperativeKernel refuses
+m, n = 4300, 12000
+A = apx.DeviceMatrix.uniform(m, n, seed=5, ctx=ctx).build_transpose()
+b = np.random.default_rng(0).standard_normal(m)
+f = apx.LinearLeastSquares(A, b, ctx=ctx)
+try:
+    s = apx.Solver(np.zeros(n), f=f, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, ctx=ctx)
+    s.step(2, sync=True)
+    print("STEPPING: NO ERROR")
+except apx.ApxError as e:
+    print("STEPPING ERROR:", e)
+f2 = apx.LinearLeastSquares(A, b, ctx=ctx)
+ctx.kernel_stats(reset=True); ctx.profile(True)
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter("always")
+    x, it = apx.adaptive_proxgrad(np.zeros(n), f=f2, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=3, ctx=ctx)
+    x3, it3 = apx.adaptive_proxgrad(np.zeros(n), f=f2, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=3, ctx=ctx)
+print("WARNINGS", len([w for w in caught if "APX_FLAG_TEAM_FALLBACK" in str(w.message)]))
+print("INCIDENT:", apx.last_incident())
+st = ctx.kernel_stats(reset=True); ctx.profile(False)
+ctx2 = apx.Context(0); ctx2.fused_small(False)
+A2 = apx.DeviceMatrix.uniform(m, n, seed=5, ctx=ctx2)
+xr, _ = apx.adaptive_proxgrad(np.zeros(n), f=apx.LinearLeastSquares(A2, b, ctx=ctx2), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7),
+                              tol=0.0, maxit=3, ctx=ctx2)
+print("ONE-SHOT it", it, it3, "gemv_t launches", st["gemv_t"]["launches"], "max diff vs two-pass context", float(max(np.max(np.abs(x - xr)), np.max(np.abs(x3 - xr)))))
+# ... and with the hook off the cooperative launch itself is fine (the ranges of tickets and sequence words did not move
+# with the refused launches: a launch that follows them draws ticket 0 ... 31 of launch 0 on every XCD)
+ctx.set_option(L.APX_OPT_TEAM_FAULT_GRID, 0)
+f4 = apx.LinearLeastSquares(A, b, ctx=ctx)
+ctx.kernel_stats(reset=True); ctx.profile(True)
+x4, _ = apx.adaptive_proxgrad(np.zeros(n), f=f4, g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-7), tol=0.0, maxit=3, ctx=ctx)
+st4 = ctx.kernel_stats(reset=True); ctx.profile(False)
+print("COOPERATIVE gemv_t launches", st4["gemv_t"]["launches"], "one_pass", st4["one_pass"]["launches"], "diff", float(np.max(np.abs(x4 - xr)) / np.max(np.abs(xr))))
+"""
+
+
+def test_a_refused_cooperative_launch_takes_the_problem_off_the_team_kernels():
+    """a team launch the runtime refuses (APX_OPT_TEAM_COOPERATIVE with a grid that cannot be co-resident — the test
+    hook asks for 512 workgroups) ran nothing: the launch / sequence counters must not advance, the error is APX_ERR_HIP with
+    the problem marked failed, the one-shot entry point runs again on the two passes and says so (each call of the Python
+    mirror builds a problem of its own: two calls, two refusals, two warnings)."""
+    out = subprocess.run([sys.executable, "-c", REFUSED % ROOT], env=dict(os.environ), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr[-2000:]
+    assert "STEPPING ERROR:" in out.stdout and "the launch was refused" in out.stdout, out.stdout
+    assert "WARNINGS 2" in out.stdout and "INCIDENT: one-pass kernel (teams): the launch was refused" in out.stdout, out.stdout
+    line = [l for l in out.stdout.splitlines() if l.startswith("ONE-SHOT")][0].split()
+    assert line[2] == "3" and line[3] == "3" and int(line[6]) == 8 and float(line[-1]) <= 1e-12, out.stdout
+    coop = [l for l in out.stdout.splitlines() if l.startswith("COOPERATIVE")][0].split()
+    assert int(coop[3]) == 0 and int(coop[5]) == 4 and float(coop[-1]) < 1e-10, out.stdout

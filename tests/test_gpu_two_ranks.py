@@ -66,18 +66,12 @@ def test_row_sharded_primal_dual():
     assert out.stdout.count("PD-SHARDED") == 2
 
 
-def test_bench_starts_its_own_ranks_and_survives_the_team_kernels_on_a_shared_gpu():
-    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command): the script starts its two
-    ranks itself, before anything has touched the GPU, and rank 0 prints ONE JSON line with n_gpus = 2.  The shards (4200 x 12000
-    fp64) are on the team kernels' path, and two processes that share one GPU are exactly what those kernels cannot have:
-    their launches interleave on the CUs and hand-offs may fail.  Whatever happens — clean, or a failure that the library
-    makes visible on BOTH ranks at the same call, after which both repeat the steps on the two GEMV passes — the job ends with
-    a number, the same 13 iterations as one rank on the whole matrix, and says which path it timed."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APX_BENCH_SHARE_GPU="1")
+def _own_ranks(rows, cols, env_extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APX_BENCH_SHARE_GPU="1", **env_extra)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    common = ["--cols", "12000", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", "4200"] + common, cwd=ROOT, env=env,
+    common = ["--cols", str(cols), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", str(rows)] + common, cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -85,11 +79,32 @@ def test_bench_starts_its_own_ranks_and_survives_the_team_kernels_on_a_shared_gp
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "row-shard x2"
     assert "launching 2 ranks" in out.stderr
-    passes = two["roofline"]["passes_over_A_per_iter"]
-    assert (passes == 1.0) != ("note_team_kernels" in two), two          # one pass, or the two passes WITH the note
-    one = _bench(["--rows", "8400"] + common, {}, 1)
+    one = _bench(["--rows", str(2 * rows)] + common, {}, 1)
     assert two["lasso_optimum"] == pytest.approx(one["lasso_optimum"], rel=1e-12)
     assert two["final_objective"] == pytest.approx(one["final_objective"], rel=1e-10)
+    return two, out.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command): the script starts its two
+    ranks itself, before anything has touched the GPU, and rank 0 prints ONE JSON line with n_gpus = 2 — the same 13
+    iterations as one rank on the whole matrix.  Launcher only: the shards (4200 x 6000 fp64, one workgroup per row) are NOT on
+    the team kernels' path, which two processes sharing one GPU cannot have (the outcome must not depend on how
+    their launches happen to interleave)."""
+    two, _ = _own_ranks(4200, 6000, {})
+    assert two["roofline"]["passes_over_A_per_iter"] == 1.0 and "note_team_kernels" not in two, two
+
+
+def test_a_team_failure_on_one_rank_is_a_fallback_on_both():
+    """The multi-rank fallback, deterministically: rank 1 launches 248 of its team kernels' 256 workgroups (the test
+    hook of tests/test_gpu_team_fault.py, through APX_BENCH_RANK_OPTIONS) with a 50 ms bound, so ITS hand-offs fail whatever
+    rank 0's do.  The library sums the error word over the ranks where it reads it: both ranks get the failure from the same
+    call, both report it, both repeat warm-up and timed steps on the two GEMV passes — the collectives stay matched, the job
+    ends with a number and the line says which path it timed."""
+    two, err = _own_ranks(4200, 12000, {"APX_BENCH_RANK_OPTIONS": "1:TEAM_FAULT_GRID=248,TEAM_WAIT_MS=50"})
+    assert two["roofline"]["passes_over_A_per_iter"] == 2.0 and "note_team_kernels" in two, two
+    assert "bench.py rank 0:" in err and "bench.py rank 1:" in err, err[-3000:]
+    assert "a hand-off wait expired" in err, err[-3000:]
 
 
 def test_ranks_agree_on_the_path_when_only_one_shard_is_eligible():
