@@ -201,7 +201,10 @@ __global__ __launch_bounds__(BS) void k_slabpd_rows(SlabPdDev d, const void* xv)
 // end of the iteration (:347-354) by block 0
 constexpr int kSlabPdCloseCols = 64;
 constexpr int kSlabPdCloseBlock = 1024;            // (sixteen threads per column: all of a thread's loads in flight at once — csrc/slab.hip)
-template <typename T>
+// L2 (h = NormL2, round 4): the launch left A' z and sum z^2 (csrc/team_rows.h team_pd_dual) ; EVERY block adds up the B
+// partial sums of z^2 — in one fixed order, so all of them scale by the same factor —, A' y+ = sigma (1 - sc) A' z, and the
+// end of the iteration waits for k_dual_post, which forms y+ and the dual residual from the norm left in Ctrl::h_pre.
+template <typename T, bool L2 = false>
 __global__ __launch_bounds__(kSlabPdCloseBlock) void k_slabpd_close(SlabPdDev d, int B, T* __restrict__ aty, apx_record* recs, int64_t rec_cap) {
   constexpr int S = kSlabPdCloseBlock / kSlabPdCloseCols;
   __shared__ double fs[2];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kSlabPdCloseBlock) void k_slabpd_close(SlabPdDev d,
   const int c = tid % kSlabPdCloseCols, sl = tid / kSlabPdCloseCols;
   const int j = blockIdx.x * kSlabPdCloseCols + c;
   const double part_sum = j < d.n ? skinny_strided_sum(d.part, d.ldpart, j, sl, S, B) : 0.0;
-  if (blockIdx.x == 0 && tid < 128) {
+  if ((L2 || blockIdx.x == 0) && tid < 128) {
     const int which = tid >> 6, lane = tid & 63;
     double s = 0.0;
     for (int b = lane; b < B; b += 64) s += d.part[(int64_t)b * d.ldpart + d.n + which];
@@ -224,14 +227,29 @@ __global__ __launch_bounds__(kSlabPdCloseBlock) void k_slabpd_close(SlabPdDev d,
     double g = sub[0][c];
 #pragma unroll
     for (int k = 1; k < S; ++k) g += sub[k][c];
+    if constexpr (L2) {
+      const double sigma = d.c->sigma, aux = sqrt(fs[0]);
+      const double sc = fmax(0.0, 1.0 - d.h.lambda * (1.0 / sigma) / aux);                 // csrc/vecops_dev.h prox_core, gamma = 1 / sigma
+      g *= sigma * (1.0 - sc);
+    }
     aty[j] = (T)g;                                                                         // :358  At_y = A' * y
   }
   if (blockIdx.x == 0 && tid == 0) {
-    const double ndr = sqrt(fs[0]);
-    d.c->ndr2 = ndr * ndr;
-    d.c->h_Ax = gval_final(d.h, fs[1]);
-    finish_iteration(d.c, recs, rec_cap);                                                  // :348-354
+    if constexpr (L2) {
+      d.c->h_pre = sqrt(fs[0]);                                                            // ||z||: what k_dual_post's conjugate prox scales by
+    } else {
+      const double ndr = sqrt(fs[0]);
+      d.c->ndr2 = ndr * ndr;
+      d.c->h_Ax = gval_final(d.h, fs[1]);
+      finish_iteration(d.c, recs, rec_cap);                                                // :348-354
+    }
   }
+}
+template <typename T>
+static void slabpd_close_launch(const SlabPdDev& d, int nparts, T* aty, apx_record* recs, int64_t rec_cap, hipStream_t q) {
+  const dim3 grid((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols));
+  if (d.h.kind == APX_G_L2) hipLaunchKernelGGL((k_slabpd_close<T, true>), grid, dim3(kSlabPdCloseBlock), 0, q, d, nparts, aty, recs, rec_cap);
+  else hipLaunchKernelGGL((k_slabpd_close<T, false>), grid, dim3(kSlabPdCloseBlock), 0, q, d, nparts, aty, recs, rec_cap);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -274,7 +292,10 @@ static bool slab_pd_shape_ok(const apx_problem* p) {
   if (!p->ctx->one_pass) return false;
   if (p->A_lin == nullptr || p->sharded()) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
-  if (p->hd.kind == APX_G_L2) return false;        // (its conjugate prox needs a norm over all rows first)
+  // (h = NormL2: its conjugate prox needs a norm over all rows first, but is linear in the rows once the norm is known — the
+  //  kernels of csrc/team_rows.h leave A' z and sum z^2 and the closing kernel scales, round 4 ; the first-generation row kernels
+  //  of this file do not)
+  if (p->hd.kind == APX_G_L2 && (slab_pd_shape(p).cpt != 27 && slab_pd_shape(p).cpt != 28)) return false;
   if ((double)p->A_lin->m * (double)p->A_lin->n * (double)p->es() < (double)p->ctx->one_pass_min_bytes) return false;   // (see slab.hip)
   // (very short rows: with two columns per thread the two passes were faster below 512 entries — 130: 7.0 against 8.8 ms at
   //  6 GB ; with one column per thread and sixteen rows per step: 130: 5.5, 200: 3.6, 450: 1.9 ms against 7.0, 4.9, 2.8)
@@ -350,16 +371,14 @@ static bool slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
   if (st->cpt == 27) {                             // k_multi_rows: H rows per step, the dual steps of a step in the row wave's lanes
     if (st->nt) multi_launch<T, kTeamFkPd, true, SlabPdDev>(d.n, st->B, st->multi_waves, d, x, q);
     else multi_launch<T, kTeamFkPd, false, SlabPdDev>(d.n, st->B, st->multi_waves, d, x, q);
-    hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
-                       d, st->B * multi_groups(d.n, 16 / (int)sizeof(T)), (T*)aty, recs, rec_cap);
+    slabpd_close_launch<T>(d, st->B * multi_groups(d.n, 16 / (int)sizeof(T)), (T*)aty, recs, rec_cap, q);
     return true;
   }
   if (st->plan.kv != 0) {
     bool ok = true;
     if constexpr (!f32) {
       ok = team_launch<kTeamFkPd, SlabPdDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
-      hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q,
-                         d, st->B, (T*)aty, recs, rec_cap);
+      slabpd_close_launch<T>(d, st->B, (T*)aty, recs, rec_cap, q);
     }
     return ok;
   }
@@ -391,8 +410,7 @@ static bool slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
     else if (st->cpt == 10) hipLaunchKernelGGL((k_slabpd_rows<T, 10, (f32 ? 4 : 2), 768, false, false>), grid, dim3(768), 0, q, d, x);
     else hipLaunchKernelGGL((k_slabpd_rows<T, 14, (f32 ? 4 : 2), 768, false, false>), grid, dim3(768), 0, q, d, x);
   }
-  hipLaunchKernelGGL((k_slabpd_close<T>), dim3((unsigned)((d.n + kSlabPdCloseCols - 1) / kSlabPdCloseCols)), dim3(kSlabPdCloseBlock), 0, q, d,
-                     st->B, (T*)aty, recs, rec_cap);
+  slabpd_close_launch<T>(d, st->B, (T*)aty, recs, rec_cap, q);
   return true;
 }
 
@@ -428,6 +446,8 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
                           : slab_pd_launch_t<double>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
   APX_TRY(prof_end(ctx));
   if (!launched) return team_launch_refused(p, "one-pass primal-dual kernel (teams)");
+  if (p->hd.kind == APX_G_L2)      // y+ and the dual residual from w (left in y's place) and ||z|| ; the end of the iteration (:345-354)
+    APX_TRY(vo_dual_post(ctx, p->dtype, s->y.p, s->axprev.p, p->m, p->hd, p->ctrl(), (apx_record*)s->recs.p, s->rec_cap));
   APX_HIP(hipGetLastError());
   *done_here = true;
   return APX_OK;

@@ -71,19 +71,32 @@ __device__ __forceinline__ TeamRowState team_row_state_of_lane(const TeamRowStat
 // The dual step of row i of the primal-dual loop in two parts: y+[i] — what the compute waves wait for — and the row's terms of
 // the residual norm and of h(A x), which nothing waits for (a division and the value of h: k_team_rows forms them BEHIND the
 // publication of its next partial, off the path between two barriers).
+//
+// h = NormL2 (the square-root lasso's l2 ball, experiments/square_root_lasso/runme.jl:39-41) is not separable — its conjugate prox
+// scales by a factor that depends on the norm of ALL rows' z[i] = w[i] / sigma + shift[i] (csrc/vecops_dev.h prox_core:
+// sc = max(0, 1 - lambda / (sigma ||z||))) — but it is LINEAR in z once that factor is known: y+ = sigma (1 - sc) z, hence
+// A' y+ = sigma (1 - sc) A' z.  So one pass over A does for it too (round 4): the row's multiplier is z[i], the launch leaves
+// A' z and sum z^2, the closing kernel forms the factor and scales ; w[i] waits in y[i]'s place for the small kernel behind it
+// that writes y+[i] and the dual residual in the two passes' own arithmetic (csrc/vecops.hip k_dual_post).
+template <class DEV>
+__device__ __forceinline__ bool team_pd_l2(const DEV& d) { return d.h.kind == APX_G_L2; }
 template <class DEV, typename T>
 __device__ __forceinline__ double team_pd_dual(const DEV& d, const TeamRowConsts<kTeamFkPd>& kc, const TeamRowState& st, double dot, int i, double& w) {
   const double ax = (double)(T)dot;
   w = st.a + kc.sigma * ((1.0 + kc.rho) * ax - kc.rho * st.b);                     // src/AdaProx.jl:344
+  if (team_pd_l2(d)) return w / kc.sigma + st.c;                                   // z[i] (k_dual_pre's expression)
   return (double)(T)prox_conj_elem_s<T>(d.h, w, kc.sigma, i, 0.0, st.c);           // :345
 }
 template <class DEV, typename T>
 __device__ __forceinline__ void team_pd_sums(const DEV& d, const TeamRowConsts<kTeamFkPd>& kc, double shift, double ax, double w, double yn, int i,
                                              double& e0, double& e1) {
-  const double dr = (w - yn) / kc.sigma - ax;                                      // :347
+  const double dr = team_pd_l2(d) ? yn : (w - yn) / kc.sigma - ax;                 // :347 (l2: sum z^2 — the residual comes later)
   e0 += dr * dr;
   e1 += gval_elem_s<T>(d.h, ax, i, shift);
 }
+// what goes to y[i] behind the row: y+[i], or (l2) w[i], from which k_dual_post forms y+[i] once the norm is known
+template <class DEV>
+__device__ __forceinline__ double team_pd_stored(const DEV& d, double w, double yn) { return team_pd_l2(d) ? w : yn; }
 // the value the compute waves multiply row i by ; the loss sums (every member forms them — member 0's are the ones stored).
 // `dot` is the row's <A[i, :], x> in Float64 ; T is the storage type: A x is rounded to T like every stored A x, and for Float32
 // data the logistic link runs in Float32, as Julia does on Float32 arrays (csrc/slab.hip slab_group) — for T = double nothing
@@ -114,7 +127,7 @@ __device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowCon
   } else {
     double w;
     const double yn = team_pd_dual<DEV, T>(d, kc, st, dot, i, w);
-    const T ynt = (T)yn;
+    const T ynt = (T)team_pd_stored(d, w, yn);
     team_pd_sums<DEV, T>(d, kc, st.c, ax, w, yn, i, e0, e1);
     if (writer) {
       ((T*)d.Y)[i] = ynt;
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       }
       if constexpr (late) {
         if (st_i >= 0 && s == 0 && lane == 0) {
-          ((T*)d.Y)[st_i] = (T)st_y;
+          ((T*)d.Y)[st_i] = (T)team_pd_stored(d, st_w, st_y);
           ((T*)d.AXP)[st_i] = (T)st_ax;                                            // :360
         }
       }

@@ -186,6 +186,27 @@ __global__ __launch_bounds__(kBlock) void k_dual(T* __restrict__ y, const T* __r
   block_partials_store<2>(q, red);
 }
 
+// The same behind a one-pass launch with h = NormL2 (csrc/slab_pd.hip, csrc/team_rows.h team_pd_dual): the row kernel left
+// w[i] in y[i]'s place and the new A_x[i] in A_x_prev[i], the closing kernel ||z|| in Ctrl::h_pre — y+ and the dual residual in
+// exactly k_dual's arithmetic.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dual_post(T* __restrict__ y, const T* __restrict__ axnew, int64_t m, ProxDev h, const Ctrl* c,
+                                                      double* __restrict__ red) {
+  if (c->done != 0) return;
+  const double sigma = c->sigma, aux = c->h_pre;
+  double q[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double a = (double)axnew[i];
+    const double w = (double)y[i];
+    const T yn = (T)prox_conj_elem<T>(h, w, sigma, i, aux);                                // :345
+    const double dr = (w - (double)yn) / sigma - a;                                        // :347
+    q[0] = fma(dr, dr, q[0]);
+    q[1] += gval_elem<T>(h, a, i);
+    y[i] = yn;
+  }
+  block_partials_store<2>(q, red);
+}
+
 __global__ __launch_bounds__(kBlock) void k_final(const double* __restrict__ red, int nblk, ProxDev h, Ctrl* c,
                                                   apx_record* recs, int64_t rec_cap) {
   if (c->done != 0) return;
@@ -607,6 +628,17 @@ int32_t vo_dual(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axpr
                                 (double*)axprev, m, h, c, ctx->red),
              hipLaunchKernelGGL(k_dual<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)y, (const float*)ax,
                                 (float*)axprev, m, h, c, ctx->red));
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, h, c, recs, rec_cap);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
+int32_t vo_dual_post(apx_ctx* ctx, int32_t dtype, void* y, const void* axnew, int64_t m, const ProxDev& h, Ctrl* c, apx_record* recs,
+                     int64_t rec_cap) {
+  const unsigned gr = vgrid(m);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_dual_post<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)y, (const double*)axnew, m, h, c, ctx->red),
+             hipLaunchKernelGGL(k_dual_post<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)y, (const float*)axnew, m, h, c, ctx->red));
   hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, h, c, recs, rec_cap);
   APX_HIP(hipGetLastError());
   return APX_OK;

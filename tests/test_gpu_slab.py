@@ -276,14 +276,25 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              # Float32 on k_multi_rows (round 3)
                                              (70000, 300, "tl1", np.float32),
                                              (4099, 5001, "tbox", np.float32),
-                                             (4100, 11264, "tl1", np.float32)])
+                                             (4100, 11264, "tl1", np.float32),
+                                             # h = the square-root lasso's l2 ball (round 4): not separable, but linear in the rows once
+                                             # the norm is known — A' z and sum z^2 in one pass, scaled by the closing kernel, y+ and the
+                                             # dual residual by k_dual_post (csrc/team_rows.h team_pd_dual, csrc/slab_pd.hip)
+                                             (9000, 1000, "tl2", np.float64),      # k_multi_rows
+                                             (80000, 600, "tl2", np.float64),      # ... two groups of compute waves
+                                             (4100, 6000, "tl2", np.float64),      # k_team_rows, one workgroup
+                                             (4100, 20000, "tl2", np.float64),     # ... teams of two (C5's row)
+                                             (4099, 30001, "tl2", np.float64),     # ... teams of four
+                                             (4098, 100000, "tl2", np.float64),    # ... teams of sixteen (C2's row)
+                                             (4099, 5001, "tl2", np.float32)])     # k_multi_rows, Float32
 def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dtype):
     rng = np.random.default_rng(m + n)
     A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]).astype(dtype))
     yv = (A.astype(np.float64) @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)).astype(dtype)
     nA = float(np.linalg.norm(A.astype(np.float64)))
     mk_h = {"tl1": lambda M: M.Translate(M.NormL1(1.0), -yv.astype(np.float64) if M is O else -yv),
-            "tbox": lambda M: M.Translate(M.IndBox(-0.5, 0.8), -yv.astype(np.float64) if M is O else -yv)}[hkind]
+            "tbox": lambda M: M.Translate(M.IndBox(-0.5, 0.8), -yv.astype(np.float64) if M is O else -yv),
+            "tl2": lambda M: M.Translate(M.NormL2(1.0), -yv.astype(np.float64) if M is O else -yv)}[hkind]
     K = 10
     x0, y0 = np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype)
     ro = []
@@ -296,9 +307,15 @@ def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dt
         ctx.one_pass_threshold(16 << 20)          # (default 192 MB: the measured break-even ; here: reach the kernel)
         dA = apx.DeviceMatrix.from_numpy(A, ctx)
         recs = []
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
         x, y, it = apx.adaptive_primal_dual(x0, y0, f=apx.Zero(), g=apx.NormL1(5.0), h=mk_h(apx), A=dA,
                                             rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx, record=recs.append)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
         assert it == K and len(recs) == K
+        # A x and A' y of the K iterations from K passes over A (the loop's two products in front of it: two GEMVs), or from 2 K + 2
+        assert st["one_pass"]["launches"] == (K if one_pass else 0) and (st["gemv_t"]["launches"] <= 2 if one_pass else st["gemv_t"]["launches"] >= K), st
         out.append((x, y, recs))
         dA.free()
     (x1, y1, r1), (x2, y2, r2) = out

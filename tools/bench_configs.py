@@ -71,6 +71,20 @@ if "c5" in which:
     s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=p.A, rule=rule, tol=0.0, ctx=ctx, poll_every=1 << 30)
     out["C5 LAD 50000x20000 fp64, condat_vu via adaptive_primal_dual"] = timed(s, 100, 10, 2 * m * n * 8)
     s.close(); p.A.free()
+if "sqrtlasso" in which:      # the square-root lasso's l2 ball on C5's matrix (experiments/square_root_lasso/runme.jl:39-41): one pass (round 4) / two passes
+    m, n = 50_000, 20_000
+    for one_pass in (True, False):
+        cx = apx.Context(0)
+        cx.one_pass(1 if one_pass else 0)
+        p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=cx)
+        if one_pass:
+            p.A.build_transpose()
+        ctx_save, ctx = ctx, cx
+        s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL2(1.0), -p.y), A=p.A,
+                       rule=apx.OurRule(t=1.0, norm_A=p.norm_A), tol=0.0, ctx=cx, poll_every=1 << 30)
+        out["square-root lasso 50000x20000 fp64, adaptive_primal_dual (OurRule), %s" % ("one pass" if one_pass else "two passes")] = timed(s, 100, 10, 2 * m * n * 8)
+        ctx = ctx_save
+        s.close(); p.A.free()
 if "c2bt" in which:
     m, n = 50_000, 100_000
     p = problems.device_lasso(m, n, seed=0, power_iters=20, ctx=ctx, dual_layout=os.environ.get("APX_SINGLE_LAYOUT") != "1")
