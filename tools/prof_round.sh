@@ -13,7 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 $GRAFT
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>> $P/bench_err.log
 echo "write done"
-cd $GRAFT_REPO_ROOT && python3 tools/summarize_prof.py $P $P/summary "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of round 3 (profiles/r03_rocprofv3_summary.*; FETCH_SIZE x2: the gfx950 correction of MI355X_MICROARCH.md), same build" > $P/summary_stdout.md
+cd $GRAFT_REPO_ROOT && python3 tools/summarize_prof.py $P $P/summary "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of ${TAG} (profiles/${TAG}_rocprofv3_summary.*; FETCH_SIZE x2: the gfx950 correction of MI355X_MICROARCH.md), same build" > $P/summary_stdout.md
 
 f=$(find $P/trace -name "*kernel_stats.csv" | head -1); cp $f $P/kernel_stats.csv
 # keep the merge small: drop the raw traces

@@ -73,7 +73,10 @@ def main():
     for name, v in gaps.items():
         v.sort()
         gp[name] = {"launches": len(v) + 1, "median_gap_us": v[len(v) // 2] / 1e3, "mean_gap_us": sum(v) / len(v) / 1e3,
-                    "kernels_in_the_gap_avg_us": {k: sum(d) / len(d) / 1e3 for k, d in between[name].items()}}
+                    "kernels_in_the_gap_avg_us": {k: sum(d) / len(d) / 1e3 for k, d in between[name].items()},
+                    # (how many of the gaps a kernel appears in: a one-off — an allocation's fill on the first iteration — is not
+                    #  part of the iteration)
+                    "kernels_in_the_gap_count": {k: len(d) for k, d in between[name].items()}}
     summary["between_consecutive_row_kernels"] = gp
     # ---- PMC passes
     pmc = defaultdict(lambda: defaultdict(list))
@@ -110,7 +113,8 @@ def main():
         fh.write("\n| row kernel | launches | median time to the NEXT launch of it (us) | kernels in between, average us |\n|---|---|---|---|\n")
         for name, e in gp.items():
             fh.write(f"| {name[:150]} | {e['launches']} | {e['median_gap_us']:.1f} | " +
-                     ", ".join(f"{k} {u:.1f}" for k, u in e["kernels_in_the_gap_avg_us"].items()) + " |\n")
+                     ", ".join(f"{k} {u:.1f}" + ("" if e["kernels_in_the_gap_count"][k] >= e["launches"] - 1 else f" (in {e['kernels_in_the_gap_count'][k]} of the gaps)")
+                               for k, u in e["kernels_in_the_gap_avg_us"].items()) + " |\n")
     # what bench.py reads for roofline.traffic
     # with the dual layout (bench default) A*x runs the column-streaming kernel on the transposed copy,
     # so both passes appear as gemv_t_kernel in the trace
