@@ -26,6 +26,13 @@ struct SlabPdDev {
   int32_t deal_stride, deal_log;            // k_multi_rows: the rows dealt in chunks (csrc/team_dev.h) ; k_slabpd_rows keeps its slabs
   void* Y;                // y (T), updated in place
   void* AXP;              // A_x_prev (T), updated in place (:360)
+  // where a row's y+ and A x go: y and A_x_prev themselves in the loop above ; buffers of their own in a linesearch TRIAL
+  // (adaptive_linesearch_primal_dual, src/AdaProx.jl:516-533: y and A_x_prev must survive a rejected trial), whose sigma and
+  // rho are the host's (csrc/team_rows.h reads YN / AXN / trial through the row functions of this loop only)
+  void* YN;
+  void* AXN;
+  double sigma_arg, rho_arg;
+  int32_t trial, _pad;
   double* part;           // [blocks][ldpart]: n column partials of A' y, then sum dual_res^2, raw h(A_x)
   int64_t ldpart;
   Ctrl* c;
@@ -228,13 +235,13 @@ __global__ __launch_bounds__(kSlabPdCloseBlock) void k_slabpd_close(SlabPdDev d,
 #pragma unroll
     for (int k = 1; k < S; ++k) g += sub[k][c];
     if constexpr (L2) {
-      const double sigma = d.c->sigma, aux = sqrt(fs[0]);
+      const double sigma = d.trial ? d.sigma_arg : d.c->sigma, aux = sqrt(fs[0]);
       const double sc = fmax(0.0, 1.0 - d.h.lambda * (1.0 / sigma) / aux);                 // csrc/vecops_dev.h prox_core, gamma = 1 / sigma
       g *= sigma * (1.0 - sc);
     }
     aty[j] = (T)g;                                                                         // :358  At_y = A' * y
   }
-  if (blockIdx.x == 0 && tid == 0) {
+  if (blockIdx.x == 0 && tid == 0 && d.trial == 0) {      // (a linesearch trial: the host's loop closes the iteration)
     if constexpr (L2) {
       d.c->h_pre = sqrt(fs[0]);                                                            // ||z||: what k_dual_post's conjugate prox scales by
     } else {
@@ -351,6 +358,9 @@ int32_t slab_pd_setup(apx_solver* s) {
   }
   d.Y = s->y.p;
   d.AXP = s->axprev.p;
+  d.YN = d.Y;
+  d.AXN = d.AXP;
+  d.trial = 0;
   d.ldpart = round_up(d.n + 2, 8);
   const int64_t nparts = B * (st->cpt == 27 ? multi_groups(A->n, p->dtype == APX_F32 ? 4 : 2) : 1);      // (k_multi_rows on very short rows: csrc/team_rows.h)
   APX_TRY(st->part.alloc_zero((size_t)nparts * d.ldpart * sizeof(double), ctx->stream));
@@ -450,6 +460,39 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
     APX_TRY(vo_dual_post(ctx, p->dtype, s->y.p, s->axprev.p, p->m, p->hd, p->ctrl(), (apx_record*)s->recs.p, s->rec_cap));
   APX_HIP(hipGetLastError());
   *done_here = true;
+  return APX_OK;
+}
+
+// One linesearch trial of adaptive_linesearch_primal_dual (src/AdaProx.jl:502, :522-526) in one pass over A: A_x = A x into
+// `axnew`, w and y_next = prox_{sigma h*}(w) row by row (into `ynext` ; for the l2 ball: w — the caller's vo_dual_trial forms
+// y_next from A_x in the two passes' own arithmetic either way), A' y_next into `aty_next`.  y and A_x_prev are only read.
+// Only the kernels of csrc/team_rows.h (k_multi_rows, k_team_rows): slab_pd_trial_ok.
+bool slab_pd_trial_ok(const apx_solver* s) {
+  return s->slab_pd != nullptr && (s->slab_pd->cpt == 27 || s->slab_pd->cpt == 28) && s->p->A_lin->dT != nullptr;
+}
+int32_t slab_pd_trial(apx_solver* s, const void* x, const void* y, const void* axprev, void* ynext, void* axnew, void* aty_next,
+                      double sigma, double rho) {
+  apx_problem* p = s->p;
+  apx_ctx* ctx = p->ctx;
+  SlabPdState* st = s->slab_pd;
+  APX_REQUIRE(slab_pd_trial_ok(s), "internal: slab_pd_trial without its kernels");
+  SlabPdDev d = st->dev;
+  d.AT = p->A_lin->dT;
+  d.ldT = p->A_lin->ldT;
+  d.Y = const_cast<void*>(y);
+  d.AXP = const_cast<void*>(axprev);
+  d.YN = ynext;
+  d.AXN = axnew;
+  d.sigma_arg = sigma;
+  d.rho_arg = rho;
+  d.trial = 1;
+  ctx->kname[APX_KSTAT_ONE_PASS] = st->cpt == 27 ? "k_multi_rows<primal_dual> (linesearch trial) + k_slabpd_close" : "k_team_rows<primal_dual> (linesearch trial) + k_slabpd_close";
+  APX_TRY(prof_begin(ctx, APX_KSTAT_ONE_PASS, (double)p->A_lin->m * (double)p->A_lin->n * (double)p->es()));
+  const bool launched = p->dtype == APX_F32 ? slab_pd_launch_t<float>(st, ctx->team_cooperative, d, x, aty_next, nullptr, 0, ctx->stream)
+                                            : slab_pd_launch_t<double>(st, ctx->team_cooperative, d, x, aty_next, nullptr, 0, ctx->stream);
+  APX_TRY(prof_end(ctx));
+  if (!launched) return team_launch_refused(p, "one-pass primal-dual kernel (teams)");
+  APX_HIP(hipGetLastError());
   return APX_OK;
 }
 

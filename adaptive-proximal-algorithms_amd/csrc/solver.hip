@@ -854,11 +854,23 @@ int32_t apx_condat_vu(apx_problem* p, double Lf, double norm_A, const void* x0, 
 // The linesearch test `eta >= ||A'y_next - A'y|| / ||y_next - y||` (:527) is a data-dependent
 // host branch per trial, like backtracking: every trial costs one GEMV-T (pass over A) plus a
 // 32-byte read-back; the step-size scalars (gamma, eta, Delta, ...) live on the host in fp64.
+// Round 4: the FIRST trial of an iteration — nearly always the only one — takes `A_x = A * x` (:502) along: the trial's step
+// sizes depend on scalars and on reductions over n-vectors only, so they are known before A x is, and one launch of the one-pass
+// primal-dual kernels (csrc/slab_pd.hip slab_pd_trial) then leaves A x AND A' y_next from ONE read of A ; a rejected trial
+// continues as before (one GEMV-T per further trial).  50 000 x 20 000 fp64, least absolute deviation: profiles/r04*.
+static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_linesearch_params* prm, const void* x0,
+                                                   const void* y0, double tol, int64_t maxit, const apx_solve_opts* opts,
+                                                   void* x_out, void* y_out, apx_result* res);
 int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch_params* prm, const void* x0,
                                             const void* y0, double tol, int64_t maxit, const apx_solve_opts* opts,
                                             void* x_out, void* y_out, apx_result* res) {
   APX_REQUIRE(p != nullptr && prm != nullptr && x0 != nullptr && y0 != nullptr && x_out != nullptr,
               "apx_adaptive_linesearch_primal_dual: NULL argument");
+  return with_team_fallback(p, res, [&] { return adaptive_linesearch_primal_dual_run(p, prm, x0, y0, tol, maxit, opts, x_out, y_out, res); });
+}
+static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_linesearch_params* prm, const void* x0,
+                                                   const void* y0, double tol, int64_t maxit, const apx_solve_opts* opts,
+                                                   void* x_out, void* y_out, apx_result* res) {
   APX_REQUIRE(p->A_lin != nullptr, "adaptive_linesearch_primal_dual needs a linear operator");
   // (its linesearch compares ||A'y+ - A'y|| with ||y+ - y||: with row shards of A_lin both would need all-reduces per
   // trial, which only the generic loop has — enqueue_iteration)
@@ -908,6 +920,13 @@ int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch
     return launch_sum_partials_rows(ctx, p->dtype, splits, p->m, p->m_pad, ax, nullptr);
   };
 
+  // the one-pass kernels of the primal-dual loop, when this problem is theirs (a shell of a solver carries their state)
+  apx_solver shell;
+  shell.p = p;
+  if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup(&shell));
+  const bool one_pass = slab_pd_trial_ok(&shell);
+  const bool teams = one_pass && slab_pd_uses_teams(&shell);
+
   double gamma_prev = gamma;                                                       // :491
   const double delta1 = 1.0 + delta;                                               // :490
   APX_TRY(mul_A());                                                                // :494
@@ -922,7 +941,7 @@ int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch
   int32_t flags = 0;
   double sigma = t * t * gamma, norm_res = std::numeric_limits<double>::quiet_NaN(), objective = norm_res;
   for (int64_t it = 1; it <= maxit; ++it) {                                        // :501
-    APX_TRY(mul_A());                                                              // :502
+    if (!one_pass) APX_TRY(mul_A());                                               // :502 (one pass: with the first trial, below)
     APX_TRY(eval_f(p, bx.p, false));                                               // :503
     APX_TRY(pullback_f(p));
     APX_TRY(vo_reduce_sums(ctx, p->dtype, bx.p, bxprev.p, p->grad.p, bgprev.p, bv.p, aty, p->n, p->gd, p->ctrl(),
@@ -956,11 +975,19 @@ int32_t apx_adaptive_linesearch_primal_dual(apx_problem* p, const apx_linesearch
       const double gamma_next = jmin(jmin(g1, g2), g3);                            // :517-521
       const double rho = gamma_next / gamma;                                       // :522
       sigma = t * t * gamma_next;                                                  // :523
-      APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, axprev, ynext, p->m, p->hd, sigma, rho, ctx->scal));   // :524-525
-      APX_TRY(launch_gemv_t(ctx, p->A_lin, ynext, aty_next, nullptr));             // :526
+      if (one_pass && trials == 0) {
+        // A x (:502), w, y_next and A' y_next (:524-526) from one read of A ; y_next and the trial's sums then once more from
+        // the stored A x, in the arithmetic of the later trials (O(m))
+        APX_TRY(slab_pd_trial(&shell, bx.p, y, axprev, ynext, ax, aty_next, sigma, rho));
+        APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, axprev, ynext, p->m, p->hd, sigma, rho, ctx->scal));
+      } else {
+        APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, axprev, ynext, p->m, p->hd, sigma, rho, ctx->scal));   // :524-525
+        APX_TRY(launch_gemv_t(ctx, p->A_lin, ynext, aty_next, nullptr));           // :526
+      }
       APX_TRY(vo_diff_sumsq(ctx, p->dtype, aty_next, aty, p->n, ctx->scal + 3));
       APX_HIP(hipMemcpyAsync(ctx->h_scal, ctx->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       APX_HIP(hipStreamSynchronize(ctx->stream));
+      if (teams && trials == 0) APX_TRY(slab_pd_check(&shell));                    // (the error word of the team hand-offs)
       trials_total++;
       const double ratio = std::sqrt(ctx->h_scal[3]) / std::sqrt(ctx->h_scal[0]);
       if (eta >= ratio) {                                                          // :527

@@ -282,6 +282,9 @@ const void* small_pd_ctrl(const apx_solver* s);
 bool slab_pd_eligible(const apx_problem* p);
 int32_t slab_pd_setup(apx_solver* s);
 int32_t slab_pd_iteration(apx_solver* s, bool* done_here);
+bool slab_pd_trial_ok(const apx_solver* s);
+int32_t slab_pd_trial(apx_solver* s, const void* x, const void* y, const void* axprev, void* ynext, void* axnew, void* aty_next,
+                      double sigma, double rho);
 int32_t slab_pd_check(apx_solver* s);
 int32_t slab_pd_team_waits(apx_solver* s, int64_t out[4]);
 int32_t slab_pd_team_wait_slots(apx_solver* s, const TeamWait** slots);

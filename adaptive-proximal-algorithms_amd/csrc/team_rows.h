@@ -31,8 +31,8 @@ struct TeamRowConsts {
   __device__ TeamRowConsts(const DEV& d, const void* xv, bool f32 = false) {
     if constexpr (FK == APX_F_LOGISTIC) bias = f32 ? (double)((const float*)xv)[d.n - 1] : ((const double*)xv)[d.n - 1];
     if constexpr (FK == kTeamFkPd) {
-      sigma = d.c->sigma;             // this iteration's, set by the rule kernel before this launch
-      rho = d.c->rho;
+      sigma = d.trial ? d.sigma_arg : d.c->sigma;      // this iteration's, set by the rule kernel before this launch — or a
+      rho = d.trial ? d.rho_arg : d.c->rho;            // linesearch trial's, from the host (csrc/slab_pd.hip slab_pd_trial)
     }
   }
 };
@@ -130,8 +130,8 @@ __device__ __forceinline__ double team_row_finish(const DEV& d, const TeamRowCon
     const T ynt = (T)team_pd_stored(d, w, yn);
     team_pd_sums<DEV, T>(d, kc, st.c, ax, w, yn, i, e0, e1);
     if (writer) {
-      ((T*)d.Y)[i] = ynt;
-      ((T*)d.AXP)[i] = (T)ax;                                                      // :360
+      ((T*)d.YN)[i] = ynt;
+      ((T*)d.AXN)[i] = (T)ax;                                                      // :360
     }
     return yn;
   }
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       }
       if constexpr (late) {
         if (st_i >= 0 && s == 0 && lane == 0) {
-          ((T*)d.Y)[st_i] = (T)team_pd_stored(d, st_w, st_y);
-          ((T*)d.AXP)[st_i] = (T)st_ax;                                            // :360
+          ((T*)d.YN)[st_i] = (T)team_pd_stored(d, st_w, st_y);
+          ((T*)d.AXN)[st_i] = (T)st_ax;                                            // :360
         }
       }
       if constexpr (P > 1) {

@@ -169,6 +169,7 @@ def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
         dA.free()
     (x1, r1), (x2, r2) = out
     tol = 1e-10 if dtype == np.float64 else 2e-3
+    assert (hkind != "tl2" or np.count_nonzero(xo) > 0) and ro[-1]["norm_res"] > 1e-6      # (a loop that is still moving)
     assert _rel(x1, xo) <= tol and _rel(x1, x2) <= tol
     for a, b_, c in zip(r1, ro, r2):
         assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10 if dtype == np.float64 else 1e-4)
@@ -296,9 +297,10 @@ def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dt
             "tbox": lambda M: M.Translate(M.IndBox(-0.5, 0.8), -yv.astype(np.float64) if M is O else -yv),
             "tl2": lambda M: M.Translate(M.NormL2(1.0), -yv.astype(np.float64) if M is O else -yv)}[hkind]
     K = 10
+    lam = 0.3 if hkind == "tl2" else 5.0       # (the l2 ball: |A' y| stays below 1.3 or so — a larger lambda keeps x at 0)
     x0, y0 = np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype)
     ro = []
-    xo, yo, _ = O.adaptive_primal_dual(x0.astype(np.float64), y0.astype(np.float64), f=O.Zero(), g=O.NormL1(5.0), h=mk_h(O),
+    xo, yo, _ = O.adaptive_primal_dual(x0.astype(np.float64), y0.astype(np.float64), f=O.Zero(), g=O.NormL1(lam), h=mk_h(O),
                                        A=A.astype(np.float64), rule=O.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, record=ro.append)
     out = []
     for one_pass in (True, False):
@@ -309,7 +311,7 @@ def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dt
         recs = []
         ctx.kernel_stats(reset=True)
         ctx.profile(True)
-        x, y, it = apx.adaptive_primal_dual(x0, y0, f=apx.Zero(), g=apx.NormL1(5.0), h=mk_h(apx), A=dA,
+        x, y, it = apx.adaptive_primal_dual(x0, y0, f=apx.Zero(), g=apx.NormL1(lam), h=mk_h(apx), A=dA,
                                             rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx, record=recs.append)
         st = ctx.kernel_stats(reset=True)
         ctx.profile(False)
@@ -835,3 +837,54 @@ def test_fused_small_keeps_one_pass_mode_two(apx):
         dA.free()
     assert launches[0][0] == 0 and launches[0][1] >= 4, launches      # mode 2: no team launch, the two passes
     assert launches[1] == (4, 0), launches                            # mode 1: the team kernels
+
+
+@pytest.mark.parametrize("m,n,hkind,t", [(9000, 1000, "tl1", 1.0),      # k_multi_rows
+                                         (9000, 1000, "tl2", 1.0),
+                                         (4100, 6000, "tl1", 0.1),      # k_team_rows, one workgroup
+                                         (4100, 20000, "tl1", 1.0),     # ... teams of two (C5's row)
+                                         (4100, 20000, "tl2", 10.0),
+                                         (4099, 30001, "tl2", 1.0)])    # ... teams of four
+def test_adapdm_plus_first_trial_in_one_pass(apx, m, n, hkind, t):
+    """adaptive_linesearch_primal_dual (AdaPDM+, src/AdaProx.jl:463-550): the first linesearch trial of an iteration takes
+    A_x = A * x (:502) along — one launch of the one-pass primal-dual kernels leaves A x AND A' y_next (csrc/slab_pd.hip
+    slab_pd_trial, round 4) ; a rejected trial continues on the stored A x with one GEMV-T each.  Against the oracle and against
+    the context that runs every product as a GEMV: iterates, records, evaluation counts ; eta0 far below ||A||, so that trials
+    ARE rejected."""
+    rng = np.random.default_rng(m + n + 7)
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+    yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+    nA = float(np.linalg.norm(A))
+    mk_h = {"tl1": lambda M: M.Translate(M.NormL1(1.0), -yv), "tl2": lambda M: M.Translate(M.NormL2(1.0), -yv)}[hkind]
+    K = 12
+    kw = dict(eta=nA / 2000.0, t=t, tol=0.0, maxit=K)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    ro = []
+    lam = 5.0 if hkind == "tl1" else 0.3       # (the l2 ball: |A' y| stays below 1.3 or so — a larger lambda keeps x at 0)
+    xo, yo, _ = O.adaptive_linesearch_primal_dual(x0, y0, f=O.Zero(), g=O.NormL1(lam), h=O.Counting(mk_h(O)), A=O.Counting(A),
+                                                  record=ro.append, **kw)
+    assert ro[-1]["At_evals"] > K + 1          # (some trial was rejected)
+    assert (hkind != "tl2" or np.count_nonzero(xo) > n // 10) and ro[-1]["norm_res"] > 1e-3       # (a loop that is still moving)
+    out = []
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        ctx.one_pass_threshold(16 << 20)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        recs = []
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        x, y, it = apx.adaptive_linesearch_primal_dual(x0, y0, f=apx.Zero(), g=apx.NormL1(lam), h=apx.Counting(mk_h(apx)),
+                                                       A=apx.Counting(dA), ctx=ctx, record=recs.append, **kw)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        assert it == K and len(recs) == K
+        assert st["one_pass"]["launches"] == (K if one_pass else 0), st      # one launch per iteration: the first trial's
+        out.append((x, y, recs))
+        dA.free()
+    (x1, y1, r1), (x2, y2, r2) = out
+    assert _rel(x1, xo) <= 1e-10 and _rel(y1, yo) <= 1e-9 and _rel(x1, x2) <= 1e-10 and _rel(y1, y2) <= 1e-9
+    for a, b_ in zip(r1, ro):
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-9) and a["sigma"] == pytest.approx(b_["sigma"], rel=1e-9)
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7) and a["objective"] == pytest.approx(b_["objective"], rel=1e-9)
+        assert (a["A_evals"], a["At_evals"], a["prox_h_evals"]) == (b_["A_evals"], b_["At_evals"], b_["prox_h_evals"])

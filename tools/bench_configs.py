@@ -80,11 +80,34 @@ if "sqrtlasso" in which:      # the square-root lasso's l2 ball on C5's matrix (
         if one_pass:
             p.A.build_transpose()
         ctx_save, ctx = ctx, cx
-        s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL2(1.0), -p.y), A=p.A,
+        # (lambda = 0.5: with the l2 ball |A' y| stays below 2.5 or so on this matrix — LAD's lambda = 10 would keep x at 0)
+        s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(0.5), h=apx.Translate(apx.NormL2(1.0), -p.y), A=p.A,
                        rule=apx.OurRule(t=1.0, norm_A=p.norm_A), tol=0.0, ctx=cx, poll_every=1 << 30)
         out["square-root lasso 50000x20000 fp64, adaptive_primal_dual (OurRule), %s" % ("one pass" if one_pass else "two passes")] = timed(s, 100, 10, 2 * m * n * 8)
         ctx = ctx_save
         s.close(); p.A.free()
+if "adapdm" in which:      # AdaPDM+ (adaptive_linesearch_primal_dual) on C5's LAD: the first trial in one pass (round 4) / every product a GEMV
+    m, n = 50_000, 20_000
+    for one_pass in (True, False):
+        cx = apx.Context(0)
+        cx.one_pass(1 if one_pass else 0)
+        p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=cx)
+        if one_pass:
+            p.A.build_transpose()
+        kw = dict(f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=apx.Counting(p.A), eta=p.norm_A, t=1.0, tol=0.0, ctx=cx)
+        apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), maxit=5, **kw)
+        cx.kernel_stats(reset=True); cx.profile(True)
+        recs = []
+        t0 = time.perf_counter()
+        x, y, it = apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), maxit=100, record=recs.append, **kw)
+        dt = time.perf_counter() - t0
+        cx.profile(False)
+        st = cx.kernel_stats(reset=True)
+        out["AdaPDM+ LAD 50000x20000 fp64, %s" % ("first trial in one pass" if one_pass else "GEMV per product")] = dict(
+            iters_per_s=100 / dt, ms_per_iter=dt * 10, trials=recs[-1]["At_evals"] - 1, objective=recs[-1]["objective"],
+            kernels={k: dict(launches=v["launches"], avg_ms=v["total_ms"] / v["launches"]) for k, v in st.items() if v["launches"]},
+            note="the call includes the upload of x0 / y0, two products in front of the loop and the read-back of the result")
+        p.A.free()
 if "c2bt" in which:
     m, n = 50_000, 100_000
     p = problems.device_lasso(m, n, seed=0, power_iters=20, ctx=ctx, dual_layout=os.environ.get("APX_SINGLE_LAYOUT") != "1")
