@@ -32,7 +32,11 @@ struct SlabPdDev {
   void* YN;
   void* AXN;
   double sigma_arg, rho_arg;
-  int32_t trial, _pad;
+  int32_t trial;
+  // a row shard of the operator (round 4): the launch's sums — A' y, sum dual_res^2, raw h(A_x) — are this rank's share ; the
+  // closing kernel leaves the two scalars in `sums_out` and the end of the iteration to the kernel behind the all-reduce
+  int32_t no_finish;
+  double* sums_out;
   double* part;           // [blocks][ldpart]: n column partials of A' y, then sum dual_res^2, raw h(A_x)
   int64_t ldpart;
   Ctrl* c;
@@ -241,7 +245,11 @@ __global__ __launch_bounds__(kSlabPdCloseBlock) void k_slabpd_close(SlabPdDev d,
     }
     aty[j] = (T)g;                                                                         // :358  At_y = A' * y
   }
-  if (blockIdx.x == 0 && tid == 0 && d.trial == 0) {      // (a linesearch trial: the host's loop closes the iteration)
+  if (blockIdx.x == 0 && tid == 0 && d.sums_out != nullptr) {
+    d.sums_out[0] = fs[0];
+    d.sums_out[1] = fs[1];
+  }
+  if (blockIdx.x == 0 && tid == 0 && d.trial == 0 && d.no_finish == 0) {      // (a linesearch trial: the host's loop closes the iteration)
     if constexpr (L2) {
       d.c->h_pre = sqrt(fs[0]);                                                            // ||z||: what k_dual_post's conjugate prox scales by
     } else {
@@ -297,7 +305,11 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
 
 static bool slab_pd_shape_ok(const apx_problem* p) {
   if (!p->ctx->one_pass) return false;
-  if (p->A_lin == nullptr || p->sharded()) return false;
+  if (p->A_lin == nullptr) return false;
+  // a row-sharded OPERATOR is as good as a whole one (the rows are local ; A' y and the two residual sums travel) with a
+  // separable h (round 4) ; the l2 ball's norm over all ranks' rows would need a collective of its own in front of the scaling,
+  // and a sharded f next to a replicated operator is nobody's use: both keep the generic kernels
+  if (p->sharded() && !(p->lin_sharded && !p->f_sharded && p->hd.kind != APX_G_L2)) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   // (h = NormL2: its conjugate prox needs a norm over all rows first, but is linear in the rows once the norm is known — the
   //  kernels of csrc/team_rows.h leave A' z and sum z^2 and the closing kernel scales, round 4 ; the first-generation row kernels
@@ -361,6 +373,8 @@ int32_t slab_pd_setup(apx_solver* s) {
   d.YN = d.Y;
   d.AXN = d.AXP;
   d.trial = 0;
+  d.no_finish = p->lin_sharded ? 1 : 0;
+  d.sums_out = p->lin_sharded ? ctx->scal + 13 : nullptr;
   d.ldpart = round_up(d.n + 2, 8);
   const int64_t nparts = B * (st->cpt == 27 ? multi_groups(A->n, p->dtype == APX_F32 ? 4 : 2) : 1);      // (k_multi_rows on very short rows: csrc/team_rows.h)
   APX_TRY(st->part.alloc_zero((size_t)nparts * d.ldpart * sizeof(double), ctx->stream));
@@ -458,6 +472,11 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   if (!launched) return team_launch_refused(p, "one-pass primal-dual kernel (teams)");
   if (p->hd.kind == APX_G_L2)      // y+ and the dual residual from w (left in y's place) and ||z|| ; the end of the iteration (:345-354)
     APX_TRY(vo_dual_post(ctx, p->dtype, s->y.p, s->axprev.p, p->m, p->hd, p->ctrl(), (apx_record*)s->recs.p, s->rec_cap));
+  if (p->lin_sharded) {            // A' y = sum_k A_k' y_k, the residual sums likewise ; the iteration closed from the global sums
+    APX_TRY(problem_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));
+    APX_TRY(problem_allreduce(p, ctx->scal + 13, 2, APX_F64));
+    APX_TRY(vo_final_sums(ctx, ctx->scal + 13, p->hd, p->ctrl(), (apx_record*)s->recs.p, s->rec_cap));
+  }
   APX_HIP(hipGetLastError());
   *done_here = true;
   return APX_OK;
@@ -505,9 +524,13 @@ int32_t slab_pd_check(apx_solver* s) {
   if (st == nullptr || st->plan.P <= 1) return APX_OK;
   int32_t err = 0;
   APX_TRY(team_read_err(s->p->ctx, &st->team, &err));
-  if (err == 0) return APX_OK;
+  double any = err != 0 ? 1.0 : 0.0;
+  APX_TRY(ranks_sum(s->p, any, &any));             // (a row shard: every rank reads the word at the same points — csrc/slab.hip slab_check)
+  if (any == 0.0) return APX_OK;
   s->p->team_failed = true;
-  const std::string what = team_describe(st->team.pinned->diag, "one-pass primal-dual kernel (teams)");
+  const std::string what = err != 0 ? team_describe(st->team.pinned->diag, "one-pass primal-dual kernel (teams)")
+                                    : std::string("one-pass primal-dual kernel (teams): a team hand-off failed on another rank of this row-sharded "
+                                                  "problem (its message has the details); the result is invalid and was discarded");
   note_incident(what);
   return fail(APX_ERR_HIP, what);
 }

@@ -73,6 +73,8 @@ static int32_t do_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dt
   return APX_OK;
 }
 
+int32_t problem_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dtype) { return do_allreduce(p, buf, count, dtype); }
+
 int32_t ranks_sum(apx_problem* p, double local, double* total) {
   *total = local;
   if (!p->sharded()) return APX_OK;
@@ -574,7 +576,25 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
                     p->gd, p->ctrl()));                                          // :330-332
     if (lin)                                                                     // :331  A_x_prev = A_x
       APX_HIP(hipMemcpyAsync(s->axprev.p, s->ax.p, (size_t)p->m_pad * es, hipMemcpyDeviceToDevice, ctx->stream));
-    if (lin && slab_pd_eligible(p)) APX_TRY(slab_pd_setup(s.get()));
+    // (a row-sharded operator: whether a rank CAN take the one pass depends on its own shard, and the two paths enqueue
+    //  different collectives — the ranks agree here, once, and take it only if every shard can: csrc/slab.hip does the same for f)
+    bool lin_one_pass = lin && slab_pd_eligible(p);
+    if (lin && p->lin_sharded) {
+      double cannot = lin_one_pass ? 0.0 : 1.0;
+      APX_TRY(ranks_sum(p, cannot, &cannot));
+      lin_one_pass = cannot == 0.0;
+    }
+    if (lin_one_pass) {
+      APX_TRY(slab_pd_setup(s.get()));
+      if (p->lin_sharded) {       // ... and so does a shard whose kernel turned out not to fit (slab_pd_setup left no state)
+        double cannot = s->slab_pd != nullptr ? 0.0 : 1.0;
+        APX_TRY(ranks_sum(p, cannot, &cannot));
+        if (cannot != 0.0 && s->slab_pd != nullptr) {
+          slab_pd_destroy(s->slab_pd);
+          s->slab_pd = nullptr;
+        }
+      }
+    }
   }
   p->active = s.get();
   *out = s.release();

@@ -257,6 +257,8 @@ inline int32_t team_launch_refused(apx_problem* p, const char* which) {
   return fail(APX_ERR_HIP, what);
 }
 
+// the problem's all-reduce (its communicator, or the callback) on the loop's stream: sums `count` elements over the ranks in place
+int32_t problem_allreduce(apx_problem* p, void* buf, int64_t count, int32_t dtype);
 int32_t h2d(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t d2h(apx_ctx* ctx, void* dst, const void* src, size_t bytes);
 // `f_x, pb = eval_with_pullback(f, x)` on a device x (need_f: f_x final in Ctrl on return to the stream)

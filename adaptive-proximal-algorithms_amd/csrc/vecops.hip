@@ -659,6 +659,14 @@ __global__ void k_final_s(const double* __restrict__ sums, ProxDev h, Ctrl* c, a
   finish_iteration(c, recs, rec_cap);
 }
 
+// the end of the iteration from two all-reduced sums (sum dual_res^2, raw h(A_x)) on the device: behind a one-pass launch on a
+// row shard of the operator (csrc/slab_pd.hip)
+int32_t vo_final_sums(apx_ctx* ctx, const double* sums, const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap) {
+  hipLaunchKernelGGL(k_final_s, dim3(1), dim3(64), 0, ctx->stream, sums, h, c, recs, rec_cap);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
 int32_t vo_dual_sharded(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axprev, int64_t m,
                         const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap,
                         const std::function<int32_t(double*, int64_t)>& reduce) {

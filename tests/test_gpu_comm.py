@@ -154,6 +154,41 @@ def test_row_sharded_linear_operator_through_the_communicator(apx, sharded, gene
     comm.close()
 
 
+def test_row_sharded_operator_on_the_one_pass_kernels(apx, sharded):
+    """A row shard of the OPERATOR is as good as a whole one for the one-pass primal-dual kernels (round 4): the rows are local,
+    A' y and the two residual sums are all-reduced behind the closing kernel, the iteration is closed from the global sums.  With
+    one rank through the communicator: the same kernels as the unsharded run (k_multi_rows, k_team_rows alone and in teams),
+    iterates equal to rounding (the residual norm is closed in a kernel of its own).  The l2 ball keeps the two passes on a shard."""
+    ctx = apx.Context(device=0)
+    ctx.one_pass_threshold(16 << 20)
+    comm = sharded.Comm.init_rank(ctx, 1, 0, sharded.Comm.unique_id())
+    rng = np.random.default_rng(23)
+    for m, n, hk in ((9000, 1000, "l1"), (4100, 6000, "box"), (4100, 20000, "l1"), (9000, 1000, "l2")):
+        A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+        yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+        nA = float(np.linalg.norm(A))
+        dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+        h = {"l1": apx.Translate(apx.NormL1(1.0), -yv), "box": apx.Translate(apx.IndBox(-0.5, 0.8), -yv),
+             "l2": apx.Translate(apx.NormL2(1.0), -yv)}[hk]
+        kw = dict(f=apx.Zero(), g=apx.NormL1(0.3 if hk == "l2" else 5.0), h=h, A=dA, rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=12, ctx=ctx)
+        out = []
+        for extra in ({}, {"A_allreduce": comm}):
+            recs = []
+            ctx.kernel_stats(reset=True)
+            ctx.profile(True)
+            x, y, it = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), record=recs.append, **kw, **extra)
+            st = ctx.kernel_stats(reset=True)
+            ctx.profile(False)
+            out.append((x, y, [r["norm_res"] for r in recs], st["one_pass"]["launches"]))
+        assert out[0][3] == 12 and out[1][3] == (0 if hk == "l2" else 12), (m, n, hk, out[0][3], out[1][3])
+        assert np.max(np.abs(out[0][0] - out[1][0])) <= 1e-12 * max(np.max(np.abs(out[0][0])), 1.0), (m, n, hk)
+        assert np.max(np.abs(out[0][1] - out[1][1])) <= 1e-12 * max(np.max(np.abs(out[0][1])), 1.0), (m, n, hk)
+        assert out[0][2] == pytest.approx(out[1][2], rel=1e-10)
+        dA.free()
+    comm.close()
+    ctx.close()
+
+
 def test_init_all_and_the_group_entry_point(apx, sharded, generic_ctx):
     """One process, one context per device (here: the one device): ncclCommInitAll + apx_adaptive_primal_dual_group, which
     runs every device's loop on its own host thread."""
