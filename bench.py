@@ -303,6 +303,42 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
                        "A x, the dual step and A' y in ONE pass over A per iteration (csrc/slab_pd.hip, csrc/team_rows.h)")
     out["C5"]["workload"] = "least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50000x20000 fp64 (Ax / A'y pair + conj-prox)"
     s.close()
+    # Two more loops on C5's matrix while it is resident (not BASELINE configs: the north star's third prox and the method the
+    # reference's LAD / square-root-lasso experiments showcase ; a failure here is reported, not raised):
+    try:
+        # the l2 ball (experiments/square_root_lasso/runme.jl:39-41) in one pass over A — lambda 0.5: at LAD's 10 x would stay 0
+        s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(0.5), h=apx.Translate(apx.NormL2(1.0), -p.y), A=p.A,
+                       rule=apx.OurRule(t=1.0, norm_A=p.norm_A), tol=0.0, ctx=ctx, poll_every=1 << 30)
+        dt, st = timed_steps(ctx, s, 100, 10, barrier)
+        x, _, res = s.result()
+        ok = bool(np.all(np.isfinite(x))) and int(res.numit) == 110 and not res.converged and bool(np.any(x != 0.0))
+        out["C5_matrix_l2_ball"] = report(m, n, 8, 100, dt, st, res, "the l2 ball's conjugate prox is linear in the rows once the norm is known: "
+                                          "A' z and sum z^2 in ONE pass over A, scaled by the closing kernel (DESIGN 4, round 4)")
+        out["C5_matrix_l2_ball"]["workload"] = "square-root-lasso terms (h = l2 ball) on C5's matrix, adaptive_primal_dual (OurRule)"
+        out["C5_matrix_l2_ball"]["timed_steps_all_real"] = ok
+        s.close()
+        # AdaPDM+ (src/AdaProx.jl:463-550): host-driven linesearch, the first trial of an iteration takes A x along
+        kw = dict(f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=apx.Counting(p.A), eta=p.norm_A, t=1.0,
+                  tol=0.0, ctx=ctx)
+        apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), maxit=5, **kw)
+        barrier()
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        recs = []
+        t0 = time.perf_counter()
+        x, _, it = apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), maxit=100, record=recs.append, **kw)
+        barrier()
+        dt = time.perf_counter() - t0
+        ctx.profile(False)
+        k = kernel_table(ctx.kernel_stats(reset=True))
+        out["C5_adapdm_plus"] = {"workload": "least_absolute_deviation via adaptive_linesearch_primal_dual (AdaPDM+), A 50000x20000 fp64",
+                                 "iters_per_s": 100 / dt, "ms_per_iter": dt * 10.0, "steps": int(it),
+                                 "linesearch_trials": int(recs[-1]["At_evals"]) - 1, "kernels": k, "objective": recs[-1]["objective"],
+                                 "note": "one CALL of 100 iterations, its upload / two products in front of the loop / read-back included ; "
+                                         "the first linesearch trial of an iteration leaves A x and A' y_next from one read of A, "
+                                         "a rejected trial costs one GEMV-T more (DESIGN 4, round 4)"}
+    except (Exception, SystemExit) as e:           # noqa: BLE001
+        out["C5_matrix_extra_error"] = f"{type(e).__name__}: {e}"
     p.A.free()
     return out
 
