@@ -368,20 +368,39 @@ static int32_t agraal_run(apx_problem* p, const void* x1, const void* x0, double
 }
 
 // malitsky_pock(x, y; f, g, h, A, sigma, t, tol, maxit) — src/AdaProx.jl:555-629
+// Round 4: every linesearch trial's `A_x = A * x` (:561 / :574) takes the NEXT iteration's dual step along — w = y + sigma A_x,
+// y = prox(h_conj, w, sigma), At_y = A' y (:601-603) with the trial's sigma, which is the one the next iteration starts from if
+// the trial is accepted: y[i] needs row i of A only, so one launch of the one-pass primal-dual kernels in their trial mode
+// (csrc/slab_pd.hip slab_pd_trial, rho = 0) leaves both from one read of A, and the GEMV-T of the dual step disappears from the
+// loop (a rejected trial's dual step is simply not used).
+static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol,
+                                 int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res);
 int32_t apx_malitsky_pock(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol,
                           int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res) {
   APX_TRY(begin(p, maxit, true));
   APX_REQUIRE(x0 != nullptr && y0 != nullptr && x_out != nullptr, "apx_malitsky_pock: NULL argument");
+  return with_team_fallback(p, res, [&] { return malitsky_pock_run(p, x0, y0, sigma, t, tol, maxit, opts, x_out, y_out, res); });
+}
+static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0, double sigma, double t, double tol,
+                                 int64_t maxit, const apx_solve_opts* opts, void* x_out, void* y_out, apx_result* res) {
   // tall, skinny dense A with f = Zero (the reference's LAD / square-root-lasso data): device-resident linesearch
   if (skinny_mp_eligible(p)) return skinny_mp_run(p, x0, y0, sigma, t, tol, maxit, opts, x_out, y_out, res);
   if (small_mpq_eligible(p)) return small_mpq_run(p, x0, y0, sigma, t, tol, maxit, opts, x_out, y_out, res);
   apx_ctx* ctx = p->ctx;
   const size_t es = p->es(), nb = (size_t)p->n_pad * es, mb = (size_t)p->m_pad * es;
-  DBuf bx, bxn, bv, bgp, baty, batyp, by, byn, bax, baxn;
-  for (DBuf* b : {&bx, &bxn, &bv, &bgp, &baty, &batyp}) APX_TRY(b->alloc_zero(nb, ctx->stream));
-  for (DBuf* b : {&by, &byn, &bax, &baxn}) APX_TRY(b->alloc_zero(mb, ctx->stream));
+  DBuf bx, bxn, bv, bgp, baty, batyp, batyq, by, byn, byq, bax, baxn;
+  for (DBuf* b : {&bx, &bxn, &bv, &bgp, &baty, &batyp, &batyq}) APX_TRY(b->alloc_zero(nb, ctx->stream));
+  for (DBuf* b : {&by, &byn, &byq, &bax, &baxn}) APX_TRY(b->alloc_zero(mb, ctx->stream));
   void *x = bx.p, *xnew = bxn.p, *aty = baty.p, *atyprev = batyp.p, *y = by.p, *ynew = byn.p, *ax = bax.p,
        *axnew = baxn.p;
+  void *yq = byq.p, *atyq = batyq.p;      // the NEXT iteration's dual step, formed with a trial (one pass over A)
+  // the one-pass kernels of the primal-dual loop, when this problem is theirs (a shell of a solver carries their state)
+  apx_solver shell;
+  shell.p = p;
+  if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup(&shell));
+  const bool one_pass = slab_pd_trial_ok(&shell);
+  const bool teams = one_pass && slab_pd_uses_teams(&shell);
+  bool have_next = false;                 // yq / atyq hold this iteration's dual step already (the last accepted trial left it)
   APX_TRY(h2d(ctx, x, x0, (size_t)p->n * es));
   APX_TRY(h2d(ctx, y, y0, (size_t)p->m * es));
   Scalars sc{ctx, p};
@@ -395,8 +414,13 @@ int32_t apx_malitsky_pock(apx_problem* p, const void* x0, const void* y0, double
   for (int64_t it = 1; it <= maxit; ++it) {                                             // :599
     std::swap(aty, atyprev);                                                            // :600  At_y_prev = At_y
     // :601-602  w = y + sigma*A_x ; y = prox(h_conj, w, sigma)   (rho = 0 => w = y + sigma*A_x exactly)
-    APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, ax, ynew, p->m, p->hd, sigma, 0.0, ctx->scal + 8));
-    APX_TRY(launch_gemv_t(ctx, p->A_lin, ynew, aty, nullptr));                          // :603
+    if (have_next) {                                                                    // (it came with the accepted trial)
+      std::swap(ynew, yq);
+      std::swap(aty, atyq);
+    } else {
+      APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, ax, ynew, p->m, p->hd, sigma, 0.0, ctx->scal + 8));
+      APX_TRY(launch_gemv_t(ctx, p->A_lin, ynew, aty, nullptr));                        // :603
+    }
     const double sigma_prev = sigma;                                                    // :605
     sigma = sigma * std::sqrt(1.0 + theta_outer);                                       // :606
     APX_TRY(eval_f(p, x, true));                                                        // :608
@@ -415,7 +439,15 @@ int32_t apx_malitsky_pock(apx_problem* p, const void* x0, const void* y0, double
       const double theta = sigma / sigma_prev;                                          // :556 / :569
       gamma = t * t * sigma;                                                            // :557 / :570
       APX_TRY(vo_mp_trial(ctx, p->dtype, x, aty, atyprev, bgp.p, bv.p, xnew, p->n, p->gd, theta, gamma, ctx->scal));
-      APX_TRY(mul_A_lin(p, xnew, axnew));                                               // :561 / :574
+      if (one_pass) {
+        // A_x = A * x (:561 / :574) and, from the same read of A, the dual step the next iteration starts with if this trial is
+        // accepted (:601-603 with this trial's sigma ; rho = 0: A_x_prev does not enter) ; for the l2 ball y once more from the
+        // stored A x, in the dual step's own arithmetic
+        APX_TRY(slab_pd_trial(&shell, xnew, ynew, ax, yq, axnew, atyq, sigma, 0.0));
+        if (p->hd.kind == APX_G_L2) APX_TRY(vo_dual_trial(ctx, p->dtype, ynew, axnew, axnew, yq, p->m, p->hd, sigma, 0.0, ctx->scal + 8));
+      } else {
+        APX_TRY(mul_A_lin(p, xnew, axnew));                                             // :561 / :574
+      }
       APX_TRY(eval_f(p, xnew, true));                                                   // :562 / :575
       APX_TRY(vo_diff_sumsq(ctx, p->dtype, axnew, ax, p->m, ctx->scal + 3));
       APX_TRY(sc.read(4, true));
@@ -424,9 +456,11 @@ int32_t apx_malitsky_pock(apx_problem* p, const void* x0, const void* y0, double
       f_x = sc.f();
       g_raw = sc[2];
       const double ndx = std::sqrt(sc[0]), ndax = std::sqrt(sc[3]);
+      if (teams) APX_TRY(slab_pd_check(&shell));                                        // (the error word of the team hand-offs)
       const double lhs = gamma * sigma * (ndax * ndax) + 2.0 * gamma * (f_x - f_x_prev - sc[1]);   // :563 / :576
       if (!(lhs > 0.95 * (ndx * ndx)) || sigma == 0.0) break;                           // :564
     }
+    have_next = one_pass;
     APX_TRY(pullback_f(p));                                                             // :612  grad_x = pb()
     grad_evals++;
     APX_TRY(vo_primal_res(ctx, p->dtype, bv.p, xnew, p->grad.p, aty, p->n, gamma, p->gd, ctx->scal));       // :616

@@ -888,3 +888,51 @@ def test_adapdm_plus_first_trial_in_one_pass(apx, m, n, hkind, t):
         assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-9) and a["sigma"] == pytest.approx(b_["sigma"], rel=1e-9)
         assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7) and a["objective"] == pytest.approx(b_["objective"], rel=1e-9)
         assert (a["A_evals"], a["At_evals"], a["prox_h_evals"]) == (b_["A_evals"], b_["At_evals"], b_["prox_h_evals"])
+
+
+@pytest.mark.parametrize("m,n,hkind", [(9000, 1000, "tl1"),       # k_multi_rows
+                                       (4100, 6000, "tl2"),       # k_team_rows, one workgroup ; the l2 ball
+                                       (4100, 20000, "tl1"),      # ... teams of two (C5's row)
+                                       (4099, 30001, "tl2")])     # ... teams of four
+def test_malitsky_pock_trials_in_one_pass(apx, m, n, hkind):
+    """malitsky_pock (src/AdaProx.jl:555-629): every linesearch trial's A_x = A * x takes the NEXT iteration's dual step along
+    (w = y + sigma A_x, y = prox, At_y = A' y with the trial's sigma) — one launch of the one-pass primal-dual kernels in trial
+    mode per trial, no GEMV-T of the dual step in the loop (csrc/baselines.hip, round 4).  Against the oracle and against the
+    context that runs every product as a GEMV ; sigma0 large enough that trials ARE rejected."""
+    rng = np.random.default_rng(m + n + 13)
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+    yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+    nA = float(np.linalg.norm(A))
+    mk_h = {"tl1": lambda M: M.Translate(M.NormL1(1.0), -yv), "tl2": lambda M: M.Translate(M.NormL2(1.0), -yv)}[hkind]
+    lam = 5.0 if hkind == "tl1" else 0.3
+    K = 12
+    kw = dict(sigma=200.0 / nA, t=1.0, tol=0.0, maxit=K)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    ro = []
+    xo, yo, _ = O.malitsky_pock(x0, y0, f=O.Zero(), g=O.NormL1(lam), h=mk_h(O), A=O.Counting(A), record=ro.append, **kw)
+    assert ro[-1]["A_evals"] > K + 1 and ro[-1]["norm_res"] > 1e-3          # (some trial was rejected ; a loop that is still moving)
+    out = []
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.fused_small(one_pass)
+        ctx.one_pass_threshold(16 << 20)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        recs = []
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        x, y, it = apx.malitsky_pock(x0, y0, f=apx.Zero(), g=apx.NormL1(lam), h=mk_h(apx), A=apx.Counting(dA), ctx=ctx, record=recs.append, **kw)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        assert it == K and len(recs) == K
+        if one_pass:      # one launch per TRIAL, and the only GEMV-Ts are the two in front of the loop's first trial
+            assert st["one_pass"]["launches"] == recs[-1]["A_evals"] - 1 and st["gemv_t"]["launches"] <= 3, (st, recs[-1])
+        else:
+            assert st["one_pass"]["launches"] == 0, st
+        out.append((x, y, recs))
+        dA.free()
+    (x1, y1, r1), (x2, y2, r2) = out
+    assert _rel(x1, xo) <= 1e-10 and _rel(y1, yo) <= 1e-9 and _rel(x1, x2) <= 1e-10 and _rel(y1, y2) <= 1e-9
+    for a, b_ in zip(r1, ro):
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-9) and a["sigma"] == pytest.approx(b_["sigma"], rel=1e-9)
+        assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7) and a["objective"] == pytest.approx(b_["objective"], rel=1e-9)
+        assert (a["A_evals"], a["At_evals"]) == (b_["A_evals"], b_["At_evals"])

@@ -108,6 +108,27 @@ if "adapdm" in which:      # AdaPDM+ (adaptive_linesearch_primal_dual) on C5's L
             kernels={k: dict(launches=v["launches"], avg_ms=v["total_ms"] / v["launches"]) for k, v in st.items() if v["launches"]},
             note="the call includes the upload of x0 / y0, two products in front of the loop and the read-back of the result")
         p.A.free()
+if "mp" in which:      # Malitsky-Pock on C5's LAD: every trial in one pass (round 4) / every product a GEMV
+    m, n = 50_000, 20_000
+    for one_pass in (True, False):
+        cx = apx.Context(0)
+        cx.one_pass(1 if one_pass else 0)
+        p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=cx)
+        if one_pass:
+            p.A.build_transpose()
+        kw = dict(f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=apx.Counting(p.A), sigma=1.0 / p.norm_A, t=1.0, tol=0.0, ctx=cx)
+        apx.malitsky_pock(np.zeros(n), np.zeros(m), maxit=5, **kw)
+        cx.kernel_stats(reset=True); cx.profile(True)
+        recs = []
+        t0 = time.perf_counter()
+        x, y, it = apx.malitsky_pock(np.zeros(n), np.zeros(m), maxit=100, record=recs.append, **kw)
+        dt = time.perf_counter() - t0
+        cx.profile(False)
+        st = cx.kernel_stats(reset=True)
+        out["Malitsky-Pock LAD 50000x20000 fp64, %s" % ("trials in one pass" if one_pass else "GEMV per product")] = dict(
+            iters_per_s=100 / dt, ms_per_iter=dt * 10, trials=recs[-1]["A_evals"] - 1, objective=recs[-1]["objective"],
+            kernels={k: dict(launches=v["launches"], avg_ms=v["total_ms"] / v["launches"]) for k, v in st.items() if v["launches"]})
+        p.A.free()
 if "c2bt" in which:
     m, n = 50_000, 100_000
     p = problems.device_lasso(m, n, seed=0, power_iters=20, ctx=ctx, dual_layout=os.environ.get("APX_SINGLE_LAYOUT") != "1")
