@@ -970,6 +970,7 @@ static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_lin
     APX_HIP(hipMemcpyAsync(ctx->h_scal + 9, (char*)p->ctrl_buf.p + offsetof(Ctrl, f_x), sizeof(double),
                            hipMemcpyDeviceToHost, ctx->stream));
     APX_HIP(hipStreamSynchronize(ctx->stream));
+    APX_TRY(slab_check(p));      // (f's own one-pass kernels, if they run as teams: their error word before f_x and the sums are used)
     const double npr = std::sqrt(ctx->h_scal[4]);
     const double ndg = std::sqrt(ctx->h_scal[5]), dgdx = ctx->h_scal[6], ndx = std::sqrt(ctx->h_scal[7]);
     const double g_x = vo_gval_final_host(p->gd, ctx->h_scal[8]);

@@ -40,6 +40,17 @@ def test_two_ranks_reproduce_one_rank():
     assert two["config"]["parallelism"] == "row-shard x2"
 
 
+def test_four_ranks_reproduce_one_rank():
+    """"until then validate numerics with P logical shards on one device" — four real ranks, each with its own
+    context, stream and row shard on device 0 (the box allows six processes on the card ; eight is the driver's to run)."""
+    common = ["--cols", "6000", "--steps", "25", "--warmup", "5", "--no-cpu-baseline"]
+    one = _bench(["--rows", "4400"] + common, {}, 1)
+    four = _bench(["--rows", "1100"] + common, {"APX_BENCH_SHARE_GPU": "1"}, 4)
+    assert four["n_gpus"] == 4 and four["config"]["parallelism"] == "row-shard x4"
+    assert four["lasso_optimum"] == pytest.approx(one["lasso_optimum"], rel=1e-12)
+    assert four["final_objective"] == pytest.approx(one["final_objective"], rel=1e-10)
+
+
 def test_strong_scaling_uneven_split():
     """`--strong`: --rows is the global row count; 4001 rows over two ranks = 2001 + 2000."""
     common = ["--rows", "4001", "--cols", "6000", "--steps", "25", "--warmup", "5", "--no-cpu-baseline"]

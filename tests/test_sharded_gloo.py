@@ -56,12 +56,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_row_sharded_iteration_matches_unsharded_oracle():
+@pytest.mark.parametrize("world", [2, 8])      # (8: BASELINE config C4's rank count, rehearsed on the CPU)
+def test_row_sharded_iteration_matches_unsharded_oracle(world):
     import torch.multiprocessing as mp
     from oracle import adaprox_oracle as O
     from oracle import problems as P
 
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -81,11 +82,15 @@ def test_row_sharded_iteration_matches_unsharded_oracle():
     lp = P.random_logreg(400, 30, seed=1, dtype=np.float64)
     xl_ref, _ = O.adaptive_proxgrad(np.zeros(31), f=O.LogisticLoss(lp.X, lp.y), g=O.NormL1(lp.lam),
                                     rule=O.OurRule(gamma=lp.gamma0), tol=0.0, maxit=25)
-    # replicated state: both ranks hold bit-identical iterates and took identical decisions
-    assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
-    assert np.array_equal(outs[0][4], outs[1][4])
+    # replicated state: all ranks hold bit-identical iterates and took identical decisions
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][1], o[1]) and outs[0][2] == o[2]
+        assert np.array_equal(outs[0][4], o[4])
     # the shards tile the rows
-    assert outs[0][5] == (0, 151) and outs[1][5] == (151, 150)
+    assert outs[0][5][0] == 0 and sum(o[5][1] for o in outs) == 301
+    assert all(a[5][0] + a[5][1] == b[5][0] for a, b in zip(outs, outs[1:]))
+    if world == 2:
+        assert outs[0][5] == (0, 151) and outs[1][5] == (151, 150)
     # and the sharded run is the unsharded algorithm up to summation order
     # (first 30 step sizes: on this small problem summation-order noise reaches 4e-9 by k=45)
     assert outs[0][3][:30] == pytest.approx([r["gamma"] for r in recs[:30]], rel=1e-9)
