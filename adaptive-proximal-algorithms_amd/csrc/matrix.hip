@@ -350,7 +350,7 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       ctx->team_interleave = (int)value;
       return APX_OK;
     case APX_OPT_TEAM_SLOTS:
-      APX_REQUIRE(value == 0 || value == 52 || value == 62 || value == 53 || value == 63, "APX_OPT_TEAM_SLOTS: 0, 52, 62, 53 or 63");
+      APX_REQUIRE(value == 0 || value == 52 || value == 62 || value == 53 || value == 63 || value == 31 || value == 42, "APX_OPT_TEAM_SLOTS: 0, 52, 62, 53, 63, 31 or 42");
       ctx->team_slots = (int)value;
       return APX_OK;
     default:

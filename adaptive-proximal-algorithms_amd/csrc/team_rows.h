@@ -962,6 +962,11 @@ inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}, int 
   else if (nvec <= 4 * v6) pl.P = 4;
   else if (nvec <= 4 * v8) pl.P = 4, pl.big = true;
   else if (nvec <= 8 * v6) pl.P = 8;
+  // (round 4: teams of eight in the three-slot shape, where sixteen members would hold three or four vectors each — their step is
+  //  the shortest of all, ~ 35 KB per member, and the communication wave's chain does not fit it: 70 000 columns, 6 GB, two builds of
+  //  the plan alternated in one process, least squares 6.36 -> 6.81 TB/s, the primal-dual form 5.11 -> 6.60 ; 85 000: 6.68 -> 6.90,
+  //  5.67 -> 6.83 — profiles/r04i_ab_teams_of_eight_three_slots.jsonl)
+  else if (nvec <= 8 * v8) pl.P = 8, pl.big = true;
   else if (nvec <= 16 * v6) pl.P = 16;
   else pl.big = true;
   // (The primal-dual form in the three-slot shape has the whole dual step of a row — a division, the conjugate prox — between two
@@ -975,7 +980,6 @@ inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}, int 
       nvec > (int64_t)tune.members * 704) {
     pl.P = tune.members;
     pl.big = nvec > (int64_t)tune.members * v6;
-    if (pl.big && pl.P == 8) pl.P = 16, pl.big = nvec > 16 * v6;      // (no three-slot instance for teams of eight)
   }
   const int64_t nvs = (nvec + pl.P - 1) / pl.P;
   pl.kv = (int)((nvs + 703) / 704);
@@ -989,6 +993,11 @@ inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}, int 
   if (pl.waves == 10 && kv10 > (pl.big || pl.P == 1 ? 8 : 6)) pl.waves = 11;      // (a forced 10 that would not fit the shape)
   if (pl.waves == 10) pl.kv = kv10;
   if (pl.P == 4 && pl.kv == 4 && !pl.big) pl.alt = tune.alt;
+  // The primal-dual form of teams of two with FIVE vectors takes the three-slot shape as well (round 4: rows of 11 265 ... 14 080
+  // entries, 6 GB, alternated in one process — 11 300: 5.74 -> 6.27 TB/s, 12 000: 6.05 -> 6.39, 14 000: 6.39 -> 6.68 ; with six
+  // vectors, 16 000: 6.94 against 6.90, left alone — profiles/r04j_ab_teams_of_two_three_slots.jsonl).  APX_OPT_TEAM_SLOTS = 42 keeps
+  // the four slots (A/B), 31 forces the three-slot shape for six vectors too.
+  if (tune.pd && pl.P == 2 && !pl.big && ((pl.kv == 5 && tune.alt != 42) || (pl.kv == 6 && tune.alt == 31))) pl.big = true, pl.waves = 11;
   return pl;
 }
 
@@ -1093,6 +1102,13 @@ inline bool team_launch_d1(TeamCall& call, int kv, int nteams, const DEV& d, con
     case 8: team_launch_one<FK, P, 8, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
     default: break;
   }
+  if constexpr (P == 2 && FK == kTeamFkPd) {       // (the primal-dual form of teams of two: five or six vectors in the three-slot shape)
+    switch (kv) {
+      case 5: team_launch_one<FK, 2, 5, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
+      case 6: team_launch_one<FK, 2, 6, NT, 3, 1, DEV, CW>(call, nteams, d, t, x, q); return true;
+      default: break;
+    }
+  }
   if constexpr (P == 1) {
     switch (kv) {
       case 1:
@@ -1123,6 +1139,7 @@ inline bool team_dispatch_w(TeamCall& call, const TeamPlan& pl, int nteams, bool
     else if (pl.big) {
       if (pl.P == 2) ok = team_launch_d1<FK, 2, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
       else if (pl.P == 4) ok = team_launch_d1<FK, 4, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
+      else if (pl.P == 8) ok = team_launch_d1<FK, 8, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
       else if (pl.P == 16) ok = team_launch_d1<FK, 16, true, DEV, CW>(call, pl.kv, nteams, d, t, x, q);
     } else if (pl.P == 2) ok = team_launch_d2<FK, 2, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);
     else if (pl.P == 4) ok = team_launch_d2<FK, 4, DEV, CW>(call, pl.kv, pl.alt, nteams, d, t, x, q);

@@ -293,7 +293,9 @@ enum {
                                     (k_team_rows) is dealt to (A/B)                                                          */
   APX_OPT_TEAM_MEMBERS = 12,     /* default 0 = by the row length ; 2 / 4 / 8 / 16: workgroups per team where the row allows (A/B) */
   APX_OPT_TEAM_SLOTS = 13,       /* default 0 ; 52 / 62 / 53 / 63: row slots x 10 + rows of slack, teams of four with four vectors
-                                    per thread in the primal-dual loop only (C5's length as teams of four: A/B)              */
+                                    per thread in the primal-dual loop only (C5's length as teams of four: A/B) ; 42 / 31: teams of
+                                    two in the primal-dual loop with five (six) vectors keep the four-slot shape / take the
+                                    three-slot one (A/B of round 4's default)                                                */
   APX_OPT_ROW_DEAL = 14,         /* default -1: the rows of A are dealt to the workgroups (teams) of a one-pass launch in CHUNKS of
                                     consecutive rows (about 4 MB), the chunks cyclically — the chip streams one window of the
                                     matrix at a time, whatever the allocation ; 0: one slab of consecutive rows each (round 2) ;

@@ -41,7 +41,9 @@ PG_SHAPES = [(4096, 10753), (4097, 11263), (4099, 11265), (5000, 16897), (4111, 
              (4101, 56320), (4096, 56321), (4100, 67585), (4097, 112640), (4300, 99999),
              # ... and of the present one: one workgroup / teams of two, five / six vectors, two / four, four / eight, the longest row
              (4100, 14080), (4099, 14081), (4100, 16896), (4101, 16897), (4100, 22528), (4097, 22529), (4098, 33793), (4098, 45056), (4096, 45057),
-             (4100, 67585), (4100, 112641), (4099, 135169), (4097, 180223)]
+             (4100, 67585), (4100, 112641), (4099, 135169), (4097, 180223),
+             # round 4: teams of eight in the three-slot shape from 67 585 to 90 112 columns (seven / eight vectors), sixteen beyond
+             (4100, 67584), (4099, 78849), (4098, 90112), (4097, 90113)]
 
 
 @pytest.mark.parametrize("m,n", PG_SHAPES)
@@ -106,7 +108,9 @@ def test_team_rows_ragged_shapes(apx, m, n, logistic):
 PD_SHAPES = [(4096, 10753), (4097, 12289), (4099, 15361), (4098, 18433), (4500, 21503), (4096, 21504), (6007, 19999),
              # the primal-dual loop on k_team_rows (round 2, last): every boundary of csrc/team_rows.h team_plan, and the longest row
              (4100, 11264), (4099, 11265), (4100, 16896), (4101, 16897), (4100, 22528), (4097, 22529), (4098, 33793), (4098, 45057),
-             (4100, 67585), (4100, 135169), (4097, 180223)]
+             (4100, 67585), (4100, 135169), (4097, 180223),
+             # round 4: teams of two with five vectors in the three-slot shape (11 265 ... 14 080), teams of eight in it (67 585 ... 90 112)
+             (4100, 12001), (4099, 14080), (4098, 14081), (4100, 67584), (4099, 78849), (4098, 90112), (4097, 90113)]
 
 
 @pytest.mark.parametrize("m,n", PD_SHAPES)
