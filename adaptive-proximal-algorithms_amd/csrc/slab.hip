@@ -629,7 +629,7 @@ static int32_t slab_setup(apx_problem* p) {
   if (st->cpt == kSlabTeamCpt) {           // teams: the fewest members whose slice fits 5 vectors per compute thread
     const bool f32 = p->dtype == APX_F32;
     const TeamPlan pl = f32 ? team_plan(A->n, TeamTune{0, ctx->multi_waves, 0}, 4)
-                            : team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, 0});      // (csrc/team_rows.h)
+                            : team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, ctx->team_slots});      // (csrc/team_rows.h)
     if (pl.P == 0) return APX_OK;
     const int P = pl.P;
     st->plan = pl;

@@ -992,7 +992,9 @@ inline TeamPlan team_plan(int64_t ncols, const TeamTune& tune = TeamTune{}, int 
   pl.waves = tune.waves == 10 || tune.waves == 11 ? tune.waves : (kv10 == pl.kv && !(pl.P > 1 && pl.big) ? 10 : 11);
   if (pl.waves == 10 && kv10 > (pl.big || pl.P == 1 ? 8 : 6)) pl.waves = 11;      // (a forced 10 that would not fit the shape)
   if (pl.waves == 10) pl.kv = kv10;
-  if (pl.P == 4 && pl.kv == 4 && !pl.big) pl.alt = tune.alt;
+  if (pl.P == 4 && pl.kv == 4 && !pl.big && tune.pd) pl.alt = tune.alt;
+  // (sixteen members in the three-slot shape — C2's five vectors with one row of slack — measured again in round 4 with the
+  //  communication wave's priority: 8.02 against 5.76 ms, profiles/r04l_ab_c2_three_slots.jsonl ; they need the second row: removed)
   // The primal-dual form of teams of two with FIVE vectors takes the three-slot shape as well (round 4: rows of 11 265 ... 14 080
   // entries, 6 GB, alternated in one process — 11 300: 5.74 -> 6.27 TB/s, 12 000: 6.05 -> 6.39, 14 000: 6.39 -> 6.68 ; with six
   // vectors, 16 000: 6.94 against 6.90, left alone — profiles/r04j_ab_teams_of_two_three_slots.jsonl).  APX_OPT_TEAM_SLOTS = 42 keeps
