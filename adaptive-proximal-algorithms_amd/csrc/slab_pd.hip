@@ -239,9 +239,11 @@ __global__ __launch_bounds__(kSlabPdCloseBlock) void k_slabpd_close(SlabPdDev d,
 #pragma unroll
     for (int k = 1; k < S; ++k) g += sub[k][c];
     if constexpr (L2) {
-      const double sigma = d.trial ? d.sigma_arg : d.c->sigma, aux = sqrt(fs[0]);
-      const double sc = fmax(0.0, 1.0 - d.h.lambda * (1.0 / sigma) / aux);                 // csrc/vecops_dev.h prox_core, gamma = 1 / sigma
-      g *= sigma * (1.0 - sc);
+      if (d.no_finish == 0) {      // (a row shard: the norm is over ALL ranks' rows — scaled behind the all-reduce, vo_l2_scale)
+        const double sigma = d.trial ? d.sigma_arg : d.c->sigma, aux = sqrt(fs[0]);
+        const double sc = fmax(0.0, 1.0 - d.h.lambda * (1.0 / sigma) / aux);               // csrc/vecops_dev.h prox_core, gamma = 1 / sigma
+        g *= sigma * (1.0 - sc);
+      }
     }
     aty[j] = (T)g;                                                                         // :358  At_y = A' * y
   }
@@ -306,10 +308,10 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
 static bool slab_pd_shape_ok(const apx_problem* p) {
   if (!p->ctx->one_pass) return false;
   if (p->A_lin == nullptr) return false;
-  // a row-sharded OPERATOR is as good as a whole one (the rows are local ; A' y and the two residual sums travel) with a
-  // separable h (round 4) ; the l2 ball's norm over all ranks' rows would need a collective of its own in front of the scaling,
-  // and a sharded f next to a replicated operator is nobody's use: both keep the generic kernels
-  if (p->sharded() && !(p->lin_sharded && !p->f_sharded && p->hd.kind != APX_G_L2)) return false;
+  // a row-sharded OPERATOR is as good as a whole one (round 4): the rows are local ; A' y and the two residual sums travel — for
+  // the l2 ball A' z and sum z^2 first, the scaling and y+ behind that all-reduce, then the residual sums (three collectives, as
+  // on the two passes).  A sharded f next to a replicated operator is nobody's use and keeps the generic kernels
+  if (p->sharded() && !(p->lin_sharded && !p->f_sharded)) return false;
   if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
   // (h = NormL2: its conjugate prox needs a norm over all rows first, but is linear in the rows once the norm is known — the
   //  kernels of csrc/team_rows.h leave A' z and sum z^2 and the closing kernel scales, round 4 ; the first-generation row kernels
@@ -470,11 +472,17 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
                           : slab_pd_launch_t<double>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
   APX_TRY(prof_end(ctx));
   if (!launched) return team_launch_refused(p, "one-pass primal-dual kernel (teams)");
-  if (p->hd.kind == APX_G_L2)      // y+ and the dual residual from w (left in y's place) and ||z|| ; the end of the iteration (:345-354)
+  const bool l2 = p->hd.kind == APX_G_L2;
+  if (l2 && !p->lin_sharded)       // y+ and the dual residual from w (left in y's place) and ||z|| ; the end of the iteration (:345-354)
     APX_TRY(vo_dual_post(ctx, p->dtype, s->y.p, s->axprev.p, p->m, p->hd, p->ctrl(), (apx_record*)s->recs.p, s->rec_cap));
   if (p->lin_sharded) {            // A' y = sum_k A_k' y_k, the residual sums likewise ; the iteration closed from the global sums
     APX_TRY(problem_allreduce(p, s->aty.p, p->A_lin->n_pad, p->dtype));
     APX_TRY(problem_allreduce(p, ctx->scal + 13, 2, APX_F64));
+    if (l2) {                      // so far A' z and sum z^2: the factor from the global norm, y+ and this rank's residual sums, summed again
+      APX_TRY(vo_l2_scale(ctx, p->dtype, s->aty.p, p->n, ctx->scal + 13, p->hd, p->ctrl()));
+      APX_TRY(vo_dual_post_sums(ctx, p->dtype, s->y.p, s->axprev.p, p->m, p->hd, p->ctrl(), ctx->scal + 13));
+      APX_TRY(problem_allreduce(p, ctx->scal + 13, 2, APX_F64));
+    }
     APX_TRY(vo_final_sums(ctx, ctx->scal + 13, p->hd, p->ctrl(), (apx_record*)s->recs.p, s->rec_cap));
   }
   APX_HIP(hipGetLastError());

@@ -18,6 +18,8 @@ int32_t vo_reduce_rule(apx_ctx* ctx, int32_t dtype, const void* x, const void* x
 // K9 then the end of the iteration
 int32_t vo_dual_post(apx_ctx* ctx, int32_t dtype, void* y, const void* axnew, int64_t m, const ProxDev& h, Ctrl* c, apx_record* recs,
                      int64_t rec_cap);
+int32_t vo_l2_scale(apx_ctx* ctx, int32_t dtype, void* aty, int64_t n, const double* sums, const ProxDev& h, Ctrl* c);
+int32_t vo_dual_post_sums(apx_ctx* ctx, int32_t dtype, void* y, const void* axnew, int64_t m, const ProxDev& h, Ctrl* c, double* out2);
 int32_t vo_final_sums(apx_ctx* ctx, const double* sums, const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap);
 int32_t vo_dual(apx_ctx* ctx, int32_t dtype, void* y, const void* ax, void* axprev, int64_t m, const ProxDev& h,
                 Ctrl* c, apx_record* recs, int64_t rec_cap);

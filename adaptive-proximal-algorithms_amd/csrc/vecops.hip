@@ -659,6 +659,36 @@ __global__ void k_final_s(const double* __restrict__ sums, ProxDev h, Ctrl* c, a
   finish_iteration(c, recs, rec_cap);
 }
 
+// A' y+ = sigma (1 - sc) A' z for the l2 ball on a row shard of the operator: `aty` holds the all-reduced A' z, sums[0] the
+// all-reduced sum z^2 (csrc/slab_pd.hip) ; leaves ||z|| in Ctrl::h_pre for k_dual_post
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_l2_scale(T* __restrict__ aty, int64_t n, const double* __restrict__ sums, ProxDev h, Ctrl* c) {
+  if (c->done != 0) return;
+  const double sigma = c->sigma, aux = sqrt(sums[0]);
+  const double sc = fmax(0.0, 1.0 - h.lambda * (1.0 / sigma) / aux);                       // csrc/vecops_dev.h prox_core, gamma = 1 / sigma
+  const double fac = sigma * (1.0 - sc);
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) aty[j] = (T)((double)aty[j] * fac);
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->h_pre = aux;
+}
+int32_t vo_l2_scale(apx_ctx* ctx, int32_t dtype, void* aty, int64_t n, const double* sums, const ProxDev& h, Ctrl* c) {
+  const unsigned gr = vgrid(n);
+  // (h_pre is written by block 0 and read by the NEXT kernel only)
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_l2_scale<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)aty, n, sums, h, c),
+             hipLaunchKernelGGL(k_l2_scale<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)aty, n, sums, h, c));
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+// k_dual_post on a row shard: this rank's two sums (sum dual_res^2, raw h(A_x)) to `out2` on the device, for the all-reduce
+int32_t vo_dual_post_sums(apx_ctx* ctx, int32_t dtype, void* y, const void* axnew, int64_t m, const ProxDev& h, Ctrl* c, double* out2) {
+  const unsigned gr = vgrid(m);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(k_dual_post<double>, dim3(gr), dim3(kBlock), 0, ctx->stream, (double*)y, (const double*)axnew, m, h, c, ctx->red),
+             hipLaunchKernelGGL(k_dual_post<float>, dim3(gr), dim3(kBlock), 0, ctx->stream, (float*)y, (const float*)axnew, m, h, c, ctx->red));
+  hipLaunchKernelGGL(k_sum_q, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->red, (int)gr, 2, out2);
+  APX_HIP(hipGetLastError());
+  return APX_OK;
+}
+
 // the end of the iteration from two all-reduced sums (sum dual_res^2, raw h(A_x)) on the device: behind a one-pass launch on a
 // row shard of the operator (csrc/slab_pd.hip)
 int32_t vo_final_sums(apx_ctx* ctx, const double* sums, const ProxDev& h, Ctrl* c, apx_record* recs, int64_t rec_cap) {

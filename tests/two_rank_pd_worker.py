@@ -68,24 +68,25 @@ def main():
         yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
         nA = float(np.linalg.norm(A))
         A_k = apx.DeviceMatrix.from_numpy(np.asfortranarray(A[r0:r0 + ml]), ctx1)
-        ctx1.kernel_stats(reset=True)
-        ctx1.profile(True)
-        x, y_k, it = apx.adaptive_primal_dual(np.zeros(n), np.zeros(ml), f=apx.Zero(), g=apx.NormL1(5.0),
-                                              h=apx.Translate(apx.NormL1(1.0), -yv[r0:r0 + ml]), A=A_k,
-                                              rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx1, A_allreduce=ar)
-        st = ctx1.kernel_stats(reset=True)
-        ctx1.profile(False)
-        ys = [None] * world
-        dist.all_gather_object(ys, (y_k, st["one_pass"]["launches"]))
-        if rank == 0:
-            A_full = apx.DeviceMatrix.from_numpy(A, ctx1)
-            xr, yr, _ = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(5.0),
-                                                 h=apx.Translate(apx.NormL1(1.0), -yv), A=A_full,
-                                                 rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx1)
-            y_cat = np.concatenate([t[0] for t in ys])
-            errs = [np.max(np.abs(x - xr)) / max(np.max(np.abs(xr)), 1e-300), np.max(np.abs(y_cat - yr)) / np.max(np.abs(yr))]
-            print(f"PD-SHARDED one-pass launches {[t[1] for t in ys]} errs " + " ".join(f"{e:.3e}" for e in errs), flush=True)
-            ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == K for t in ys)
+        A_full = apx.DeviceMatrix.from_numpy(A, ctx1) if rank == 0 else None
+        for hname, lam, hmk in (("l1", 5.0, lambda b: apx.Translate(apx.NormL1(1.0), -b)),
+                                ("l2", 0.05, lambda b: apx.Translate(apx.NormL2(1.0), -b))):      # (the l2 ball: three collectives)
+            ctx1.kernel_stats(reset=True)
+            ctx1.profile(True)
+            x, y_k, it = apx.adaptive_primal_dual(np.zeros(n), np.zeros(ml), f=apx.Zero(), g=apx.NormL1(lam), h=hmk(yv[r0:r0 + ml]), A=A_k,
+                                                  rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx1, A_allreduce=ar)
+            st = ctx1.kernel_stats(reset=True)
+            ctx1.profile(False)
+            ys = [None] * world
+            dist.all_gather_object(ys, (y_k, st["one_pass"]["launches"]))
+            if rank == 0:
+                xr, yr, _ = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(lam), h=hmk(yv), A=A_full,
+                                                     rule=apx.OurRule(t=1.0, norm_A=nA), tol=0.0, maxit=K, ctx=ctx1)
+                y_cat = np.concatenate([t[0] for t in ys])
+                errs = [np.max(np.abs(x - xr)) / max(np.max(np.abs(xr)), 1e-300), np.max(np.abs(y_cat - yr)) / np.max(np.abs(yr))]
+                print(f"PD-SHARDED one-pass {hname} launches {[t[1] for t in ys]} errs " + " ".join(f"{e:.3e}" for e in errs) +
+                      f" nonzeros {np.count_nonzero(xr)}", flush=True)
+                ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == K for t in ys) and (hname == "l1" or np.count_nonzero(xr) > 0)
     flag = torch.tensor([1 if ok else 0])
     dist.broadcast(flag, 0)
     dist.destroy_process_group()
