@@ -248,6 +248,62 @@ def test_lad_c5_solver_at_full_size(apx):
     p.A.free()
 
 
+def test_c5_matrix_round4_loops_at_full_size(apx):
+    """The loops that moved onto one pass over A in round 4, on C5's matrix at full size (50 000 x 20 000 fp64, teams of two),
+    through properties no oracle is needed for: (1) the square-root lasso's l2 ball — the FIRST dual step from y0 = 0 in closed
+    form (y1 = sigma (1 - sc) z with z = -b, a point of the ball's interior or its boundary), then the one-pass loop against the
+    two GEMV passes: the same objective and residual to rounding after 40 iterations, x moving ; (2) AdaPDM+
+    (adaptive_linesearch_primal_dual) and Malitsky-Pock with the linesearch trials in one pass against the same entry points on
+    the GEMVs: identical step sizes, trial counts and objectives."""
+    problems = importlib.import_module("adaptive-proximal-algorithms_amd.problems")
+    m, n, seed = 50_000, 20_000, 0
+    out = {}
+    for one_pass in (True, False):
+        ctx = apx.Context(0)
+        ctx.one_pass(1 if one_pass else 0)
+        p = problems.device_lad(m, n, seed=seed, lam=10.0, ctx=ctx)
+        if one_pass:
+            p.A.build_transpose()
+        rule = apx.OurRule(t=1.0, norm_A=p.norm_A)
+        l2 = dict(f=apx.Zero(), g=apx.NormL1(0.5), h=apx.Translate(apx.NormL2(1.0), -p.y), A=p.A, ctx=ctx)
+        if one_pass:      # the first dual step: w = 0, z = w / sigma - b, sc = max(0, 1 - 1 / (sigma ||z||)), y1 = sigma (1 - sc) z
+            recs = []
+            _, y1, _ = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), rule=rule, tol=0.0, maxit=1, record=recs.append, **l2)
+            sig = recs[0]["sigma"]
+            z = -p.y
+            sc = max(0.0, 1.0 - 1.0 / (sig * np.linalg.norm(z)))
+            assert np.max(np.abs(y1 - sig * (1.0 - sc) * z)) <= 1e-13 * np.max(np.abs(z)) * sig and np.linalg.norm(y1) <= 1.0 + 1e-12
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        recs = []
+        x, y, it = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), rule=rule, tol=0.0, maxit=40, record=recs.append, **l2)
+        st = ctx.kernel_stats(reset=True)
+        assert it == 40 and np.count_nonzero(x) > 100 and np.linalg.norm(y) <= 1.0 + 1e-12
+        assert st["one_pass"]["launches"] == (40 if one_pass else 0), st
+        lad = dict(f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), tol=0.0, maxit=25, ctx=ctx)
+        ra, rm = [], []
+        xa, ya, _ = apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), A=apx.Counting(p.A), eta=p.norm_A / 100.0, t=1.0,
+                                                        record=ra.append, **lad)
+        st_a = ctx.kernel_stats(reset=True)
+        xm, ym, _ = apx.malitsky_pock(np.zeros(n), np.zeros(m), A=apx.Counting(p.A), sigma=20.0 / p.norm_A, t=1.0, record=rm.append, **lad)
+        st_m = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        if one_pass:      # one launch per iteration (AdaPDM+: the first trial's) / per trial (Malitsky-Pock)
+            assert st_a["one_pass"]["launches"] == 25 and st_m["one_pass"]["launches"] == rm[-1]["A_evals"] - 1, (st_a, st_m)
+        out[one_pass] = (recs, x, ra, xa, rm, xm)
+        p.A.free()
+    a, b = out[True], out[False]
+    assert [r["objective"] for r in a[0]] == pytest.approx([r["objective"] for r in b[0]], rel=1e-11)
+    assert [r["norm_res"] for r in a[0]] == pytest.approx([r["norm_res"] for r in b[0]], rel=1e-8)
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-10 * np.max(np.abs(b[1]))
+    for k in (2, 4):      # AdaPDM+, Malitsky-Pock: rejected trials on both sides, the same decisions
+        assert a[k][-1]["At_evals" if k == 2 else "A_evals"] > 26
+        assert [(r["gamma"], r["sigma"], r["A_evals"], r["At_evals"]) for r in a[k]] == \
+            pytest.approx([(r["gamma"], r["sigma"], r["A_evals"], r["At_evals"]) for r in b[k]], rel=1e-9)
+        assert [r["objective"] for r in a[k]] == pytest.approx([r["objective"] for r in b[k]], rel=1e-10)
+        assert np.max(np.abs(a[k + 1] - b[k + 1])) <= 1e-10 * max(np.max(np.abs(b[k + 1])), 1e-300)
+
+
 def test_native_allreduce_hook_world_size_one(apx):
     """The RCCL hook of the row-sharded path with a single rank: all-reduce over one rank is the
     identity, so the run must equal the un-hooked one bit for bit."""
