@@ -940,3 +940,42 @@ def test_malitsky_pock_trials_in_one_pass(apx, m, n, hkind):
         assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-9) and a["sigma"] == pytest.approx(b_["sigma"], rel=1e-9)
         assert a["norm_res"] == pytest.approx(b_["norm_res"], rel=1e-7) and a["objective"] == pytest.approx(b_["objective"], rel=1e-9)
         assert (a["A_evals"], a["At_evals"]) == (b_["A_evals"], b_["At_evals"])
+
+
+def test_one_pass_l2_ball_termination_and_stepping(apx):
+    """The l2 ball on the one-pass kernels closes its iteration in a kernel BEHIND the closing kernel (k_dual_post + k_final:
+    the convergence flag is set there): termination at the oracle's iteration for every polling interval, stepping in pieces
+    equal to one call bit for bit, on k_multi_rows and on k_team_rows."""
+    for m, n in ((9000, 1000), (4100, 12000)):
+        rng = np.random.default_rng(m + n + 3)
+        A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+        yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+        nA = float(np.linalg.norm(A))
+        ctx = apx.Context(0)
+        ctx.one_pass_threshold(16 << 20)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        t = dict(f=apx.Zero(), g=apx.NormL1(0.05), h=apx.Translate(apx.NormL2(1.0), -yv), A=dA, ctx=ctx)
+        to = dict(f=O.Zero(), g=O.NormL1(0.05), h=O.Translate(O.NormL2(1.0), -yv), A=A)
+        x0, y0 = np.zeros(n), np.zeros(m)
+        rule, rule_o = apx.OurRule(t=1.0, norm_A=nA), O.OurRule(t=1.0, norm_A=nA)
+        recs = []
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        x, y, it = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=0.0, maxit=30, record=recs.append, **t)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        assert it == 30 and st["one_pass"]["launches"] == 30, st
+        tol = recs[19]["norm_res"] * (1 + 1e-9)
+        kstar = 1 + next(k for k, r in enumerate(recs) if r["norm_res"] <= tol)
+        xo, yo, ito = O.adaptive_primal_dual(x0, y0, rule=rule_o, tol=tol, maxit=1000, **to)
+        for poll in (1, 7, 64):
+            xt, yt, itt = apx.adaptive_primal_dual(x0, y0, rule=rule, tol=tol, maxit=1000, poll_every=poll, **t)
+            assert itt == kstar == ito and _rel(xt, xo) <= 1e-10 and _rel(yt, yo) <= 1e-9, (m, n, poll, itt, kstar, ito)
+        s = apx.Solver(x0, y0, rule=rule, tol=0.0, **t)
+        for k in (1, 9, 20):
+            s.step(k)
+            s.result()
+        xs, ys, res = s.result()
+        s.close()
+        assert res.numit == 30 and np.array_equal(xs, x) and np.array_equal(ys, y)
+        dA.free()
