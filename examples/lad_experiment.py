@@ -4,11 +4,13 @@
 t_values, records as JSONL.
 
     python examples/lad_experiment.py --m 2000 --n 400 --maxit 1000
+    python examples/lad_experiment.py --m 50000 --n 20000 --maxit 200      # BASELINE config C5's size: one pass over A per iteration / trial
 """
 import argparse
 import importlib
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -26,14 +28,22 @@ def run_least_absolute_deviation(m, n, lam=10.0, seed=0, tol=1e-5, maxit=1000, r
     f, g, h = apx.Zero(), apx.NormL1(lam), apx.Translate(apx.NormL1(), -p.y)
     x0, y0 = np.zeros(n), np.zeros(m)
     kw = dict(f=f, g=g, h=h, tol=tol, maxit=maxit, record=record)
-    out = {"Condat-Vu": apx.condat_vu(x0, y0, A=apx.Counting(p.A), Lf=0.0, norm_A=p.norm_A, name="Condat-Vu", **kw)}
+    out, secs = {}, {}
+
+    def timed(name, call):
+        t0 = time.perf_counter()
+        out[name] = call()
+        secs[name] = time.perf_counter() - t0
+
+    timed("Condat-Vu", lambda: apx.condat_vu(x0, y0, A=apx.Counting(p.A), Lf=0.0, norm_A=p.norm_A, name="Condat-Vu", **kw))
     for t in t_values:                                                                    # :64-78
-        out[f"Malitsky-Pock (t={t})"] = apx.malitsky_pock(x0, y0, A=apx.Counting(p.A), sigma=1.0, t=t,
-                                                          name=f"Malitsky-Pock (t={t})", **kw)
+        timed(f"Malitsky-Pock (t={t})", lambda: apx.malitsky_pock(x0, y0, A=apx.Counting(p.A), sigma=1.0, t=t,
+                                                                   name=f"Malitsky-Pock (t={t})", **kw))
     for t in t_values:                                                                    # :80-94
-        out[f"AdaPDM+ (t={t})"] = apx.adaptive_linesearch_primal_dual(x0, y0, A=apx.Counting(p.A), eta=p.norm_A, t=t,
-                                                                      name=f"AdaPDM+ (t={t})", **kw)
-    return p, out
+        timed(f"AdaPDM+ (t={t})", lambda: apx.adaptive_linesearch_primal_dual(x0, y0, A=apx.Counting(p.A), eta=p.norm_A, t=t,
+                                                                              name=f"AdaPDM+ (t={t})", **kw))
+    run_least_absolute_deviation.seconds = secs          # (wall time per method: at BASELINE config C5's size — --m 50000 --n 20000 —
+    return p, out                                        #  every method reads A once per iteration / per linesearch trial)
 
 
 def main():
@@ -53,7 +63,8 @@ def main():
     sink.close()
     for name, (x, y, it) in out.items():
         obj = a.lam * np.sum(np.abs(x)) + np.sum(np.abs(p.A.matvec(x) - p.y))
-        print(f"{name:28s} it={it:5d}  objective={obj:.8g}")
+        sec = run_least_absolute_deviation.seconds[name]
+        print(f"{name:28s} it={it:5d}  objective={obj:.8g}  {sec:7.2f} s  {it / sec:8.1f} it/s")
     print("records ->", path)
 
 
