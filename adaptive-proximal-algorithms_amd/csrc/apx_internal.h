@@ -108,6 +108,7 @@ struct apx_ctx {
   bool team_cooperative = false; // APX_OPT_TEAM_COOPERATIVE
   int team_fault_grid = 0;       // APX_OPT_TEAM_FAULT_GRID (test hook)
   int team_interleave = 1;       // APX_OPT_TEAM_INTERLEAVE
+  int team_pd_defer = 1;         // APX_OPT_TEAM_PD_DEFER
   bool fused_tail = true;        // APX_OPT_FUSED_TAIL
   int64_t one_pass_min_bytes = 192ll << 20;   // slab.hip / slab_pd.hip take matrices from this size on (apx_ctx_one_pass_threshold)
   bool auto_transpose = true;    // a one-pass-eligible problem may give its matrix the transposed copy (apx_ctx_auto_transpose)

@@ -349,6 +349,10 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       APX_REQUIRE(value >= 0 && value <= 2, "APX_OPT_TEAM_INTERLEAVE: 0 (off), 1 (teams of four or more members) or 2 (every team)");
       ctx->team_interleave = (int)value;
       return APX_OK;
+    case APX_OPT_TEAM_PD_DEFER:
+      APX_REQUIRE(value == 0 || value == 1, "APX_OPT_TEAM_PD_DEFER: 0 or 1");
+      ctx->team_pd_defer = (int)value;
+      return APX_OK;
     case APX_OPT_TEAM_SLOTS:
       APX_REQUIRE(value == 0 || value == 52 || value == 62 || value == 53 || value == 63 || value == 31 || value == 42, "APX_OPT_TEAM_SLOTS: 0, 52, 62, 53, 63, 31 or 42");
       ctx->team_slots = (int)value;
@@ -376,6 +380,7 @@ int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
     case APX_OPT_TEAM_SLOTS: *value = ctx->team_slots; return APX_OK;
     case APX_OPT_ROW_DEAL: *value = ctx->row_deal; return APX_OK;
     case APX_OPT_TEAM_INTERLEAVE: *value = ctx->team_interleave; return APX_OK;
+    case APX_OPT_TEAM_PD_DEFER: *value = ctx->team_pd_defer; return APX_OK;
     default:
       return fail(APX_ERR_INVALID, "apx_ctx_get_option: unknown key");
   }

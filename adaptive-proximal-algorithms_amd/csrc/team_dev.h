@@ -106,6 +106,7 @@ struct TeamDev {
   int32_t interleave;     // 1: the members' slices of a row are INTERLEAVED in pieces of one workgroup's load (member s holds pieces
                           //    s, s + P, s + 2 P, ... of BSC vectors) ; 0: member s holds the s-th contiguous P-th of the row (round 2)
   int32_t fault_grid;     // TEST hook (APX_OPT_TEAM_FAULT_GRID): launch this many workgroups instead of all 256
+  int32_t pd_defer;       // the primal-dual form: residual sums and member 0's stores 64 rows at a time, lane-parallel (APX_OPT_TEAM_PD_DEFER)
 };
 
 }  // namespace apx

@@ -344,6 +344,25 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       team_row_state_landed<FK>(bcur);             // (a wait is for everything asked for before it: each batch is waited for BEFORE the next is asked for)
       bnext = batch(kBatch);
     }
+    // (round 4) What nothing waits for — a row's terms of the residual norm and of h(A x): a division and the value of h ; member
+    // 0's stores of y+ and A x — is kept in the LANE of the row's number and worked off sixteen rows at a time by sixteen lanes at
+    // once: one division sequence per sixteen rows instead of one per row on the path between two hand-offs (t.pd_defer ; e0 / e1
+    // are then per-lane sums, added up in the wave's fixed order at the end).
+    [[maybe_unused]] double df_w = 0.0, df_y = 0.0, df_ax = 0.0, df_c = 0.0;
+    [[maybe_unused]] int df_i = -1;
+    const bool defer = late && t.pd_defer != 0;
+    auto flush_deferred = [&]() {
+      if constexpr (late) {
+        if (df_i >= 0) {
+          team_pd_sums<DEV, T>(d, kc, df_c, df_ax, df_w, df_y, df_i, e0, e1);
+          if (s == 0) {
+            ((T*)d.YN)[df_i] = (T)team_pd_stored(d, df_w, df_y);
+            ((T*)d.AXN)[df_i] = (T)df_ax;                                          // :360
+          }
+        }
+        df_i = -1;
+      }
+    };
     for (long long seq = 0; seq < nsteps; ++seq) {
       [[maybe_unused]] double st_y = 0.0, st_ax = 0.0, st_w = 0.0, st_c = 0.0;      // (the primal-dual loop: row r's y+, A x, w and shift, for what
       [[maybe_unused]] int st_i = -1;                                                //  is done behind the publication of the next partial)
@@ -460,7 +479,15 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         }
       }
       if constexpr (late) {
-        if (st_i >= 0) team_pd_sums<DEV, T>(d, kc, st_c, st_ax, st_w, st_y, st_i, e0, e1);
+        if (defer) {
+          // (sixteen rows at a time, one step BEHIND the rotation of the row-state batches: that rotation waits for everything the
+          //  wave has in flight — a burst of stores right in front of it stood on the hand-off's path, teams of four 6.80 -> 6.36
+          //  TB/s with 64 rows flushed at step 63 — and these stores have fifteen steps to drain before the next one)
+          if (st_i >= 0 && lane == (int)(seq & 15)) df_w = st_w, df_y = st_y, df_ax = st_ax, df_c = st_c, df_i = st_i;
+          if ((seq & 15) == 1) flush_deferred();
+        } else if (st_i >= 0) {
+          team_pd_sums<DEV, T>(d, kc, st_c, st_ax, st_w, st_y, st_i, e0, e1);
+        }
       }
       if constexpr (kBatched) {
 #pragma unroll
@@ -474,13 +501,20 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
         if (r + 1 >= 0) h[0] = team_row_state<FK, DEV, T>(d, rowi(r + 1));
       }
       if constexpr (late) {
-        if (st_i >= 0 && s == 0 && lane == 0) {
+        if (!defer && st_i >= 0 && s == 0 && lane == 0) {
           ((T*)d.YN)[st_i] = (T)team_pd_stored(d, st_w, st_y);
           ((T*)d.AXN)[st_i] = (T)st_ax;                                            // :360
         }
       }
       if constexpr (P > 1) {
         if (r + 1 >= 0) fetch(r + 1);
+      }
+    }
+    if constexpr (late) {
+      if (defer) {                                 // the rows still waiting, then the lanes' sums in the wave's fixed order
+        flush_deferred();
+        e0 = wave_sum(e0);
+        e1 = wave_sum(e1);
       }
     }
     if (lane == 0 && s == 0) {
@@ -1203,6 +1237,7 @@ inline int32_t team_alloc(apx_ctx* ctx, TeamHost* th, int nteams, int P, int64_t
   for (int r = ctx->row_deal; r > 1; r >>= 1) th->dev.chunk_log += 1;
   th->dev.wait_ticks = (unsigned long long)ctx->team_wait_ms * 100000ull;      // (s_memrealtime: 100 MHz)
   th->dev.fault_grid = ctx->team_fault_grid;
+  th->dev.pd_defer = ctx->team_pd_defer;
   // (teams of two gain nothing in the pure-read probe and LOSE 1.7 % in the product — C5: 1.289 -> 1.312 ms — : from four members on)
   th->dev.interleave = (ctx->team_interleave == 2 && P > 1) || (ctx->team_interleave == 1 && P >= 4) ? 1 : 0;
   APX_HIP(hipHostMalloc((void**)&th->pinned, sizeof(TeamHost::Pinned), hipHostMallocDefault));

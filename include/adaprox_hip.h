@@ -303,6 +303,11 @@ enum {
   APX_OPT_TEAM_INTERLEAVE = 15   /* default 1: the members of a team of FOUR OR MORE take a row's 10 KB pieces in turn (with every
                                     load instruction a team covers one contiguous stretch of the row) ; 2: teams of two as well ;
                                     0: each member its contiguous P-th of the row (round 2 ; A/B: profiles/r03_ab_interleave.jsonl) */
+  ,
+  APX_OPT_TEAM_PD_DEFER = 16     /* default 1: the communication wave of the primal-dual team kernels keeps a row's terms of the
+                                    residual norm and of h(A x), and member 0's stores of y+ and A x, in the lane of the row's
+                                    number and works them off sixteen rows at a time, lane-parallel — off the path between two
+                                    hand-offs ; 0: row by row behind each publication (round 3 ; A/B)                          */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);

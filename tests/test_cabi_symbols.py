@@ -130,3 +130,15 @@ def test_rule_constructors_mirror_reference_errors(apx):
     r = apx.OurRule(norm_A=2.0, t=0.5)                 # :244  1 / (2 * Theta * t * norm_A)
     assert r.gamma == pytest.approx(1 / (2 * 1.2 * 0.5 * 2.0))
     assert (r.t, r.delta, r.Theta) == (0.5, 0.0, 1.2)
+
+
+def test_graft_entry_build_passes():
+    """`__graft_entry__.build()` is the driver's "does it build" check: the in-tree make, the library loaded with every symbol of
+    the header, its ABI version the header's (round 4: the check had the number 3 written into it and would have failed the round
+    that made it 4), the oracle importable, the C restatement of the bench workload built."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+    assert not ge.is_stale()

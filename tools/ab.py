@@ -28,7 +28,7 @@ L = import_module("adaptive-proximal-algorithms_amd._lib")
 problems = import_module("adaptive-proximal-algorithms_amd.problems")
 
 DEFAULTS = {"MULTI_ROWS_MASK": 15, "SLAB_GENERATION": 0, "TEAM_COOPERATIVE": 0, "FUSED_TAIL": 1, "MULTI_WAVES": 0, "TEAM_MEMBERS": 0,
-            "TEAM_SLOTS": 0, "ROW_DEAL": -1, "TEAM_INTERLEAVE": 1}
+            "TEAM_SLOTS": 0, "ROW_DEAL": -1, "TEAM_INTERLEAVE": 1, "TEAM_PD_DEFER": 1}
 
 
 def parse_variant(text):
