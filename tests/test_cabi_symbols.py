@@ -142,3 +142,18 @@ def test_graft_entry_build_passes():
     ge = importlib.import_module("__graft_entry__")
     ge.build()
     assert not ge.is_stale()
+
+
+def test_ctypes_constants_equal_the_header(apx, tmp_path):
+    """Every APX_* constant the ctypes mirror spells out — the ABI version, status codes, flags, kinds, kernel-stat slots, option
+    keys — against the header's own value, from a C compile (a key renumbered in one place only would silently set another option)."""
+    L = __import__("importlib").import_module("adaptive-proximal-algorithms_amd._lib")
+    names = sorted(n for n in dir(L) if n.startswith("APX_") and isinstance(getattr(L, n), int))
+    assert len(names) >= 50 and "APX_ABI_VERSION" in names and "APX_OPT_TEAM_PD_DEFER" in names
+    prog = tmp_path / "consts.c"
+    prog.write_text('#include <stdio.h>\n#include "adaprox_hip.h"\nint main(void) {\n' +
+                    "".join(f'  printf("{n} %lld\\n", (long long){n});\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "consts"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert {n: int(v) for n, v in out.items()} == {n: getattr(L, n) for n in names}
