@@ -528,6 +528,41 @@ __global__ __launch_bounds__(kSlabCloseBlock) void k_slab_close(SlabDev d, int B
   }
 }
 
+// The same end of the iteration BEHIND THE ALL-REDUCE of a row shard (round 4): the closing kernel left this rank's A_k' r_k and
+// its loss sums, the collective summed them over the ranks into `grad` / `fsc`, and what k_slab_close<TAIL> does with its own
+// column sums this kernel does with the all-reduced gradient — k_reduce_n's terms as wave partials in the same layout, f's value,
+// the snapshot — so that k_step_rule closes the iteration: two kernels behind the collective instead of four (vo_f_final,
+// k_reduce_n, k_rule, k_step).  Blocks of 256 entries = four of the closing kernel's 64-column waves.
+template <typename T, int FK>
+__global__ __launch_bounds__(kBlock) void k_slab_tail(Ctrl* c, const T* __restrict__ grad, const double* __restrict__ fsc, int64_t n, SlabTail tl) {
+  if (c->done != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t j = (int64_t)blockIdx.x * kBlock + tid;
+  const double gamma = c->gamma;
+  double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if (j < n) {
+    const double xi = (double)((const T*)tl.x)[j], gi = (double)grad[j];
+    const double pr = ((double)((const T*)tl.v)[j] - xi) / gamma + gi;       // :338 (A = 0: no At_y term)
+    const double dg = gi - (double)((const T*)tl.gprev)[j];
+    const double dx = xi - (double)((const T*)tl.xprev)[j];
+    q[0] = fma(pr, pr, q[0]);
+    q[1] = fma(dg, dg, q[1]);
+    q[2] = fma(dg, dx, q[2]);
+    q[3] = fma(dx, dx, q[3]);
+    q[4] += gval_elem<T>(tl.g, xi, j);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double w = wave_sum(q[k]);
+    if (lane == 0) tl.wred[(int64_t)k * tl.ldw + (int64_t)blockIdx.x * (kBlock / 64) + wv] = w;
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    const double fs[2] = {fsc[0], fsc[1]};
+    f_finalize(c, FK, fs);
+    *tl.snap = *c;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -866,6 +901,39 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   if (!launched) return team_launch_refused(p, "one-pass kernel (teams)");
   APX_HIP(hipGetLastError());
   *done_here = true;
+  return APX_OK;
+}
+
+// The end of the iteration behind the all-reduce of a row-sharded f (k_slab_tail): true in *done when it took the request
+// (p->tail_req, the fused tail switched on, n within the partial buffer) — f's value is final in Ctrl then and the caller's
+// step is vo_step_rule ; else the caller closes f and runs the separate kernels
+int32_t slab_tail_after_allreduce(apx_problem* p, bool* done) {
+  *done = false;
+  SlabState* st = p->slab;
+  apx_ctx* ctx = p->ctx;
+  if (st == nullptr || p->tail_req == nullptr || !ctx->fused_tail || p->n > (int64_t)kMaxRedBlocks * kBlock) return APX_OK;
+  SlabTail tl{};
+  static_cast<SlabTailReq&>(tl) = *p->tail_req;
+  tl.ldw = (int32_t)(round_up(4 * ((p->n + kBlock - 1) / kBlock), 64) + 64);
+  tl.wred = (double*)st->tail_buf.p;
+  tl.snap = (Ctrl*)((char*)st->tail_buf.p + (size_t)5 * tl.ldw * sizeof(double));
+  tl.enabled = 1;
+  SlabTailReq* rq = (SlabTailReq*)p->tail_req;
+  rq->wred = tl.wred;
+  rq->ldw = tl.ldw;
+  rq->snap = tl.snap;
+  const dim3 grid((unsigned)((p->n + kBlock - 1) / kBlock));
+  const bool ls = p->f_kind == APX_F_LEAST_SQUARES;
+  if (p->dtype == APX_F32) {
+    if (ls) hipLaunchKernelGGL((k_slab_tail<float, APX_F_LEAST_SQUARES>), grid, dim3(kBlock), 0, ctx->stream, p->ctrl(), (const float*)p->grad.p, p->fsc(), p->n, tl);
+    else hipLaunchKernelGGL((k_slab_tail<float, APX_F_LOGISTIC>), grid, dim3(kBlock), 0, ctx->stream, p->ctrl(), (const float*)p->grad.p, p->fsc(), p->n, tl);
+  } else {
+    if (ls) hipLaunchKernelGGL((k_slab_tail<double, APX_F_LEAST_SQUARES>), grid, dim3(kBlock), 0, ctx->stream, p->ctrl(), (const double*)p->grad.p, p->fsc(), p->n, tl);
+    else hipLaunchKernelGGL((k_slab_tail<double, APX_F_LOGISTIC>), grid, dim3(kBlock), 0, ctx->stream, p->ctrl(), (const double*)p->grad.p, p->fsc(), p->n, tl);
+  }
+  APX_HIP(hipGetLastError());
+  p->tail_done = true;
+  *done = true;
   return APX_OK;
 }
 

@@ -114,7 +114,11 @@ int32_t eval_f(apx_problem* p, const void* x_dev, bool need_f) {
             APX_TRY(do_allreduce(p, p->grad.p, p->fsc_off(), p->dtype));
             APX_TRY(do_allreduce(p, p->fsc(), 2, APX_F64));
           }
-          APX_TRY(vo_f_final(ctx, p->f_kind, p->fsc(), p->ctrl()));
+          // (the generic loop's request for the end of the iteration: behind the collective on a row shard — k_slab_tail closes f
+          //  and leaves the reductions' wave partials for k_step_rule, two kernels instead of four ; round 4)
+          bool tail = false;
+          APX_TRY(slab_tail_after_allreduce(p, &tail));
+          if (!tail) APX_TRY(vo_f_final(ctx, p->f_kind, p->fsc(), p->ctrl()));
         }
         p->grad_ready = true;
         p->fsc_reduced = true;

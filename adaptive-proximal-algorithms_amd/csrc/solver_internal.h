@@ -295,6 +295,7 @@ bool slab_uses_teams(const apx_problem* p);   // (team kernels: host-side launch
 // slab.hip: true when f and grad f at x_dev were formed in one pass over A (f -> Ctrl, grad -> p->grad)
 int32_t slab_eval_with_gradient(apx_problem* p, const void* x_dev, bool* done_here);
 int32_t slab_check(apx_problem* p);        // the team kernel's error word (a timed-out hand-off): APX_ERR_HIP
+int32_t slab_tail_after_allreduce(apx_problem* p, bool* done);
 int32_t slab_team_waits(apx_problem* p, int64_t out[4]);
 int32_t slab_team_wait_slots(apx_problem* p, const TeamWait** slots);
 // sum of a scalar over the ranks of a row-sharded problem (the value itself otherwise): what the ranks agree on paths with
