@@ -848,7 +848,10 @@ def test_fused_small_keeps_one_pass_mode_two(apx):
                                          (4100, 6000, "tl1", 0.1),      # k_team_rows, one workgroup
                                          (4100, 20000, "tl1", 1.0),     # ... teams of two (C5's row)
                                          (4100, 20000, "tl2", 10.0),
-                                         (4099, 30001, "tl2", 1.0)])    # ... teams of four
+                                         (4099, 30001, "tl2", 1.0),     # ... teams of four
+                                         (100001, 250, "tl2", 1.0),     # k_multi_rows, five groups of two waves, a ragged last chunk
+                                         (4097, 21505, "tl1", 1.0),     # teams of two, eight vectors, three slots, an odd row length
+                                         (4099, 70001, "tl2", 1.0)])    # teams of eight, three slots (round 4's plan)
 def test_adapdm_plus_first_trial_in_one_pass(apx, m, n, hkind, t):
     """adaptive_linesearch_primal_dual (AdaPDM+, src/AdaProx.jl:463-550): the first linesearch trial of an iteration takes
     A_x = A * x (:502) along — one launch of the one-pass primal-dual kernels leaves A x AND A' y_next (csrc/slab_pd.hip
@@ -897,7 +900,9 @@ def test_adapdm_plus_first_trial_in_one_pass(apx, m, n, hkind, t):
 @pytest.mark.parametrize("m,n,hkind", [(9000, 1000, "tl1"),       # k_multi_rows
                                        (4100, 6000, "tl2"),       # k_team_rows, one workgroup ; the l2 ball
                                        (4100, 20000, "tl1"),      # ... teams of two (C5's row)
-                                       (4099, 30001, "tl2")])     # ... teams of four
+                                       (4099, 30001, "tl2"),      # ... teams of four
+                                       (90001, 380, "tl1"),       # k_multi_rows, three groups of three waves
+                                       (4099, 70001, "tl2")])     # teams of eight, three slots (round 4's plan)
 def test_malitsky_pock_trials_in_one_pass(apx, m, n, hkind):
     """malitsky_pock (src/AdaProx.jl:555-629): every linesearch trial's A_x = A * x takes the NEXT iteration's dual step along
     (w = y + sigma A_x, y = prox, At_y = A' y with the trial's sigma) — one launch of the one-pass primal-dual kernels in trial
