@@ -1056,8 +1056,9 @@ def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=
 def adaptive_linesearch_primal_dual(x, y, *, f, g, h, A, gamma=None, eta=1.0, t=1.0, delta=1e-8, Theta=1.2, r=2,
                                     R=0.95, tol=1e-5, maxit=10_000, name="AdaPDM+", record: Record = None,
                                     ctx: Optional[Context] = None, max_linesearch: int = 0, A_allreduce=None):
-    """src/AdaProx.jl:463-550 ("AdaPDM+").  Returns (x, y, it).  (``A_allreduce``: a row-sharded A is refused by the
-    library — only the generic loop has the all-reduces for it.)"""
+    """src/AdaProx.jl:463-550 ("AdaPDM+").  Returns (x, y, it).  (``A_allreduce``: the rows of A, y and h's shift are
+    sharded over ranks — A' y_next and the trial's three sums are all-reduced per linesearch trial, so every rank takes the
+    same decisions ; a separable h only: the l2 ball on a shard is refused.)"""
     maxit = int(math.floor(maxit))
     # the @assert's of :481-488 (AssertionError in Julia)
     assert eta > 0, "eta must be positive"

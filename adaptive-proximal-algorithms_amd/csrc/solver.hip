@@ -896,11 +896,13 @@ static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_lin
                                                    const void* y0, double tol, int64_t maxit, const apx_solve_opts* opts,
                                                    void* x_out, void* y_out, apx_result* res) {
   APX_REQUIRE(p->A_lin != nullptr, "adaptive_linesearch_primal_dual needs a linear operator");
-  // (its linesearch compares ||A'y+ - A'y|| with ||y+ - y||: with row shards of A_lin both would need all-reduces per
-  // trial, which only the generic loop has — enqueue_iteration)
-  if (p->lin_sharded)
-    return fail(APX_ERR_UNSUPPORTED, "adaptive_linesearch_primal_dual does not take a row-sharded linear operator "
-                                     "(shard_mask bit 1): use adaptive_primal_dual / condat_vu");
+  // Round 4: a row-sharded A_lin — y, A_x and the trial's y_next are row shards, x and A' y replicated.  Three things cross the
+  // ranks per trial: A' y_next (n elements) and the trial's three sums (||y_next - y||^2, ||dual_res||^2, raw h(A_x)) ; the
+  // linesearch test is then taken from identical numbers on every rank.  The l2 ball (a norm over all ranks' rows in front of
+  // every trial's prox) is not wired for the linesearch loops.
+  if (p->lin_sharded && p->hd.kind == APX_G_L2)
+    return fail(APX_ERR_UNSUPPORTED, "adaptive_linesearch_primal_dual with a row-sharded linear operator (shard_mask bit 1) takes a "
+                                     "separable h only: the l2 ball runs on adaptive_primal_dual / condat_vu");
   APX_REQUIRE(p->active == nullptr, "a solver is active on this problem");
   APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
   double eta = prm->eta;
@@ -948,7 +950,12 @@ static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_lin
   apx_solver shell;
   shell.p = p;
   if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup(&shell));
-  const bool one_pass = slab_pd_trial_ok(&shell);
+  bool one_pass = slab_pd_trial_ok(&shell);
+  if (p->lin_sharded) {      // (the two paths enqueue the same collectives here, but the ranks' iterates must come from the same arithmetic)
+    double cannot = one_pass ? 0.0 : 1.0;
+    APX_TRY(ranks_sum(p, cannot, &cannot));
+    one_pass = cannot == 0.0;
+  }
   const bool teams = one_pass && slab_pd_uses_teams(&shell);
 
   double gamma_prev = gamma;                                                       // :491
@@ -957,6 +964,7 @@ static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_lin
   APX_TRY(eval_f(p, bx.p, false));                                                 // :495
   APX_TRY(pullback_f(p));
   APX_TRY(launch_gemv_t(ctx, p->A_lin, y, aty, nullptr));                          // :496
+  if (p->lin_sharded) APX_TRY(do_allreduce(p, aty, p->A_lin->n_pad, p->dtype));    // A' y = sum_k A_k' y_k
   APX_TRY(vo_step(ctx, p->dtype, bx.p, bxprev.p, p->grad.p, bgprev.p, bv.p, aty, p->n, p->gd, p->ctrl()));   // :497-499
   std::swap(ax, axprev);                                                           // :498  A_x_prev = A_x
 
@@ -1008,6 +1016,10 @@ static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_lin
       } else {
         APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, axprev, ynext, p->m, p->hd, sigma, rho, ctx->scal));   // :524-525
         APX_TRY(launch_gemv_t(ctx, p->A_lin, ynext, aty_next, nullptr));           // :526
+      }
+      if (p->lin_sharded) {                                                        // A' y_next and the trial's sums over the ranks
+        APX_TRY(do_allreduce(p, aty_next, p->A_lin->n_pad, p->dtype));
+        APX_TRY(do_allreduce(p, ctx->scal, 3, APX_F64));
       }
       APX_TRY(vo_diff_sumsq(ctx, p->dtype, aty_next, aty, p->n, ctx->scal + 3));
       APX_HIP(hipMemcpyAsync(ctx->h_scal, ctx->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -87,6 +87,27 @@ def main():
                 print(f"PD-SHARDED one-pass {hname} launches {[t[1] for t in ys]} errs " + " ".join(f"{e:.3e}" for e in errs) +
                       f" nonzeros {np.count_nonzero(xr)}", flush=True)
                 ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == K for t in ys) and (hname == "l1" or np.count_nonzero(xr) > 0)
+        # AdaPDM+ on the sharded operator (round 4): A' y_next and the trial's three sums all-reduced per trial — the first trial of an
+        # iteration in one pass over the shard, rejected trials on GEMVs ; the decisions and iterates of the unsharded run
+        kwp = dict(f=apx.Zero(), g=apx.NormL1(5.0), eta=nA / 2000.0, t=1.0, tol=0.0, maxit=12, ctx=ctx1)
+        recs = []
+        ctx1.kernel_stats(reset=True)
+        ctx1.profile(True)
+        x, y_k, it = apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(ml), h=apx.Translate(apx.NormL1(1.0), -yv[r0:r0 + ml]),
+                                                         A=apx.Counting(A_k), record=recs.append, A_allreduce=ar, **kwp)
+        st = ctx1.kernel_stats(reset=True)
+        ctx1.profile(False)
+        ys = [None] * world
+        dist.all_gather_object(ys, (y_k, st["one_pass"]["launches"], recs[-1]["At_evals"]))
+        if rank == 0:
+            rr = []
+            xr, yr, _ = apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), h=apx.Translate(apx.NormL1(1.0), -yv),
+                                                            A=apx.Counting(A_full), record=rr.append, **kwp)
+            y_cat = np.concatenate([t[0] for t in ys])
+            errs = [np.max(np.abs(x - xr)) / max(np.max(np.abs(xr)), 1e-300), np.max(np.abs(y_cat - yr)) / np.max(np.abs(yr))]
+            print(f"PD-SHARDED AdaPDM+ launches {[t[1] for t in ys]} A' products {[t[2] for t in ys]} (unsharded {rr[-1]['At_evals']}) errs " +
+                  " ".join(f"{e:.3e}" for e in errs), flush=True)
+            ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == 12 and t[2] == rr[-1]["At_evals"] for t in ys) and rr[-1]["At_evals"] > 13
     flag = torch.tensor([1 if ok else 0])
     dist.broadcast(flag, 0)
     dist.destroy_process_group()
