@@ -116,12 +116,14 @@ def agraal(x1, *, f, g, x0=None, gamma0=None, gamma_max=1e6, phi=1.5, tol=1e-5, 
 
 
 def malitsky_pock(x, y, *, f, g, h, A, sigma, t=1.0, tol=1e-5, maxit=10_000, name="MP-ls", record: Record = None,
-                  ctx: Optional[Context] = None):
-    """src/AdaProx.jl:581-629 (+ backtrack_stepsize_MP :555-579).  Returns (x, y, it)."""
+                  ctx: Optional[Context] = None, A_allreduce=None):
+    """src/AdaProx.jl:581-629 (+ backtrack_stepsize_MP :555-579).  Returns (x, y, it).  (``A_allreduce``: the rows of A, y and
+    h's shift are sharded over ranks — A' y, a trial's ||A_x - A_x_prev||^2 and the residual sums are all-reduced, every rank
+    takes the same linesearch decisions ; a separable h only.)"""
     maxit = int(math.floor(maxit))
     dtype = _problem_dtype(x, f, A)
     x = _as_vec(x, dtype)
-    prob = _Problem(f, g, h, A, dtype, ctx).finalize(x.size)
+    prob = _Problem(f, g, h, A, dtype, ctx, lin_allreduce=A_allreduce).finalize(x.size)
     try:
         yv = _as_vec(y, dtype)
         if yv.size != prob._d.m:

@@ -43,10 +43,12 @@ int32_t begin(apx_problem* p, int64_t maxit, bool need_lin) {
   APX_REQUIRE(maxit >= 0, "maxit must be non-negative");
   if (need_lin) {
     APX_REQUIRE(p->A_lin != nullptr, "this method needs a linear operator A");
-    // (only the generic loop all-reduces A'y, the dual residual and h(Ax) over row shards of A_lin: solver.hip enqueue_iteration)
-    if (p->lin_sharded)
-      return fail(APX_ERR_UNSUPPORTED, "malitsky_pock does not take a row-sharded linear operator (shard_mask bit 1): "
-                                       "use adaptive_primal_dual / condat_vu");
+    // (a row-sharded A_lin, round 4: y, A_x and the dual residual are row shards — A' y, ||A_x - A_x_prev||^2 of a trial and the
+    //  residual sums are all-reduced, so every rank takes the linesearch's decisions from identical numbers ; a separable h only:
+    //  the l2 ball's norm over all ranks' rows in front of every dual step is not wired here)
+    if (p->lin_sharded && p->hd.kind == APX_G_L2)
+      return fail(APX_ERR_UNSUPPORTED, "malitsky_pock with a row-sharded linear operator (shard_mask bit 1) takes a separable h only: "
+                                       "the l2 ball runs on adaptive_primal_dual / condat_vu");
   } else APX_REQUIRE(p->A_lin == nullptr, "this method takes no linear operator (A = 0)");
   APX_HIP(hipSetDevice(p->ctx->device));
   apx_rule r{};
@@ -398,7 +400,13 @@ static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0,
   apx_solver shell;
   shell.p = p;
   if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup(&shell));
-  const bool one_pass = slab_pd_trial_ok(&shell);
+  bool one_pass = slab_pd_trial_ok(&shell);
+  const bool shard = p->lin_sharded;
+  if (shard) {                            // (the ranks' iterates must come from the same arithmetic: all of them, or none)
+    double cannot = one_pass ? 0.0 : 1.0;
+    APX_TRY(ranks_sum(p, cannot, &cannot));
+    one_pass = cannot == 0.0;
+  }
   const bool teams = one_pass && slab_pd_uses_teams(&shell);
   bool have_next = false;                 // yq / atyq hold this iteration's dual step already (the last accepted trial left it)
   APX_TRY(h2d(ctx, x, x0, (size_t)p->n * es));
@@ -409,6 +417,7 @@ static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0,
   const double theta_outer = 1.0;                                                       // :595 (never updated in the reference)
   APX_TRY(mul_A_lin(p, x, ax));                                                         // :597
   APX_TRY(launch_gemv_t(ctx, p->A_lin, y, aty, nullptr));                               // :598
+  if (shard) APX_TRY(problem_allreduce(p, aty, p->A_lin->n_pad, p->dtype));             // A' y = sum_k A_k' y_k
   bool conv = false;
   double gamma = kNaN, norm_res = kNaN, objective = kNaN;
   for (int64_t it = 1; it <= maxit; ++it) {                                             // :599
@@ -420,6 +429,7 @@ static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0,
     } else {
       APX_TRY(vo_dual_trial(ctx, p->dtype, y, ax, ax, ynew, p->m, p->hd, sigma, 0.0, ctx->scal + 8));
       APX_TRY(launch_gemv_t(ctx, p->A_lin, ynew, aty, nullptr));                        // :603
+      if (shard) APX_TRY(problem_allreduce(p, aty, p->A_lin->n_pad, p->dtype));
     }
     const double sigma_prev = sigma;                                                    // :605
     sigma = sigma * std::sqrt(1.0 + theta_outer);                                       // :606
@@ -450,6 +460,7 @@ static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0,
       }
       APX_TRY(eval_f(p, xnew, true));                                                   // :562 / :575
       APX_TRY(vo_diff_sumsq(ctx, p->dtype, axnew, ax, p->m, ctx->scal + 3));
+      if (shard) APX_TRY(problem_allreduce(p, ctx->scal + 3, 1, APX_F64));              // ||A_x - A_x_prev||^2 over the row shards
       APX_TRY(sc.read(4, true));
       trials_total++;
       f_evals++;
@@ -461,10 +472,13 @@ static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0,
       if (!(lhs > 0.95 * (ndx * ndx)) || sigma == 0.0) break;                           // :564
     }
     have_next = one_pass;
+    // (the accepted trial's dual step: its A' y over the row shards — only now, every rank accepts the same trial)
+    if (have_next && shard) APX_TRY(problem_allreduce(p, atyq, p->A_lin->n_pad, p->dtype));
     APX_TRY(pullback_f(p));                                                             // :612  grad_x = pb()
     grad_evals++;
     APX_TRY(vo_primal_res(ctx, p->dtype, bv.p, xnew, p->grad.p, aty, p->n, gamma, p->gd, ctx->scal));       // :616
     APX_TRY(vo_mp_dualres(ctx, p->dtype, y, ax, ynew, axnew, p->m, sigma_prev, p->hd, ctx->scal + 2));      // :617
+    if (shard) APX_TRY(problem_allreduce(p, ctx->scal + 2, 2, APX_F64));                // ||dual_res||^2, raw h(A_x)
     APX_TRY(sc.read(4, false));
     const double npr = std::sqrt(sc[0]), ndr = std::sqrt(sc[2]);
     norm_res = std::sqrt(npr * npr + ndr * ndr);                                        // :618

@@ -148,14 +148,22 @@ def test_row_sharded_linear_operator_through_the_communicator(apx, sharded, gene
         assert np.max(np.abs(xa - xb)) <= 1e-12 * max(np.max(np.abs(xa)), 1.0)
     # AdaPDM+ on the sharded operator (round 4: A' y_next and the trial's three sums are all-reduced per trial) — with one rank the
     # unsharded iterates to rounding, rejected trials included ; the l2 ball (a norm over all ranks' rows in front of every trial's
-    # prox) is refused, not silently wrong (ADVICE r1 ; Malitsky-Pock refuses every sharded operator in the C-ABI, the Python mirror
-    # has no way to hand it one)
+    # prox) is refused, not silently wrong ; Malitsky-Pock the same way
     kw = dict(f=apx.Zero(), g=apx.NormL1(2.0), h=apx.Translate(apx.NormL1(1.0), -b), eta=norm_A / 200.0, t=1.0, tol=0.0, maxit=30, ctx=ctx)
     ra, rb = [], []
     xa, ya, _ = apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), A=apx.Counting(Ad), record=ra.append, **kw)
     xb, yb, _ = apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), A=apx.Counting(Ad), record=rb.append, A_allreduce=comm, **kw)
     assert ra[-1]["At_evals"] > 31 and [r["At_evals"] for r in ra] == [r["At_evals"] for r in rb]
     assert np.max(np.abs(xa - xb)) <= 1e-12 * max(np.max(np.abs(xa)), 1.0) and np.max(np.abs(ya - yb)) <= 1e-12
+    kwm = dict(f=apx.Zero(), g=apx.NormL1(2.0), h=apx.Translate(apx.NormL1(1.0), -b), sigma=50.0 / norm_A, t=1.0, tol=0.0, maxit=30, ctx=ctx)
+    ra, rb = [], []
+    xa, ya, _ = apx.malitsky_pock(np.zeros(n), np.zeros(m), A=apx.Counting(Ad), record=ra.append, **kwm)
+    xb, yb, _ = apx.malitsky_pock(np.zeros(n), np.zeros(m), A=apx.Counting(Ad), record=rb.append, A_allreduce=comm, **kwm)
+    assert ra[-1]["A_evals"] > 31 and [r["A_evals"] for r in ra] == [r["A_evals"] for r in rb]
+    assert np.max(np.abs(xa - xb)) <= 1e-12 * max(np.max(np.abs(xa)), 1.0) and np.max(np.abs(ya - yb)) <= 1e-12
+    with pytest.raises(apx.ApxError, match="separable h only"):
+        apx.malitsky_pock(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(2.0), h=apx.Translate(apx.NormL2(1.0), -b), A=Ad,
+                          sigma=1.0 / norm_A, tol=0.0, maxit=3, ctx=ctx, A_allreduce=comm)
     with pytest.raises(apx.ApxError, match="separable h only"):
         apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(2.0),
                                             h=apx.Translate(apx.NormL2(1.0), -b), A=Ad, eta=norm_A, tol=0.0, maxit=3,

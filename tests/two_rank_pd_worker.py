@@ -108,6 +108,22 @@ def main():
             print(f"PD-SHARDED AdaPDM+ launches {[t[1] for t in ys]} A' products {[t[2] for t in ys]} (unsharded {rr[-1]['At_evals']}) errs " +
                   " ".join(f"{e:.3e}" for e in errs), flush=True)
             ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == 12 and t[2] == rr[-1]["At_evals"] for t in ys) and rr[-1]["At_evals"] > 13
+        # ... and Malitsky-Pock: every trial in one pass over the shard, A' y of the accepted trial's dual step, ||A_x - A_x_prev||^2
+        # and the residual sums all-reduced
+        kwm = dict(f=apx.Zero(), g=apx.NormL1(5.0), sigma=200.0 / nA, t=1.0, tol=0.0, maxit=12, ctx=ctx1)
+        recs = []
+        x, y_k, it = apx.malitsky_pock(np.zeros(n), np.zeros(ml), h=apx.Translate(apx.NormL1(1.0), -yv[r0:r0 + ml]), A=apx.Counting(A_k),
+                                       record=recs.append, A_allreduce=ar, **kwm)
+        ys = [None] * world
+        dist.all_gather_object(ys, (y_k, recs[-1]["A_evals"]))
+        if rank == 0:
+            rr = []
+            xr, yr, _ = apx.malitsky_pock(np.zeros(n), np.zeros(m), h=apx.Translate(apx.NormL1(1.0), -yv), A=apx.Counting(A_full),
+                                          record=rr.append, **kwm)
+            y_cat = np.concatenate([t[0] for t in ys])
+            errs = [np.max(np.abs(x - xr)) / max(np.max(np.abs(xr)), 1e-300), np.max(np.abs(y_cat - yr)) / np.max(np.abs(yr))]
+            print(f"PD-SHARDED Malitsky-Pock A products {[t[1] for t in ys]} (unsharded {rr[-1]['A_evals']}) errs " + " ".join(f"{e:.3e}" for e in errs), flush=True)
+            ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == rr[-1]["A_evals"] for t in ys) and rr[-1]["A_evals"] > 13
     flag = torch.tensor([1 if ok else 0])
     dist.broadcast(flag, 0)
     dist.destroy_process_group()
