@@ -617,7 +617,10 @@ static bool slab_shape_ok(const apx_problem* p) {
   if (!p->ctx->one_pass) return false;
   // (a row shard of f — communicator or callback — is as good as a whole matrix: the rows are local, only the block sums
   //  travel ; eval_f all-reduces them)
-  if (p->A_lin != nullptr || (p->sharded() && !p->f_sharded)) return false;
+  // (a linear operator next to f — the primal-dual loops with a smooth term — does not stand in the way since round 4: f and
+  //  grad f come from one read of A_f as everywhere else, the operator's half from its own kernels, csrc/slab_pd.hip ; the
+  //  fused end of the iteration is the proximal-gradient loop's only, solver.hip enqueue_iteration)
+  if (p->sharded() && !p->f_sharded) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
   if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
   // large matrices only: every block walks its slab in steps of R rows with two barriers each, and below ~200 MB

@@ -1018,3 +1018,47 @@ def test_deferred_residual_sums_leave_the_iterates_alone(apx, m, n, hkind):
     assert [r["norm_res"] for r in a[2]] == pytest.approx([r["norm_res"] for r in b[2]], rel=1e-12)
     assert [r["objective"] for r in a[2]] == pytest.approx([r["objective"] for r in b[2]], rel=1e-12)
     assert a[5] == b[5] <= 37 and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_primal_dual_loops_with_a_smooth_f_on_its_own_one_pass_kernels(apx):
+    """The primal-dual loops with a smooth f whose matrix is large enough for ITS one-pass kernels (f and grad f from one read of
+    Q, csrc/slab.hip — round 4: a linear operator in the problem no longer keeps f on the two GEMV passes) next to the operator's
+    (A x, the dual step and A' y from one read of A, csrc/slab_pd.hip): adaptive_primal_dual, AdaPDM+ and Malitsky-Pock against
+    the oracle — all branches of the step-size formulas are live (C, L != 0)."""
+    rng = np.random.default_rng(77)
+    m, n, k = 9000, 1000, 8300
+    A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (m, n - 1)), np.ones((m, 1))]))
+    Q = np.asfortranarray(rng.uniform(-1, 1, (k, n)) / np.sqrt(n))
+    q = rng.standard_normal(k)
+    yv = A @ (rng.standard_normal(n) / np.sqrt(n)) + rng.laplace(size=m)
+    nA = float(np.linalg.norm(A))
+    K = 12
+    ctx = apx.Context(0)
+    ctx.one_pass_threshold(16 << 20)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    dQ = apx.DeviceMatrix.from_numpy(Q, ctx).build_transpose()
+    for name, run, kw in (("adapdm", "adaptive_linesearch_primal_dual", dict(eta=nA / 500.0, t=0.5)),
+                          ("mp", "malitsky_pock", dict(sigma=100.0 / nA, t=1.0)),
+                          ("pd", "adaptive_primal_dual", dict(rule_args=dict(t=1.0, norm_A=nA)))):
+        ro, rd = [], []
+        kwo, kwd = dict(kw), dict(kw)
+        if "rule_args" in kw:
+            kwo = dict(rule=O.OurRule(**kw["rule_args"]))
+            kwd = dict(rule=apx.OurRule(**kw["rule_args"]))
+        xo, yo, _ = getattr(O, run)(np.zeros(n), np.zeros(m), f=O.LinearLeastSquares(Q, q), g=O.NormL1(0.3), h=O.Translate(O.NormL1(1.0), -yv),
+                                    A=O.Counting(A), tol=0.0, maxit=K, record=ro.append, **kwo)
+        ctx.kernel_stats(reset=True)
+        ctx.profile(True)
+        x, y, it = getattr(apx, run)(np.zeros(n), np.zeros(m), f=apx.LinearLeastSquares(dQ, q, ctx=ctx), g=apx.NormL1(0.3),
+                                     h=apx.Translate(apx.NormL1(1.0), -yv), A=apx.Counting(dA), tol=0.0, maxit=K, ctx=ctx, record=rd.append, **kwd)
+        st = ctx.kernel_stats(reset=True)
+        ctx.profile(False)
+        # both kinds of one-pass launches ran: f's (one per evaluation) and the operator's (one per iteration / per trial) — the
+        # only GEMVs left are the two in front of the loop and the rejected trials'
+        assert it == K and st["one_pass"]["launches"] >= 2 * K and st["gemv_n"]["launches"] <= 1, (name, st)
+        assert _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-9, name
+        for a, b_ in zip(rd, ro):
+            assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-9) and a["objective"] == pytest.approx(b_["objective"], rel=1e-9), name
+            assert (a["A_evals"], a["At_evals"]) == (b_["A_evals"], b_["At_evals"]), name
+    dA.free()
+    dQ.free()
