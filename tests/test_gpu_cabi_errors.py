@@ -218,5 +218,12 @@ def test_options_one_pass_switch_and_names(lib, ctx):
     out = (C.c_int64 * 4)(1, 2, 3, 4)
     assert lib.apx_problem_team_waits(p, out) == L.APX_OK and list(out) == [0, 0, 0, 0]
     assert lib.apx_problem_team_waits(None, out) == L.APX_ERR_INVALID and lib.apx_problem_team_waits(p, None) == L.APX_ERR_INVALID
+    # ... and slot by slot (ABI 4): nothing to report for a problem without team kernels ; a count without a buffer is fine
+    slots, cnt = (L.TeamWaitSlot * 4)(), C.c_int32(-1)
+    assert lib.apx_problem_team_wait_slots(p, slots, 4, C.byref(cnt)) == L.APX_OK and cnt.value == 0
+    assert lib.apx_problem_team_wait_slots(p, None, 0, C.byref(cnt)) == L.APX_OK and cnt.value == 0
+    assert lib.apx_problem_team_wait_slots(p, None, 4, C.byref(cnt)) == L.APX_ERR_INVALID
+    assert lib.apx_problem_team_wait_slots(None, slots, 4, C.byref(cnt)) == L.APX_ERR_INVALID
+    assert lib.apx_problem_team_wait_slots(p, slots, 4, None) == L.APX_ERR_INVALID
     lib.apx_problem_destroy(p)
     lib.apx_matrix_free(A)

@@ -1062,3 +1062,28 @@ def test_primal_dual_loops_with_a_smooth_f_on_its_own_one_pass_kernels(apx):
             assert (a["A_evals"], a["At_evals"]) == (b_["A_evals"], b_["At_evals"]), name
     dA.free()
     dQ.free()
+
+
+def test_team_wait_slots_after_a_team_run(apx):
+    """apx_problem_team_wait_slots (ABI 4) behind a run on the team kernels: every reported slot waited at least once, its longest
+    wait lies inside the run (a launch of the run, a row of the team's deal, a member of its team, an XCD of the part), and the
+    per-slot maxima add up to apx_problem_team_waits' summary."""
+    rng = np.random.default_rng(5)
+    m, n = 4100, 30000
+    A = np.asfortranarray(rng.uniform(-1, 1, (m, n)))
+    b = rng.standard_normal(m)
+    ctx = apx.Context(0)
+    ctx.one_pass_threshold(16 << 20)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
+    s = apx.Solver(np.zeros(n), f=apx.LinearLeastSquares(dA, b, ctx=ctx), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-8), tol=0.0, ctx=ctx)
+    s.step(40, sync=True)
+    summary, slots = s.team_waits(), s.team_wait_slots()
+    assert summary["team_launches"] == 41
+    assert 0 < len(slots) <= 256 and all(q["waits"] > 0 and q["kind"] == 0 for q in slots)
+    assert sum(q["waits"] for q in slots) == summary["waits"]
+    assert max(q["max_wait_ns"] for q in slots) == summary["max_wait_ns"] and max(q["max_polls"] for q in slots) == summary["max_polls"]
+    for q in slots:
+        assert 0 <= q["at_launch"] < 41 and 0 <= q["at_step"] < m and 0 <= q["team"] < 64 and 0 <= q["member"] < 4 and 0 <= q["xcc"] < 8
+        assert q["long_waits"] <= q["waits"] and q["at_clock_ns"] > 0 and 0 <= q["block"] < 256
+    s.close()
+    dA.free()
