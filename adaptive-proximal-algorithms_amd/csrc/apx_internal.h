@@ -107,6 +107,7 @@ struct apx_ctx {
   int team_wait_ms = 1000;       // APX_OPT_TEAM_WAIT_MS
   bool team_cooperative = false; // APX_OPT_TEAM_COOPERATIVE
   int team_fault_grid = 0;       // APX_OPT_TEAM_FAULT_GRID (test hook)
+  int fault_setup = 0;           // APX_OPT_FAULT_SETUP (test hook)
   int team_interleave = 1;       // APX_OPT_TEAM_INTERLEAVE
   int team_pd_defer = 1;         // APX_OPT_TEAM_PD_DEFER
   bool fused_tail = true;        // APX_OPT_FUSED_TAIL

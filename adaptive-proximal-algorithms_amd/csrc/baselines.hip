@@ -399,7 +399,7 @@ static int32_t malitsky_pock_run(apx_problem* p, const void* x0, const void* y0,
   // the one-pass kernels of the primal-dual loop, when this problem is theirs (a shell of a solver carries their state)
   apx_solver shell;
   shell.p = p;
-  if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup(&shell));
+  if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup_voted(&shell));      // (a shard: a failed set-up is this rank's vote)
   bool one_pass = slab_pd_trial_ok(&shell);
   const bool shard = p->lin_sharded;
   if (shard) {                            // (the ranks' iterates must come from the same arithmetic: all of them, or none)

@@ -325,6 +325,10 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       APX_REQUIRE(value >= 0 && value <= 512, "APX_OPT_TEAM_FAULT_GRID: 0 (off) ... 256 workgroups (257 ... 512: with APX_OPT_TEAM_COOPERATIVE only)");
       ctx->team_fault_grid = (int)value;
       return APX_OK;
+    case APX_OPT_FAULT_SETUP:
+      APX_REQUIRE(value >= 0 && value <= 1, "APX_OPT_FAULT_SETUP: 0 or 1");
+      ctx->fault_setup = (int)value;
+      return APX_OK;
     case APX_OPT_GEMV_N_VARIANT: return apx_ctx_set_gemv_config(ctx, (int32_t)value, -1, 0, 0);
     case APX_OPT_GEMV_T_VARIANT: return apx_ctx_set_gemv_config(ctx, -1, (int32_t)value, 0, 0);
     case APX_OPT_GEMV_N_BLOCKS: return apx_ctx_set_gemv_config(ctx, -1, -1, value, 0);
@@ -370,6 +374,7 @@ int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
     case APX_OPT_TEAM_WAIT_MS: *value = ctx->team_wait_ms; return APX_OK;
     case APX_OPT_TEAM_COOPERATIVE: *value = ctx->team_cooperative ? 1 : 0; return APX_OK;
     case APX_OPT_TEAM_FAULT_GRID: *value = ctx->team_fault_grid; return APX_OK;
+    case APX_OPT_FAULT_SETUP: *value = ctx->fault_setup; return APX_OK;
     case APX_OPT_GEMV_N_VARIANT: *value = ctx->cfg.n_variant; return APX_OK;
     case APX_OPT_GEMV_T_VARIANT: *value = ctx->cfg.t_variant; return APX_OK;
     case APX_OPT_GEMV_N_BLOCKS: *value = ctx->cfg.n_target_blocks; return APX_OK;

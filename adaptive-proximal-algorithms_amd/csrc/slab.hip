@@ -792,8 +792,9 @@ static bool slab_launch_t(SlabState* st, bool cooperative, const SlabDev& d, con
   const dim3 grid((unsigned)st->B);
   if (st->plan.P != 0) {
     const bool ok = team_launch<FK, SlabDev, T>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+    if (!ok) return false;                         // (a refused launch: nothing runs, the closing kernel included)
     slab_close_launch<T, FK>(d, st->B, grad, tl, q);
-    return ok;
+    return true;
   }
   if (st->cpt == kSlabMultiCpt) {
     if (st->nt) multi_launch<T, FK, true, SlabDev>(d.ncols, st->B, st->multi_waves, d, x, q);
@@ -892,13 +893,16 @@ int32_t slab_eval_with_gradient(apx_problem* p, const void* x, bool* done_here) 
   if (st->kname.empty()) st->kname = slab_kernel_name(st, p);
   ctx->kname[APX_KSTAT_ONE_PASS] = st->kname;
   APX_TRY(prof_begin(ctx, APX_KSTAT_ONE_PASS, (double)p->A_f->m * (double)p->A_f->n * (double)p->es()));
+  // (a cooperative launch can be refused, and a refusal is ONE rank's: on a row shard the peers would be left in the iteration's
+  //  collectives — the option is not honoured there )
+  const bool coop = ctx->team_cooperative && !p->sharded();
   bool launched;
   if (p->dtype == APX_F32) {
-    launched = ls ? slab_launch_t<float, APX_F_LEAST_SQUARES>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream)
-                  : slab_launch_t<float, APX_F_LOGISTIC>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream);
+    launched = ls ? slab_launch_t<float, APX_F_LEAST_SQUARES>(st, coop, d, x, p->grad.p, tl, ctx->stream)
+                  : slab_launch_t<float, APX_F_LOGISTIC>(st, coop, d, x, p->grad.p, tl, ctx->stream);
   } else {
-    launched = ls ? slab_launch_t<double, APX_F_LEAST_SQUARES>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream)
-                  : slab_launch_t<double, APX_F_LOGISTIC>(st, ctx->team_cooperative, d, x, p->grad.p, tl, ctx->stream);
+    launched = ls ? slab_launch_t<double, APX_F_LEAST_SQUARES>(st, coop, d, x, p->grad.p, tl, ctx->stream)
+                  : slab_launch_t<double, APX_F_LOGISTIC>(st, coop, d, x, p->grad.p, tl, ctx->stream);
   }
   APX_TRY(prof_end(ctx));
   if (!launched) return team_launch_refused(p, "one-pass kernel (teams)");

@@ -334,9 +334,25 @@ bool slab_pd_eligible(const apx_problem* p) {
   return A->dT != nullptr;
 }
 
+// On a row shard the ranks VOTE on the path after the set-up (csrc/solver.hip, AdaPDM+, Malitsky-Pock): a rank whose set-up fails
+// — team_alloc, a partial buffer, the pinned diagnostics — must reach that vote like everybody else, or its peers wait in the
+// all-reduce forever.  Here the failure becomes "this rank cannot" (no state left behind): every rank then takes the
+// two passes.  An unsharded problem gets the error.
+int32_t slab_pd_setup_voted(apx_solver* s) {
+  const int32_t rc = slab_pd_setup(s);
+  if (rc == APX_OK || !s->p->lin_sharded) return rc;
+  (void)hipGetLastError();
+  if (s->slab_pd != nullptr) {
+    slab_pd_destroy(s->slab_pd);
+    s->slab_pd = nullptr;
+  }
+  return APX_OK;
+}
+
 int32_t slab_pd_setup(apx_solver* s) {
   apx_problem* p = s->p;
   apx_ctx* ctx = p->ctx;
+  if (ctx->fault_setup & 1) return fail(APX_ERR_HIP, "slab_pd_setup: allocation failed (APX_OPT_FAULT_SETUP, a test hook)");
   const apx_matrix* A = p->A_lin;
   std::unique_ptr<SlabPdState> st(new SlabPdState());
   const SlabPdShape sh = slab_pd_shape(p);
@@ -404,6 +420,7 @@ static bool slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
     bool ok = true;
     if constexpr (!f32) {
       ok = team_launch<kTeamFkPd, SlabPdDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+      if (!ok) return false;                       // (a refused launch: NOTHING runs — not the closing kernel on the last launch's partials either)
       slabpd_close_launch<T>(d, st->B, (T*)aty, recs, rec_cap, q);
     }
     return ok;
@@ -468,8 +485,8 @@ int32_t slab_pd_iteration(apx_solver* s, bool* done_here) {
   ctx->kname[APX_KSTAT_ONE_PASS] = st->kname;
   APX_TRY(prof_begin(ctx, APX_KSTAT_ONE_PASS, (double)p->A_lin->m * (double)p->A_lin->n * (double)p->es()));
   const bool launched =
-      p->dtype == APX_F32 ? slab_pd_launch_t<float>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream)
-                          : slab_pd_launch_t<double>(st, ctx->team_cooperative, d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
+      p->dtype == APX_F32 ? slab_pd_launch_t<float>(st, (ctx->team_cooperative && !p->sharded()), d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream)
+                          : slab_pd_launch_t<double>(st, (ctx->team_cooperative && !p->sharded()), d, s->x.p, s->aty.p, (apx_record*)s->recs.p, s->rec_cap, ctx->stream);
   APX_TRY(prof_end(ctx));
   if (!launched) return team_launch_refused(p, "one-pass primal-dual kernel (teams)");
   const bool l2 = p->hd.kind == APX_G_L2;
@@ -515,8 +532,8 @@ int32_t slab_pd_trial(apx_solver* s, const void* x, const void* y, const void* a
   d.trial = 1;
   ctx->kname[APX_KSTAT_ONE_PASS] = st->cpt == 27 ? "k_multi_rows<primal_dual> (linesearch trial) + k_slabpd_close" : "k_team_rows<primal_dual> (linesearch trial) + k_slabpd_close";
   APX_TRY(prof_begin(ctx, APX_KSTAT_ONE_PASS, (double)p->A_lin->m * (double)p->A_lin->n * (double)p->es()));
-  const bool launched = p->dtype == APX_F32 ? slab_pd_launch_t<float>(st, ctx->team_cooperative, d, x, aty_next, nullptr, 0, ctx->stream)
-                                            : slab_pd_launch_t<double>(st, ctx->team_cooperative, d, x, aty_next, nullptr, 0, ctx->stream);
+  const bool launched = p->dtype == APX_F32 ? slab_pd_launch_t<float>(st, (ctx->team_cooperative && !p->sharded()), d, x, aty_next, nullptr, 0, ctx->stream)
+                                            : slab_pd_launch_t<double>(st, (ctx->team_cooperative && !p->sharded()), d, x, aty_next, nullptr, 0, ctx->stream);
   APX_TRY(prof_end(ctx));
   if (!launched) return team_launch_refused(p, "one-pass primal-dual kernel (teams)");
   APX_HIP(hipGetLastError());

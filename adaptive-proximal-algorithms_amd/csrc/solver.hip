@@ -589,7 +589,9 @@ int32_t apx_solver_create(apx_problem* p, const apx_rule* rule, const void* x0, 
       lin_one_pass = cannot == 0.0;
     }
     if (lin_one_pass) {
-      APX_TRY(slab_pd_setup(s.get()));
+      // (a rank whose set-up FAILS — an allocation — must still take part in the vote its peers are in: it votes "cannot",
+      //  every rank falls back to the two passes, nobody is left waiting in the collective )
+      APX_TRY(slab_pd_setup_voted(s.get()));
       if (p->lin_sharded) {       // ... and so does a shard whose kernel turned out not to fit (slab_pd_setup left no state)
         double cannot = s->slab_pd != nullptr ? 0.0 : 1.0;
         APX_TRY(ranks_sum(p, cannot, &cannot));
@@ -949,7 +951,7 @@ static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_lin
   // the one-pass kernels of the primal-dual loop, when this problem is theirs (a shell of a solver carries their state)
   apx_solver shell;
   shell.p = p;
-  if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup(&shell));
+  if (slab_pd_eligible(p)) APX_TRY(slab_pd_setup_voted(&shell));      // (a shard: a failed set-up is this rank's vote)
   bool one_pass = slab_pd_trial_ok(&shell);
   if (p->lin_sharded) {      // (the two paths enqueue the same collectives here, but the ranks' iterates must come from the same arithmetic)
     double cannot = one_pass ? 0.0 : 1.0;

@@ -283,6 +283,7 @@ const void* small_pd_ctrl(const apx_solver* s);
 // skinny_pg.hip
 bool slab_pd_eligible(const apx_problem* p);
 int32_t slab_pd_setup(apx_solver* s);
+int32_t slab_pd_setup_voted(apx_solver* s);      // ... on a row shard: a failure is a vote, not a return
 int32_t slab_pd_iteration(apx_solver* s, bool* done_here);
 bool slab_pd_trial_ok(const apx_solver* s);
 int32_t slab_pd_trial(apx_solver* s, const void* x, const void* y, const void* axprev, void* ynext, void* axnew, void* aty_next,

@@ -523,8 +523,8 @@ __global__ __launch_bounds__(768) void k_team_rows(DEV d, TeamDev t, const void*
       out[d.ncols + 1] = e1;
     }
     if constexpr (P > 1) {
-      if (lane == 0 && w_waits != 0) {             // (this launch's only writer of the slot ; launches are serialised)
-        TeamWait* w = t.wait + blockIdx.x;
+      if (lane == 0 && w_waits != 0 && blockIdx.x < 256u) {      // (this launch's only writer of the slot ; launches are serialised ;
+        TeamWait* w = t.wait + blockIdx.x;         //  256 slots: a test hook's over-sized grid keeps no statistics beyond them)
         w->waits += w_waits;
         w->long_waits += w_long;
         w->max_polls = max(w->max_polls, w_polls);

@@ -240,6 +240,49 @@ def timed_steps(ctx, solver, steps: int, warmup: int, barrier) -> tuple:
     return dt, ctx.kernel_stats(reset=True)
 
 
+def backtracking_leg(apx, prob, ctx, barrier, m: int, n: int, iters: int = 100, xi: float = 1.5) -> dict:
+    """`backtracking_proxgrad` (src/AdaProx.jl:34-64) on the headline's matrix while it is resident: xi = 1.5, the middle one of
+    the reference's settings (experiments/lasso/runme.jl:96-108), gamma0 = 1/Lf.  ONE call of `iters` iterations — its upload
+    of x0, the evaluation in front of the loop and the read-back included ; the linesearch is host-driven (four scalars read
+    back per trial: the accept test is a data-dependent branch).  Every trial evaluates f at the trial point, and
+    on the one-pass kernels that evaluation leaves the gradient too, so an accepted trial's gradient is free: passes over A
+    per iteration = trials per iteration, bytes read per iteration = trials x m n sizeof(T)."""
+    f = apx.Counting(apx.LinearLeastSquares(prob.A, prob.b))
+    g = apx.NormL1(prob.lam)
+    kw = dict(f=f, g=g, gamma0=1.0 / prob.Lf, xi=xi, tol=0.0, ctx=ctx)
+    apx.backtracking_proxgrad(np.zeros(n), maxit=3, **kw)                 # warm-up
+    e0 = f.eval_count
+    barrier()
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    recs = []
+    t0 = time.perf_counter()
+    z, it = apx.backtracking_proxgrad(np.zeros(n), maxit=iters, record=recs.append, **kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    k = kernel_table(ctx.kernel_stats(reset=True))
+    trials = f.eval_count - e0 - 1                                        # (one evaluation at x0 in front of the loop, :52)
+    launches = sum(v["launches"] for v in k.values())
+    dom = max(k, key=lambda q: k[q]["avg_ms"] * k[q]["launches"])
+    its = iters / dt
+    real = (int(it) == iters and bool(np.all(np.isfinite(z))) and trials >= iters and len(recs) == iters
+            and recs[-1]["objective"] < recs[0]["objective"])
+    return {"workload": f"lasso, dense A {m}x{n} fp64, backtracking_proxgrad (xi = {xi}, shrink = 0.5, gamma0 = 1/Lf) on 1 MI355X",
+            "iters_per_s": its, "ms_per_iter": dt / iters * 1e3, "steps": int(it), "linesearch_trials": int(trials),
+            "trials_per_iter": trials / iters, "passes_over_A_per_iter": launches / iters, "kernels": k,
+            "roofline": {"bound": "hbm", "kernel": ctx.kernel_name(dom), "achieved": k[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": k[dom]["GBps"] / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": float(m) * n * 8,
+                         # of the bytes the whole call reads: (1 + n_bt) m n sizeof(T) per iteration, n_bt rejected trials
+                         "bytes_read_iteration_frac": launches * float(m) * n * 8 / dt / 1e9 / HBM_PEAK_GBS,
+                         # SURVEY 8d's own model for this loop: (2 + n_bt) m n sizeof(T) per iteration
+                         "two_pass_equivalent_frac": (launches + iters) * float(m) * n * 8 / dt / 1e9 / HBM_PEAK_GBS},
+            "objective": recs[-1]["objective"], "gamma": recs[-1]["gamma"], "timed_steps_all_real": real,
+            "note": "one CALL of %d iterations (upload, the evaluation in front of the loop and the read-back included) ; every "
+                    "linesearch trial is one launch of the one-pass kernel, which leaves f AND grad f at the trial point: "
+                    "an accepted trial's gradient costs nothing more" % iters}
+
+
 def other_configs(apx, problems, ctx, barrier) -> dict:
     """BASELINE configs C3 and C5 at full size, same protocol as the headline (data resident, warm-up, K timed
     iterations, HIP-event durations of the passes over A).  Each reports the fraction of the HBM peak twice: of the
@@ -536,12 +579,19 @@ def main():
         kernel_names = {k: ctx.kernel_name(k) for k in ("gemv_n", "gemv_t", "one_pass")}
         final_objective, optimum = res.objective, prob.optimum
         if world == 1 and not use_dist and not args.no_other_configs and (args.m, args.n) == (50_000, 100_000):
-            prob.A.free()                                  # give the 80 GB back before the other configs
+            bt = None
+            try:                                           # the second of north_star's three entry points, on the headline's matrix
+                bt = backtracking_leg(apx, prob, ctx, barrier, args.m, args.n)
+            except (Exception, SystemExit) as e:           # noqa: BLE001
+                bt = {"error": f"{type(e).__name__}: {e}"}
+                print(f"bench.py: the backtracking leg failed: {bt['error']}", file=sys.stderr)
+            prob.A.free()                                  # give the matrix back before the other configs
             try:                                           # (a side leg that fails must not take the headline line with it)
                 other = other_configs(apx, problems, ctx, barrier)
             except (Exception, SystemExit) as e:           # noqa: BLE001
                 other = {"error": f"{type(e).__name__}: {e}"}
                 print(f"bench.py: other_configs failed: {other['error']}", file=sys.stderr)
+            other["C2_backtracking"] = bt
 
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}" if transport == "torch-nccl" else "cpu")

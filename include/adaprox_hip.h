@@ -280,7 +280,8 @@ enum {
                                     single-workgroup kernel for rows of 5121 ... 10 752 entries (A/B)                       */
   APX_OPT_TEAM_WAIT_MS = 3,      /* default 1000: wall-clock bound of a team hand-off wait                                  */
   APX_OPT_TEAM_COOPERATIVE = 4,  /* default 0 ; 1: team kernels through hipLaunchCooperativeKernel (the runtime refuses a grid
-                                    that cannot be co-resident ; measured no faster and not needed: DESIGN.md section 9)     */
+                                    that cannot be co-resident ; measured no faster and not needed: DESIGN.md section 9) ; not
+                                    honoured on a row-sharded problem (a refusal is one rank's, the collectives are all ranks') */
   APX_OPT_TEAM_FAULT_GRID = 5,   /* TEST hook, default 0: launch this many of a team launch's 256 workgroups, so that teams
                                     miss members (tests/test_gpu_team_fault.py) ; 257 ... 512 (with APX_OPT_TEAM_COOPERATIVE
                                     only): a grid that cannot be co-resident, which the runtime refuses to launch          */
@@ -308,6 +309,10 @@ enum {
                                     residual norm and of h(A x), and member 0's stores of y+ and A x, in the lane of the row's
                                     number and works them off sixteen rows at a time, lane-parallel — off the path between two
                                     hand-offs ; 0: row by row behind each publication (round 3 ; A/B)                          */
+  ,
+  APX_OPT_FAULT_SETUP = 17       /* TEST hook, default 0 ; bit 0: the set-up of the one-pass primal-dual kernels fails as if an
+                                    allocation had (on ONE rank of a row shard: the ranks must still agree on the two passes —
+                                    tests/two_rank_pd_worker.py)                                                              */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);

@@ -245,6 +245,31 @@ def test_lad_c5_solver_at_full_size(apx):
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
     assert all(np.isfinite(runs[0][2])) and all(np.isfinite(runs[0][3]))
     assert np.max(np.abs(runs[0][1])) <= 1.0                    # y stays in the dual ball of the l1 norm
+    # Solver-free certificates at full size, one GEMV pair each: with y scaled INTO the dual feasible set
+    # (||y||_inf <= 1, ||A'y||_inf <= lam) D = -b'y~ is a true lower bound of the optimal value, so 0 <= P(x) - D(y~) bounds the
+    # suboptimality of x whatever the solver did ; and the distance of (x, y) from the KKT set — -A'y in lam d||x||_1,
+    # A x - b in the normal cone of [-1, 1]^m at y — evaluated in numpy.  Both must shrink along the run.
+    def certificates(x, y):
+        r = p.A.matvec(x) - p.y
+        aty = p.A.rmatvec(y)
+        P = float(np.abs(r).sum() + lam * np.abs(x).sum())
+        s = max(1.0, float(np.max(np.abs(y))), float(np.max(np.abs(aty))) / lam)
+        gap = (P + float(p.y @ y) / s) / P
+        nz = x != 0
+        kp = np.where(nz, aty + lam * np.sign(x), np.maximum(np.abs(aty) - lam, 0.0))
+        kd = np.where(y >= 1.0, np.minimum(r, 0.0), np.where(y <= -1.0, np.maximum(r, 0.0), r))
+        return P, gap, float(np.sqrt(kp @ kp + kd @ kd))
+    certs = [certificates(runs[0][0], runs[0][1])]
+    for K in (100, 400):
+        recs = []
+        x, y, it = apx.condat_vu(np.zeros(n), np.zeros(m), Lf=0.0, norm_A=norm_A, tol=0.0, maxit=K, record=recs.append, **t)
+        certs.append(certificates(x, y))
+        # (the loop's own objective is P at the iterate it tested, one step behind the returned one: the same to a few per cent)
+        assert certs[-1][0] == pytest.approx(recs[-1]["objective"], rel=0.05)
+    print("C5 certificates (P, rigorous relative gap, KKT distance) after 10 / 100 / 400 iterations:", certs)
+    assert all(c[1] >= -1e-13 for c in certs)                   # weak duality, rigorously
+    assert certs[2][1] < certs[1][1] < certs[0][1] and certs[2][1] < 0.2 * certs[0][1]
+    assert certs[2][2] < certs[1][2] < certs[0][2]
     p.A.free()
 
 

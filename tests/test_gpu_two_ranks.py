@@ -74,7 +74,8 @@ def test_row_sharded_primal_dual():
            "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "tests", "two_rank_pd_worker.py")]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
-    assert out.stdout.count("PD-SHARDED") == 6 and "PD-SHARDED AdaPDM+ launches [12, 12]" in out.stdout, out.stdout[-1500:]
+    assert out.stdout.count("PD-SHARDED failed set-up on rank 1") == 3 and "one-pass launches [0, 0]" in out.stdout, out.stdout[-2500:]
+    assert out.stdout.count("PD-SHARDED") == 9 and "PD-SHARDED AdaPDM+ launches [12, 12]" in out.stdout, out.stdout[-1500:]
     assert "PD-SHARDED Malitsky-Pock" in out.stdout, out.stdout[-1500:]
     assert "PD-SHARDED one-pass l1 launches [15, 15]" in out.stdout and "PD-SHARDED one-pass l2 launches [15, 15]" in out.stdout, out.stdout[-1500:]
 

@@ -124,6 +124,39 @@ def main():
             errs = [np.max(np.abs(x - xr)) / max(np.max(np.abs(xr)), 1e-300), np.max(np.abs(y_cat - yr)) / np.max(np.abs(yr))]
             print(f"PD-SHARDED Malitsky-Pock A products {[t[1] for t in ys]} (unsharded {rr[-1]['A_evals']}) errs " + " ".join(f"{e:.3e}" for e in errs), flush=True)
             ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == rr[-1]["A_evals"] for t in ys) and rr[-1]["A_evals"] > 13
+        # A rank whose one-pass SET-UP FAILS: rank 1's does (a test hook standing in for a failed allocation).  The
+        # ranks vote on the path AFTER the set-up — rank 1 must still reach that vote ("cannot"), both then take the two GEMV
+        # passes, nobody waits in a collective its peer never entered ; generic loop, AdaPDM+ and Malitsky-Pock alike.
+        L = importlib.import_module("adaptive-proximal-algorithms_amd._lib")
+        ctx2 = apx.Context(device=0, stream=stream.cuda_stream)
+        ctx2.one_pass_threshold(16 << 20)
+        if rank == 1:
+            ctx2.set_option(L.APX_OPT_FAULT_SETUP, 1)
+        A_k2 = apx.DeviceMatrix.from_numpy(np.asfortranarray(A[r0:r0 + ml]), ctx2)
+        hk = apx.Translate(apx.NormL1(1.0), -yv[r0:r0 + ml])
+        hf = apx.Translate(apx.NormL1(1.0), -yv)
+        common = dict(f=apx.Zero(), g=apx.NormL1(5.0), tol=0.0, maxit=8)
+        runs = {"generic": (lambda A_, h_, m_, **kw: apx.adaptive_primal_dual(np.zeros(n), np.zeros(m_), h=h_, A=A_, rule=apx.OurRule(t=1.0, norm_A=nA),
+                                                                            **common, **kw)),
+                "AdaPDM+": (lambda A_, h_, m_, **kw: apx.adaptive_linesearch_primal_dual(np.zeros(n), np.zeros(m_), h=h_, A=A_, eta=nA / 2000.0,
+                                                                                      t=1.0, **common, **kw)),
+                "Malitsky-Pock": (lambda A_, h_, m_, **kw: apx.malitsky_pock(np.zeros(n), np.zeros(m_), h=h_, A=A_, sigma=200.0 / nA, t=1.0,
+                                                                            **common, **kw))}
+        for name, run in runs.items():
+            ctx2.kernel_stats(reset=True)
+            ctx2.profile(True)
+            x, y_k, it = run(A_k2, hk, ml, ctx=ctx2, A_allreduce=ar)
+            st = ctx2.kernel_stats(reset=True)
+            ctx2.profile(False)
+            ys = [None] * world
+            dist.all_gather_object(ys, (y_k, st["one_pass"]["launches"], st["gemv_t"]["launches"]))
+            if rank == 0:
+                xr, yr, _ = run(A_full, hf, m, ctx=ctx1)
+                y_cat = np.concatenate([t[0] for t in ys])
+                errs = [np.max(np.abs(x - xr)) / max(np.max(np.abs(xr)), 1e-300), np.max(np.abs(y_cat - yr)) / np.max(np.abs(yr))]
+                print(f"PD-SHARDED failed set-up on rank 1, {name}: one-pass launches {[t[1] for t in ys]} GEMV-T launches {[t[2] for t in ys]} errs " +
+                      " ".join(f"{e:.3e}" for e in errs), flush=True)
+                ok = ok and all(e <= 1e-10 for e in errs) and all(t[1] == 0 and t[2] >= 8 for t in ys)
     flag = torch.tensor([1 if ok else 0])
     dist.broadcast(flag, 0)
     dist.destroy_process_group()

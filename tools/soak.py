@@ -2,12 +2,14 @@
 process — sequence numbers, ring re-use and the per-XCD tickets run far past their first wrap of the 8-slot rings; any
 timed-out hand-off raises (the error word is read with every poll and with the result).  Prints one JSON line per leg."""
 import json
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")      # (run from anywhere: tools/prof_round.sh does `cd /tmp` first)
+sys.path.insert(0, _ROOT)
 import adaprox_amd as apx  # noqa: E402
 
 apx.load()
@@ -16,7 +18,7 @@ from importlib import import_module  # noqa: E402
 problems = import_module("adaptive-proximal-algorithms_amd.problems")
 
 
-THRESHOLDS = json.load(open("profiles/incidents/wait_thresholds.json"))
+THRESHOLDS = json.load(open(os.path.join(_ROOT, "profiles", "incidents", "wait_thresholds.json")))
 
 
 def where_the_long_waits_are(slots_by_solve, nsteps_hint=None) -> dict:
