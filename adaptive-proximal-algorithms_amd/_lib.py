@@ -16,10 +16,11 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libadaprox_hip.so")
 
 # ---- enums (include/adaprox_hip.h) ---------------------------------------------------
 APX_OK, APX_ERR_INVALID, APX_ERR_HIP, APX_ERR_UNSUPPORTED, APX_ERR_DOMAIN, APX_ERR_CALLBACK, APX_ERR_COMM = range(7)
-APX_ABI_VERSION = 4
+APX_ABI_VERSION = 5
 APX_COMM_ID_BYTES = 128
 APX_FLAG_TINY_GAMMA, APX_FLAG_NAN_GAMMA, APX_FLAG_DOMAIN, APX_FLAG_TEAM_FALLBACK = 1, 2, 4, 8
 APX_F64, APX_F32 = 0, 1
+APX_LAYOUT_COLS, APX_LAYOUT_ROWS = 0, 1
 APX_F_ZERO, APX_F_LEAST_SQUARES, APX_F_LOGISTIC, APX_F_CALLBACK, APX_F_QUADRATIC = range(5)
 APX_G_ZERO, APX_G_L1, APX_G_BOX, APX_G_BOXV, APX_G_INDZERO, APX_G_L2 = range(6)
 APX_RULE_FIXED, APX_RULE_MM, APX_RULE_OURS, APX_RULE_OURS_PLUS = range(4)
@@ -125,6 +126,10 @@ PROTOTYPES = {
     "apx_gemv_variant_name": (C.c_char_p, [c_int32, c_int32]),
     "apx_matrix_create": (c_int32, [c_void_p, c_int64, c_int64, c_int32, _P(c_void_p)]),
     "apx_matrix_upload": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, _P(c_void_p)]),
+    "apx_matrix_create_layout": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, _P(c_void_p)]),
+    "apx_matrix_upload_layout": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, _P(c_void_p)]),
+    "apx_matrix_drop_primary": (c_int32, [c_void_p]),
+    "apx_matrix_layout": (c_int32, [c_void_p, _P(c_int32)]),
     "apx_matrix_upload_sparse": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                            c_int32, _P(c_void_p)]),
     "apx_matrix_build_transpose": (c_int32, [c_void_p]),

@@ -180,8 +180,17 @@ class DeviceMatrix:
         self._lib = ctx._lib
 
     # -- constructors
+    @staticmethod
+    def _layout(layout) -> int:
+        """"cols" (column-major in HBM, Julia's layout — the default) or "rows" (ONLY the row-contiguous storage the one-pass
+        kernels read: one resident copy instead of two ; include/adaprox_hip.h APX_LAYOUT_*)."""
+        try:
+            return {"cols": L.APX_LAYOUT_COLS, "rows": L.APX_LAYOUT_ROWS, 0: 0, 1: 1}[layout]
+        except KeyError:
+            raise ValueError(f"layout must be 'cols' or 'rows', not {layout!r}") from None
+
     @classmethod
-    def from_numpy(cls, A: np.ndarray, ctx: Optional[Context] = None) -> "DeviceMatrix":
+    def from_numpy(cls, A: np.ndarray, ctx: Optional[Context] = None, layout="cols") -> "DeviceMatrix":
         ctx = ctx or default_context()
         A = np.asarray(A)
         if A.ndim != 2:
@@ -189,7 +198,8 @@ class DeviceMatrix:
         Af = np.asfortranarray(A)          # column-major, like Julia
         m, n = Af.shape
         h = C.c_void_p()
-        L.check(ctx._lib.apx_matrix_upload(ctx._h, _ptr(Af), m, n, max(m, 1), _code(Af.dtype), C.byref(h)))
+        L.check(ctx._lib.apx_matrix_upload_layout(ctx._h, _ptr(Af), m, n, max(m, 1), _code(Af.dtype), cls._layout(layout),
+                                                  C.byref(h)))
         return cls(ctx, h, m, n, _code(Af.dtype))
 
     @classmethod
@@ -219,20 +229,32 @@ class DeviceMatrix:
         return M
 
     @classmethod
-    def zeros(cls, m: int, n: int, dtype=np.float64, ctx: Optional[Context] = None) -> "DeviceMatrix":
+    def zeros(cls, m: int, n: int, dtype=np.float64, ctx: Optional[Context] = None, layout="cols") -> "DeviceMatrix":
         ctx = ctx or default_context()
         h = C.c_void_p()
-        L.check(ctx._lib.apx_matrix_create(ctx._h, m, n, _code(dtype), C.byref(h)))
+        L.check(ctx._lib.apx_matrix_create_layout(ctx._h, m, n, _code(dtype), cls._layout(layout), C.byref(h)))
         return cls(ctx, h, m, n, _code(dtype))
 
     @classmethod
     def uniform(cls, m: int, n: int, seed: int, lo: float = -1.0, hi: float = 1.0, dtype=np.float64,
-                row_offset: int = 0, m_total: Optional[int] = None, ctx: Optional[Context] = None):
+                row_offset: int = 0, m_total: Optional[int] = None, ctx: Optional[Context] = None, layout="cols"):
         """`rand(m, n) .* 2 .- 1` generated on the device (counter-based; a row shard of a
-        global m_total x n matrix can be generated independently on every GPU)."""
-        A = cls.zeros(m, n, dtype, ctx)
+        global m_total x n matrix can be generated independently on every GPU ; the same values in either layout)."""
+        A = cls.zeros(m, n, dtype, ctx, layout)
         L.check(A._lib.apx_matrix_fill_uniform(A._h, seed, lo, hi, row_offset, m_total or m))
         return A
+
+    def drop_primary(self):
+        """Keeps ONLY the row-contiguous storage (building it first if it is not there): one resident copy of A."""
+        L.check(self._lib.apx_matrix_drop_primary(self._h))
+        return self
+
+    @property
+    def layout(self) -> str:
+        """"cols", "rows" (rows-only), "dual" (both copies resident) or "sparse"."""
+        mask = C.c_int32()
+        L.check(self._lib.apx_matrix_layout(self._h, C.byref(mask)))
+        return {0: "sparse", 1: "cols", 2: "rows", 3: "dual"}[int(mask.value)]
 
     # -- element access helpers used by the generators
     def scale_columns(self, alpha: np.ndarray):

@@ -130,9 +130,12 @@ struct apx_matrix {
   apx_ctx* ctx = nullptr;
   int64_t m = 0, n = 0, ld = 0, n_pad = 0;
   int32_t dtype = APX_F64;
-  void* d = nullptr;           // dense: column-major ld x n_pad
-  // optional second copy, A' column-major (ldT = round_up(n,32) rows x ld columns): with it `A*x`
-  // streams whole rows of A contiguously like `A'*r` streams whole columns (apx_matrix_build_transpose)
+  void* d = nullptr;           // dense: column-major ld x n_pad (Julia's layout) — nullptr for a ROWS-ONLY matrix (below)
+  // the ROW storage, A' column-major (ldT = round_up(n,32) rows x ld columns: row i of A contiguous at dT + i * ldT).  Next to d
+  // it is the optional second copy (apx_matrix_build_transpose: `A*x` then streams whole rows like `A'*r` streams whole
+  // columns) ; it is what the one-pass kernels read, and a matrix may live in it ALONE (APX_LAYOUT_ROWS, apx_matrix_drop_primary):
+  // one resident copy for a loop that reads one — the two GEMV orientations are served from it by the same kernel pair with the
+  // roles swapped (gemv.hip), the small-size kernels (which read d) do not apply
   void* dT = nullptr;
   int64_t ldT = 0;
   // sparse storage: BOTH orientations are kept, each as compressed rows, so
@@ -152,6 +155,9 @@ struct apx_matrix {
 };
 
 namespace apx {
+
+// the small-size / tall-skinny kernel families read the column-major storage: not for sparse or rows-only matrices
+inline bool no_column_storage(const apx_matrix* A) { return A->sparse || A->d == nullptr; }
 
 void ctx_retain(apx_ctx* ctx);
 void ctx_release(apx_ctx* ctx);

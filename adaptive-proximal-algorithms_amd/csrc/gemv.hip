@@ -144,58 +144,66 @@ static int32_t launch_gemv_n_nz(apx_ctx* ctx, const apx_matrix* A, const void* x
   return APX_OK;
 }
 
-int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
-  if (A->sparse) return launch_spmv_n(ctx, A, x, splits_out, done);
-  if (ctx->skip_zero_cols) return launch_gemv_n_nz(ctx, A, x, splits_out, done);
-  if (A->dT != nullptr)   // dual layout: A*x as the column-streaming kernel over the transposed copy
-    return launch_t_core(ctx, A->dT, A->ldT, A->ld, A->dtype, (double)A->m * (double)A->n * dtype_size(A->dtype),
-                         APX_KSTAT_GEMV_N, x, nullptr, splits_out, done);
-  const int V = A->dtype == APX_F32 ? 4 : 2;
+// One launch of the row-tiled kernel (gemv_n_kernel: block = a tile of rows x one split of the columns, the vector staged through
+// LDS) on a dense column-major operand (d, ld = padded rows, ncols columns, ncols_pad their padded count): fp64 partials
+// [splits][ld] left in ctx->part.  `A*x` on the column-major storage ; `A'*r` on the ROW storage of a rows-only matrix (operand A').
+static int32_t launch_n_core(apx_ctx* ctx, const void* d, int64_t ld, int64_t ncols, int64_t ncols_pad, int32_t dtype, double bytes,
+                             int stat_kind, const void* x, int* splits_out, const int* done) {
+  const int V = dtype == APX_F32 ? 4 : 2;
   int vi = ctx->cfg.n_variant;
   int64_t target = ctx->cfg.n_target_blocks;
-  if (ctx->cfg.n_auto && A->n * (int64_t)dtype_size(A->dtype) <= 256 * 1024) {
+  if (ctx->cfg.n_auto && ncols * (int64_t)dtype_size(dtype) <= 256 * 1024) {
     // short rows (C5: 160 KB, C3: 40 KB per row of A): the narrow 512-row tile with ~8 blocks per
     // CU measured 4 % (C5) / 1 % (C3) faster than the wide-tile default (gpurun_out/sweep_c5.log)
     vi = ctx->cfg.n_variant_narrow;
     target = 8 * (int64_t)ctx->num_cu;
   }
   int64_t rows_per_block = (int64_t)kBlock * V * kNVars[vi].rpt;
-  int64_t row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
+  int64_t row_tiles = (ld + rows_per_block - 1) / rows_per_block;
   int64_t S = std::max<int64_t>(1, (target + row_tiles - 1) / row_tiles);
-  if (ctx->cfg.n_auto && (double)A->ld * (double)A->n * (double)dtype_size(A->dtype) > 256e6) {
+  if (ctx->cfg.n_auto && (double)ld * (double)ncols * (double)dtype_size(dtype) > 256e6) {
     // (cache-resident matrices are latency-bound: there more blocks matter more than partial traffic)
     // every column split writes and re-reads an m-vector of fp64 partials: keep that below ~1 %
     // of the A stream (S*16 B per row against n*sizeof(T)); when that leaves too few blocks for a
     // wide row tile, fall back to the narrow-tile variant (short-and-wide problems such as C3)
-    const int64_t s_cap = std::max<int64_t>(1, A->n * (int64_t)dtype_size(A->dtype) / 1600);
+    const int64_t s_cap = std::max<int64_t>(1, ncols * (int64_t)dtype_size(dtype) / 1600);
     if (S > s_cap) {
       S = s_cap;
       if (row_tiles * S < 8 * (int64_t)ctx->num_cu && kNVars[vi].rpt > 1) {
         vi = ctx->cfg.n_variant_narrow;
         rows_per_block = (int64_t)kBlock * V * kNVars[vi].rpt;
-        row_tiles = (A->ld + rows_per_block - 1) / rows_per_block;
+        row_tiles = (ld + rows_per_block - 1) / rows_per_block;
       }
     }
   }
   const NVar& v = kNVars[vi];
-  int64_t cps = round_up((A->n + S - 1) / S, v.unr);
+  int64_t cps = round_up((ncols + S - 1) / S, v.unr);
   if (cps < v.unr) cps = v.unr;
-  S = (A->n + cps - 1) / cps;
+  S = (ncols + cps - 1) / cps;
   if (S < 1) S = 1;
-  int64_t n_arg = A->n;
-  if (v.il) {   // chunks of v.unr columns dealt round-robin to the S splits; n_pad % unr == 0
-    n_arg = A->n_pad;
-    S = std::min<int64_t>(S, A->n_pad / v.unr);
+  int64_t n_arg = ncols;
+  if (v.il) {   // chunks of v.unr columns dealt round-robin to the S splits; ncols_pad % unr == 0
+    n_arg = ncols_pad;
+    S = std::min<int64_t>(S, ncols_pad / v.unr);
   }
   APX_REQUIRE(S <= 65535 && row_tiles <= 2147483647LL, "gemv_n grid too large");
-  APX_TRY(ensure_part(ctx, (size_t)S * A->ld * sizeof(double)));
-  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, (double)A->m * (double)A->n * dtype_size(A->dtype)));
+  APX_TRY(ensure_part(ctx, (size_t)S * ld * sizeof(double)));
+  APX_TRY(prof_begin(ctx, stat_kind, bytes));
   dim3 grid((unsigned)row_tiles, (unsigned)S);
-  (A->dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, A->d, A->ld, x, ctx->part, A->ld, n_arg, cps, done);
+  (dtype == APX_F32 ? v.f32 : v.f64)(grid, ctx->stream, d, ld, x, ctx->part, ld, n_arg, cps, done);
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
   *splits_out = (int)S;
   return APX_OK;
+}
+
+int32_t launch_gemv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
+  if (A->sparse) return launch_spmv_n(ctx, A, x, splits_out, done);
+  const double bytes = (double)A->m * (double)A->n * dtype_size(A->dtype);
+  if (ctx->skip_zero_cols && A->d != nullptr) return launch_gemv_n_nz(ctx, A, x, splits_out, done);
+  if (A->dT != nullptr)   // the row storage (dual layout, or a rows-only matrix): A*x as the column-streaming kernel over A'
+    return launch_t_core(ctx, A->dT, A->ldT, A->ld, A->dtype, bytes, APX_KSTAT_GEMV_N, x, nullptr, splits_out, done);
+  return launch_n_core(ctx, A->d, A->ld, A->n, A->n_pad, A->dtype, bytes, APX_KSTAT_GEMV_N, x, splits_out, done);
 }
 
 // One launch of the column-streaming kernel on a dense column-major operand (d, ld, rows m_pad,
@@ -233,6 +241,14 @@ static int32_t launch_t_core(apx_ctx* ctx, const void* d, int64_t ld, int64_t n_
 
 int32_t launch_gemv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
   if (A->sparse) return launch_spmv_t(ctx, A, r, out, done);
+  if (A->d == nullptr) {
+    // a rows-only matrix: A'*r = (the row storage as an n_pad x m column-major operand) * r — the row-tiled kernel with the roles
+    // of the two dimensions swapped, its column-split partials summed in a fixed order (r is padded to ld = the operand's ncols_pad)
+    int S = 0;
+    APX_TRY(launch_n_core(ctx, A->dT, A->ldT, A->m, A->ld, A->dtype, (double)A->m * (double)A->n * dtype_size(A->dtype),
+                          APX_KSTAT_GEMV_T, r, &S, done));
+    return launch_sum_partials_rows(ctx, A->dtype, S, A->ldT, A->ldT, out, done);
+  }
   return launch_t_core(ctx, A->d, A->ld, A->n_pad, A->dtype, (double)A->m * (double)A->n * dtype_size(A->dtype),
                        APX_KSTAT_GEMV_T, r, out, nullptr, done);
 }

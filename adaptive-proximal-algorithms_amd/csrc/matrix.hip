@@ -91,6 +91,32 @@ __global__ __launch_bounds__(kBlock) void k_fill_column(T* __restrict__ col, int
     col[i] = (T)value;
 }
 
+// The same three edits on the ROW storage (A' column-major: element (i, j) of A at AT[i * ldT + j]) — a row of A per blockIdx.y,
+// the threads along it (coalesced) ; the values are those of the column-major kernels, element for element.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fill_uniform_rows(T* __restrict__ AT, int64_t ldT, int64_t n, uint64_t seed, double lo,
+                                                              double hi, int64_t row_offset, int64_t m_total) {
+  const int64_t i = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+    const uint64_t idx = (uint64_t)j * (uint64_t)m_total + (uint64_t)(row_offset + i);
+    AT[i * ldT + j] = (T)(lo + (hi - lo) * hash_uniform(seed, idx));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scale_columns_rows(T* __restrict__ AT, int64_t ldT, int64_t n,
+                                                               const double* __restrict__ alpha) {
+  const int64_t i = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock)
+    AT[i * ldT + j] = (T)((double)AT[i * ldT + j] * alpha[j]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fill_column_rows(T* __restrict__ AT, int64_t ldT, int64_t m, int64_t j, double value) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock)
+    AT[i * ldT + j] = (T)value;
+}
+
 // sum of squares over the whole padded buffer (pads are zero); block partials in a fixed order
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ A, int64_t total, double* __restrict__ red) {
@@ -147,6 +173,17 @@ __global__ __launch_bounds__(kBlock) void k_sumsq_elems(const T* __restrict__ v,
     double t = sh[0];
     for (int w = 1; w < kBlock / 64; ++w) t += sh[w];
     red[blockIdx.x] = t;
+  }
+}
+
+template <typename T>
+static void transpose_block(hipStream_t q, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t m, int64_t n) {
+  // dst (n x m column-major, ld_dst) = src' (src m x n column-major, ld_src) ; gridDim.y <= 65535 tiles of 32 columns
+  const int64_t slab = 65535LL * 32;
+  for (int64_t j0 = 0; j0 < n; j0 += slab) {
+    const int64_t nj = std::min<int64_t>(slab, n - j0);
+    hipLaunchKernelGGL(k_transpose<T>, dim3((unsigned)((m + 31) / 32), (unsigned)((nj + 31) / 32)), dim3(kBlock), 0, q,
+                       (const T*)src + (size_t)j0 * ld_src, ld_src, (T*)dst + j0, ld_dst, m, nj);
   }
 }
 
@@ -419,10 +456,11 @@ const char* apx_gemv_variant_name(int32_t transposed, int32_t i) {
 }
 
 // ---- matrices ----------------------------------------------------------------------
-int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx_matrix** out) {
+int32_t apx_matrix_create_layout(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, int32_t layout, apx_matrix** out) {
   APX_REQUIRE(ctx != nullptr && out != nullptr, "apx_matrix_create: NULL argument");
   APX_REQUIRE(m >= 0 && n >= 0, "apx_matrix_create: negative dimension");
   APX_REQUIRE(dtype == APX_F64 || dtype == APX_F32, "apx_matrix_create: bad dtype");
+  APX_REQUIRE(layout == APX_LAYOUT_COLS || layout == APX_LAYOUT_ROWS, "apx_matrix_create_layout: layout must be APX_LAYOUT_COLS or APX_LAYOUT_ROWS");
   *out = nullptr;
   APX_HIP(hipSetDevice(ctx->device));
   apx_matrix* A = new apx_matrix();
@@ -432,34 +470,71 @@ int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx
   A->dtype = dtype;
   A->ld = round_up(std::max<int64_t>(m, 1), kPad);
   A->n_pad = round_up(std::max<int64_t>(n, 1), kPad);
+  // (the two storages have the same size: ld x n_pad column-major, or n_pad (= ldT) x ld for the rows)
   const size_t bytes = (size_t)A->ld * (size_t)A->n_pad * dtype_size(dtype);
-  hipError_t e = hipMalloc(&A->d, bytes);
+  void* buf = nullptr;
+  hipError_t e = hipMalloc(&buf, bytes);
   if (e != hipSuccess) {
     delete A;
     return fail(APX_ERR_HIP, std::string("apx_matrix_create: hipMalloc of ") + std::to_string(bytes) + " B: " +
                                  hipGetErrorString(e));
   }
-  e = hipMemsetAsync(A->d, 0, bytes, ctx->stream);
+  e = hipMemsetAsync(buf, 0, bytes, ctx->stream);
   if (e != hipSuccess) {
-    (void)hipFree(A->d);
+    (void)hipFree(buf);
     delete A;
     return fail(APX_ERR_HIP, std::string("apx_matrix_create: memset: ") + hipGetErrorString(e));
+  }
+  if (layout == APX_LAYOUT_ROWS) {
+    A->dT = buf;
+    A->ldT = A->n_pad;
+  } else {
+    A->d = buf;
   }
   ctx_retain(ctx);
   *out = A;
   return APX_OK;
 }
 
-int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, int64_t lda, int32_t dtype,
-                          apx_matrix** out) {
+int32_t apx_matrix_create(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, apx_matrix** out) {
+  return apx_matrix_create_layout(ctx, m, n, dtype, APX_LAYOUT_COLS, out);
+}
+
+// the budget of the staging slabs of a rows-only matrix's upload / download (bytes)
+static constexpr size_t kStageBytes = (size_t)256 << 20;
+
+int32_t apx_matrix_upload_layout(apx_ctx* ctx, const void* host, int64_t m, int64_t n, int64_t lda, int32_t dtype, int32_t layout,
+                                 apx_matrix** out) {
   APX_REQUIRE(host != nullptr || m * n == 0, "apx_matrix_upload: host is NULL");
   APX_REQUIRE(lda >= m, "apx_matrix_upload: lda < m");
-  APX_TRY(apx_matrix_create(ctx, m, n, dtype, out));
+  APX_TRY(apx_matrix_create_layout(ctx, m, n, dtype, layout, out));
   apx_matrix* A = *out;
   if (m > 0 && n > 0) {
     const size_t es = dtype_size(dtype);
-    hipError_t e = hipMemcpy2DAsync(A->d, (size_t)A->ld * es, host, (size_t)lda * es, (size_t)m * es, (size_t)n,
-                                    hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (layout == APX_LAYOUT_COLS) {
+      e = hipMemcpy2DAsync(A->d, (size_t)A->ld * es, host, (size_t)lda * es, (size_t)m * es, (size_t)n, hipMemcpyHostToDevice,
+                           ctx->stream);
+    } else {
+      // the host matrix is column-major (Julia's): slabs of columns through a staging buffer, transposed into the row storage
+      const int64_t cols = std::max<int64_t>(32, std::min<int64_t>(n, (int64_t)(kStageBytes / ((size_t)A->ld * es)) / 32 * 32));
+      DBuf stage;
+      if (int32_t rc = stage.alloc_zero((size_t)A->ld * (size_t)cols * es, ctx->stream); rc != APX_OK) {
+        apx_matrix_free(A);
+        *out = nullptr;
+        return rc;
+      }
+      for (int64_t j0 = 0; j0 < n && e == hipSuccess; j0 += cols) {
+        const int64_t nj = std::min<int64_t>(cols, n - j0);
+        e = hipMemcpy2DAsync(stage.p, (size_t)A->ld * es, (const char*)host + (size_t)j0 * lda * es, (size_t)lda * es, (size_t)m * es,
+                             (size_t)nj, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) break;
+        if (dtype == APX_F32) transpose_block<float>(ctx->stream, stage.p, A->ld, (float*)A->dT + j0, A->ldT, m, nj);
+        else transpose_block<double>(ctx->stream, stage.p, A->ld, (double*)A->dT + j0, A->ldT, m, nj);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // (the staging buffer goes out of scope)
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
       apx_matrix_free(A);
@@ -470,15 +545,34 @@ int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, 
   return APX_OK;
 }
 
+int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, int64_t lda, int32_t dtype,
+                          apx_matrix** out) {
+  return apx_matrix_upload_layout(ctx, host, m, n, lda, dtype, APX_LAYOUT_COLS, out);
+}
+
 int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda) {
   APX_REQUIRE(A != nullptr && host != nullptr, "apx_matrix_download: NULL argument");
   APX_REQUIRE(!A->sparse, "apx_matrix_download: dense matrices only");
   APX_REQUIRE(lda >= A->m, "apx_matrix_download: lda < m");
   APX_HIP(hipSetDevice(A->ctx->device));
   const size_t es = dtype_size(A->dtype);
-  if (A->m > 0 && A->n > 0) {
+  if (A->m > 0 && A->n > 0 && A->d != nullptr) {
     APX_HIP(hipMemcpy2DAsync(host, (size_t)lda * es, A->d, (size_t)A->ld * es, (size_t)A->m * es, (size_t)A->n,
                              hipMemcpyDeviceToHost, A->ctx->stream));
+  } else if (A->m > 0 && A->n > 0) {
+    // rows-only: slabs of ROWS of A transposed back into a staging buffer (column-major, rows x n), copied out column by column
+    const int64_t rows = std::max<int64_t>(32, std::min<int64_t>(A->ld, (int64_t)(kStageBytes / ((size_t)A->n * es)) / 32 * 32));
+    DBuf stage;
+    APX_TRY(stage.alloc_zero((size_t)rows * (size_t)A->n * es, A->ctx->stream));
+    for (int64_t i0 = 0; i0 < A->m; i0 += rows) {
+      const int64_t ni = std::min<int64_t>(rows, A->m - i0);
+      // (the block of the row storage: an n x ni column-major operand at dT + i0 * ldT)
+      if (A->dtype == APX_F32) transpose_block<float>(A->ctx->stream, (const float*)A->dT + (size_t)i0 * A->ldT, A->ldT, stage.p, rows, A->n, ni);
+      else transpose_block<double>(A->ctx->stream, (const double*)A->dT + (size_t)i0 * A->ldT, A->ldT, stage.p, rows, A->n, ni);
+      APX_HIP(hipGetLastError());
+      APX_HIP(hipMemcpy2DAsync((char*)host + (size_t)i0 * es, (size_t)lda * es, stage.p, (size_t)rows * es, (size_t)ni * es, (size_t)A->n,
+                               hipMemcpyDeviceToHost, A->ctx->stream));
+    }
   }
   APX_HIP(hipStreamSynchronize(A->ctx->stream));
   return APX_OK;
@@ -503,7 +597,7 @@ int32_t apx_matrix_free(apx_matrix* A) {
 }
 
 static void drop_transpose(apx_matrix* A) {
-  if (A->dT == nullptr) return;
+  if (A->dT == nullptr || A->d == nullptr) return;      // (a rows-only matrix: that IS the matrix — its edits work on it in place)
   (void)hipStreamSynchronize(A->ctx->stream);
   (void)hipFree(A->dT);
   A->dT = nullptr;
@@ -540,6 +634,7 @@ int32_t apx_matrix_build_transpose(apx_matrix* A) {
   APX_REQUIRE(!A->sparse, "apx_matrix_build_transpose: dense matrices only (sparse storage keeps both orientations)");
   apx_ctx* ctx = A->ctx;
   APX_HIP(hipSetDevice(ctx->device));
+  if (A->d == nullptr) return APX_OK;      // a rows-only matrix already is what this builds
   if (A->dT != nullptr) {
     APX_HIP(hipStreamSynchronize(ctx->stream));
     (void)hipFree(A->dT);
@@ -567,8 +662,27 @@ int32_t apx_matrix_build_transpose(apx_matrix* A) {
 
 int32_t apx_matrix_drop_transpose(apx_matrix* A) {
   APX_REQUIRE(A != nullptr, "apx_matrix_drop_transpose: A is NULL");
+  APX_REQUIRE(A->sparse || A->d != nullptr, "apx_matrix_drop_transpose: a rows-only matrix has no other copy (apx_matrix_free)");
   APX_HIP(hipSetDevice(A->ctx->device));
   drop_transpose(A);
+  return APX_OK;
+}
+
+int32_t apx_matrix_drop_primary(apx_matrix* A) {
+  APX_REQUIRE(A != nullptr, "apx_matrix_drop_primary: A is NULL");
+  APX_REQUIRE(!A->sparse, "apx_matrix_drop_primary: dense matrices only");
+  if (A->d == nullptr) return APX_OK;                              // rows-only already
+  if (A->dT == nullptr) APX_TRY(apx_matrix_build_transpose(A));   // (both copies are resident for the moment of the transpose)
+  APX_HIP(hipSetDevice(A->ctx->device));
+  APX_HIP(hipStreamSynchronize(A->ctx->stream));
+  (void)hipFree(A->d);
+  A->d = nullptr;
+  return APX_OK;
+}
+
+int32_t apx_matrix_layout(const apx_matrix* A, int32_t* mask) {
+  APX_REQUIRE(A != nullptr && mask != nullptr, "apx_matrix_layout: NULL argument");
+  *mask = A->sparse ? 0 : ((A->d != nullptr ? 1 : 0) | (A->dT != nullptr ? 2 : 0));
   return APX_OK;
 }
 
@@ -593,6 +707,20 @@ int32_t apx_matrix_fill_uniform(apx_matrix* A, uint64_t seed, double lo, double 
   APX_REQUIRE(row_offset >= 0 && row_offset + A->m <= m_total, "apx_matrix_fill_uniform: shard outside the global matrix");
   if (A->m == 0 || A->n == 0) return APX_OK;
   APX_HIP(hipSetDevice(A->ctx->device));
+  if (A->d == nullptr) {      // rows-only: the same values, written along the rows (gridDim.y: slabs of 65535 rows)
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (A->n + kBlock - 1) / kBlock));
+    for (int64_t i0 = 0; i0 < A->m; i0 += 65535) {
+      const int64_t ni = std::min<int64_t>(65535, A->m - i0);
+      if (A->dtype == APX_F32)
+        hipLaunchKernelGGL(k_fill_uniform_rows<float>, dim3(gx, (unsigned)ni), dim3(kBlock), 0, A->ctx->stream,
+                           (float*)A->dT + (size_t)i0 * A->ldT, A->ldT, A->n, seed, lo, hi, row_offset + i0, m_total);
+      else
+        hipLaunchKernelGGL(k_fill_uniform_rows<double>, dim3(gx, (unsigned)ni), dim3(kBlock), 0, A->ctx->stream,
+                           (double*)A->dT + (size_t)i0 * A->ldT, A->ldT, A->n, seed, lo, hi, row_offset + i0, m_total);
+    }
+    APX_HIP(hipGetLastError());
+    return APX_OK;
+  }
   // gridDim.y is limited to 65535: walk the columns in slabs
   for (int64_t j0 = 0; j0 < A->n; j0 += 65535) {
     const int64_t nj = std::min<int64_t>(65535, A->n - j0);
@@ -622,6 +750,21 @@ int32_t apx_matrix_scale_columns(apx_matrix* A, const double* alpha) {
   DBuf d_alpha;
   APX_TRY(d_alpha.alloc_zero((size_t)A->n * sizeof(double), A->ctx->stream));
   APX_HIP(hipMemcpyAsync(d_alpha.p, alpha, (size_t)A->n * sizeof(double), hipMemcpyHostToDevice, A->ctx->stream));
+  if (A->d == nullptr) {      // rows-only
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (A->n + kBlock - 1) / kBlock));
+    for (int64_t i0 = 0; i0 < A->m; i0 += 65535) {
+      const int64_t ni = std::min<int64_t>(65535, A->m - i0);
+      if (A->dtype == APX_F32)
+        hipLaunchKernelGGL(k_scale_columns_rows<float>, dim3(gx, (unsigned)ni), dim3(kBlock), 0, A->ctx->stream,
+                           (float*)A->dT + (size_t)i0 * A->ldT, A->ldT, A->n, (const double*)d_alpha.p);
+      else
+        hipLaunchKernelGGL(k_scale_columns_rows<double>, dim3(gx, (unsigned)ni), dim3(kBlock), 0, A->ctx->stream,
+                           (double*)A->dT + (size_t)i0 * A->ldT, A->ldT, A->n, (const double*)d_alpha.p);
+    }
+    APX_HIP(hipGetLastError());
+    APX_HIP(hipStreamSynchronize(A->ctx->stream));
+    return APX_OK;
+  }
   for (int64_t j0 = 0; j0 < A->n; j0 += 65535) {
     const int64_t nj = std::min<int64_t>(65535, A->n - j0);
     const size_t es = dtype_size(A->dtype);
@@ -646,8 +789,16 @@ int32_t apx_matrix_fill_column(apx_matrix* A, int64_t j, double value) {
   if (A->m == 0) return APX_OK;
   APX_HIP(hipSetDevice(A->ctx->device));
   const size_t es = dtype_size(A->dtype);
-  char* col = (char*)A->d + (size_t)j * A->ld * es;
   const unsigned g = (unsigned)std::min<int64_t>(1024, (A->m + kBlock - 1) / kBlock);
+  if (A->d == nullptr) {      // rows-only: a strided write
+    if (A->dtype == APX_F32)
+      hipLaunchKernelGGL(k_fill_column_rows<float>, dim3(g), dim3(kBlock), 0, A->ctx->stream, (float*)A->dT, A->ldT, A->m, j, value);
+    else
+      hipLaunchKernelGGL(k_fill_column_rows<double>, dim3(g), dim3(kBlock), 0, A->ctx->stream, (double*)A->dT, A->ldT, A->m, j, value);
+    APX_HIP(hipGetLastError());
+    return APX_OK;
+  }
+  char* col = (char*)A->d + (size_t)j * A->ld * es;
   if (A->dtype == APX_F32)
     hipLaunchKernelGGL(k_fill_column<float>, dim3(g), dim3(kBlock), 0, A->ctx->stream, (float*)col, A->m, value);
   else
@@ -667,11 +818,12 @@ int32_t apx_matrix_sumsq(const apx_matrix* A, double* out) {
     else
       hipLaunchKernelGGL(k_sumsq_elems<double>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const double*)A->rval, A->nnz, ctx->red);
   } else {
-    const int64_t total = A->ld * A->n_pad;
+    const int64_t total = A->ld * A->n_pad;                       // (either storage: the same number of elements, pads zero)
+    const void* base = A->d != nullptr ? A->d : A->dT;
     if (A->dtype == APX_F32)
-      hipLaunchKernelGGL(k_sumsq<float>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const float*)A->d, total, ctx->red);
+      hipLaunchKernelGGL(k_sumsq<float>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const float*)base, total, ctx->red);
     else
-      hipLaunchKernelGGL(k_sumsq<double>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const double*)A->d, total, ctx->red);
+      hipLaunchKernelGGL(k_sumsq<double>, dim3(nblk), dim3(kBlock), 0, ctx->stream, (const double*)base, total, ctx->red);
   }
   APX_HIP(hipGetLastError());
   std::vector<double> h(nblk);

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_ls_close(LsDev d, int B) 
 bool skinny_ls_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin == nullptr || p->sharded() || p->f_kind != APX_F_ZERO) return false;
-  if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
+  if (no_column_storage(p->A_lin) || p->ctx->skip_zero_cols) return false;
   const int64_t m = p->A_lin->m;
   return p->n <= kSkinnyMaxN && m > 0 && m <= 256 * 1024 && p->n * 4 <= m;
 }

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kSkinnyCloseBlock) void k_skinny_close(SkinnyDev d,
 bool skinny_pd_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin == nullptr || p->sharded() || p->f_kind != APX_F_ZERO) return false;
-  if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
+  if (no_column_storage(p->A_lin) || p->ctx->skip_zero_cols) return false;
   const int64_t m = p->A_lin->m;
   // a block per 256 rows; the closing block sums that many partials per column.  Below ~1000 rows (3000 for the
   // three-launch l2 form) small_pd.hip's redundant m side is cheaper (tools/small_bench.py: 506 x 14 12.2 vs 14.3 us)

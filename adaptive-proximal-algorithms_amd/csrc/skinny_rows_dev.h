@@ -136,7 +136,7 @@ inline bool skinny_rows_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin != nullptr || p->sharded()) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
-  if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
+  if (p->A_f == nullptr || no_column_storage(p->A_f) || p->ctx->skip_zero_cols) return false;
   const int64_t m = p->A_f->m;
   // below ~2000 rows small.hip's redundant scheme is as fast (logistic 2000 x 120: 14.8 us)
   // (no upper limit that matters: a block walks as many groups of 64 rows as it takes to leave 512 partial rows, and

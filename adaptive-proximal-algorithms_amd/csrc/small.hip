@@ -235,7 +235,7 @@ bool small_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin != nullptr || p->sharded()) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
-  if (p->A_f == nullptr || p->A_f->sparse) return false;
+  if (p->A_f == nullptr || no_column_storage(p->A_f)) return false;
   if (p->ctx->skip_zero_cols) return false;
   return small_shape_ok(p->A_f->m, p->n) && p->A_f->n > 0;
 }

@@ -256,7 +256,7 @@ bool small_bt_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin != nullptr || p->sharded()) return false;
   if (p->f_kind != APX_F_LEAST_SQUARES && p->f_kind != APX_F_LOGISTIC) return false;
-  if (p->A_f == nullptr || p->A_f->sparse || p->ctx->skip_zero_cols) return false;
+  if (p->A_f == nullptr || no_column_storage(p->A_f) || p->ctx->skip_zero_cols) return false;
   return p->n <= kSmallMax && p->A_f->m <= kSmallMax && p->A_f->m > 0 && p->A_f->n > 0;
 }
 

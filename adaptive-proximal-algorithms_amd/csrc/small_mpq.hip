@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kMpqBlockB) void k_mpq_b(MpqDev d) {
 bool small_mpq_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin == nullptr || p->sharded() || p->f_kind != APX_F_QUADRATIC) return false;
-  if (p->A_f == nullptr || p->A_f->sparse || p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
+  if (p->A_f == nullptr || no_column_storage(p->A_f) || no_column_storage(p->A_lin) || p->ctx->skip_zero_cols) return false;
   if (p->hd.kind == APX_G_L2) return false;           // (its conjugate prox needs a norm over all rows first)
   return p->n <= kMpqMaxN && p->n > 0 && p->A_lin->m > 0 && p->A_lin->m <= kMpqMaxM;
 }

@@ -295,8 +295,8 @@ bool small_pd_eligible(const apx_problem* p) {
   if (!p->ctx->fused_small) return false;
   if (p->A_lin == nullptr || p->sharded()) return false;
   if (p->f_kind != APX_F_ZERO && p->f_kind != APX_F_QUADRATIC) return false;
-  if (p->f_kind == APX_F_QUADRATIC && (p->A_f == nullptr || p->A_f->sparse)) return false;
-  if (p->A_lin->sparse || p->ctx->skip_zero_cols) return false;
+  if (p->f_kind == APX_F_QUADRATIC && (p->A_f == nullptr || no_column_storage(p->A_f))) return false;
+  if (no_column_storage(p->A_lin) || p->ctx->skip_zero_cols) return false;
   return small_shape_ok(p->A_lin->m, p->n);
 }
 

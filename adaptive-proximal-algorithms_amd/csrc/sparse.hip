@@ -10,6 +10,7 @@
 // are those of the dense kernels, so every fused epilogue (residual, logistic link, ...) is
 // shared: spmv_n writes one fp64 "split" into the partial buffer, spmv_t writes T.
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #include "apx_internal.h"
@@ -176,22 +177,39 @@ static int group_for(int64_t nnz, int64_t nrows) {
   return g;
 }
 
+// (apx_ctx_profile: the algorithmic bytes of a sparse product are its values and indices, nnz * (sizeof(T) + 4) — the gathered
+//  operand and the row pointers are excluded, SURVEY 8d's convention for the dense path carried over)
+static double spmv_bytes(const apx_matrix* A) { return (double)A->nnz * (double)(dtype_size(A->dtype) + 4); }
+static void spmv_name(apx_ctx* ctx, int kind, const apx_matrix* A, bool lng, int g_or_chunks) {
+  if (!ctx->profile) return;
+  char b[128];
+  if (lng) snprintf(b, sizeof b, "spmv_long<%s, %d chunk(s) of %d entries per row>", A->dtype == APX_F32 ? "float" : "double", g_or_chunks, kLongChunk);
+  else snprintf(b, sizeof b, "spmv_rows<%s, %d lane(s) per row>", A->dtype == APX_F32 ? "float" : "double", g_or_chunks);
+  ctx->kname[kind] = b;
+}
+
 int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
   int chunks = 1;
   if (long_rows(A->nnz, A->m, A->ld, A->r_maxlen, &chunks)) {      // every chunk is one fp64 split of A x
     APX_TRY(ensure_part(ctx, (size_t)chunks * A->ld * sizeof(double)));
+    spmv_name(ctx, APX_KSTAT_GEMV_N, A, true, chunks);
+    APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, spmv_bytes(A)));
     if (A->dtype == APX_F32) launch_long<float>(ctx, chunks, A->rptr, A->rind, A->rval, x, A->m, A->ld, done);
     else launch_long<double>(ctx, chunks, A->rptr, A->rind, A->rval, x, A->m, A->ld, done);
+    APX_TRY(prof_end(ctx));
     APX_HIP(hipGetLastError());
     *splits_out = chunks;
     return APX_OK;
   }
   APX_TRY(ensure_part(ctx, (size_t)A->ld * sizeof(double)));
   const int G = group_for(A->nnz, A->m);
+  spmv_name(ctx, APX_KSTAT_GEMV_N, A, false, G);
+  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, spmv_bytes(A)));
   if (A->dtype == APX_F32)
     launch_rows<float, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done);
   else
     launch_rows<double, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done);
+  APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
   *splits_out = 1;
   return APX_OK;
@@ -201,16 +219,22 @@ int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* ou
   int chunks = 1;
   if (long_rows(A->nnz, A->n, A->n_pad, A->t_maxlen, &chunks)) {
     APX_TRY(ensure_part(ctx, (size_t)chunks * A->n_pad * sizeof(double)));
+    spmv_name(ctx, APX_KSTAT_GEMV_T, A, true, chunks);
+    APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, spmv_bytes(A)));
     if (A->dtype == APX_F32) launch_long<float>(ctx, chunks, A->tptr, A->tind, A->tval, r, A->n, A->n_pad, done);
     else launch_long<double>(ctx, chunks, A->tptr, A->tind, A->tval, r, A->n, A->n_pad, done);
+    APX_TRY(prof_end(ctx));
     APX_HIP(hipGetLastError());
     return launch_sum_partials_rows(ctx, A->dtype, chunks, A->n_pad, A->n_pad, out, done);
   }
   const int G = group_for(A->nnz, A->n);
+  spmv_name(ctx, APX_KSTAT_GEMV_T, A, false, G);
+  APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, spmv_bytes(A)));
   if (A->dtype == APX_F32)
     launch_rows<float, float>(ctx, G, A->tptr, A->tind, A->tval, r, (float*)out, A->n, A->n_pad, done);
   else
     launch_rows<double, double>(ctx, G, A->tptr, A->tind, A->tval, r, (double*)out, A->n, A->n_pad, done);
+  APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
   return APX_OK;
 }

@@ -33,6 +33,7 @@ class DeviceLasso:
     optimum: float
     Lf: float
     dual_layout: bool = False      # a transposed copy of A is resident too
+    layout: str = "cols"           # DeviceMatrix.layout of A: "cols", "dual" or "rows" (one resident copy, row-contiguous)
 
 
 def _ident(v):
@@ -43,8 +44,9 @@ def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, la
                  rank: int = 0, world: int = 1, power_iters: int = 50, ctx: Optional[Context] = None,
                  allreduce_host: Optional[Callable[[np.ndarray], np.ndarray]] = None,
                  dual_layout: bool = False, m_total: Optional[int] = None,
-                 row_offset: Optional[int] = None) -> DeviceLasso:
+                 row_offset: Optional[int] = None, layout: str = "cols") -> DeviceLasso:
     """``dual_layout``: keep the transposed copy of A too (DeviceMatrix.build_transpose).
+    ``layout="rows"``: A lives in the row-contiguous storage ALONE from the start (one resident copy ; ``dual_layout`` is moot).
     ``m_total`` / ``row_offset``: an uneven row split (default: ``world`` equal shards of ``m_local`` rows)."""
     ar = allreduce_host or _ident
     m_total = m_local * world if m_total is None else m_total
@@ -55,7 +57,7 @@ def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, la
     y_loc = y_loc / y_norm
     # :49  C = rand(m, n) .* 2 .- 1   (on device)
     A = DeviceMatrix.uniform(m_local, n, seed=seed, lo=-1.0, hi=1.0, dtype=np.float64, row_offset=r0,
-                             m_total=m_total, ctx=ctx)
+                             m_total=m_total, ctx=ctx, layout=layout)
     # :51  CTy = abs.(C' * y_star)    (HIP GEMV-T, partial sums all-reduced over the row shards)
     cty_signed = ar(A.rmatvec(y_loc))
     cty = np.abs(cty_signed)
@@ -72,7 +74,7 @@ def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, la
     alpha[perm] = a_sorted
     A.scale_columns(alpha)                                      # :68  A = C * diagm(alpha)
     have_dual = False
-    if dual_layout:                                             # A is final from here on
+    if dual_layout and layout != "rows":                        # A is final from here on
         try:
             A.build_transpose()
             have_dual = True
@@ -93,7 +95,7 @@ def device_lasso(m_local: int, n: int, *, pfactor: float = 10, seed: int = 0, la
         w = ar(A.rmatvec(A.matvec(v)))
         Lf = math.sqrt(float(np.dot(w, w)))
         v = w / Lf
-    return DeviceLasso(A, b, x_star, lam, optimum, Lf, have_dual)
+    return DeviceLasso(A, b, x_star, lam, optimum, Lf, have_dual, A.layout)
 
 
 @dataclass

@@ -55,8 +55,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exploit-sparsity", action="store_true",
                     help="NOT the BASELINE metric: let A*x skip the columns with x_j == 0 (flagged in the JSON line)")
-    ap.add_argument("--single-layout", action="store_true",
-                    help="do not keep the transposed copy of A (40 GB instead of 80 GB; A*x ~5 %% slower)")
+    ap.add_argument("--layout", choices=("rows", "dual", "cols"), default="rows",
+                    help="storage of A: rows = ONE resident copy, row-contiguous (40 GB ; default) ; dual = column-major + the row copy "
+                         "(2 x 40 GB: rounds 1-4) ; cols = column-major only (the two GEMV passes)")
+    ap.add_argument("--single-layout", action="store_true", help="= --layout cols (kept for older command lines)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --rows is the GLOBAL row count, split over the ranks (default: weak, rows per GPU)")
     # CPU baseline sample: 10 000 x 100 000 fp64 (8 GB) when the host has >= 32 GB of RAM, else 4000 rows
@@ -311,7 +313,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     # C3: sparse_logreg, dense synthetic X 100 000 x 10 000 fp32, logistic gradient + NormL1 prox
     m, n = 100_000, 10_000
     p = problems.device_logreg(m, n, seed=0, lam=0.01, dtype=np.float32, ctx=ctx)
-    p.X.build_transpose()
+    p.X.drop_primary()                                          # one resident copy: the row storage the one-pass kernels read
     s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(p.X, p.y), g=apx.NormL1(p.lam),
                    rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
     # (150 timed iterations after 10: this problem — SURVEY 8d's lambda, step size and generator — is solved to sixteen digits
@@ -333,7 +335,7 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     # C5: least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50 000 x 20 000 fp64
     m, n = 50_000, 20_000
     p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx)
-    p.A.build_transpose()
+    p.A.drop_primary()
     gamma = 1.0 / (0.0 / 2 + p.norm_A / 1.0)                    # condat_vu with Lf = 0 (src/AdaProx.jl:405-411)
     sigma = 0.99 / (p.norm_A * 1.0)
     s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y),
@@ -383,11 +385,55 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     except (Exception, SystemExit) as e:           # noqa: BLE001
         out["C5_matrix_extra_error"] = f"{type(e).__name__}: {e}"
     p.A.free()
+    try:
+        out["sparse_logreg_1Mx100k"] = sparse_leg(apx, ctx, barrier)
+    except (Exception, SystemExit) as e:           # noqa: BLE001
+        out["sparse_logreg_1Mx100k"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def sparse_leg(apx, ctx, barrier, m: int = 1_000_000, n: int = 100_000, per_row: int = 60, steps: int = 100) -> dict:
+    """The orientation the reference's real datasets use (experiments/sparse_logreg/runme.jl:24,31: `f.X * w`, `f.X' * r` on a
+    SparseMatrixCSC, Float64): l1-logistic regression on a SPARSE X, here 1 000 000 x 100 000 with ~60 entries per row (60 M stored
+    entries: 720 MB of values + indices per orientation — beyond the Infinity Cache, so both products stream from HBM and gather
+    their operand through L2).  Not a BASELINE config.  Algorithmic bytes per product: nnz * (sizeof(T) + 4)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    nnz_row = np.clip(rng.poisson(per_row, m), 1, n)
+    indptr = np.concatenate([[0], np.cumsum(nnz_row)]).astype(np.int64)
+    X = sp.csr_matrix((rng.uniform(-1, 1, indptr[-1]), rng.integers(0, n, indptr[-1]).astype(np.int32), indptr), shape=(m, n))
+    X.sum_duplicates()
+    w = np.random.default_rng(3).standard_normal(n)
+    y = (1.0 / (1.0 + np.exp(-(X @ w))) > np.random.default_rng(4).uniform(size=m)).astype(np.float64)
+    gam = 4.0 * m / (float(X.multiply(X).sum()) + m)
+    dX = apx.DeviceMatrix.from_sparse(X, ctx)
+    nnz = int(X.nnz)
+    del X
+    s = apx.Solver(np.zeros(n + 1), f=apx.LogisticLoss(dX, y, ctx=ctx), g=apx.NormL1(1e-4), rule=apx.OurRule(gamma=gam), tol=0.0, ctx=ctx,
+                   poll_every=1 << 30)
+    dt, st = timed_steps(ctx, s, steps, 10, barrier)
+    x, _, res = s.result()
+    ok = bool(np.all(np.isfinite(x))) and int(res.numit) == steps + 10 and not res.converged and bool(np.any(x != 0.0))
+    k = kernel_table(st)
+    dom = max(k, key=lambda q: k[q]["avg_ms"] * k[q]["launches"])
+    names = {q: ctx.kernel_name(q) for q in k}
+    s.close()
+    dX.free()
+    per_pass = float(nnz) * 12.0
+    return {"workload": f"sparse_logreg on a sparse X {m}x{n}, {nnz} stored entries, fp64 values + int32 indices, adaptive_proxgrad (OurRule)",
+            "iters_per_s": steps / dt, "ms_per_iter": dt / steps * 1e3, "steps": steps, "kernels": k, "kernel_names": names,
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": k[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": k[dom]["GBps"] / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_pass,
+                         "iteration_frac": 2.0 * per_pass * steps / dt / 1e9 / HBM_PEAK_GBS,
+                         "note": "values + indices per product ; the gathered operand (0.8 MB for X w, 8 MB for X' r) and the row "
+                                 "pointers are excluded.  The ceiling of this access pattern is not the HBM peak: profiles/r05_gather_probe.log"},
+            "objective": res.objective, "timed_steps_all_real": ok}
 
 
 def main():
     args = parse()
+    if args.single_layout:
+        args.layout = "cols"
     maybe_relaunch(args, sys.argv[1:])               # (--gpus N > 1 outside a launcher: this process starts the ranks and exits)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -490,7 +536,7 @@ def main():
         t_setup = time.perf_counter()
         prob = problems.device_lasso(args.m, args.n, pfactor=10, seed=args.seed, rank=rank, world=world,
                                      power_iters=30, ctx=ctx, allreduce_host=ar_host,
-                                     dual_layout=not args.single_layout,   # dual: both passes stream contiguously (80 of 288 GB)
+                                     dual_layout=args.layout == "dual", layout="rows" if args.layout == "rows" else "cols",
                                      m_total=m_global, row_offset=row0)
         t_setup = time.perf_counter() - t_setup
 
@@ -576,6 +622,7 @@ def main():
         if int(res.numit) != args.warmup + args.steps or res.converged:
             sys.exit("bench.py: the loop stopped after %d iterations: the timed steps were not all real" % int(res.numit))
         dual_layout = prob.dual_layout
+        layout = prob.layout
         kernel_names = {k: ctx.kernel_name(k) for k in ("gemv_n", "gemv_t", "one_pass")}
         final_objective, optimum = res.objective, prob.optimum
         if world == 1 and not use_dist and not args.no_other_configs and (args.m, args.n) == (50_000, 100_000):
@@ -618,7 +665,7 @@ def main():
             try:
                 # with the dual layout both passes run the column-streaming kernel (the "gemv_t" entry)
                 tj = json.load(open(tpath))
-                tkey = "k_team_rows" if one_pass else ("gemv_t" if dual_layout else dom)      # (keys of profiles/pmc_traffic.json)
+                tkey = "k_team_rows" if one_pass else ("gemv_t" if dual_layout or layout == "rows" else dom)      # (keys of profiles/pmc_traffic.json)
                 traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
                 traffic_source = tj.get("source", "profiles/pmc_traffic.json") + f" [{tkey}]"
             except Exception:
@@ -632,7 +679,10 @@ def main():
                                    f"{world} MI355X (GEMV + soft-threshold + stepsize reductions)"
                                    + ("" if world == 1 else f"; row-sharded {m_global}x{args.n}, RCCL all-reduce of A'r"),
                        "rows_per_gpu": args.m, "cols": args.n, "rule": "OurRule(gamma=1/Lf)",
-                       "layout": ("single: A column-major, 40 GB" if not dual_layout else
+                       "layout": (("single, %.0f GB: A resident ONCE, in the row-contiguous storage the one-pass kernels read"
+                                   % (algo_bytes / 1e9)
+                                   + ("" if one_pass else " ; two GEMV passes per iteration, both served from it")) if layout == "rows" else
+                                  "single: A column-major, 40 GB" if not dual_layout else
                                   "dual: A and its transposed copy resident (2 x 40 GB of the 288 GB)"
                                   + (", the iteration reads the transposed copy ONCE (40 GB)" if one_pass
                                      else ", each pass still reads 40 GB")),

