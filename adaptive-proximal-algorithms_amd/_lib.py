@@ -124,6 +124,7 @@ PROTOTYPES = {
                                                  c_int64, _P(SolveOpts), c_void_p, _P(c_void_p), _P(Result)]),
     "apx_gemv_variant_count": (c_int32, [c_int32]),
     "apx_gemv_variant_name": (C.c_char_p, [c_int32, c_int32]),
+    "apx_ctx_device_clock": (c_int32, [c_void_p, _P(c_int64), _P(c_int64), _P(c_int64)]),
     "apx_matrix_create": (c_int32, [c_void_p, c_int64, c_int64, c_int32, _P(c_void_p)]),
     "apx_matrix_upload": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, _P(c_void_p)]),
     "apx_matrix_create_layout": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, _P(c_void_p)]),

@@ -87,6 +87,12 @@ class Context:
             out[name] = dict(launches=int(arr[k].launches), total_ms=float(arr[k].total_ms), bytes=float(arr[k].bytes))
         return out
 
+    def device_clock(self) -> tuple:
+        """apx_ctx_device_clock: (device wall clock ns, host CLOCK_REALTIME ns, uncertainty ns) for one instant."""
+        d, h, u = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self._lib.apx_ctx_device_clock(self._h, C.byref(d), C.byref(h), C.byref(u)))
+        return int(d.value), int(h.value), int(u.value)
+
     def kernel_name(self, slot: str) -> str:
         """The kernels last booked under a timing slot ("gemv_n", "gemv_t", "one_pass"), as the library launched them."""
         k = {"gemv_n": L.APX_KSTAT_GEMV_N, "gemv_t": L.APX_KSTAT_GEMV_T, "one_pass": L.APX_KSTAT_ONE_PASS}[slot]

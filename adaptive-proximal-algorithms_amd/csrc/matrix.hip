@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "apx_internal.h"
 #include "gemv_kernels.h"
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(kBlock) void k_transpose(const T* __restrict__ A, i
   }
 }
 
+__global__ void k_device_clock(unsigned long long* out) { *out = (unsigned long long)wall_clock64(); }
+
 // the same over a plain array of `count` elements (sparse value arrays)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_sumsq_elems(const T* __restrict__ v, int64_t count, double* __restrict__ red) {
@@ -300,6 +303,30 @@ int32_t apx_ctx_kernel_stats(apx_ctx* ctx, apx_kernel_stat* stats, int32_t reset
   ctx->ev_pending.clear();
   if (stats != nullptr) memcpy(stats, ctx->stats, sizeof(ctx->stats));
   if (reset) memset(ctx->stats, 0, sizeof(ctx->stats));
+  return APX_OK;
+}
+
+int32_t apx_ctx_device_clock(apx_ctx* ctx, int64_t* device_ns, int64_t* host_realtime_ns, int64_t* uncertainty_ns) {
+  APX_REQUIRE(ctx != nullptr && device_ns != nullptr && host_realtime_ns != nullptr, "apx_ctx_device_clock: NULL argument");
+  APX_HIP(hipSetDevice(ctx->device));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  auto now = []() -> int64_t {
+    timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+  };
+  // (the pinned scalars' slot 58: a spin-free hand-shake would need a mapped flag ; the launch + synchronise round trip is ~10 us)
+  const int64_t t0 = now();
+  hipLaunchKernelGGL(k_device_clock, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long*)(ctx->scal + 15));
+  APX_HIP(hipGetLastError());
+  APX_HIP(hipMemcpyAsync(&ctx->h_scal[58], ctx->scal + 15, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  APX_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t t1 = now();
+  unsigned long long ticks;
+  memcpy(&ticks, &ctx->h_scal[58], sizeof ticks);
+  *device_ns = (int64_t)(ticks * 10ull);                     // s_memrealtime: 100 MHz
+  *host_realtime_ns = t0 + (t1 - t0) / 2;
+  if (uncertainty_ns != nullptr) *uncertainty_ns = (t1 - t0) / 2;
   return APX_OK;
 }
 

@@ -39,7 +39,7 @@ extern "C" {
                                   longer switches the one-pass kernels ; no environment variables are read any more
                                4: apx_problem_team_wait_slots (additive: everything of version 3 is unchanged)
                                5: one resident copy of A — APX_LAYOUT_ROWS, apx_matrix_create_layout / upload_layout,
-                                  apx_matrix_drop_primary, apx_matrix_layout ; APX_OPT_FAULT_SETUP (additive) */
+                                  apx_matrix_drop_primary, apx_matrix_layout ; APX_OPT_FAULT_SETUP ; apx_ctx_device_clock (additive) */
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -457,6 +457,11 @@ typedef struct apx_team_wait_slot {
   int32_t _pad;
 } apx_team_wait_slot;
 int32_t apx_problem_team_wait_slots(apx_problem* p, apx_team_wait_slot* out, int32_t cap, int32_t* count);
+/* The device's wall clock (s_memrealtime, in ns — what apx_team_wait_slot.at_clock_ns is counted in) and the host's
+ * CLOCK_REALTIME (ns since the epoch) for the same instant, to within the latency of a one-thread kernel and a stream
+ * synchronisation (the host time is the midpoint of the two host readings around the device's ; *uncertainty_ns half their
+ * distance): lines the moments a team kernel recorded up against what the host did (tools/pause_probe.py).  ABI 5. */
+int32_t apx_ctx_device_clock(apx_ctx* ctx, int64_t* device_ns, int64_t* host_realtime_ns, int64_t* uncertainty_ns);
 /* `y, g_y = prox(g, v, gamma)` (ProximalCore.prox); conj != 0 applies convex_conjugate(desc) */
 int32_t apx_prox(apx_ctx* ctx, const apx_prox_desc* desc, int32_t conj, int32_t dtype,
                  const void* v, int64_t n, double gamma, void* y, double* g_y);

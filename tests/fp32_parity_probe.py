@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))      # (lives in tests/: only tests may import oracle/)
 import adaprox_amd as apx  # noqa: E402
 from oracle import adaprox_oracle as O  # noqa: E402
 

@@ -177,16 +177,20 @@ def test_logreg_c3_solver_at_full_size(apx):
     rows = [0, 1, 767, 768, m // 2, m - 2, m - 1]
     ref = _cpu_rows(seed, rows, m, n, np.float32) @ w[:-1].astype(np.float64)
     assert np.max(np.abs(Xw[rows] - ref)) <= 3e-5 * max(np.max(np.abs(ref)), 1.0)
-    logits = Xw + float(w[-1])                                                      # :24
-    u = 1.0 + np.exp(-logits)                                                       # :25
-    y64 = p.y.astype(np.float64)
-    f_ref = -np.mean((y64 - 1.0) * logits - np.log(u))                              # :36
-    assert fx == pytest.approx(f_ref, rel=2e-5)
-    r = 1.0 / u - y64                                                               # :28-30
+    # the link as the kernels evaluate it for Float32 data (csrc/team_rows.h team_row_finish, csrc/slab.hip): `X w` stored Float32,
+    # the logit and the link in Float32, the loss and the gradient summed in Float64 — what oracle LogisticLoss(emulate=float32) does
+    f32 = np.float32
+    lf = (Xw.astype(f32).astype(np.float64) + float(w[-1])).astype(f32)             # :24
+    ef = f32(1) + np.exp(-lf)                                                       # :25
+    f_ref = -np.sum(((p.y - f32(1)) * lf - np.log(ef)).astype(np.float64)) / m      # :36
+    r = (f32(1) / ef - p.y).astype(np.float64)                                      # :28-30
     cols = [0, 1, 767, 768, 769, n // 2, n - 2, n - 1]
     g_ref = _cpu_cols(seed, cols, m, m, np.float32).T @ r / m                       # :31
-    assert np.max(np.abs(grad[cols] - g_ref)) <= 2e-4 * np.max(np.abs(grad[:-1]))
-    assert grad[-1] == pytest.approx(np.mean(r), rel=2e-4, abs=1e-7)                # :32 bias = last coordinate
+    print("C3 op level: f rel %.2e, grad rel-to-max %.2e, bias grad rel %.2e" % (abs(fx - f_ref) / abs(f_ref),
+          np.max(np.abs(grad[cols] - g_ref)) / np.max(np.abs(grad[:-1])), abs(grad[-1] - np.mean(r)) / abs(np.mean(r))))
+    assert fx == pytest.approx(f_ref, rel=2e-6)
+    assert np.max(np.abs(grad[cols] - g_ref)) <= 2e-6 * np.max(np.abs(grad[:-1]))
+    assert grad[-1] == pytest.approx(np.mean(r), rel=2e-5, abs=1e-7)                # :32 bias = last coordinate
     # the solver on this path
     kw = dict(g=apx.NormL1(p.lam), rule=apx.OurRule(gamma=p.gamma0), tol=0.0, maxit=12)
     runs = []
@@ -204,7 +208,8 @@ def test_logreg_c3_solver_at_full_size(apx):
     # (same device matrix; a problem created on ctx2 needs a matrix of ctx2: regenerate — counter-based, identical bits)
     X2 = apx.DeviceMatrix.uniform(m, n, seed=seed, lo=-1.0, hi=1.0, dtype=np.float32, ctx=ctx2)
     x2, _ = apx.adaptive_proxgrad(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(X2, p.y, ctx=ctx2), ctx=ctx2, **kw)
-    assert np.max(np.abs(x2 - runs[0][0])) <= 2e-3 * max(np.max(np.abs(x2)), 1e-30)
+    print("C3 solver: one pass against two passes after 12 iterations, rel %.2e" % (np.max(np.abs(x2 - runs[0][0])) / max(np.max(np.abs(x2)), 1e-30)))
+    assert np.max(np.abs(x2 - runs[0][0])) <= 2e-5 * max(np.max(np.abs(x2)), 1e-30)
     X2.free()
     p.X.free()
 

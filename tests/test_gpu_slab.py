@@ -154,8 +154,15 @@ def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
     K = 12
     x0 = (0.01 * rng.standard_normal(nx)).astype(dtype)
     ro = []
-    xo, _ = O.adaptive_proxgrad(x0.astype(np.float64), f=mko(), g=O.NormL1(lam), rule=O.OurRule(gamma=gam), tol=0.0, maxit=K,
-                                record=ro.append)
+    # Float32 data: the oracle in its Float32-STORAGE mode (vectors rounded to Float32 where the product stores them, the logistic
+    # link in Float32, sums in Float64 — oracle storage_rounding / emulate ): the arithmetic the kernels implement,
+    # so the comparison is as tight as the Float64 one up to Float32's own epsilon (measured over these cases, 12 iterations:
+    # iterates <= 1.2e-7, step sizes <= 1.3e-7 — tests/fp32_parity_probe.py, profiles/r05_fp32_parity.jsonl)
+    emu = np.float32 if dtype == np.float32 else None
+    fo = mko()
+    fo.emulate = emu
+    xo, _ = O.adaptive_proxgrad(x0.astype(np.float64), f=fo, g=O.NormL1(lam), rule=O.OurRule(gamma=gam), tol=0.0, maxit=K,
+                                record=ro.append, storage=emu)
     out = []
     for one_pass in (True, False):
         ctx = apx.Context(0)
@@ -170,11 +177,13 @@ def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
         out.append((x, recs))
         dA.free()
     (x1, r1), (x2, r2) = out
-    tol = 1e-10 if dtype == np.float64 else 2e-3
-    assert _rel(x1, xo) <= tol and _rel(x1, x2) <= tol
+    f64 = dtype == np.float64
+    assert _rel(x1, xo) <= (1e-10 if f64 else 1e-6)
+    assert _rel(x1, x2) <= (1e-10 if f64 else 5e-6)                # (the two GEMV passes round their Float32 partial sums elsewhere)
     for a, b_, c in zip(r1, ro, r2):
-        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10 if dtype == np.float64 else 1e-4)
-        assert a["gamma"] == pytest.approx(c["gamma"], rel=1e-7 if dtype == np.float64 else 5e-2)
+        assert a["objective"] == pytest.approx(b_["objective"], rel=1e-10 if f64 else 2e-6)
+        assert a["gamma"] == pytest.approx(b_["gamma"], rel=1e-7 if f64 else 1e-6)
+        assert a["gamma"] == pytest.approx(c["gamma"], rel=1e-7 if f64 else 1e-5)
 
 
 def test_one_pass_builds_its_transposed_copy_and_survives_losing_it(apx):

@@ -239,13 +239,19 @@ def test_sparse_logreg_iterates(apx, dtype, xtol, gtol):
     K = 30      # the problem reaches 1e-8 residual in ~35 iterations; past that gamma is rounding noise
     X64, y64 = prob.X.astype(np.float64), prob.y.astype(np.float64)
     orecs, drecs = [], []
-    xo, _ = O.adaptive_proxgrad(np.zeros(n + 1), f=O.LogisticLoss(X64, y64), g=O.NormL1(prob.lam),
-                                rule=O.OurRule(gamma=prob.gamma0), tol=0.0, maxit=K, record=orecs.append)
+    # (Float32: the oracle in its Float32-storage mode — the arithmetic the kernels implement, oracle storage_rounding)
+    emu = np.float32 if dtype == np.float32 else None
+    xo, _ = O.adaptive_proxgrad(np.zeros(n + 1), f=O.LogisticLoss(X64, y64, emulate=emu), g=O.NormL1(prob.lam),
+                                rule=O.OurRule(gamma=prob.gamma0), tol=0.0, maxit=K, record=orecs.append, storage=emu)
     x, _ = apx.adaptive_proxgrad(np.zeros(n + 1, dtype=dtype), f=apx.LogisticLoss(prob.X, prob.y),
                                  g=apx.NormL1(prob.lam), rule=apx.OurRule(gamma=prob.gamma0), tol=0.0, maxit=K,
                                  record=drecs.append)
     assert x.dtype == dtype
+    gerr = [abs(rd["gamma"] - ro["gamma"]) / ro["gamma"] for ro, rd in zip(orecs, drecs)]
+    print("sparse_logreg %s: x error %.2e after %d iterations, gamma error first 10 / 20 iterations %.2e / %.2e"
+          % (np.dtype(dtype).name, _rel_inf(x, xo), K, max(gerr[:10]), max(gerr[:20])))
     assert _rel_inf(x, xo) <= xtol
+    assert max(gerr[:10]) <= (1e-8 if dtype == np.float64 else 1e-4)          # (the first ten step sizes to 1e-4)
     for ro, rd in zip(orecs[:20], drecs[:20]):
         assert rd["gamma"] == pytest.approx(ro["gamma"], rel=gtol)
     assert drecs[-1]["objective"] == pytest.approx(orecs[-1]["objective"], rel=max(xtol, 1e-9))
