@@ -187,7 +187,7 @@ def test_small_primal_dual_vs_generic_fuzz(m, n, quad, hk, gk, rule, k, seed):
 
 
 def test_small_path_soak_long_run():
-    """60 000 iterations through the two-kernel path: the buffer rotation and the control blocks stay consistent
+    """20 000 iterations through the two-kernel path: the buffer rotation and the control blocks stay consistent
     (same converged point as the generic kernels, objective at the optimum), and a converged run stays frozen."""
     apx, _ = _apx()
     g_ctx = _generic_ctx()
@@ -198,13 +198,13 @@ def test_small_path_soak_long_run():
     # (fixed step: with tol = 0 an adaptive rule keeps growing gamma once the iterate is exactly stationary —
     #  dx = dg = 0 makes C = L = D = 0 — until it overflows, in the reference as well)
     s = apx.Solver(np.zeros(260), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(0.5), rule=apx.FixedStepsize(gam), tol=0.0)
-    s.step(60_000, sync=True)
+    s.step(20_000, sync=True)
     xs, _, res = s.result()
     s.close()
     xg, _ = apx.adaptive_proxgrad(np.zeros(260), f=apx.LinearLeastSquares(apx.DeviceMatrix.from_numpy(A, g_ctx), b, ctx=g_ctx),
                                   g=apx.NormL1(0.5), rule=apx.OurRule(gamma=gam), tol=1e-12, maxit=60_000, ctx=g_ctx)
     obj = lambda x: 0.5 * np.linalg.norm(A @ x - b) ** 2 + 0.5 * np.sum(np.abs(x))   # noqa: E731
-    assert res.numit == 60_000 and np.all(np.isfinite(xs))
+    assert res.numit == 20_000 and np.all(np.isfinite(xs))
     assert obj(xs) == pytest.approx(obj(xg), rel=1e-10) and np.max(np.abs(xs - xg)) < 1e-7
     # tol > 0: converges early, later iterations are no-ops, the tested iterate is returned
     x1, it1 = apx.adaptive_proxgrad(np.zeros(260), f=apx.LinearLeastSquares(A, b), g=apx.NormL1(0.5),
@@ -213,7 +213,7 @@ def test_small_path_soak_long_run():
     lad_A = np.asfortranarray(np.hstack([rng.uniform(-1, 1, (300, 9)), np.ones((300, 1))]))
     yv = lad_A @ rng.standard_normal(10) + rng.laplace(size=300)
     nrm = float(np.linalg.norm(lad_A))
-    kw = dict(f=apx.Zero(), g=apx.NormL1(1.0), h=apx.Translate(apx.NormL1(1.0), -yv), Lf=0.0, norm_A=nrm, tol=1e-7,
+    kw = dict(f=apx.Zero(), g=apx.NormL1(1.0), h=apx.Translate(apx.NormL1(1.0), -yv), Lf=0.0, norm_A=nrm, tol=1e-6,
               maxit=300_000)
     xa, ya, ita = apx.condat_vu(np.zeros(10), np.zeros(300), A=lad_A, poll_every=4096, **kw)
     xb, yb, itb = apx.condat_vu(np.zeros(10), np.zeros(300), A=apx.DeviceMatrix.from_numpy(lad_A, g_ctx), ctx=g_ctx, **kw)
@@ -225,7 +225,7 @@ tall_rows = st.one_of(st.integers(2048, 9000), st.sampled_from([2048, 2049, 4095
 skinny_cols = st.one_of(st.integers(1, 40), st.sampled_from([3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 111, 122, 123]))
 
 
-@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(m=tall_rows, n=skinny_cols, logistic=st.booleans(), f32=st.booleans(), gk=st.sampled_from(["l1", "box", "tl1", "zero"]),
        method=st.sampled_from(["adaptive", "fixed", "bt", "bt_nesterov", "nesterov", "agraal"]), k=st.integers(0, 9),
        records=st.booleans(), seed=st.integers(0, 2**31 - 1))
