@@ -108,6 +108,7 @@ struct apx_ctx {
   bool team_cooperative = false; // APX_OPT_TEAM_COOPERATIVE
   int team_fault_grid = 0;       // APX_OPT_TEAM_FAULT_GRID (test hook)
   int fault_setup = 0;           // APX_OPT_FAULT_SETUP (test hook)
+  int sparse_windows = 1;        // APX_OPT_SPARSE_WINDOWS: a sparse matrix uploaded on this context gets its L2 window tables
   int team_interleave = 1;       // APX_OPT_TEAM_INTERLEAVE
   int team_pd_defer = 1;         // APX_OPT_TEAM_PD_DEFER
   bool fused_tail = true;        // APX_OPT_FUSED_TAIL
@@ -151,6 +152,13 @@ struct apx_matrix {
   // a small sparse matrix also keeps a dense copy, built on first use (apx::small_dense_view): the small-size
   // execution policy (apx_ctx_fused_small) runs on dense storage
   int64_t r_maxlen = 0, t_maxlen = 0;   // longest row of A / of A' (entries)
+  // L2 windows of the gathered operand (round 5, sparse.hip): a product whose operand is larger than an XCD's L2 keeps next to
+  // the streams (X' r with a million rows: 8 MB) is run window by window of the operand — the entries of a compressed row are
+  // sorted by index, so a row splits into W contiguous runs.  rwin / twin: (W + 1) pointer slabs of nrows_pad entries each
+  // (slab 0 = the row starts, slab W = the row ends) ; nullptr where the operand is small or the indices were not sorted.
+  int64_t* rwin = nullptr;     // rows of A, windows over the n columns (operand x)
+  int64_t* twin = nullptr;     // rows of A', windows over the m rows (operand r)
+  int32_t rwin_count = 0, twin_count = 0;
   mutable apx_matrix* dense_view = nullptr;
 };
 

@@ -389,6 +389,10 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       APX_REQUIRE(value >= 0 && value <= 512, "APX_OPT_TEAM_FAULT_GRID: 0 (off) ... 256 workgroups (257 ... 512: with APX_OPT_TEAM_COOPERATIVE only)");
       ctx->team_fault_grid = (int)value;
       return APX_OK;
+    case APX_OPT_SPARSE_WINDOWS:
+      APX_REQUIRE(value == 0 || value == 1, "APX_OPT_SPARSE_WINDOWS: 0 or 1");
+      ctx->sparse_windows = (int)value;
+      return APX_OK;
     case APX_OPT_FAULT_SETUP:
       APX_REQUIRE(value >= 0 && value <= 1, "APX_OPT_FAULT_SETUP: 0 or 1");
       ctx->fault_setup = (int)value;
@@ -439,6 +443,7 @@ int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
     case APX_OPT_TEAM_COOPERATIVE: *value = ctx->team_cooperative ? 1 : 0; return APX_OK;
     case APX_OPT_TEAM_FAULT_GRID: *value = ctx->team_fault_grid; return APX_OK;
     case APX_OPT_FAULT_SETUP: *value = ctx->fault_setup; return APX_OK;
+    case APX_OPT_SPARSE_WINDOWS: *value = ctx->sparse_windows; return APX_OK;
     case APX_OPT_GEMV_N_VARIANT: *value = ctx->cfg.n_variant; return APX_OK;
     case APX_OPT_GEMV_T_VARIANT: *value = ctx->cfg.t_variant; return APX_OK;
     case APX_OPT_GEMV_N_BLOCKS: *value = ctx->cfg.n_target_blocks; return APX_OK;
@@ -613,7 +618,7 @@ int32_t apx_matrix_free(apx_matrix* A) {
     if (A->dense_view) apx_matrix_free(A->dense_view);
     if (A->d) (void)hipFree(A->d);
     if (A->dT) (void)hipFree(A->dT);
-    for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval})
+    for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval, (void*)A->rwin, (void*)A->twin})
       if (q) (void)hipFree(q);
     apx_ctx* ctx = A->ctx;
     delete A;

@@ -10,6 +10,7 @@
 // are those of the dense kernels, so every fused epilogue (residual, logistic link, ...) is
 // shared: spmv_n writes one fp64 "split" into the partial buffer, spmv_t writes T.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -32,13 +33,16 @@ namespace apx {
 // 1.1 - 1.7 TB/s of value + index bytes whatever the loads in flight — every random 8-byte gather moves a
 // whole cache line from L2, which is what bounds it; an operand that fits LDS / a row-blocked layout is the
 // next step for that regime, not this kernel's schedule.
-template <typename T, typename OUT, int G>
-__global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ ptr, const int32_t* __restrict__ ind,
+// (p0 / p1: where a row's entries begin and end — the row pointers `ptr` and `ptr + 1`, or two consecutive slabs of a window
+//  table: the entries of the row whose index falls into one L2 window of the operand, see launch_windows)
+template <typename T, typename OUT, int G, int U = 2>
+__global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ p0, const int64_t* __restrict__ p1,
+                                                    const int32_t* __restrict__ ind,
                                                     const T* __restrict__ val, const T* __restrict__ x,
                                                     OUT* __restrict__ out, int64_t nrows, int64_t nrows_pad,
                                                     const int* __restrict__ done) {
   if (done != nullptr && *done != 0) return;
-  constexpr int R = 4, U = 2;
+  constexpr int R = 4;
   const int lane = threadIdx.x % G;
   const int64_t groups = (int64_t)gridDim.x * (kBlock / G);
   for (int64_t base = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; base < nrows_pad; base += R * groups) {
@@ -47,8 +51,8 @@ __global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ 
     for (int r = 0; r < R; ++r) {
       const int64_t row = base + r * groups;
       const bool ok = row < nrows;
-      k0[r] = ok ? ptr[row] : 0;
-      k1[r] = ok ? ptr[row + 1] : 0;
+      k0[r] = ok ? p0[row] : 0;
+      k1[r] = ok ? p1[row] : 0;
     }
     int32_t j[R][U];
     double v[R][U], xv[R][U], s[R];
@@ -100,14 +104,22 @@ __global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ 
   }
 }
 
+// (U: strides of G entries a group takes of its rows before the remainder loop — 2 by default ; 3 where the rows are long enough for
+//  64 lanes and their lengths spread beyond 2 G (avg + 3 sqrt(avg) entries: a Poisson row of 150 entries in a window, `avg` given),
+//  so that almost no row enters the four-way unrolled remainder, most of whose lanes would be masked)
 template <typename T, typename OUT>
-static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* ind, const void* val, const void* x,
-                        OUT* out, int64_t nrows, int64_t nrows_pad, const int* done) {
+static void launch_rows_pp(apx_ctx* ctx, int G, const int64_t* p0, const int64_t* p1, const int32_t* ind, const void* val, const void* x,
+                           OUT* out, int64_t nrows, int64_t nrows_pad, const int* done, double avg = 0.0) {
   const int64_t want = (nrows_pad * G + kBlock - 1) / kBlock;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, 16 * (int64_t)ctx->num_cu));
+  const bool u3 = ctx->sparse_windows != 0 && G >= 32 && avg + 3.0 * std::sqrt(std::max(avg, 0.0)) > 2.0 * G;
 #define APX_SPMV(GG)                                                                                      \
-  hipLaunchKernelGGL((spmv_rows<T, OUT, GG>), dim3(grid), dim3(kBlock), 0, ctx->stream, ptr, ind, (const T*)val, \
-                     (const T*)x, out, nrows, nrows_pad, done)
+  if (u3 && GG >= 32)                                                                                     \
+    hipLaunchKernelGGL((spmv_rows<T, OUT, (GG >= 32 ? GG : 32), 3>), dim3(grid), dim3(kBlock), 0, ctx->stream, p0, p1, ind, (const T*)val, \
+                       (const T*)x, out, nrows, nrows_pad, done);                                          \
+  else                                                                                                    \
+    hipLaunchKernelGGL((spmv_rows<T, OUT, GG>), dim3(grid), dim3(kBlock), 0, ctx->stream, p0, p1, ind, (const T*)val, \
+                       (const T*)x, out, nrows, nrows_pad, done)
   switch (G) {
     case 1: APX_SPMV(1); break;
     case 2: APX_SPMV(2); break;
@@ -118,6 +130,31 @@ static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* 
     default: APX_SPMV(64); break;
   }
 #undef APX_SPMV
+}
+template <typename T, typename OUT>
+static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* ind, const void* val, const void* x,
+                        OUT* out, int64_t nrows, int64_t nrows_pad, const int* done, double avg = 0.0) {
+  launch_rows_pp<T, OUT>(ctx, G, ptr, ptr + 1, ind, val, x, out, nrows, nrows_pad, done, avg);
+}
+
+// L2 WINDOWS of the gathered operand (round 5).  tools/gather_probe.hip: one 8-byte gather per stored entry runs at 2.0 TB/s of the
+// entries' 12 bytes while the operand (0.8 MB) stays in an XCD's L2 and at 1.1 TB/s when it does not (8 MB: X' r of a
+// 1 000 000-row X).  The entries of a compressed row are sorted by index, so the product can be run WINDOW BY WINDOW of the
+// operand: launch w takes, of every row, the run of entries whose index lies in window w (two consecutive slabs of the window
+// table are its begin / end pointers) and leaves an fp64 partial per row — one "split" per window, summed in window order by
+// the consumers that sum the column splits of the dense path (the row-finishing kernels, sum_partials_rows): fixed order, no
+// atomics.  The launches follow each other on the stream, so the chip gathers from ONE window at a time.
+constexpr int64_t kWindowBytes = (int64_t)1 << 21;       // 2 MB of operand per window: half an XCD's L2
+static int64_t window_elems(int32_t dtype) { return kWindowBytes / (int64_t)dtype_size(dtype); }
+template <typename T>
+static void launch_windows(apx_ctx* ctx, int W, const int64_t* win, const int32_t* ind, const void* val, const void* x,
+                           int64_t nnz, int64_t nrows, int64_t nrows_pad, const int* done) {
+  int g = 1;
+  const double avg = nrows > 0 ? (double)nnz / (double)nrows / (double)W : 0.0;
+  while (g < 64 && g * 2 <= avg) g *= 2;
+  for (int w = 0; w < W; ++w)
+    launch_rows_pp<T, double>(ctx, g, win + (int64_t)w * nrows_pad, win + (int64_t)(w + 1) * nrows_pad, ind, val, x,
+                              ctx->part + (int64_t)w * nrows_pad, nrows, nrows_pad, done, avg);
 }
 
 // LONG rows (few rows, thousands of entries each: A' of a tall LIBSVM matrix — covtype is 581 012 x 54 — or A of a
@@ -184,6 +221,7 @@ static void spmv_name(apx_ctx* ctx, int kind, const apx_matrix* A, bool lng, int
   if (!ctx->profile) return;
   char b[128];
   if (lng) snprintf(b, sizeof b, "spmv_long<%s, %d chunk(s) of %d entries per row>", A->dtype == APX_F32 ? "float" : "double", g_or_chunks, kLongChunk);
+  else if (g_or_chunks < 0) snprintf(b, sizeof b, "spmv_rows<%s> in %d L2 windows of the gathered operand (%d launches)", A->dtype == APX_F32 ? "float" : "double", -g_or_chunks, -g_or_chunks);
   else snprintf(b, sizeof b, "spmv_rows<%s, %d lane(s) per row>", A->dtype == APX_F32 ? "float" : "double", g_or_chunks);
   ctx->kname[kind] = b;
 }
@@ -201,14 +239,26 @@ int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
     *splits_out = chunks;
     return APX_OK;
   }
+  if (A->rwin != nullptr) {                                         // the operand x does not fit an L2 window: one split per window
+    const int W = A->rwin_count;
+    APX_TRY(ensure_part(ctx, (size_t)W * A->ld * sizeof(double)));
+    spmv_name(ctx, APX_KSTAT_GEMV_N, A, false, -W);
+    APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, spmv_bytes(A)));
+    if (A->dtype == APX_F32) launch_windows<float>(ctx, W, A->rwin, A->rind, A->rval, x, A->nnz, A->m, A->ld, done);
+    else launch_windows<double>(ctx, W, A->rwin, A->rind, A->rval, x, A->nnz, A->m, A->ld, done);
+    APX_TRY(prof_end(ctx));
+    APX_HIP(hipGetLastError());
+    *splits_out = W;
+    return APX_OK;
+  }
   APX_TRY(ensure_part(ctx, (size_t)A->ld * sizeof(double)));
   const int G = group_for(A->nnz, A->m);
   spmv_name(ctx, APX_KSTAT_GEMV_N, A, false, G);
   APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, spmv_bytes(A)));
   if (A->dtype == APX_F32)
-    launch_rows<float, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done);
+    launch_rows<float, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done, (double)A->nnz / std::max<int64_t>(A->m, 1));
   else
-    launch_rows<double, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done);
+    launch_rows<double, double>(ctx, G, A->rptr, A->rind, A->rval, x, ctx->part, A->m, A->ld, done, (double)A->nnz / std::max<int64_t>(A->m, 1));
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
   *splits_out = 1;
@@ -227,13 +277,24 @@ int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* ou
     APX_HIP(hipGetLastError());
     return launch_sum_partials_rows(ctx, A->dtype, chunks, A->n_pad, A->n_pad, out, done);
   }
+  if (A->twin != nullptr) {                                         // the operand r does not fit an L2 window
+    const int W = A->twin_count;
+    APX_TRY(ensure_part(ctx, (size_t)W * A->n_pad * sizeof(double)));
+    spmv_name(ctx, APX_KSTAT_GEMV_T, A, false, -W);
+    APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, spmv_bytes(A)));
+    if (A->dtype == APX_F32) launch_windows<float>(ctx, W, A->twin, A->tind, A->tval, r, A->nnz, A->n, A->n_pad, done);
+    else launch_windows<double>(ctx, W, A->twin, A->tind, A->tval, r, A->nnz, A->n, A->n_pad, done);
+    APX_TRY(prof_end(ctx));
+    APX_HIP(hipGetLastError());
+    return launch_sum_partials_rows(ctx, A->dtype, W, A->n_pad, A->n_pad, out, done);
+  }
   const int G = group_for(A->nnz, A->n);
   spmv_name(ctx, APX_KSTAT_GEMV_T, A, false, G);
   APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, spmv_bytes(A)));
   if (A->dtype == APX_F32)
-    launch_rows<float, float>(ctx, G, A->tptr, A->tind, A->tval, r, (float*)out, A->n, A->n_pad, done);
+    launch_rows<float, float>(ctx, G, A->tptr, A->tind, A->tval, r, (float*)out, A->n, A->n_pad, done, (double)A->nnz / std::max<int64_t>(A->n, 1));
   else
-    launch_rows<double, double>(ctx, G, A->tptr, A->tind, A->tval, r, (double*)out, A->n, A->n_pad, done);
+    launch_rows<double, double>(ctx, G, A->tptr, A->tind, A->tval, r, (double*)out, A->n, A->n_pad, done, (double)A->nnz / std::max<int64_t>(A->n, 1));
   APX_TRY(prof_end(ctx));
   APX_HIP(hipGetLastError());
   return APX_OK;
@@ -286,6 +347,35 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
   const int64_t* tp = (const int64_t*)p1;
   for (int64_t i = 0; i < A->m; ++i) A->r_maxlen = std::max(A->r_maxlen, rp[i + 1] - rp[i]);
   for (int64_t j = 0; j < A->n; ++j) A->t_maxlen = std::max(A->t_maxlen, tp[j + 1] - tp[j]);
+  // the window tables (launch_windows): for an orientation whose gathered operand is longer than a window and a half, whose rows
+  // are not the long-row form's, and whose indices are sorted within every row (the transposed side always is: a stable
+  // counting sort over rows in order ; the caller's side is checked)
+  auto windows = [&](const int64_t* ptr_h, const int32_t* ind_h, int64_t nrows, int64_t nrows_pad, int64_t ncols, int64_t maxlen,
+                     int64_t** dev, int32_t* count) -> int32_t {
+    const int64_t we = window_elems(A->dtype);
+    int chunks = 0;
+    if (ctx->sparse_windows == 0 || ncols <= we + we / 2 || nnz == 0 || long_rows(nnz, nrows, nrows_pad, maxlen, &chunks)) return APX_OK;
+    const int W = (int)((ncols + we - 1) / we);
+    if (W > 64) return APX_OK;
+    for (int64_t i = 0; i < nrows; ++i)
+      for (int64_t k = ptr_h[i] + 1; k < ptr_h[i + 1]; ++k)
+        if (ind_h[k] < ind_h[k - 1]) return APX_OK;                    // unsorted row: the plain kernel
+    std::vector<int64_t> tab((size_t)(W + 1) * (size_t)nrows_pad, 0);
+    for (int64_t i = 0; i < nrows; ++i) {
+      const int32_t* b = ind_h + ptr_h[i];
+      const int32_t* e = ind_h + ptr_h[i + 1];
+      tab[(size_t)i] = ptr_h[i];
+      for (int w = 1; w < W; ++w)
+        tab[(size_t)w * nrows_pad + i] = ptr_h[i] + (std::lower_bound(b, e, (int32_t)std::min<int64_t>((int64_t)w * we, 2147483647LL)) - b);
+      tab[(size_t)W * nrows_pad + i] = ptr_h[i + 1];
+    }
+    APX_TRY(up((void**)dev, tab.data(), tab.size() * sizeof(int64_t)));
+    APX_HIP(hipStreamSynchronize(ctx->stream));      // (tab dies with this lambda's frame)
+    *count = W;
+    return APX_OK;
+  };
+  APX_TRY(windows((const int64_t*)p0, (const int32_t*)i0, A->m, A->ld, A->n, A->r_maxlen, &A->rwin, &A->rwin_count));
+  APX_TRY(windows((const int64_t*)p1, (const int32_t*)i1, A->n, A->n_pad, A->m, A->t_maxlen, &A->twin, &A->twin_count));
   APX_HIP(hipStreamSynchronize(ctx->stream));   // the host staging vectors die with this frame
   return APX_OK;
 }

@@ -315,6 +315,12 @@ enum {
   APX_OPT_FAULT_SETUP = 17       /* TEST hook, default 0 ; bit 0: the set-up of the one-pass primal-dual kernels fails as if an
                                     allocation had (on ONE rank of a row shard: the ranks must still agree on the two passes —
                                     tests/two_rank_pd_worker.py)                                                              */
+  ,
+  APX_OPT_SPARSE_WINDOWS = 18    /* default 1: a sparse matrix uploaded on this context whose gathered operand (x for A x: n entries ;
+                                    r for A' r: m entries) exceeds 3 MB gets a window table, and that product runs window by window
+                                    of the operand (2 MB: half an XCD's L2) — the gathers then hit L2 (tools/gather_probe.hip: 2.0
+                                    against 1.1 TB/s of the entries' bytes) ; 0: one launch over whole rows (round 1 ; A/B).  Read
+                                    at upload time.                                                                             */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);

@@ -51,6 +51,56 @@ def test_sparse_products(apx, m, n, density, fmt, dtype):
         dA.to_numpy()
 
 
+@pytest.mark.parametrize("m,n,per_row,dtype", [(450_000, 10_000, 6, np.float64),      # X' r gathers from 450 000 doubles: 2 windows
+                                               (1_100_000, 20_000, 3, np.float32),    # ... from 1.1 M floats: 3 windows
+                                               (3_000, 500_000, 300, np.float64),     # X w gathers from 500 000 doubles: 2 windows
+                                               (800_000, 400_000, 2, np.float64)])    # both products windowed (4 and 2)
+def test_products_in_l2_windows_of_the_gathered_operand(apx, m, n, per_row, dtype):
+    """Round 5 (csrc/sparse.hip launch_windows): a product whose gathered operand exceeds 3 MB runs window by window of that
+    operand — a partial per row and window, summed in window order.  Against scipy, against the one-launch form (the A/B option, read
+    at upload), reproducible bit for bit, and through a solver (the fused epilogues take the windows as their splits)."""
+    L = importlib.import_module("adaptive-proximal-algorithms_amd._lib")
+    rng = np.random.default_rng(m + n)
+    nnz_row = np.clip(rng.poisson(per_row, m), 0, n)
+    indptr = np.concatenate([[0], np.cumsum(nnz_row)]).astype(np.int64)
+    A = sp.csr_matrix((rng.uniform(-1, 1, indptr[-1]).astype(dtype), rng.integers(0, n, indptr[-1]).astype(np.int32), indptr), shape=(m, n))
+    A.sum_duplicates()
+    x = rng.standard_normal(n).astype(dtype)
+    r = rng.standard_normal(m).astype(dtype)
+    A64 = A.astype(np.float64)
+    y_ref, g_ref = A64 @ x.astype(np.float64), A64.T @ r.astype(np.float64)
+    tol = 1e-13 if dtype == np.float64 else 3e-6
+    out = {}
+    for windows in (1, 0):
+        ctx = apx.Context(0)
+        ctx.fused_small(False)
+        ctx.set_option(L.APX_OPT_SPARSE_WINDOWS, windows)
+        dA = apx.DeviceMatrix.from_sparse(A, ctx)
+        ctx.profile(True)
+        y, g = dA @ x, dA.T @ r
+        ctx.kernel_stats(reset=True)
+        names = (ctx.kernel_name("gemv_n"), ctx.kernel_name("gemv_t"))
+        assert np.max(np.abs(y - y_ref)) <= tol * max(1.0, np.max(np.abs(y_ref)))
+        assert np.max(np.abs(g - g_ref)) <= tol * max(1.0, np.max(np.abs(g_ref)))
+        assert np.array_equal(dA @ x, y) and np.array_equal(dA.T @ r, g)
+        out[windows] = (y, g, names)
+        if windows and m >= 400_000 and dtype == np.float64:      # a few logistic iterations on the windowed storage against the plain one
+            yy = (rng.uniform(size=m) < 0.5).astype(np.float64)
+            gam = 4.0 * m / (float(A64.multiply(A64).sum()) + m)
+            out["x_win"] = apx.adaptive_proxgrad(np.full(n + 1, 0.01), f=apx.LogisticLoss(dA, yy, ctx=ctx), g=apx.NormL1(1e-7), rule=apx.OurRule(gamma=gam),
+                                                 tol=0.0, maxit=8, ctx=ctx)[0]
+            out["yy"], out["gam"] = yy, gam
+        elif not windows and "yy" in out:
+            x_plain = apx.adaptive_proxgrad(np.full(n + 1, 0.01), f=apx.LogisticLoss(dA, out["yy"], ctx=ctx), g=apx.NormL1(1e-7),
+                                            rule=apx.OurRule(gamma=out["gam"]), tol=0.0, maxit=8, ctx=ctx)[0]
+            assert _rel(out["x_win"], x_plain) <= 1e-10 and np.any(x_plain != 0)
+        dA.free()
+    assert "L2 windows" in out[1][2][0] or "L2 windows" in out[1][2][1], out[1][2]
+    assert "L2 windows" not in out[0][2][0] and "L2 windows" not in out[0][2][1], out[0][2]
+    assert ("L2 windows" in out[1][2][1]) == (m * np.dtype(dtype).itemsize > 3 << 20)
+    assert ("L2 windows" in out[1][2][0]) == (n * np.dtype(dtype).itemsize > 3 << 20)
+
+
 @pytest.mark.parametrize("m,n,spmv", [(3000, 112, True), (3000, 112, False), (6414, 123, False), (1500, 400, False),
                                       (20000, 12, True)])          # (long rows of X': the chunked SpMV)
 def test_sparse_logreg_matches_oracle(apx, generic_ctx, m, n, spmv):

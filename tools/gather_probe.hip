@@ -95,7 +95,7 @@ int main() {
   for (int blocks : {1024, 2048, 4096, 8192}) {
     printf("grid %d blocks of 256:\n", blocks);
     printf("  stream only                U=4 %7.0f  U=8 %7.0f GB/s\n", run<0, 4>(ind, val, x, nnz, 1, out, blocks), run<0, 8>(ind, val, x, nnz, 1, out, blocks));
-    for (int n_x : {2000, 100'000, 1'000'000, 16'000'000}) {
+    for (int n_x : {2000, 100'000, 262'144, 524'288, 1'000'000, 16'000'000}) {
       for (auto& j : hi) j = (int32_t)(rng() % (uint64_t)n_x);
       CK(hipMemcpy(ind, hi.data(), nnz * 4, hipMemcpyHostToDevice));
       printf("  gather, operand %9d  U=4 %7.0f  U=8 %7.0f  U=16 %7.0f GB/s", n_x, run<1, 4>(ind, val, x, nnz, n_x, out, blocks),

@@ -1,0 +1,20 @@
+import sys, json, time, numpy as np
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+import adaprox_amd as apx
+from importlib import import_module
+L=import_module("adaptive-proximal-algorithms_amd._lib")
+from sparse_bench import rand_csr
+for dtype in (np.float64, np.float32):
+    A=rand_csr(1_000_000,100_000,60,0,dtype)
+    x=np.random.default_rng(1).standard_normal(100_000).astype(dtype); r=np.random.default_rng(2).standard_normal(1_000_000).astype(dtype)
+    for win in (1,0):
+        ctx=apx.Context(0); ctx.set_option(L.APX_OPT_SPARSE_WINDOWS,win)
+        dA=apx.DeviceMatrix.from_sparse(A,ctx)
+        ctx.profile(True)
+        for _ in range(3): dA@x; dA.T@r
+        ctx.kernel_stats(reset=True)
+        for _ in range(10): dA@x; dA.T@r
+        st=ctx.kernel_stats(reset=True)
+        print(json.dumps({"dtype":np.dtype(dtype).name,"windows":win,"A@x":{"kernel":ctx.kernel_name("gemv_n"),"us":st["gemv_n"]["total_ms"]/st["gemv_n"]["launches"]*1e3,"GBps":st["gemv_n"]["bytes"]/st["gemv_n"]["total_ms"]/1e6},
+                          "A.T@r":{"kernel":ctx.kernel_name("gemv_t"),"us":st["gemv_t"]["total_ms"]/st["gemv_t"]["launches"]*1e3,"GBps":st["gemv_t"]["bytes"]/st["gemv_t"]["total_ms"]/1e6}}),flush=True)
+        dA.free()
