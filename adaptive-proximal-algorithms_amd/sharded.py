@@ -36,6 +36,42 @@ def shard_rows(m_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 # ---- RCCL inside the library -----------------------------------------------------------
+_PREFETCHED = set()
+
+
+def prefetch_library_image(path: str) -> float:
+    """Reads a shared library's file once, sequentially, so that the loader's page faults hit the page cache.  librccl is
+    0.3 - 0.6 GB of device code ; on a box whose image is not cached yet the first communicator demand-pages it at ~2 MB/s —
+    141 s for PyTorch's copy and more than 300 s for /opt/rocm's on one box of round 5 (profiles/incidents/README.md), against
+    seconds for a sequential read.  Returns the seconds it took (0.0 when there is nothing to read)."""
+    import os
+    import time
+    real = os.path.realpath(path)
+    if real in _PREFETCHED or not os.path.isfile(real):
+        return 0.0
+    _PREFETCHED.add(real)
+    t0 = time.perf_counter()
+    try:
+        with open(real, "rb", buffering=0) as fh:
+            while fh.read(64 << 20):
+                pass
+    except OSError:
+        pass
+    return time.perf_counter() - t0
+
+
+def rccl_candidates() -> list:
+    """The librccl files a process may end up binding (csrc/comm.hip rccl_api: the copy next to PyTorch's HIP runtime where
+    torch is installed, else the system's)."""
+    import os
+    out = []
+    if "torch" in sys.modules:
+        out.append(os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "librccl.so"))
+    for d in (os.environ.get("ROCM_PATH", "/opt/rocm"),):
+        out.append(os.path.join(d, "lib", "librccl.so"))
+    return [p for p in out if os.path.exists(p)]
+
+
 class Comm:
     """An RCCL communicator bound to one Context (apx_comm_*).  Pass it where a row-sharded
     term takes its collective: ``LinearLeastSquares(A_k, b_k, allreduce=comm)``,
@@ -56,6 +92,8 @@ class Comm:
                 import torch  # noqa: F401
             except ImportError:
                 pass
+        for path in rccl_candidates()[:1]:          # the copy this process will bind (see rccl_candidates)
+            prefetch_library_image(path)
 
     @staticmethod
     def library() -> str:

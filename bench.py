@@ -506,6 +506,9 @@ def main():
             rccl_error = ""
             try:
                 with _StdoutToStderr():
+                    # (librccl is 0.3 GB of device code: on a box whose image is not cached yet the loader demand-pages it at
+                    #  ~2 MB/s — minutes ; a sequential read first takes seconds.  sharded.Comm does it: said here because it is
+                    #  the first thing a fresh N-GPU node spends time on)
                     if os.environ.get("APX_BENCH_SIMULATE_RCCL_FAILURE") == "1":      # (test hook: tests/test_gpu_comm.py)
                         raise RuntimeError("simulated failure of the communicator set-up")
                     uid = [sharded.Comm.unique_id() if rank == 0 else None]      # ncclGetUniqueId on rank 0 ...
