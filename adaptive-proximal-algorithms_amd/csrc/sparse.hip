@@ -45,14 +45,26 @@ __global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ 
   constexpr int R = 4;
   const int lane = threadIdx.x % G;
   const int64_t groups = (int64_t)gridDim.x * (kBlock / G);
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; base < nrows_pad; base += R * groups) {
+  // (the pointer pairs of the NEXT batch of rows are requested while this batch's entries are in flight: one dependent trip to
+  //  memory less per batch — round 5)
+  int64_t n0[R], n1[R];
+  auto ptrs = [&](int64_t b, int64_t (&a0)[R], int64_t (&a1)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = b + r * groups;
+      const bool ok = row < nrows;
+      a0[r] = ok ? p0[row] : 0;
+      a1[r] = ok ? p1[row] : 0;
+    }
+  };
+  const int64_t base0 = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (base0 < nrows_pad) ptrs(base0, n0, n1);
+  for (int64_t base = base0; base < nrows_pad; base += R * groups) {
     int64_t k0[R], k1[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row = base + r * groups;
-      const bool ok = row < nrows;
-      k0[r] = ok ? p0[row] : 0;
-      k1[r] = ok ? p1[row] : 0;
+      k0[r] = n0[r];
+      k1[r] = n1[r];
     }
     int32_t j[R][U];
     double v[R][U], xv[R][U], s[R];
@@ -65,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ 
         j[r][u] = ok ? ind[kk] : 0;
         v[r][u] = ok ? (double)val[kk] : 0.0;
       }
+    if (base + R * groups < nrows_pad) ptrs(base + R * groups, n0, n1);
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll

@@ -319,7 +319,7 @@ def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dt
     mk_h = {"tl1": lambda M: M.Translate(M.NormL1(1.0), -yv.astype(np.float64) if M is O else -yv),
             "tbox": lambda M: M.Translate(M.IndBox(-0.5, 0.8), -yv.astype(np.float64) if M is O else -yv),
             "tl2": lambda M: M.Translate(M.NormL2(1.0), -yv.astype(np.float64) if M is O else -yv)}[hkind]
-    K = 10 if n < 60000 else 6
+    K = 10 if (n < 60000 or hkind == "tl2") else 6          # (the l2 ball's x leaves 0 only around iteration 8)
     lam = 0.05 if hkind == "tl2" else 5.0      # (the l2 ball: |A' y| <= 2 ||y|| or so, and y grows from 0 in steps of sigma b — a larger lambda keeps x at 0 for these ten iterations)
     x0, y0 = np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype)
     ro = []
