@@ -58,7 +58,7 @@ def flag(leg: str, waits: dict) -> dict:
 
 def leg_c2(iters):
     ctx = apx.Context(0)
-    p = problems.device_lasso(50_000, 100_000, pfactor=10, seed=0, power_iters=30, ctx=ctx, dual_layout=True)
+    p = problems.device_lasso(50_000, 100_000, pfactor=10, seed=0, power_iters=30, ctx=ctx, layout="rows")      # (bench.py's default: one resident copy)
     f = apx.LinearLeastSquares(p.A, p.b)
     t0 = time.perf_counter()
     obj, slots = [], []
@@ -92,7 +92,7 @@ def leg_c5(iters):
     ctx = apx.Context(0)
     m, n = 50_000, 20_000
     p = problems.device_lad(m, n, seed=0, lam=10.0, ctx=ctx)
-    p.A.build_transpose()
+    p.A.drop_primary()
     gamma = 1.0 / p.norm_A
     sigma = 0.99 / p.norm_A
     s = apx.Solver(np.zeros(n), np.zeros(m), f=apx.Zero(), g=apx.NormL1(p.lam), h=apx.Translate(apx.NormL1(1.0), -p.y), A=p.A,

@@ -1,3 +1,7 @@
+"""The two products of the large sparse case (1 000 000 x 100 000, ~60 entries per row, Float64 and Float32) per KERNEL — HIP-event
+times of `X w` and `X' r` from the library's own statistics — with the round-5 forms on and off in one process
+(APX_OPT_SPARSE_WINDOWS: L2 windows of the gathered operand, three strides per group).  One JSON line per dtype and setting ;
+profiles/r05_sparse_kernels_windows_ab.jsonl.  `python tools/sparse_kernels.py` on an MI355X."""
 import sys, json, time, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
 import adaprox_amd as apx
