@@ -13,7 +13,10 @@
 //       every device's loop then needs its own host thread — apx_adaptive_primal_dual_group runs them
 //
 // xGMI is a point-to-point mesh (7 links per GPU) and the message is n + 2 elements (0.8 MB at n = 100 000) against
-// >= 11 ms of local streaming per iteration: latency-bound, one collective per gradient, nothing to bucket or overlap.
+// 5.8 ms of local streaming per iteration at C4's shard (one pass over 40 GB ; 0.77 ms at an eighth of it — DESIGN.md section 6):
+// latency-bound, one collective per gradient, nothing to bucket or overlap.
+// (librccl is 0.3 - 0.6 GB of device code: on a box whose image is not in the page cache its first use demand-pages it at ~2 MB/s
+//  — minutes.  The host mirror reads the file sequentially first, sharded.prefetch_library_image ; a Julia host would do the same.)
 //
 // librccl is bound at the FIRST apx_comm_* call, not at load time (rccl_api below): a single-GPU user never maps its
 // 570 MB, and — what decides it — the copy must be the one that belongs to the HIP runtime this library is bound to.
