@@ -367,8 +367,8 @@ def test_malitsky_pock_quadratic_vs_host_driven_fuzz(N, rows, t, f32, k, seed):
 @settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(n=st.sampled_from([125, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5119, 5120, 5121, 7679, 10751, 10752]),
        extra_rows=st.integers(0, 9), logistic=st.booleans(), f32=st.booleans(), rule=st.sampled_from(["ours", "fixed", "mm"]),
-       k=st.integers(0, 6), seed=st.integers(0, 2**31 - 1))
-def test_one_pass_vs_two_passes_fuzz(n, extra_rows, logistic, f32, rule, k, seed):
+       k=st.integers(0, 6), seed=st.integers(0, 2**31 - 1), layout=st.sampled_from(["cols", "rows"]))
+def test_one_pass_vs_two_passes_fuzz(n, extra_rows, logistic, f32, rule, k, seed, layout):
     """csrc/slab.hip (f and grad f in one pass over A) against the two GEMV passes: column counts around the 2 / 5 / 14
     columns-per-thread shapes, row counts that are not multiples of the step or of the slab."""
     apx, _ = _apx()
@@ -395,7 +395,7 @@ def test_one_pass_vs_two_passes_fuzz(n, extra_rows, logistic, f32, rule, k, seed
         ctx = apx.Context(0)
         ctx.fused_small(one_pass)
         ctx.one_pass_threshold(16 << 20)
-        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx, layout=layout)      # (where the library keeps A's bytes must not show: round 5)
         f = apx.LogisticLoss(dA, b, ctx=ctx) if logistic else apx.LinearLeastSquares(dA, b, ctx=ctx)
         recs = []
         x, it = apx.adaptive_proxgrad(x0, f=f, g=apx.NormL1(0.01 if logistic else 1.0), rule=mk(), tol=0.0, maxit=k, ctx=ctx,
@@ -413,8 +413,8 @@ def test_one_pass_vs_two_passes_fuzz(n, extra_rows, logistic, f32, rule, k, seed
 @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(n=st.sampled_from([125, 1024, 2048, 2049, 5120, 5121, 10752]), extra_rows=st.integers(0, 9),
        hk=st.sampled_from(["tl1", "tbox"]), f32=st.booleans(), fixed=st.booleans(), k=st.integers(0, 5),
-       seed=st.integers(0, 2**31 - 1))
-def test_one_pass_primal_dual_vs_two_passes_fuzz(n, extra_rows, hk, f32, fixed, k, seed):
+       seed=st.integers(0, 2**31 - 1), layout=st.sampled_from(["cols", "rows"]))
+def test_one_pass_primal_dual_vs_two_passes_fuzz(n, extra_rows, hk, f32, fixed, k, seed, layout):
     """csrc/slab_pd.hip (A x, the dual step, A' y in one pass over A) against the generic kernels."""
     apx, _ = _apx()
     dtype = np.float32 if f32 else np.float64
@@ -432,7 +432,7 @@ def test_one_pass_primal_dual_vs_two_passes_fuzz(n, extra_rows, hk, f32, fixed, 
         ctx = apx.Context(0)
         ctx.fused_small(one_pass)
         ctx.one_pass_threshold(16 << 20)
-        dA = apx.DeviceMatrix.from_numpy(A, ctx)
+        dA = apx.DeviceMatrix.from_numpy(A, ctx, layout=layout)
         h = apx.Translate(apx.NormL1(1.0) if hk == "tl1" else apx.IndBox(-0.5, 0.8), -yv)
         rule = apx.FixedStepsize(1.0 / nA, 0.99) if fixed else apx.OurRule(t=1.0, norm_A=nA)
         x, y, it = apx.adaptive_primal_dual(x0, y0, f=apx.Zero(), g=apx.NormL1(3.0), h=h, A=dA, rule=rule, tol=0.0, maxit=k,
