@@ -90,7 +90,8 @@ def test_hip_vs_sklearn_lasso(apx):
                                                 maxit=100_000),
                   lambda: apx.backtracking_proxgrad(np.zeros(150), f=f, g=g, gamma0=gam, xi=1.5, tol=1e-10,
                                                     maxit=100_000),
-                  lambda: apx.fixed_nesterov(np.zeros(150), f=f, g=g, gamma=gam, tol=1e-10, maxit=200_000)):
+                  lambda: apx.fixed_nesterov(np.zeros(150), f=f, g=g, gamma=gam, tol=1e-10, maxit=200_000),
+                  lambda: apx.agraal(np.zeros(150), f=f, g=g, x0=np.full(150, 0.01), tol=1e-10, maxit=200_000)):
         w, it = solve()
         assert np.max(np.abs(w - w_ref)) < 1e-7
         assert lasso_kkt(A, b, lam, w) < 1e-6
