@@ -936,10 +936,14 @@ static int32_t adaptive_linesearch_primal_dual_run(apx_problem* p, const apx_lin
   const int64_t rec_cap = (opts && opts->records) ? opts->record_cap : 0;
   double* d_gamma = (double*)((char*)p->ctrl_buf.p + offsetof(Ctrl, gamma));
 
-  auto set_gamma = [&](double g) -> int32_t {     // Ctrl.gamma feeds k_reduce_n / k_step
-    ctx->h_scal[48] = g;
-    APX_HIP(hipMemcpyAsync(d_gamma, &ctx->h_scal[48], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    APX_HIP(hipStreamSynchronize(ctx->stream));
+  // Ctrl.gamma feeds k_reduce_n / k_step.  No synchronisation behind the upload (round 5: one idle gap of the GPU per iteration
+  // less): the value travels from a ring of eight pinned slots, and a slot is written again only eight iterations later — every
+  // one of which has synchronised the stream twice (the sums, the trial's read-back).
+  int64_t gamma_uploads = 0;
+  auto set_gamma = [&](double g) -> int32_t {
+    double* slot = &ctx->h_scal[20 + (int)(gamma_uploads++ & 7)];
+    *slot = g;
+    APX_HIP(hipMemcpyAsync(d_gamma, slot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     return APX_OK;
   };
   auto mul_A = [&]() -> int32_t {                 // A_x = A * x
