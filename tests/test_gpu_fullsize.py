@@ -435,6 +435,40 @@ def test_c5_matrix_round4_loops_at_full_size(apx):
         assert np.max(np.abs(a[k + 1] - b[k + 1])) <= 1e-10 * max(np.max(np.abs(b[k + 1])), 1e-300)
 
 
+def test_c4_shard_through_the_n_rank_path():
+    """BASELINE config C4 (lasso 400 000 x 100 000 over 8 GPUs) cannot run here — one GPU, and RCCL refuses two ranks on a device.
+    What one GPU CAN hold of it is a rank's whole job: C4's shard (50 000 x 100 000 fp64, 40 GB) through the N-rank code path —
+    bench.py with APX_BENCH_FORCE_DIST=1: the in-library communicator (ncclCommInitRank), one ncclAllReduce(n + 2) per iteration
+    enqueued by the loop, the sharded loop's kernels (k_slab_tail + k_step_rule behind the collective) — against the plain
+    single-GPU run of the same matrix: the same one-pass team kernel, the same iterates.  (The sharding algebra with 2 - 8 ranks:
+    tests/test_sharded_gloo.py, test_gpu_two_ranks.py ; N > 1 over xGMI has never run: no node.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--rows", "50000", "--cols", "100000", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs"]
+    lines = {}
+    for dist in (True, False):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env.pop("APX_BENCH_FORCE_DIST", None)
+        if dist:
+            env["APX_BENCH_FORCE_DIST"] = "1"
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines[dist] = json.loads(out.stdout.strip().splitlines()[-1])
+    d, p = lines[True], lines[False]
+    assert d["rccl_ranks"] == 1 and d["collective"]["transport"] == "rccl" and "rccl_ranks" not in p
+    assert "k_team_rows" in d["roofline"]["kernel"] and d["roofline"]["kernel"] == p["roofline"]["kernel"]
+    assert d["roofline"]["passes_over_A_per_iter"] == 1.0 == p["roofline"]["passes_over_A_per_iter"]
+    assert d["final_objective"] == pytest.approx(p["final_objective"], rel=1e-13)      # (bit-equal in practice: one rank's sum is the sum)
+    assert d["lasso_optimum"] == p["lasso_optimum"]
+    assert d["config"]["rows_per_gpu"] == 50000 and d["config"]["layout"].startswith("single, 40 GB")
+    print("C4's shard through the N-rank path: %.2f ms per iteration (plain: %.2f), row kernel at %.3f of the HBM peak"
+          % (d["ms_per_step"], p["ms_per_step"], d["roofline"]["frac"]))
+    assert d["ms_per_step"] <= 1.10 * p["ms_per_step"]                                  # what a rank pays on top is the collective itself (measured: + 0.7 %)
+
+
 def test_native_allreduce_hook_world_size_one(apx):
     """The RCCL hook of the row-sharded path with a single rank: all-reduce over one rank is the
     identity, so the run must equal the un-hooked one bit for bit."""
