@@ -35,7 +35,7 @@ namespace apx {
 // next step for that regime, not this kernel's schedule.
 // (p0 / p1: where a row's entries begin and end — the row pointers `ptr` and `ptr + 1`, or two consecutive slabs of a window
 //  table: the entries of the row whose index falls into one L2 window of the operand, see launch_windows)
-template <typename T, typename OUT, int G, int U = 2>
+template <typename T, typename OUT, int G, int U = 2, int RU = 4>
 __global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ p0, const int64_t* __restrict__ p1,
                                                     const int32_t* __restrict__ ind,
                                                     const T* __restrict__ val, const T* __restrict__ x,
@@ -90,20 +90,20 @@ __global__ __launch_bounds__(kBlock) void spmv_rows(const int64_t* __restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      for (int64_t k = k0[r] + lane + (int64_t)U * G; k < k1[r]; k += 4 * G) {     // long rows
-        int32_t jj[4];
-        double vv[4], xx[4];
+      for (int64_t k = k0[r] + lane + (int64_t)U * G; k < k1[r]; k += RU * G) {     // long rows
+        int32_t jj[RU];
+        double vv[RU], xx[RU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RU; ++u) {
           const int64_t kk = k + (int64_t)u * G;
           const bool ok = kk < k1[r];
           jj[u] = ok ? ind[kk] : 0;
           vv[u] = ok ? (double)val[kk] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xx[u] = (double)x[jj[u]];
+        for (int u = 0; u < RU; ++u) xx[u] = (double)x[jj[u]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[r] = fma(vv[u], xx[u], s[r]);
+        for (int u = 0; u < RU; ++u) s[r] = fma(vv[u], xx[u], s[r]);
       }
     }
 #pragma unroll
@@ -126,6 +126,8 @@ static void launch_rows_pp(apx_ctx* ctx, int G, const int64_t* p0, const int64_t
   const int64_t want = (nrows_pad * G + kBlock - 1) / kBlock;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, 16 * (int64_t)ctx->num_cu));
   const bool u3 = ctx->sparse_windows != 0 && G >= 32 && avg + 3.0 * std::sqrt(std::max(avg, 0.0)) > 2.0 * G;
+  // (measured and not taken, round 5: half the lanes with four strides and a remainder that advances one stride at a time — 94 % of the
+  //  lane slots filled instead of 62 %: X w 429 -> 419 us, X' r 462 -> 449, Float32 X' r 377 -> 399: the kernel is not bound by its lane slots)
 #define APX_SPMV(GG)                                                                                      \
   if (u3 && GG >= 32)                                                                                     \
     hipLaunchKernelGGL((spmv_rows<T, OUT, (GG >= 32 ? GG : 32), 3>), dim3(grid), dim3(kBlock), 0, ctx->stream, p0, p1, ind, (const T*)val, \

@@ -2,7 +2,7 @@
 times of `X w` and `X' r` from the library's own statistics — with the round-5 forms on and off in one process
 (APX_OPT_SPARSE_WINDOWS: L2 windows of the gathered operand, three strides per group).  One JSON line per dtype and setting ;
 profiles/r05_sparse_kernels_windows_ab.jsonl.  `python tools/sparse_kernels.py` on an MI355X."""
-import sys, json, time, numpy as np
+import os, sys, json, time, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
 import adaprox_amd as apx
 from importlib import import_module
@@ -11,7 +11,7 @@ from sparse_bench import rand_csr
 for dtype in (np.float64, np.float32):
     A=rand_csr(1_000_000,100_000,60,0,dtype)
     x=np.random.default_rng(1).standard_normal(100_000).astype(dtype); r=np.random.default_rng(2).standard_normal(1_000_000).astype(dtype)
-    for win in (1,0):
+    for win in [int(v) for v in os.environ.get('WINS', '1,0').split(',')]:
         ctx=apx.Context(0); ctx.set_option(L.APX_OPT_SPARSE_WINDOWS,win)
         dA=apx.DeviceMatrix.from_sparse(A,ctx)
         ctx.profile(True)
