@@ -214,6 +214,76 @@ def test_logreg_c3_solver_at_full_size(apx):
     p.X.free()
 
 
+def test_logreg_c3_reaches_a_kkt_point_at_full_size(apx):
+    """BASELINE config C3 solved on its product path (f and grad f from ONE read of the 4 GB, Float32) to the residual test of
+    src/AdaProx.jl:354, then certified WITHOUT that path: the gradient of the logistic loss at the returned w formed from the two
+    GEMV products of the library (other kernels than the one-pass kernel that produced w) and numpy in Float64, and the KKT
+    conditions of min f(w) + lam ||w||_1 with the PENALISED bias as last coordinate (experiments/sparse_logreg/runme.jl:18-39,56)
+    checked coordinate by coordinate: grad_j = -lam sign(w_j) where w_j != 0, |grad_j| <= lam where w_j = 0."""
+    problems = importlib.import_module("adaptive-proximal-algorithms_amd.problems")
+    m, n = 100_000, 10_000
+    ctx = apx.Context(0)
+    p = problems.device_logreg(m, n, seed=0, lam=0.01, dtype=np.float32, ctx=ctx)
+    p.X.drop_primary()
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    w, it = apx.adaptive_proxgrad(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(p.X, p.y, ctx=ctx), g=apx.NormL1(p.lam),
+                                  rule=apx.OurRule(gamma=p.gamma0), tol=2e-7, maxit=2000, ctx=ctx)
+    st = ctx.kernel_stats(reset=True)
+    ctx.profile(False)
+    assert it < 2000 and st["gemv_t"]["launches"] == 0 and st["one_pass"]["launches"] >= it, (it, st)
+    ctx2 = apx.Context(0)
+    ctx2.one_pass(0)                                                   # the certificate comes from the GEMV kernels
+    X2 = apx.DeviceMatrix.uniform(m, n, seed=0, lo=-1.0, hi=1.0, dtype=np.float32, ctx=ctx2)      # (counter-based: the same matrix)
+    z = (X2 @ w[:-1]).astype(np.float64) + float(w[-1])
+    r = 1.0 / (1.0 + np.exp(-z)) - p.y.astype(np.float64)
+    grad = np.concatenate([(X2.T @ r.astype(np.float32)).astype(np.float64), [np.sum(r)]]) / m
+    nz = w != 0
+    v_nz = float(np.max(np.abs(grad[nz] + p.lam * np.sign(w[nz]))))
+    v_z = float(np.max(np.maximum(np.abs(grad[~nz]) - p.lam, 0.0)))
+    print("C3 at full size: %d iterations, %d of %d weights nonzero, bias %.4f ; KKT violation on the support %.2e, off it %.2e (lam = %g)"
+          % (it, int(nz.sum()), n + 1, float(w[-1]), v_nz, v_z, p.lam))
+    assert 10 < nz.sum() < n                                           # a sparse solution
+    assert v_nz <= 2e-7 and v_z <= 2e-7                                # (measured: 6.5e-9 on the support, 0 off it ; Float32 storage, lam = 1e-2)
+    # the bias is coordinate `end` and pays lam like every other one: here (balanced classes, no bias in the generator) the threshold
+    # holds it at exactly 0 — |grad_bias| <= lam — where an unpenalised bias would have moved until its gradient vanished
+    assert (w[-1] == 0 and abs(grad[-1]) <= p.lam + 2e-7) or abs(grad[-1] + p.lam * np.sign(w[-1])) <= 2e-7
+    X2.free()
+    p.X.free()
+
+
+def test_backtracking_c2_at_full_size(apx):
+    """`backtracking_proxgrad` (src/AdaProx.jl:34-64) on C2's matrix at full size, every trial ONE launch of the one-pass team
+    kernel: the properties the linesearch guarantees whatever the data — the objective never increases (the accepted point
+    satisfies f(z) <= f(x) + <grad f(x), z - x> + |z - x|^2 / (2 gamma), `upper_bound` :26), stays above the generator's analytic
+    optimum, gamma only ever moves by the factors xi and shrink — and the evaluation counts of SURVEY 3.4."""
+    problems = importlib.import_module("adaptive-proximal-algorithms_amd.problems")
+    ctx = apx.Context(0)
+    prob = problems.device_lasso(50_000, 100_000, pfactor=10, seed=0, power_iters=20, ctx=ctx, layout="rows")
+    f, g = apx.Counting(apx.LinearLeastSquares(prob.A, prob.b, ctx=ctx)), apx.NormL1(prob.lam)
+    K, xi, shrink = 30, 1.5, 0.5
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    recs = []
+    z, it = apx.backtracking_proxgrad(np.zeros(100_000), f=f, g=g, gamma0=1.0 / prob.Lf, xi=xi, shrink=shrink, tol=0.0, maxit=K,
+                                      ctx=ctx, record=recs.append)
+    st = ctx.kernel_stats(reset=True)
+    ctx.profile(False)
+    obj = [r["objective"] for r in recs]
+    assert it == K and len(obj) == K and np.all(np.isfinite(z))
+    assert all(b <= a * (1 + 1e-14) for a, b in zip(obj, obj[1:])) and obj[-1] < 0.9 * obj[0]      # monotone (the linesearch's guarantee)
+    assert obj[-1] > prob.optimum
+    trials = f.eval_count - 1                                            # one evaluation at x0 in front of the loop (:52)
+    assert K <= trials <= 3 * K and f.grad_count == K + 1                # a gradient per accepted point (+ x0's)
+    assert st["one_pass"]["launches"] == trials + 1 and st["gemv_n"]["launches"] == 0 and st["gemv_t"]["launches"] == 0, st
+    gam = [1.0 / prob.Lf] + [r["gamma"] for r in recs]
+    for a, b in zip(gam, gam[1:]):                                       # gamma_k = xi gamma_{k-1} shrink^j, j = 0, 1, 2, ...
+        j = np.log(b / (xi * a)) / np.log(shrink)
+        assert abs(j - round(j)) < 1e-9 and round(j) >= 0, (a, b, j)
+    print("backtracking at C2's size: %d trials in %d iterations, objective %.4f -> %.4f (optimum %.4f)" % (trials, K, obj[0], obj[-1], prob.optimum))
+    prob.A.free()
+
+
 def test_one_resident_copy_holds_a_160_gb_matrix(apx):
     """What the dual layout of rounds 2-4 could not hold on one MI355X (2 x 160 GB > 288 GB): a 125 000 x 160 000 fp64 lasso
     (160 GB, rows of 160 000 entries = teams of sixteen) in the row-contiguous storage alone.  Properties:
