@@ -300,6 +300,9 @@ static SlabPdShape slab_pd_shape(const apx_problem* p) {
   if (!f32 && (cols <= 2 * kTeamSingleKv * 704 || (cols <= kTeamMaxCols && p->ctx->num_cu == 256 && p->ctx->teams && !p->teams_dead()))) return {768, 28, 1};
   if (cols <= 10 * 768) return {768, 10, f32 ? 4 : 2};
   if (cols <= 14 * 768) return {768, 14, f32 ? 4 : 2};
+  // Float32 rows beyond one workgroup (round 5): the teams of csrc/team_rows.h in their Float32 form — two to five vectors per
+  // thread, four slots, teams of 2 ... 16 up to 225 280 entries — as f's gradient has had them since round 3 (csrc/slab.hip)
+  if (f32 && cols <= kTeamMaxColsF32 && p->ctx->num_cu == 256 && p->ctx->teams && !p->teams_dead() && (multi & 8)) return {768, 28, 1};
   // (C5's row length, 20 000 fp64, is out of reach of ONE workgroup's row kernel: x, the accumulator and one row are 480 KB of
   //  a CU's 512 KB of VGPRs — 1024 threads x 20 columns x 1 row spilled 432 B and ran at 3.4 ms against 2.36 ms for the two passes)
   return {0, 0, 0};
@@ -364,12 +367,16 @@ int32_t slab_pd_setup(apx_solver* s) {
   int64_t rpb = (A->m + B - 1) / B;                // dealt evenly, nothing rounded up: a block's last step may be partial
   B = (A->m + rpb - 1) / rpb;                      // (csrc/slab.hip: rounding to 16 left CUs without a block)
   if (st->cpt == 28) {                             // k_team_rows: slabs = teams, ALL P x B workgroups launched
-    const TeamPlan pl = team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, ctx->team_slots, true});
+    const bool f32 = p->dtype == APX_F32;
+    const TeamPlan pl = f32 ? team_plan(A->n, TeamTune{0, ctx->multi_waves, 0, true}, 4)
+                            : team_plan(A->n, TeamTune{ctx->team_members, ctx->multi_waves, ctx->team_slots, true});
+    if (pl.P == 0) return APX_OK;                    // (no plan for this length: the generic kernels)
     st->plan = pl;
     B = ctx->num_cu / pl.P;
     rpb = (A->m + B - 1) / B;
-    if (pl.P > 1 && team_blocks_per_cu<kTeamFkPd, SlabPdDev>(pl, true) < 1) return APX_OK;      // (it does not fit a CU: the generic kernels)
-    APX_TRY(team_alloc(ctx, &st->team, (int)B, pl.P, rpb, A->n * (int64_t)sizeof(double)));
+    const int per_cu = pl.P > 1 ? (f32 ? team_blocks_per_cu<kTeamFkPd, SlabPdDev, float>(pl, true) : team_blocks_per_cu<kTeamFkPd, SlabPdDev>(pl, true)) : 1;
+    if (per_cu < 1) return APX_OK;                   // (it does not fit a CU: the generic kernels)
+    APX_TRY(team_alloc(ctx, &st->team, (int)B, pl.P, rpb, A->n * (int64_t)dtype_size(p->dtype)));
   }
   st->B = (int)B;
   SlabPdDev d{};
@@ -417,13 +424,10 @@ static bool slab_pd_launch_t(SlabPdState* st, bool cooperative, const SlabPdDev&
     return true;
   }
   if (st->plan.kv != 0) {
-    bool ok = true;
-    if constexpr (!f32) {
-      ok = team_launch<kTeamFkPd, SlabPdDev>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
-      if (!ok) return false;                       // (a refused launch: NOTHING runs — not the closing kernel on the last launch's partials either)
-      slabpd_close_launch<T>(d, st->B, (T*)aty, recs, rec_cap, q);
-    }
-    return ok;
+    const bool ok = team_launch<kTeamFkPd, SlabPdDev, T>(st->plan, st->B, st->nt, cooperative, d, st->team.dev, x, q);
+    if (!ok) return false;                         // (a refused launch: NOTHING runs — not the closing kernel on the last launch's partials either)
+    slabpd_close_launch<T>(d, st->B, (T*)aty, recs, rec_cap, q);
+    return true;
   }
   // two row groups in flight only where it measured faster here — Float32 at two columns per thread (400 000 x 2000: 0.572 ->
   // 0.552 ms) ; with the per-row state of y and A_x_prev on top of the rows, the other shapes lose (200 000 x 5000 fp64

@@ -162,7 +162,7 @@ def test_one_pass_matches_oracle_and_two_passes(apx, m, n, logistic, dtype):
         b = rng.standard_normal(m).astype(dtype)
         gam, lam = 1.0 / (m * n / 3.0), 1.0
         mko = lambda: O.LinearLeastSquares(A.astype(np.float64), b.astype(np.float64))      # noqa: E731
-    K = 12 if n < 60000 else (6 if n < 160000 else 4)          # (the widest rows: the CPU oracle's products on a 6 GB matrix are the test's time)
+    K = 8 if n < 60000 else (6 if n < 160000 else 4)          # (the CPU oracle's products are this test's time: on a 6 GB matrix for the widest rows)
     x0 = (0.01 * rng.standard_normal(nx)).astype(dtype)
     ro = []
     # Float32 data: the oracle in its Float32-STORAGE mode (vectors rounded to Float32 where the product stores them, the logistic
@@ -297,6 +297,12 @@ def test_one_pass_every_rule_termination_and_stepping(apx):
                                              (4098, 150000, "tl1", np.float64),
                                              (4100, 12000, "tl1", np.float64),     # teams of two, five vectors, three slots (round 4)
                                              (4099, 80000, "tbox", np.float64),    # teams of eight, eight vectors, three slots (round 4)
+                                             # Float32 teams in the primal-dual form (round 5: rows of 11 265 ... 225 280 Float32 entries)
+                                             (4100, 11265, "tl1", np.float32),     # teams of two, two vectors
+                                             (4099, 28160, "tbox", np.float32),    # teams of two, five vectors
+                                             (4098, 50001, "tl2", np.float32),     # teams of four, the l2 ball
+                                             (4097, 90112, "tl1", np.float32),     # teams of eight
+                                             (4100, 200000, "tl1", np.float32),    # teams of sixteen
                                              # Float32 on k_multi_rows (round 3)
                                              (70000, 300, "tl1", np.float32),
                                              (4099, 5001, "tbox", np.float32),
@@ -319,7 +325,7 @@ def test_one_pass_primal_dual_matches_oracle_and_two_passes(apx, m, n, hkind, dt
     mk_h = {"tl1": lambda M: M.Translate(M.NormL1(1.0), -yv.astype(np.float64) if M is O else -yv),
             "tbox": lambda M: M.Translate(M.IndBox(-0.5, 0.8), -yv.astype(np.float64) if M is O else -yv),
             "tl2": lambda M: M.Translate(M.NormL2(1.0), -yv.astype(np.float64) if M is O else -yv)}[hkind]
-    K = 10 if (n < 60000 or hkind == "tl2") else 6          # (the l2 ball's x leaves 0 only around iteration 8)
+    K = 10 if hkind == "tl2" else (8 if n < 60000 else 6)          # (the l2 ball's x leaves 0 only around iteration 8)
     lam = 0.05 if hkind == "tl2" else 5.0      # (the l2 ball: |A' y| <= 2 ||y|| or so, and y grows from 0 in steps of sigma b — a larger lambda keeps x at 0 for these ten iterations)
     x0, y0 = np.zeros(n, dtype=dtype), np.zeros(m, dtype=dtype)
     ro = []
