@@ -258,7 +258,7 @@ int32_t apx_ctx_fused_small(apx_ctx* ctx, int32_t enable);
  *     which a matrix of up to 16 GB is given when a solver is created on it (apx_ctx_auto_transpose).
  *   - rows short enough for one workgroup's registers (Float64 <= 11 264 entries, Float32 <= 22 528) need nothing else.
  *   - rows beyond that (BASELINE config C2's 100 000, C5's 20 000 ; Float64 up to 180 224 entries, Float32 up to 225 280 — the
- *     primal-dual loop Float64 only) are split over TEAMS of 2 / 4 / 8 / 16 workgroups that
+ *     primal-dual loop alike since round 5) are split over TEAMS of 2 / 4 / 8 / 16 workgroups that
  *     hand their partial dot products over through the XCD's L2 (csrc/team_rows.h).  The teams need the part's 8 XCDs x 32 CUs
  *     to themselves: all 256 workgroups of a launch resident together.  That the kernel FITS (one workgroup per CU) is asked of
  *     the runtime when the problem is set up ; that the CUs are FREE cannot be known in advance, so every hand-off wait is
