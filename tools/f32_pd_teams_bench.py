@@ -1,7 +1,7 @@
 """Float32 teams in the primal-dual form (round 5): a 16 GB Float32 LAD-type problem (Condat-Vu steps) on the one-pass team kernels against
 the two GEMV passes, three row lengths.  One JSON line each ; profiles/r05_f32_pd_teams.jsonl.  `python tools/f32_pd_teams_bench.py`."""
-import sys, json, time, numpy as np
-sys.path.insert(0,'/root/repo')
+import os, sys, json, time, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import adaprox_amd as apx
 for (m,n) in ((200000,20000),(60000,60000),(40000,100000)):
     out={}

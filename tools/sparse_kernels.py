@@ -3,7 +3,7 @@ times of `X w` and `X' r` from the library's own statistics — with the round-5
 (APX_OPT_SPARSE_WINDOWS: L2 windows of the gathered operand, three strides per group).  One JSON line per dtype and setting ;
 profiles/r05_sparse_kernels_windows_ab.jsonl.  `python tools/sparse_kernels.py` on an MI355X."""
 import os, sys, json, time, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import adaprox_amd as apx
 from importlib import import_module
 L=import_module("adaptive-proximal-algorithms_amd._lib")
