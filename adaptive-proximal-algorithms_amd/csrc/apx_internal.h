@@ -159,6 +159,9 @@ struct apx_matrix {
   int64_t* rwin = nullptr;     // rows of A, windows over the n columns (operand x)
   int64_t* twin = nullptr;     // rows of A', windows over the m rows (operand r)
   int32_t rwin_count = 0, twin_count = 0;
+  // problems created on this matrix and not yet destroyed: a solver of theirs may hold pointers into the column-major storage (the
+  // small-size kernels), so apx_matrix_drop_primary refuses while there are any
+  mutable int64_t users = 0;
   mutable apx_matrix* dense_view = nullptr;
 };
 

@@ -605,6 +605,7 @@ int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda) {
       APX_HIP(hipMemcpy2DAsync((char*)host + (size_t)i0 * es, (size_t)lda * es, stage.p, (size_t)rows * es, (size_t)ni * es, (size_t)A->n,
                                hipMemcpyDeviceToHost, A->ctx->stream));
     }
+    APX_HIP(hipStreamSynchronize(A->ctx->stream));      // (the staging buffer goes out of scope)
   }
   APX_HIP(hipStreamSynchronize(A->ctx->stream));
   return APX_OK;
@@ -704,6 +705,8 @@ int32_t apx_matrix_drop_primary(apx_matrix* A) {
   APX_REQUIRE(A != nullptr, "apx_matrix_drop_primary: A is NULL");
   APX_REQUIRE(!A->sparse, "apx_matrix_drop_primary: dense matrices only");
   if (A->d == nullptr) return APX_OK;                              // rows-only already
+  APX_REQUIRE(A->users == 0, "apx_matrix_drop_primary: problems created on this matrix still exist — their solvers may be reading its "
+                             "column-major storage (the small-size kernels): drop the primary copy before creating problems, or destroy them first");
   if (A->dT == nullptr) APX_TRY(apx_matrix_build_transpose(A));   // (both copies are resident for the moment of the transpose)
   APX_HIP(hipSetDevice(A->ctx->device));
   APX_HIP(hipStreamSynchronize(A->ctx->stream));

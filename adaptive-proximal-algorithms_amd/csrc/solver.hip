@@ -375,6 +375,10 @@ int32_t apx_problem_create(apx_ctx* ctx, const apx_problem_desc* d, apx_problem*
   APX_TRY(init_ctrl(p.get(), &r, 0.0));
   ctx_retain(ctx);
   comm_retain(p->comm);
+  p->held[0] = d->A_f;
+  p->held[1] = d->A_lin;
+  for (const apx_matrix* M : p->held)
+    if (M != nullptr) M->users += 1;
   *out = p.release();
   return APX_OK;
 }
@@ -386,6 +390,8 @@ int32_t apx_problem_destroy(apx_problem* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     apx_ctx* ctx = p->ctx;
     apx_comm* comm = p->comm;
+    for (const apx_matrix* M : p->held)
+      if (M != nullptr) M->users -= 1;
     delete p;
     comm_release(comm);
     ctx_release(ctx);

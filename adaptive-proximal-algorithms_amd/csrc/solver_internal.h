@@ -32,6 +32,7 @@ struct apx_problem {
   int64_t n = 0, m = 0, n_pad = 0, m_pad = 0;
   const apx_matrix* A_f = nullptr;
   const apx_matrix* A_lin = nullptr;
+  const apx_matrix* held[2] = {nullptr, nullptr};      // the caller's handles (A_f / A_lin above may be their dense views): apx_matrix::users
   apx_eval_fn eval_cb = nullptr;
   apx_pullback_fn pb_cb = nullptr;
   void* cb_user = nullptr;

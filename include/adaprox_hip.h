@@ -399,7 +399,8 @@ int32_t apx_matrix_download(const apx_matrix* A, void* host, int64_t lda);
  *                    upload / download (transposing through a 256 MB staging buffer).  The small-size kernel families
  *                    (apx_ctx_fused_small) read column-major storage and do not apply: this layout is for matrices that fill HBM.
  * apx_matrix_drop_primary turns a column-major matrix into a rows-only one (building the row copy first if it is not there:
- * both are resident for that moment) ; apx_matrix_layout reports bit 0 = column-major storage present, bit 1 = row storage
+ * both are resident for that moment ; APX_ERR_INVALID while problems created on the matrix exist — a solver of theirs may be
+ * reading the column-major storage) ; apx_matrix_layout reports bit 0 = column-major storage present, bit 1 = row storage
  * present (0 for a sparse matrix). */
 enum { APX_LAYOUT_COLS = 0, APX_LAYOUT_ROWS = 1 };
 int32_t apx_matrix_create_layout(apx_ctx* ctx, int64_t m, int64_t n, int32_t dtype, int32_t layout, apx_matrix** out);

@@ -197,3 +197,28 @@ def test_a_live_solver_survives_an_edit_of_a_rows_only_matrix(apx):
     # the last evaluation really used the scaled matrix: f(x9) = 0.5 ||0.5 A x9 - b||^2 is what the record says
     s.close()
     dA.free()
+
+
+def test_drop_primary_waits_for_the_problems_on_the_matrix(apx):
+    """A solver on a SMALL problem holds pointers into the column-major storage (the small-size kernels read it): the primary copy
+    cannot be taken away under it — APX_ERR_INVALID while problems created on the matrix exist, fine once they are gone."""
+    rng = np.random.default_rng(4)
+    A = np.asfortranarray(rng.uniform(-1, 1, (300, 200)))
+    b = rng.standard_normal(300)
+    ctx = apx.Context(0)
+    dA = apx.DeviceMatrix.from_numpy(A, ctx)
+    s = apx.Solver(np.zeros(200), f=apx.LinearLeastSquares(dA, b, ctx=ctx), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-3), tol=0.0, ctx=ctx)
+    s.step(3, sync=True)
+    with pytest.raises(apx.ApxInvalid, match="problems created on this matrix"):
+        dA.drop_primary()
+    s.step(3, sync=True)
+    x_small, _, _ = s.result()
+    s.close()
+    assert dA.drop_primary().layout == "rows"
+    s2 = apx.Solver(np.zeros(200), f=apx.LinearLeastSquares(dA, b, ctx=ctx), g=apx.NormL1(1.0), rule=apx.OurRule(gamma=1e-3), tol=0.0, ctx=ctx)
+    s2.step(6, sync=True)
+    x_rows, _, _ = s2.result()
+    s2.close()
+    assert _rel(x_rows, x_small) <= 1e-12 and np.any(x_small != 0)      # (the generic kernels on the row storage: the same six iterations)
+    dA.free()
+
