@@ -152,13 +152,21 @@ struct apx_matrix {
   // a small sparse matrix also keeps a dense copy, built on first use (apx::small_dense_view): the small-size
   // execution policy (apx_ctx_fused_small) runs on dense storage
   int64_t r_maxlen = 0, t_maxlen = 0;   // longest row of A / of A' (entries)
-  // L2 windows of the gathered operand (round 5, sparse.hip): a product whose operand is larger than an XCD's L2 keeps next to
-  // the streams (X' r with a million rows: 8 MB) is run window by window of the operand — the entries of a compressed row are
-  // sorted by index, so a row splits into W contiguous runs.  rwin / twin: (W + 1) pointer slabs of nrows_pad entries each
-  // (slab 0 = the row starts, slab W = the row ends) ; nullptr where the operand is small or the indices were not sorted.
-  int64_t* rwin = nullptr;     // rows of A, windows over the n columns (operand x)
-  int64_t* twin = nullptr;     // rows of A', windows over the m rows (operand r)
+  // Round 5 (sparse.hip), per orientation (r: rows of A, operand x ; t: rows of A', operand r):
+  //  * L2 WINDOWS of the gathered operand: where it is larger than an XCD's L2 keeps next to the streams (X' r with a million rows:
+  //    8 MB) the entries are stored WINDOW-MAJOR — all rows' entries whose index falls into window 0, then window 1, ... — and the
+  //    product runs window by window.  win: W slabs of nrows + 1 pointers into ind / val (each slab a CSR of its own) ; nullptr where
+  //    the operand is small, the rows are the long-row form's or the caller's indices were not sorted.  With it, ptr no longer
+  //    describes ind / val (only the row lengths).
+  //  * ROW BLOCKS of the streaming form (spmv_stream): consecutive rows whose entries together fill a workgroup's LDS tile ;
+  //    blk: first rows, concatenated per window, blk_off[w] .. blk_off[w + 1] the entries of window w (one "window" without win) ;
+  //    a window whose rows do not fit a tile has no blocks and runs on the lanes-per-row kernel.
+  int64_t* rwin = nullptr;
+  int64_t* twin = nullptr;
   int32_t rwin_count = 0, twin_count = 0;
+  int32_t* rblk = nullptr;
+  int32_t* tblk = nullptr;
+  std::vector<int32_t> rblk_off, tblk_off;
   // problems created on this matrix and not yet destroyed: a solver of theirs may hold pointers into the column-major storage (the
   // small-size kernels), so apx_matrix_drop_primary refuses while there are any
   mutable int64_t users = 0;

@@ -619,7 +619,7 @@ int32_t apx_matrix_free(apx_matrix* A) {
     if (A->dense_view) apx_matrix_free(A->dense_view);
     if (A->d) (void)hipFree(A->d);
     if (A->dT) (void)hipFree(A->dT);
-    for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval, (void*)A->rwin, (void*)A->twin})
+    for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval, (void*)A->rwin, (void*)A->twin, (void*)A->rblk, (void*)A->tblk})
       if (q) (void)hipFree(q);
     apx_ctx* ctx = A->ctx;
     delete A;

@@ -152,6 +152,70 @@ static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* 
   launch_rows_pp<T, OUT>(ctx, G, ptr, ptr + 1, ind, val, x, out, nrows, nrows_pad, done, avg);
 }
 
+// The STREAMING form (round 5): the entries of a block of consecutive rows — up to kStreamTile of them, whole rows only — are
+// loaded without regard to the rows (every lane of every load instruction busy, the loads perfectly coalesced), multiplied with
+// the gathered operand and left in LDS ; then eight lanes per row add each row's run of products in a fixed order.  One barrier
+// per tile, no pointer-dependent load in front of the stream.  For matrices whose rows all fit a tile (row blocks built at upload).
+constexpr int kStreamU = 8;
+constexpr int kStreamTile = kBlock * kStreamU;      // 2048 entries: 16 KB of products
+template <typename T, typename OUT>
+__global__ __launch_bounds__(kBlock) void spmv_stream(const int32_t* __restrict__ blk, const int64_t* __restrict__ ptr,
+                                                      const int32_t* __restrict__ ind, const T* __restrict__ val,
+                                                      const T* __restrict__ x, OUT* __restrict__ out, int64_t nrows, int64_t nrows_pad,
+                                                      const int* __restrict__ done) {
+  __shared__ double prod[kStreamTile];
+  if (done != nullptr && *done != 0) return;
+  const int r0 = blk[blockIdx.x], r1 = blk[blockIdx.x + 1];
+  const int64_t k0 = ptr[r0], k1 = ptr[r1];
+  if (k1 - k0 > kStreamTile) {                       // ONE row longer than a tile (the host makes it a block of its own): the whole
+    double s = 0.0;                                  // workgroup strides over it, then a fixed tree over the 256 partial sums
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += kBlock) s = fma((double)val[k], (double)x[ind[k]], s);
+    prod[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = kBlock / 2; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) prod[threadIdx.x] += prod[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[r0] = (OUT)prod[0];
+    if (blockIdx.x == gridDim.x - 1)
+      for (int64_t row = nrows + threadIdx.x; row < nrows_pad; row += kBlock) out[row] = (OUT)0;
+    return;
+  }
+  int32_t j[kStreamU];
+  double v[kStreamU];
+#pragma unroll
+  for (int u = 0; u < kStreamU; ++u) {
+    const int64_t kk = k0 + threadIdx.x + (int64_t)u * kBlock;
+    const bool ok = kk < k1;
+    j[u] = ok ? ind[kk] : 0;
+    v[u] = ok ? (double)val[kk] : 0.0;
+  }
+  // (the rows' bounds for the second phase, asked for while the entries are in flight: eight lanes per row, 32 rows per round)
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  int64_t a0 = 0, a1 = 0;
+  if (r0 + grp < r1) {
+    a0 = ptr[r0 + grp];
+    a1 = ptr[r0 + grp + 1];
+  }
+#pragma unroll
+  for (int u = 0; u < kStreamU; ++u) prod[threadIdx.x + u * kBlock] = v[u] * (double)x[j[u]];
+  __syncthreads();
+  for (int row = r0 + grp; row < r1; row += kBlock / 8) {
+    if (row != r0 + grp) {
+      a0 = ptr[row];
+      a1 = ptr[row + 1];
+    }
+    double s = 0.0;
+    for (int64_t i = a0 - k0 + sub; i < a1 - k0; i += 8) s += prod[i];
+    s += __shfl_down(s, 4, 8);
+    s += __shfl_down(s, 2, 8);
+    s += __shfl_down(s, 1, 8);
+    if (sub == 0) out[row] = (OUT)s;
+  }
+  if (blockIdx.x == gridDim.x - 1)                  // rows in [nrows, nrows_pad) get exact zeros
+    for (int64_t row = nrows + threadIdx.x; row < nrows_pad; row += kBlock) out[row] = (OUT)0;
+}
+
 // L2 WINDOWS of the gathered operand (round 5).  tools/gather_probe.hip: one 8-byte gather per stored entry runs at 2.0 TB/s of the
 // entries' 12 bytes while the operand (0.8 MB) stays in an XCD's L2 and at 1.1 TB/s when it does not (8 MB: X' r of a
 // 1 000 000-row X).  The entries of a compressed row are sorted by index, so the product can be run WINDOW BY WINDOW of the
@@ -161,15 +225,28 @@ static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* 
 // atomics.  The launches follow each other on the stream, so the chip gathers from ONE window at a time.
 constexpr int64_t kWindowBytes = (int64_t)1 << 21;       // 2 MB of operand per window: half an XCD's L2
 static int64_t window_elems(int32_t dtype) { return kWindowBytes / (int64_t)dtype_size(dtype); }
-template <typename T>
-static void launch_windows(apx_ctx* ctx, int W, const int64_t* win, const int32_t* ind, const void* val, const void* x,
-                           int64_t nnz, int64_t nrows, int64_t nrows_pad, const int* done) {
+
+// one orientation's product: window by window (W >= 1 slabs of nrows + 1 pointers), or the whole rows (win == nullptr: ptr) ;
+// each window by the streaming form where it has row blocks, else by the lanes-per-row kernel.  OUT: double partials into `out`
+// ([W][nrows_pad], one split per window) — or, without windows, whatever the caller's output type is.
+template <typename T, typename OUT>
+static void launch_side(apx_ctx* ctx, int W, const int64_t* win, const int64_t* ptr, const int32_t* blk, const std::vector<int32_t>& blk_off,
+                        const int32_t* ind, const void* val, const void* x, OUT* out, int64_t nnz, int64_t nrows, int64_t nrows_pad,
+                        const int* done) {
+  const int nw = win != nullptr ? W : 1;
+  const double avg = nrows > 0 ? (double)nnz / (double)nrows / (double)nw : 0.0;
   int g = 1;
-  const double avg = nrows > 0 ? (double)nnz / (double)nrows / (double)W : 0.0;
   while (g < 64 && g * 2 <= avg) g *= 2;
-  for (int w = 0; w < W; ++w)
-    launch_rows_pp<T, double>(ctx, g, win + (int64_t)w * nrows_pad, win + (int64_t)(w + 1) * nrows_pad, ind, val, x,
-                              ctx->part + (int64_t)w * nrows_pad, nrows, nrows_pad, done, avg);
+  for (int w = 0; w < nw; ++w) {
+    const int64_t* p = win != nullptr ? win + (int64_t)w * (nrows + 1) : ptr;
+    OUT* o = out + (int64_t)w * nrows_pad;
+    const int nb = blk != nullptr && (int)blk_off.size() > w + 1 ? blk_off[w + 1] - blk_off[w] - 1 : 0;
+    if (nb > 0)
+      hipLaunchKernelGGL((spmv_stream<T, OUT>), dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream, blk + blk_off[w], p, ind, (const T*)val,
+                         (const T*)x, o, nrows, nrows_pad, done);
+    else
+      launch_rows_pp<T, OUT>(ctx, g, p, p + 1, ind, val, x, o, nrows, nrows_pad, done, avg);
+  }
 }
 
 // LONG rows (few rows, thousands of entries each: A' of a tall LIBSVM matrix — covtype is 581 012 x 54 — or A of a
@@ -241,6 +318,15 @@ static void spmv_name(apx_ctx* ctx, int kind, const apx_matrix* A, bool lng, int
   ctx->kname[kind] = b;
 }
 
+static void side_name(apx_ctx* ctx, int kind, const apx_matrix* A, int W, const int32_t* blk) {
+  if (!ctx->profile) return;
+  char b[160];
+  const char* t = A->dtype == APX_F32 ? "float" : "double";
+  if (W > 0) snprintf(b, sizeof b, "%s<%s> in %d L2 windows of the gathered operand (%d launches)", blk ? "spmv_stream" : "spmv_rows", t, W, W);
+  else snprintf(b, sizeof b, "spmv_stream<%s>", t);
+  ctx->kname[kind] = b;
+}
+
 int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
   int chunks = 1;
   if (long_rows(A->nnz, A->m, A->ld, A->r_maxlen, &chunks)) {      // every chunk is one fp64 split of A x
@@ -254,16 +340,16 @@ int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
     *splits_out = chunks;
     return APX_OK;
   }
-  if (A->rwin != nullptr) {                                         // the operand x does not fit an L2 window: one split per window
-    const int W = A->rwin_count;
-    APX_TRY(ensure_part(ctx, (size_t)W * A->ld * sizeof(double)));
-    spmv_name(ctx, APX_KSTAT_GEMV_N, A, false, -W);
+  if (A->rwin != nullptr || A->rblk != nullptr) {                   // windows of x (one split each) and / or the streaming form
+    const int W = A->rwin != nullptr ? A->rwin_count : 0;
+    APX_TRY(ensure_part(ctx, (size_t)std::max(W, 1) * A->ld * sizeof(double)));
+    side_name(ctx, APX_KSTAT_GEMV_N, A, W, A->rblk);
     APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, spmv_bytes(A)));
-    if (A->dtype == APX_F32) launch_windows<float>(ctx, W, A->rwin, A->rind, A->rval, x, A->nnz, A->m, A->ld, done);
-    else launch_windows<double>(ctx, W, A->rwin, A->rind, A->rval, x, A->nnz, A->m, A->ld, done);
+    if (A->dtype == APX_F32) launch_side<float, double>(ctx, W, A->rwin, A->rptr, A->rblk, A->rblk_off, A->rind, A->rval, x, ctx->part, A->nnz, A->m, A->ld, done);
+    else launch_side<double, double>(ctx, W, A->rwin, A->rptr, A->rblk, A->rblk_off, A->rind, A->rval, x, ctx->part, A->nnz, A->m, A->ld, done);
     APX_TRY(prof_end(ctx));
     APX_HIP(hipGetLastError());
-    *splits_out = W;
+    *splits_out = std::max(W, 1);
     return APX_OK;
   }
   APX_TRY(ensure_part(ctx, (size_t)A->ld * sizeof(double)));
@@ -292,16 +378,25 @@ int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* ou
     APX_HIP(hipGetLastError());
     return launch_sum_partials_rows(ctx, A->dtype, chunks, A->n_pad, A->n_pad, out, done);
   }
-  if (A->twin != nullptr) {                                         // the operand r does not fit an L2 window
+  if (A->twin != nullptr) {                                         // the operand r does not fit an L2 window: a partial per window
     const int W = A->twin_count;
     APX_TRY(ensure_part(ctx, (size_t)W * A->n_pad * sizeof(double)));
-    spmv_name(ctx, APX_KSTAT_GEMV_T, A, false, -W);
+    side_name(ctx, APX_KSTAT_GEMV_T, A, W, A->tblk);
     APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, spmv_bytes(A)));
-    if (A->dtype == APX_F32) launch_windows<float>(ctx, W, A->twin, A->tind, A->tval, r, A->nnz, A->n, A->n_pad, done);
-    else launch_windows<double>(ctx, W, A->twin, A->tind, A->tval, r, A->nnz, A->n, A->n_pad, done);
+    if (A->dtype == APX_F32) launch_side<float, double>(ctx, W, A->twin, A->tptr, A->tblk, A->tblk_off, A->tind, A->tval, r, ctx->part, A->nnz, A->n, A->n_pad, done);
+    else launch_side<double, double>(ctx, W, A->twin, A->tptr, A->tblk, A->tblk_off, A->tind, A->tval, r, ctx->part, A->nnz, A->n, A->n_pad, done);
     APX_TRY(prof_end(ctx));
     APX_HIP(hipGetLastError());
     return launch_sum_partials_rows(ctx, A->dtype, W, A->n_pad, A->n_pad, out, done);
+  }
+  if (A->tblk != nullptr) {                                         // the streaming form over whole rows, straight into the output
+    side_name(ctx, APX_KSTAT_GEMV_T, A, 0, A->tblk);
+    APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, spmv_bytes(A)));
+    if (A->dtype == APX_F32) launch_side<float, float>(ctx, 0, nullptr, A->tptr, A->tblk, A->tblk_off, A->tind, A->tval, r, (float*)out, A->nnz, A->n, A->n_pad, done);
+    else launch_side<double, double>(ctx, 0, nullptr, A->tptr, A->tblk, A->tblk_off, A->tind, A->tval, r, (double*)out, A->nnz, A->n, A->n_pad, done);
+    APX_TRY(prof_end(ctx));
+    APX_HIP(hipGetLastError());
+    return APX_OK;
   }
   const int G = group_for(A->nnz, A->n);
   spmv_name(ctx, APX_KSTAT_GEMV_T, A, false, G);
@@ -352,45 +447,95 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
   };
   const void *p0 = ptr, *i0 = idx, *v0 = vals, *p1 = tptr.data(), *i1 = tind.data(), *v1 = tval.data();
   if (layout == 1) { std::swap(p0, p1); std::swap(i0, i1); std::swap(v0, v1); }
-  APX_TRY(up((void**)&A->rptr, p0, (size_t)(A->m + 1) * sizeof(int64_t)));
-  APX_TRY(up((void**)&A->rind, i0, (size_t)nnz * sizeof(int32_t)));
-  APX_TRY(up(&A->rval, v0, (size_t)nnz * sizeof(T)));
-  APX_TRY(up((void**)&A->tptr, p1, (size_t)(A->n + 1) * sizeof(int64_t)));
-  APX_TRY(up((void**)&A->tind, i1, (size_t)nnz * sizeof(int32_t)));
-  APX_TRY(up(&A->tval, v1, (size_t)nnz * sizeof(T)));
   const int64_t* rp = (const int64_t*)p0;
   const int64_t* tp = (const int64_t*)p1;
   for (int64_t i = 0; i < A->m; ++i) A->r_maxlen = std::max(A->r_maxlen, rp[i + 1] - rp[i]);
   for (int64_t j = 0; j < A->n; ++j) A->t_maxlen = std::max(A->t_maxlen, tp[j + 1] - tp[j]);
-  // the window tables (launch_windows): for an orientation whose gathered operand is longer than a window and a half, whose rows
-  // are not the long-row form's, and whose indices are sorted within every row (the transposed side always is: a stable
-  // counting sort over rows in order ; the caller's side is checked)
-  auto windows = [&](const int64_t* ptr_h, const int32_t* ind_h, int64_t nrows, int64_t nrows_pad, int64_t ncols, int64_t maxlen,
-                     int64_t** dev, int32_t* count) -> int32_t {
-    const int64_t we = window_elems(A->dtype);
-    int chunks = 0;
-    if (ctx->sparse_windows == 0 || ncols <= we + we / 2 || nnz == 0 || long_rows(nnz, nrows, nrows_pad, maxlen, &chunks)) return APX_OK;
-    const int W = (int)((ncols + we - 1) / we);
-    if (W > 64) return APX_OK;
-    for (int64_t i = 0; i < nrows; ++i)
-      for (int64_t k = ptr_h[i] + 1; k < ptr_h[i + 1]; ++k)
-        if (ind_h[k] < ind_h[k - 1]) return APX_OK;                    // unsorted row: the plain kernel
-    std::vector<int64_t> tab((size_t)(W + 1) * (size_t)nrows_pad, 0);
-    for (int64_t i = 0; i < nrows; ++i) {
-      const int32_t* b = ind_h + ptr_h[i];
-      const int32_t* e = ind_h + ptr_h[i + 1];
-      tab[(size_t)i] = ptr_h[i];
-      for (int w = 1; w < W; ++w)
-        tab[(size_t)w * nrows_pad + i] = ptr_h[i] + (std::lower_bound(b, e, (int32_t)std::min<int64_t>((int64_t)w * we, 2147483647LL)) - b);
-      tab[(size_t)W * nrows_pad + i] = ptr_h[i + 1];
-    }
-    APX_TRY(up((void**)dev, tab.data(), tab.size() * sizeof(int64_t)));
-    APX_HIP(hipStreamSynchronize(ctx->stream));      // (tab dies with this lambda's frame)
-    *count = W;
-    return APX_OK;
+  // What an orientation gets besides its rows (launch_side): the WINDOW-MAJOR order of its entries with a table of W CSR slabs, where
+  // its gathered operand is longer than a window and a half, its rows are not the long-row form's and the indices are sorted within
+  // every row (the transposed side always is: a stable counting sort over rows in order ; the caller's side is checked) ; and the ROW
+  // BLOCKS of the streaming form, per window, where every row (of that window) fits a tile and the rows are not too short for it.
+  struct Side {
+    std::vector<int64_t> win;
+    std::vector<int32_t> ind, blk, blk_off;
+    std::vector<T> val;
+    int W = 0;
   };
-  APX_TRY(windows((const int64_t*)p0, (const int32_t*)i0, A->m, A->ld, A->n, A->r_maxlen, &A->rwin, &A->rwin_count));
-  APX_TRY(windows((const int64_t*)p1, (const int32_t*)i1, A->n, A->n_pad, A->m, A->t_maxlen, &A->twin, &A->twin_count));
+  auto plan = [&](const int64_t* ptr_h, const int32_t* ind_h, const T* val_h, int64_t nrows, int64_t nrows_pad, int64_t ncols, int64_t maxlen,
+                  Side& sd) {
+    int chunks = 0;
+    if (ctx->sparse_windows == 0 || nnz == 0 || nrows == 0 || nrows >= 2147483647LL || long_rows(nnz, nrows, nrows_pad, maxlen, &chunks)) return;
+    const int64_t we = window_elems(A->dtype);
+    int W = ncols > we + we / 2 ? (int)((ncols + we - 1) / we) : 0;
+    if (W > 64) W = 0;
+    if (W > 0)
+      for (int64_t i = 0; i < nrows && W > 0; ++i)
+        for (int64_t k = ptr_h[i] + 1; k < ptr_h[i + 1]; ++k)
+          if (ind_h[k] < ind_h[k - 1]) { W = 0; break; }               // an unsorted row: whole rows, in the caller's order
+    const int64_t stride = nrows + 1;
+    if (W > 0) {
+      // cut[w * stride + i]: first entry of row i with index >= w * we (relative to the row) ; then the window-major offsets
+      sd.win.assign((size_t)W * (size_t)stride, 0);
+      std::vector<int64_t> cut((size_t)(W + 1) * (size_t)nrows);
+      for (int64_t i = 0; i < nrows; ++i) {
+        const int32_t* b = ind_h + ptr_h[i];
+        const int32_t* e = ind_h + ptr_h[i + 1];
+        cut[(size_t)i] = 0;
+        for (int w = 1; w < W; ++w) cut[(size_t)w * nrows + i] = std::lower_bound(b, e, (int32_t)std::min<int64_t>((int64_t)w * we, 2147483647LL)) - b;
+        cut[(size_t)W * nrows + i] = e - b;
+      }
+      sd.ind.resize((size_t)nnz);
+      sd.val.resize((size_t)nnz);
+      int64_t pos = 0;
+      for (int w = 0; w < W; ++w) {
+        int64_t* slab = sd.win.data() + (size_t)w * stride;
+        for (int64_t i = 0; i < nrows; ++i) {
+          slab[i] = pos;
+          const int64_t a = ptr_h[i] + cut[(size_t)w * nrows + i], e = ptr_h[i] + cut[(size_t)(w + 1) * nrows + i];
+          for (int64_t k = a; k < e; ++k, ++pos) {
+            sd.ind[(size_t)pos] = ind_h[k];
+            sd.val[(size_t)pos] = val_h[k];
+          }
+        }
+        slab[nrows] = pos;
+      }
+      sd.W = W;
+    }
+    // row blocks, per window (or over whole rows): <= kStreamTile entries and <= 256 rows each
+    const int nw = std::max(W, 1);
+    if (nnz / nrows / nw < 4) return;                                   // (rows too short for eight lanes each: the lanes-per-row kernel)
+    sd.blk_off.assign(1, 0);
+    for (int w = 0; w < nw; ++w) {
+      const int64_t* q = W > 0 ? sd.win.data() + (size_t)w * stride : ptr_h;
+      sd.blk.push_back(0);                             // (a row longer than a tile ends up as a block of its own: the kernel strides over it)
+      int64_t r0 = 0;
+      for (int64_t r = 1; r < nrows; ++r)
+        if (q[r + 1] - q[r0] > kStreamTile || r - r0 >= 256) {
+          sd.blk.push_back((int32_t)r);
+          r0 = r;
+        }
+      sd.blk.push_back((int32_t)nrows);
+      sd.blk_off.push_back((int32_t)sd.blk.size());
+    }
+    if (sd.blk.empty()) sd.blk_off.clear();
+  };
+  Side sr, st;
+  plan((const int64_t*)p0, (const int32_t*)i0, (const T*)v0, A->m, A->ld, A->n, A->r_maxlen, sr);
+  plan((const int64_t*)p1, (const int32_t*)i1, (const T*)v1, A->n, A->n_pad, A->m, A->t_maxlen, st);
+  APX_TRY(up((void**)&A->rptr, p0, (size_t)(A->m + 1) * sizeof(int64_t)));
+  APX_TRY(up((void**)&A->rind, sr.W ? (const void*)sr.ind.data() : i0, (size_t)nnz * sizeof(int32_t)));
+  APX_TRY(up(&A->rval, sr.W ? (const void*)sr.val.data() : v0, (size_t)nnz * sizeof(T)));
+  APX_TRY(up((void**)&A->tptr, p1, (size_t)(A->n + 1) * sizeof(int64_t)));
+  APX_TRY(up((void**)&A->tind, st.W ? (const void*)st.ind.data() : i1, (size_t)nnz * sizeof(int32_t)));
+  APX_TRY(up(&A->tval, st.W ? (const void*)st.val.data() : v1, (size_t)nnz * sizeof(T)));
+  if (sr.W) APX_TRY(up((void**)&A->rwin, sr.win.data(), sr.win.size() * sizeof(int64_t)));
+  if (st.W) APX_TRY(up((void**)&A->twin, st.win.data(), st.win.size() * sizeof(int64_t)));
+  A->rwin_count = sr.W;
+  A->twin_count = st.W;
+  if (!sr.blk.empty()) APX_TRY(up((void**)&A->rblk, sr.blk.data(), sr.blk.size() * sizeof(int32_t)));
+  if (!st.blk.empty()) APX_TRY(up((void**)&A->tblk, st.blk.data(), st.blk.size() * sizeof(int32_t)));
+  A->rblk_off = sr.blk_off;
+  A->tblk_off = st.blk_off;
   APX_HIP(hipStreamSynchronize(ctx->stream));   // the host staging vectors die with this frame
   return APX_OK;
 }
@@ -411,6 +556,7 @@ __global__ __launch_bounds__(256) void k_densify(const int64_t* __restrict__ rpt
 int32_t small_dense_view(const apx_matrix* A, const apx_matrix** out) {
   *out = A;
   if (A == nullptr || !A->sparse || !A->ctx->fused_small) return APX_OK;
+  if (A->rwin != nullptr) return APX_OK;      // (window-major storage: rptr no longer walks rind / rval row by row — and such a matrix is not small)
   const int64_t m = A->m, n = A->n;
   const bool tall_skinny = n + 1 <= kSkinnyMaxN && m <= 256 * 1024;
   if (!(tall_skinny || small_shape_ok(m, n + 1)) || m <= 0 || n <= 0) return APX_OK;

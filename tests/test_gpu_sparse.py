@@ -54,7 +54,8 @@ def test_sparse_products(apx, m, n, density, fmt, dtype):
 @pytest.mark.parametrize("m,n,per_row,dtype", [(450_000, 10_000, 6, np.float64),      # X' r gathers from 450 000 doubles: 2 windows
                                                (1_100_000, 20_000, 3, np.float32),    # ... from 1.1 M floats: 3 windows
                                                (3_000, 500_000, 300, np.float64),     # X w gathers from 500 000 doubles: 2 windows
-                                               (800_000, 400_000, 2, np.float64)])    # both products windowed (4 and 2)
+                                               (800_000, 400_000, 2, np.float64),     # both products windowed (4 and 2)
+                                               (450_001, 9_000, 7, np.float64)])      # ... and a column / a row too heavy for the streaming tile
 def test_products_in_l2_windows_of_the_gathered_operand(apx, m, n, per_row, dtype):
     """Round 5 (csrc/sparse.hip launch_windows): a product whose gathered operand exceeds 3 MB runs window by window of that
     operand — a partial per row and window, summed in window order.  Against scipy, against the one-launch form (the A/B option, read
@@ -64,6 +65,11 @@ def test_products_in_l2_windows_of_the_gathered_operand(apx, m, n, per_row, dtyp
     nnz_row = np.clip(rng.poisson(per_row, m), 0, n)
     indptr = np.concatenate([[0], np.cumsum(nnz_row)]).astype(np.int64)
     A = sp.csr_matrix((rng.uniform(-1, 1, indptr[-1]).astype(dtype), rng.integers(0, n, indptr[-1]).astype(np.int32), indptr), shape=(m, n))
+    if m == 450_001:      # column 0 with 6000 entries (a row of X' beyond the tile of 2048 in both of its windows), row 5 of X with 3000
+        heavy = sp.csr_matrix((rng.uniform(-1, 1, 9000), (np.concatenate([rng.choice(m, 6000, replace=False), np.full(3000, 5)]),
+                                                           np.concatenate([np.zeros(6000, dtype=np.int64), rng.choice(n, 3000, replace=False)]))),
+                              shape=(m, n))
+        A = (A + heavy).tocsr()
     A.sum_duplicates()
     x = rng.standard_normal(n).astype(dtype)
     r = rng.standard_normal(m).astype(dtype)
@@ -96,6 +102,11 @@ def test_products_in_l2_windows_of_the_gathered_operand(apx, m, n, per_row, dtyp
             assert _rel(out["x_win"], x_plain) <= 1e-10 and np.any(x_plain != 0)
         dA.free()
     assert "L2 windows" in out[1][2][0] or "L2 windows" in out[1][2][1], out[1][2]
+    # the streaming form where every row (of a window) fits its tile — and the lanes-per-row kernel where one does not
+    if m == 450_000:
+        assert out[1][2][0] == "spmv_stream<double>" and out[1][2][1].startswith("spmv_stream<double> in 2 L2 windows"), out[1][2]
+    if m == 450_001:      # (X' row 0 has ~3000 entries in each of its two windows, X row 5 has 3000: blocks of their own in the streaming form)
+        assert out[1][2][0] == "spmv_stream<double>" and out[1][2][1].startswith("spmv_stream<double> in 2 L2 windows"), out[1][2]
     assert "L2 windows" not in out[0][2][0] and "L2 windows" not in out[0][2][1], out[0][2]
     assert ("L2 windows" in out[1][2][1]) == (m * np.dtype(dtype).itemsize > 3 << 20)
     assert ("L2 windows" in out[1][2][0]) == (n * np.dtype(dtype).itemsize > 3 << 20)
