@@ -4,11 +4,14 @@
 // experiments/sparse_logreg/runme.jl:24,31).
 //
 // Both orientations are stored as compressed ROWS (A and A'), built once at upload by a
-// stable counting sort, so that both products are gather-style row dot products: a group of
-// G lanes per row, strided over the row's entries, reduced with width-G shuffles in a fixed
-// order.  No scatter, no atomics => bit-reproducible like the dense path.  Output conventions
+// stable counting sort, so that both products are gather-style row dot products, summed in a
+// fixed order.  No scatter, no atomics => bit-reproducible like the dense path.  Output conventions
 // are those of the dense kernels, so every fused epilogue (residual, logistic link, ...) is
-// shared: spmv_n writes one fp64 "split" into the partial buffer, spmv_t writes T.
+// shared: spmv_n writes fp64 "splits" into the partial buffer, spmv_t writes T.
+// Three kernels: spmv_stream (round 5, the default wherever rows have a few entries each: a block of rows' entries as
+// one run, products through LDS, eight lanes per row — with the gathered operand taken in L2 WINDOWS where it is large,
+// launch_side), spmv_rows (round 1: G lanes per row ; short rows, unsorted input, the A/B option) and spmv_long (few rows of
+// thousands of entries: chunks).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

@@ -316,11 +316,12 @@ enum {
                                     allocation had (on ONE rank of a row shard: the ranks must still agree on the two passes —
                                     tests/two_rank_pd_worker.py)                                                              */
   ,
-  APX_OPT_SPARSE_WINDOWS = 18    /* default 1: a sparse matrix uploaded on this context whose gathered operand (x for A x: n entries ;
-                                    r for A' r: m entries) exceeds 3 MB gets a window table, and that product runs window by window
-                                    of the operand (2 MB: half an XCD's L2) — the gathers then hit L2 (tools/gather_probe.hip: 2.0
-                                    against 1.1 TB/s of the entries' bytes) ; 0: one launch over whole rows (round 1 ; A/B).  Read
-                                    at upload time.                                                                             */
+  APX_OPT_SPARSE_WINDOWS = 18    /* default 1: the round-5 forms of the sparse products, decided when a sparse matrix is uploaded on this
+                                    context — (a) an orientation whose gathered operand (x for A x: n entries ; r for A' r: m entries)
+                                    exceeds 3 MB is stored WINDOW-MAJOR and its product runs window by window of the operand (2 MB: half
+                                    an XCD's L2 ; tools/gather_probe.hip: 2.0 against 1.1 TB/s of the entries' bytes) ; (b) the
+                                    STREAMING form: blocks of rows whose entries are loaded as one run, products through LDS, eight lanes
+                                    per row.  0: round 1's lanes-per-row kernel over whole rows (A/B).                              */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);
