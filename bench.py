@@ -314,22 +314,42 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
     m, n = 100_000, 10_000
     p = problems.device_logreg(m, n, seed=0, lam=0.01, dtype=np.float32, ctx=ctx)
     p.X.drop_primary()                                          # one resident copy: the row storage the one-pass kernels read
-    s = apx.Solver(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(p.X, p.y), g=apx.NormL1(p.lam),
-                   rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
-    # (150 timed iterations after 10: this problem — SURVEY 8d's lambda, step size and generator — is solved to sixteen digits
-    # by iteration 40; in Float32 rounding noise keeps the loop moving until iteration ~230, where it meets an exact fixed point
-    # and the reference's rule lets gamma grow without bound (Float64: by iteration 80).  The kernels do the same work per
-    # iteration either way ; the check below refuses a run whose iterate is no longer finite)
-    dt, st = timed_steps(ctx, s, 150, 10, barrier)
-    x, _, res = s.result()
-    if not np.all(np.isfinite(x)) or int(res.numit) != 160 or res.converged:
-        raise RuntimeError("C3 leg: the loop stopped after %d iterations or left the finite numbers: the timed steps were not all real"
-                           % int(res.numit))
+    # This problem — SURVEY 8d's lambda, step size and generator — reaches the residual 2e-7 at iteration 27 and is solved to sixteen
+    # digits by iteration 40 ; past that the iterations do the same work on the same bytes but their objective says nothing (VERDICT
+    # r4).  So the 150 timed iterations are SIX solves of 25 iterations from x0 = 0, every one of them ahead of convergence: six
+    # solvers created beforehand (set-up and the evaluation in front of the loop are outside the timed region, as for every leg),
+    # 10 warm-up iterations on a seventh, then step(25) on each between the two barriers.
+    mk = lambda: apx.Solver(np.zeros(n + 1, dtype=np.float32), f=apx.LogisticLoss(p.X, p.y), g=apx.NormL1(p.lam),      # noqa: E731
+                            rule=apx.OurRule(gamma=p.gamma0), tol=0.0, ctx=ctx, poll_every=1 << 30)
+    warm = mk()
+    warm.step(10, sync=True)
+    warm.close()
+    solvers = [mk() for _ in range(6)]
+    ctx.kernel_stats(reset=True)
+    ctx.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for s in solvers:
+        s.step(25, sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    st = ctx.kernel_stats(reset=True)
+    ends = [s.result() for s in solvers]
+    x, _, res = ends[-1]
+    real = all(np.all(np.isfinite(xx)) and int(rr.numit) == 25 and not rr.converged for xx, _, rr in ends) and \
+        len({float(rr.objective) for _, _, rr in ends}) == 1 and res.norm_res > 0.0
+    if not real:
+        raise RuntimeError("C3 leg: a solve stopped early, left the finite numbers or differs from the others (%s): the timed steps were not all real"
+                           % [(int(rr.numit), bool(rr.converged), float(rr.objective), float(rr.norm_res)) for _, _, rr in ends])
     out["C3"] = report(m, n, 4, 150, dt, st, res,
                        "f and grad f in ONE pass over X per iteration (csrc/slab.hip): "
                        "two_pass_equivalent_frac prices SURVEY 8d's 2 m n sizeof(T) and may exceed 1; frac is of the bytes read")
     out["C3"]["workload"] = "sparse_logreg, dense synthetic A 100000x10000 fp32, logistic grad + NormL1 prox, adaptive_proxgrad (OurRule)"
-    s.close()
+    out["C3"]["timed_steps_all_real"] = True
+    out["C3"]["protocol"] = "six solves of 25 iterations from x0 = 0 (all ahead of convergence: residual %.2e at their end), bit-identical objectives" % res.norm_res
+    for s in solvers:
+        s.close()
     p.X.free()
 
     # C5: least_absolute_deviation via adaptive_primal_dual (Condat-Vu), A 50 000 x 20 000 fp64
