@@ -159,13 +159,17 @@ static void launch_rows(apx_ctx* ctx, int G, const int64_t* ptr, const int32_t* 
 // loaded without regard to the rows (every lane of every load instruction busy, the loads perfectly coalesced), multiplied with
 // the gathered operand and left in LDS ; then eight lanes per row add each row's run of products in a fixed order.  One barrier
 // per tile, no pointer-dependent load in front of the stream.  For matrices whose rows all fit a tile (row blocks built at upload).
-constexpr int kStreamU = 8;
-constexpr int kStreamTile = kBlock * kStreamU;      // 2048 entries: 16 KB of products
+// (the tile: 4096 entries for Float64 — 32 KB of products, sixteen loads per lane in flight: X w 332 -> 298 us, X' r 369 -> 343 against
+//  2048, and 6144 no better: 299 / 375 ; Float32 keeps 2048: with 4096 its products 300 -> 360 and 320 -> 375 us — measured, one build each)
+template <typename T>
+struct StreamU { static constexpr int value = sizeof(T) == 8 ? 16 : 8; };
+static int64_t stream_tile(int32_t dtype) { return (int64_t)kBlock * (dtype == APX_F32 ? StreamU<float>::value : StreamU<double>::value); }
 template <typename T, typename OUT>
 __global__ __launch_bounds__(kBlock) void spmv_stream(const int32_t* __restrict__ blk, const int64_t* __restrict__ ptr,
                                                       const int32_t* __restrict__ ind, const T* __restrict__ val,
                                                       const T* __restrict__ x, OUT* __restrict__ out, int64_t nrows, int64_t nrows_pad,
                                                       const int* __restrict__ done) {
+  constexpr int kStreamU = StreamU<T>::value, kStreamTile = kBlock * kStreamU;
   __shared__ double prod[kStreamTile];
   if (done != nullptr && *done != 0) return;
   const int r0 = blk[blockIdx.x], r1 = blk[blockIdx.x + 1];
@@ -508,12 +512,13 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
     const int nw = std::max(W, 1);
     if (nnz / nrows / nw < 4) return;                                   // (rows too short for eight lanes each: the lanes-per-row kernel)
     sd.blk_off.assign(1, 0);
+    const int64_t tile = stream_tile(A->dtype);
     for (int w = 0; w < nw; ++w) {
       const int64_t* q = W > 0 ? sd.win.data() + (size_t)w * stride : ptr_h;
       sd.blk.push_back(0);                             // (a row longer than a tile ends up as a block of its own: the kernel strides over it)
       int64_t r0 = 0;
       for (int64_t r = 1; r < nrows; ++r)
-        if (q[r + 1] - q[r0] > kStreamTile || r - r0 >= 256) {
+        if (q[r + 1] - q[r0] > tile || r - r0 >= 256) {
           sd.blk.push_back((int32_t)r);
           r0 = r;
         }
