@@ -22,6 +22,7 @@ module AdaProxHIP
 
 using Logging
 using LinearAlgebra
+using SparseArrays
 import AdaProx
 using ProximalCore: Zero, IndZero
 using ProximalOperators: NormL1, NormL2, IndBox, Translate
@@ -176,6 +177,22 @@ mutable struct HipMatrix{T}
         GC.@preserve A check(ccall((:apx_matrix_upload_layout, LIB), Int32,
             (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Int32, Int32, Ref{Ptr{Cvoid}}),
             ctx.h, pointer(A), m, n, stride(A, 2), dtype_code(T), layout === :rows ? APX_LAYOUT_ROWS : APX_LAYOUT_COLS, out))
+        M = new{T}(ctx, out[], m, n)
+        finalizer(M -> ccall((:apx_matrix_free, LIB), Int32, (Ptr{Cvoid},), M.h), M)
+        return M
+    end
+    # the `SparseMatrixCSC` the experiments load from LIBSVM files (experiments/libsvm.jl:3-61 ; `f.X * w`, `f.X' * r` at
+    # experiments/sparse_logreg/runme.jl:24,31): Julia's colptr / rowval, 0-based, as the CSC layout of apx_matrix_upload_sparse —
+    # the library keeps both orientations as compressed rows and picks its kernels from them (csrc/sparse.hip)
+    function HipMatrix(ctx::Context, A::SparseMatrixCSC{T,<:Integer}) where {T<:Union{Float32,Float64}}
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        m, n = size(A)
+        colptr = Int64.(A.colptr .- 1)
+        rowval = Int32.(A.rowval .- 1)
+        nz = A.nzval
+        GC.@preserve colptr rowval nz check(ccall((:apx_matrix_upload_sparse, LIB), Int32,
+            (Ptr{Cvoid}, Int64, Int64, Int64, Int32, Ptr{Int64}, Ptr{Int32}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}),
+            ctx.h, m, n, length(nz), Int32(1), colptr, rowval, nz, dtype_code(T), out))
         M = new{T}(ctx, out[], m, n)
         finalizer(M -> ccall((:apx_matrix_free, LIB), Int32, (Ptr{Cvoid},), M.h), M)
         return M
