@@ -28,7 +28,7 @@ APX_KSTAT_GEMV_N, APX_KSTAT_GEMV_T, APX_KSTAT_ONE_PASS, APX_KSTAT_COUNT = 0, 1, 
 (APX_OPT_MULTI_ROWS_MASK, APX_OPT_SLAB_GENERATION, APX_OPT_TEAM_WAIT_MS, APX_OPT_TEAM_COOPERATIVE, APX_OPT_TEAM_FAULT_GRID,
  APX_OPT_GEMV_N_VARIANT, APX_OPT_GEMV_T_VARIANT, APX_OPT_GEMV_N_BLOCKS, APX_OPT_GEMV_T_BLOCKS, APX_OPT_FUSED_TAIL,
  APX_OPT_MULTI_WAVES, APX_OPT_TEAM_MEMBERS, APX_OPT_TEAM_SLOTS, APX_OPT_ROW_DEAL, APX_OPT_TEAM_INTERLEAVE, APX_OPT_TEAM_PD_DEFER,
- APX_OPT_FAULT_SETUP, APX_OPT_SPARSE_WINDOWS) = range(1, 19)
+ APX_OPT_FAULT_SETUP, APX_OPT_SPARSE_WINDOWS, APX_OPT_ONE_PASS_MIN_ROWS) = range(1, 20)
 
 c_void_p, c_int32, c_int64, c_double = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 

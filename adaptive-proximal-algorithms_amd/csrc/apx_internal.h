@@ -108,6 +108,7 @@ struct apx_ctx {
   bool team_cooperative = false; // APX_OPT_TEAM_COOPERATIVE
   int team_fault_grid = 0;       // APX_OPT_TEAM_FAULT_GRID (test hook)
   int fault_setup = 0;           // APX_OPT_FAULT_SETUP (test hook)
+  int64_t one_pass_min_rows = 4096;   // APX_OPT_ONE_PASS_MIN_ROWS (test hook: the parity tests of the widest rows use matrices of ~1000 rows)
   int sparse_windows = 1;        // APX_OPT_SPARSE_WINDOWS: a sparse matrix uploaded on this context gets its L2 window tables
   int team_interleave = 1;       // APX_OPT_TEAM_INTERLEAVE
   int team_pd_defer = 1;         // APX_OPT_TEAM_PD_DEFER

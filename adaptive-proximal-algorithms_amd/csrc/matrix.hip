@@ -389,6 +389,10 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       APX_REQUIRE(value >= 0 && value <= 512, "APX_OPT_TEAM_FAULT_GRID: 0 (off) ... 256 workgroups (257 ... 512: with APX_OPT_TEAM_COOPERATIVE only)");
       ctx->team_fault_grid = (int)value;
       return APX_OK;
+    case APX_OPT_ONE_PASS_MIN_ROWS:
+      APX_REQUIRE(value >= 256 && value <= 4096, "APX_OPT_ONE_PASS_MIN_ROWS: 256 ... 4096");
+      ctx->one_pass_min_rows = value;
+      return APX_OK;
     case APX_OPT_SPARSE_WINDOWS:
       APX_REQUIRE(value == 0 || value == 1, "APX_OPT_SPARSE_WINDOWS: 0 or 1");
       ctx->sparse_windows = (int)value;
@@ -444,6 +448,7 @@ int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value) {
     case APX_OPT_TEAM_FAULT_GRID: *value = ctx->team_fault_grid; return APX_OK;
     case APX_OPT_FAULT_SETUP: *value = ctx->fault_setup; return APX_OK;
     case APX_OPT_SPARSE_WINDOWS: *value = ctx->sparse_windows; return APX_OK;
+    case APX_OPT_ONE_PASS_MIN_ROWS: *value = ctx->one_pass_min_rows; return APX_OK;
     case APX_OPT_GEMV_N_VARIANT: *value = ctx->cfg.n_variant; return APX_OK;
     case APX_OPT_GEMV_T_VARIANT: *value = ctx->cfg.t_variant; return APX_OK;
     case APX_OPT_GEMV_N_BLOCKS: *value = ctx->cfg.n_target_blocks; return APX_OK;

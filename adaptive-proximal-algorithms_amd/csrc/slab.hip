@@ -632,7 +632,7 @@ static bool slab_shape_ok(const apx_problem* p) {
   //  entries — 130: 7.7 against 7.0 ms at 6 GB ; the one-column shape with 32 rows per step reversed that: 130: 4.4, 200: 3.0,
   //  300: 2.1 ms against 7.0, 4.9, 3.6 — tools/shape_sweep.py.  Below ~125 columns the tall-skinny family takes over.)
   if (p->A_f->n < 128) return false;
-  return p->A_f->m >= 4096 && p->A_f->m < ((int64_t)1 << 30) && slab_shape(p).bs != 0;
+  return p->A_f->m >= p->ctx->one_pass_min_rows && p->A_f->m < ((int64_t)1 << 30) && slab_shape(p).bs != 0;
 }
 
 // The kernel reads only the transposed copy.  A matrix of up to 16 GB that has none gets one here (the same second

@@ -324,7 +324,7 @@ static bool slab_pd_shape_ok(const apx_problem* p) {
   // (very short rows: with two columns per thread the two passes were faster below 512 entries — 130: 7.0 against 8.8 ms at
   //  6 GB ; with one column per thread and sixteen rows per step: 130: 5.5, 200: 3.6, 450: 1.9 ms against 7.0, 4.9, 2.8)
   if (p->A_lin->n < 128) return false;
-  return p->A_lin->m >= 4096 && p->A_lin->m < ((int64_t)1 << 30) && slab_pd_shape(p).bs != 0;
+  return p->A_lin->m >= p->ctx->one_pass_min_rows && p->A_lin->m < ((int64_t)1 << 30) && slab_pd_shape(p).bs != 0;
 }
 
 // (reads only the transposed copy, which a matrix of up to 16 GB is given here: see slab_eligible)

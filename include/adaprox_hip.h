@@ -322,6 +322,10 @@ enum {
                                     an XCD's L2 ; tools/gather_probe.hip: 2.0 against 1.1 TB/s of the entries' bytes) ; (b) the
                                     STREAMING form: blocks of rows whose entries are loaded as one run, products through LDS, eight lanes
                                     per row.  0: round 1's lanes-per-row kernel over whole rows (A/B).                              */
+  ,
+  APX_OPT_ONE_PASS_MIN_ROWS = 19 /* TEST hook, default 4096: the fewest rows a matrix needs for the one-pass kernels (below, a launch's
+                                    fixed costs outweigh the second pass) ; 256 ... 4096 — the parity tests of the widest rows run on
+                                    matrices of ~1000 rows, so that the CPU oracle beside them takes a second instead of five       */
 };
 int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value);
 int32_t apx_ctx_get_option(apx_ctx* ctx, int32_t key, int64_t* value);
