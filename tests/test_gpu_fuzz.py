@@ -225,7 +225,7 @@ tall_rows = st.one_of(st.integers(2048, 9000), st.sampled_from([2048, 2049, 4095
 skinny_cols = st.one_of(st.integers(1, 40), st.sampled_from([3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 111, 122, 123]))
 
 
-@settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(m=tall_rows, n=skinny_cols, logistic=st.booleans(), f32=st.booleans(), gk=st.sampled_from(["l1", "box", "tl1", "zero"]),
        method=st.sampled_from(["adaptive", "fixed", "bt", "bt_nesterov", "nesterov", "agraal"]), k=st.integers(0, 9),
        records=st.booleans(), seed=st.integers(0, 2**31 - 1))

@@ -248,7 +248,7 @@ def logistic_problem(m, n, seed, lam):
 
 def logistic_liblinear(X, y, lam):
     m = X.shape[0]
-    clf = LogisticRegression(penalty="l1", solver="liblinear", fit_intercept=False, C=1.0 / (m * lam), tol=1e-12,
+    clf = LogisticRegression(penalty="l1", solver="liblinear", fit_intercept=False, C=1.0 / (m * lam), tol=1e-10,
                              max_iter=100_000)
     clf.fit(np.hstack([X, np.ones((m, 1))]), 2 * y - 1)
     return clf.coef_.ravel()
