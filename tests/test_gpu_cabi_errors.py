@@ -68,6 +68,35 @@ def test_null_and_bad_handles(lib, ctx):
     assert lib.apx_solver_destroy(None) == L.APX_OK
 
 
+def test_matrix_layout_entry_points_validate(lib, ctx):
+    """ABI 5: the one-copy layout (apx_matrix_create_layout / upload_layout / drop_primary / layout) and apx_ctx_device_clock
+    through the raw C-ABI — bad layouts and NULLs are status codes, a rows-only matrix refuses to give its only copy away."""
+    h = C.c_void_p()
+    assert lib.apx_matrix_create_layout(ctx, 4, 3, L.APX_F64, 2, C.byref(h)) == L.APX_ERR_INVALID and "layout" in _err(lib)
+    assert lib.apx_matrix_create_layout(ctx, 4, 3, L.APX_F64, L.APX_LAYOUT_ROWS, None) == L.APX_ERR_INVALID
+    assert lib.apx_matrix_upload_layout(ctx, None, 4, 3, 4, L.APX_F64, L.APX_LAYOUT_ROWS, C.byref(h)) == L.APX_ERR_INVALID
+    A = np.asfortranarray(np.arange(12.0).reshape(4, 3))
+    assert lib.apx_matrix_upload_layout(ctx, A.ctypes.data_as(C.c_void_p), 4, 3, 3, L.APX_F64, L.APX_LAYOUT_ROWS, C.byref(h)) == L.APX_ERR_INVALID   # lda < m
+    assert lib.apx_matrix_upload_layout(ctx, A.ctypes.data_as(C.c_void_p), 4, 3, 4, L.APX_F64, L.APX_LAYOUT_ROWS, C.byref(h)) == L.APX_OK
+    mask = C.c_int32(-1)
+    assert lib.apx_matrix_layout(h, C.byref(mask)) == L.APX_OK and mask.value == 2          # the row storage alone
+    assert lib.apx_matrix_layout(h, None) == L.APX_ERR_INVALID and lib.apx_matrix_layout(None, C.byref(mask)) == L.APX_ERR_INVALID
+    assert lib.apx_matrix_drop_transpose(h) == L.APX_ERR_INVALID and "no other copy" in _err(lib)
+    assert lib.apx_matrix_build_transpose(h) == L.APX_OK and lib.apx_matrix_drop_primary(h) == L.APX_OK      # nothing to do, twice
+    out = np.zeros((4, 3), order="F")
+    assert lib.apx_matrix_download(h, out.ctypes.data_as(C.c_void_p), 4) == L.APX_OK and np.array_equal(out, A)
+    y = np.zeros(4)
+    x = np.array([1.0, -1.0, 2.0])
+    assert lib.apx_gemv_n(h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) == L.APX_OK and np.allclose(y, A @ x, rtol=1e-15)
+    assert lib.apx_matrix_drop_primary(None) == L.APX_ERR_INVALID
+    lib.apx_matrix_free(h)
+    d, hh, u = C.c_int64(), C.c_int64(), C.c_int64()
+    assert lib.apx_ctx_device_clock(ctx, None, C.byref(hh), C.byref(u)) == L.APX_ERR_INVALID
+    assert lib.apx_ctx_device_clock(ctx, C.byref(d), C.byref(hh), None) == L.APX_OK and d.value > 0 and hh.value > 1_600_000_000 * 10**9
+    d2 = C.c_int64()
+    assert lib.apx_ctx_device_clock(ctx, C.byref(d2), C.byref(hh), C.byref(u)) == L.APX_OK and d2.value > d.value and 0 <= u.value < 10**9
+
+
 def test_problem_shape_dtype_and_term_checks(lib, ctx):
     A = _matrix(lib, ctx, np.ones((4, 3)))
     b = np.zeros(4)
@@ -188,14 +217,16 @@ def test_options_one_pass_switch_and_names(lib, ctx):
     for key, default in ((L.APX_OPT_MULTI_ROWS_MASK, 15), (L.APX_OPT_SLAB_GENERATION, 0), (L.APX_OPT_TEAM_WAIT_MS, 1000),
                          (L.APX_OPT_TEAM_COOPERATIVE, 0), (L.APX_OPT_TEAM_FAULT_GRID, 0), (L.APX_OPT_FUSED_TAIL, 1),
                          (L.APX_OPT_MULTI_WAVES, 0), (L.APX_OPT_TEAM_MEMBERS, 0), (L.APX_OPT_TEAM_SLOTS, 0), (L.APX_OPT_ROW_DEAL, -1),
-                         (L.APX_OPT_TEAM_INTERLEAVE, 1), (L.APX_OPT_TEAM_PD_DEFER, 1)):
+                         (L.APX_OPT_TEAM_INTERLEAVE, 1), (L.APX_OPT_TEAM_PD_DEFER, 1), (L.APX_OPT_FAULT_SETUP, 0),
+                         (L.APX_OPT_SPARSE_WINDOWS, 1), (L.APX_OPT_ONE_PASS_MIN_ROWS, 4096)):
         assert lib.apx_ctx_get_option(ctx, key, C.byref(v)) == L.APX_OK and v.value == default, (key, v.value)
     assert lib.apx_ctx_set_option(ctx, L.APX_OPT_TEAM_WAIT_MS, 250) == L.APX_OK
     assert lib.apx_ctx_get_option(ctx, L.APX_OPT_TEAM_WAIT_MS, C.byref(v)) == L.APX_OK and v.value == 250
     assert lib.apx_ctx_set_option(ctx, L.APX_OPT_TEAM_WAIT_MS, 1000) == L.APX_OK
     for key, bad in ((999, 1), (L.APX_OPT_MULTI_ROWS_MASK, 16), (L.APX_OPT_TEAM_WAIT_MS, 0), (L.APX_OPT_TEAM_MEMBERS, 3),
                      (L.APX_OPT_ROW_DEAL, 3), (L.APX_OPT_MULTI_WAVES, 9), (L.APX_OPT_TEAM_SLOTS, 43), (L.APX_OPT_TEAM_FAULT_GRID, 513),
-                     (L.APX_OPT_TEAM_INTERLEAVE, 3), (L.APX_OPT_TEAM_PD_DEFER, 2)):
+                     (L.APX_OPT_TEAM_INTERLEAVE, 3), (L.APX_OPT_TEAM_PD_DEFER, 2), (L.APX_OPT_FAULT_SETUP, 2), (L.APX_OPT_SPARSE_WINDOWS, 2),
+                     (L.APX_OPT_ONE_PASS_MIN_ROWS, 255), (L.APX_OPT_ONE_PASS_MIN_ROWS, 4097)):
         assert lib.apx_ctx_set_option(ctx, key, bad) == L.APX_ERR_INVALID and _err(lib), (key, bad)
     assert lib.apx_ctx_get_option(ctx, 999, C.byref(v)) == L.APX_ERR_INVALID
     assert lib.apx_ctx_get_option(ctx, L.APX_OPT_ROW_DEAL, None) == L.APX_ERR_INVALID
