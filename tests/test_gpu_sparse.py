@@ -112,6 +112,55 @@ def test_products_in_l2_windows_of_the_gathered_operand(apx, m, n, per_row, dtyp
     assert ("L2 windows" in out[1][2][0]) == (n * np.dtype(dtype).itemsize > 3 << 20)
 
 
+def test_sparse_products_fuzz(apx):
+    """Shapes, fills and irregularities drawn at random against scipy: empty rows and columns, a row / a column that holds a large
+    share of the entries (a block of its own in the streaming form, or the long-row form), operands on both sides of the 3 MB
+    from which a product runs in L2 windows, CSR and CSC input, both element types ; every product twice (bit-reproducible)."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    big = st.sampled_from([393_215, 393_217, 450_000, 700_001])
+    small = st.one_of(st.integers(1, 3000), st.sampled_from([1, 2, 31, 32, 33, 255, 256, 257, 4097]))
+
+    @settings(max_examples=100, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(m=st.one_of(small, big), n=st.one_of(small, big), per_row=st.sampled_from([0.3, 1.0, 3.0, 9.0, 40.0]), heavy=st.sampled_from([0, 1, 2]),
+           fmt=st.sampled_from(["csr", "csc"]), f32=st.booleans(), seed=st.integers(0, 2**31 - 1))
+    def body(m, n, per_row, heavy, fmt, f32, seed):
+        if m * per_row > 3_000_000:
+            per_row = 3_000_000 / m
+        rng = np.random.default_rng(seed)
+        dtype = np.float32 if f32 else np.float64
+        cnt = np.minimum(rng.poisson(per_row, m), n)
+        rows = np.repeat(np.arange(m), cnt)
+        cols = rng.integers(0, n, rows.size)
+        if heavy == 1 and m > 1:      # one row with up to 5000 entries
+            k = min(n, 5000)
+            rows = np.concatenate([rows, np.full(k, m // 2)])
+            cols = np.concatenate([cols, rng.choice(n, k, replace=False)])
+        if heavy == 2 and n > 1:      # one column with up to 5000 entries
+            k = min(m, 5000)
+            rows = np.concatenate([rows, rng.choice(m, k, replace=False)])
+            cols = np.concatenate([cols, np.full(k, n // 3)])
+        A = sp.coo_matrix((rng.uniform(-1, 1, rows.size).astype(dtype), (rows, cols)), shape=(m, n)).asformat(fmt)
+        A.sum_duplicates()
+        x, r = rng.standard_normal(n).astype(dtype), rng.standard_normal(m).astype(dtype)
+        ctx = apx.Context(0)
+        ctx.fused_small(False)
+        dA = apx.DeviceMatrix.from_sparse(A, ctx)
+        A64 = A.astype(np.float64)
+        y_ref, g_ref = A64 @ x.astype(np.float64), A64.T @ r.astype(np.float64)
+        tol = 1e-13 if dtype == np.float64 else 3e-6
+        y, g = dA @ x, dA.T @ r
+        scale_y = max(1.0, float(np.max(np.abs(y_ref))) if m else 1.0)
+        scale_g = max(1.0, float(np.max(np.abs(g_ref))) if n else 1.0)
+        assert np.max(np.abs(y - y_ref)) <= tol * scale_y * max(1.0, np.sqrt(A.nnz / max(m, 1)) / 4), (m, n, per_row, heavy, fmt, f32)
+        assert np.max(np.abs(g - g_ref)) <= tol * scale_g * max(1.0, np.sqrt(A.nnz / max(n, 1)) / 4), (m, n, per_row, heavy, fmt, f32)
+        assert np.array_equal(dA @ x, y) and np.array_equal(dA.T @ r, g)
+        assert dA.norm() == pytest.approx(np.sqrt(A64.multiply(A64).sum()), rel=1e-6 if f32 else 1e-12, abs=1e-300)
+        dA.free()
+
+    body()
+
+
 @pytest.mark.parametrize("m,n,spmv", [(3000, 112, True), (3000, 112, False), (6414, 123, False), (1500, 400, False),
                                       (20000, 12, True)])          # (long rows of X': the chunked SpMV)
 def test_sparse_logreg_matches_oracle(apx, generic_ctx, m, n, spmv):
