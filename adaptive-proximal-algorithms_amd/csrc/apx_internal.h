@@ -109,7 +109,8 @@ struct apx_ctx {
   int team_fault_grid = 0;       // APX_OPT_TEAM_FAULT_GRID (test hook)
   int fault_setup = 0;           // APX_OPT_FAULT_SETUP (test hook)
   int64_t one_pass_min_rows = 4096;   // APX_OPT_ONE_PASS_MIN_ROWS (test hook: the parity tests of the widest rows use matrices of ~1000 rows)
-  int sparse_windows = 1;        // APX_OPT_SPARSE_WINDOWS: a sparse matrix uploaded on this context gets its L2 window tables
+  int sparse_windows = 2;        // APX_OPT_SPARSE_WINDOWS: what a sparse matrix uploaded on this context gets besides its rows — 0 nothing,
+                                 // 1 L2 window tables + row blocks, 2 (default) LDS tiles where they pay and 1's forms elsewhere, 3 tiles always
   int team_interleave = 1;       // APX_OPT_TEAM_INTERLEAVE
   int team_pd_defer = 1;         // APX_OPT_TEAM_PD_DEFER
   bool fused_tail = true;        // APX_OPT_FUSED_TAIL
@@ -168,6 +169,18 @@ struct apx_matrix {
   int32_t* rblk = nullptr;
   int32_t* tblk = nullptr;
   std::vector<int32_t> rblk_off, tblk_off;
+  //  * LDS TILES (spmv_tiles): the orientation cut into tiles of 8192 rows x one 64 KB window of the gathered operand, the entries of a
+  //    tile stored together (row-major within it) with their row and index LOCAL to the tile packed into 32 bits — the window of the
+  //    operand is staged in LDS and every gather is an LDS read, the rows' sums are kept in LDS across the windows.  A side that has
+  //    tiles keeps its plain compressed rows (ptr / ind / val) next to them and has neither windows nor row blocks.
+  struct Tiles {
+    int32_t* items = nullptr;   // n_items x 6: row block, split, first / one past the last window, splits to fill with zeros [z0, z1)
+    int32_t* off = nullptr;     // [row blocks x windows + 1]: where the tiles begin, in chunks of 256 entries
+    int32_t* ind = nullptr;     // packed entries (pad << 31 | local row << 14 | local index), every tile padded to whole chunks
+    void* val = nullptr;
+    int32_t n_items = 0, nw = 0, splits = 0;
+  };
+  Tiles rtile, ttile;
   // problems created on this matrix and not yet destroyed: a solver of theirs may hold pointers into the column-major storage (the
   // small-size kernels), so apx_matrix_drop_primary refuses while there are any
   mutable int64_t users = 0;

@@ -394,7 +394,7 @@ int32_t apx_ctx_set_option(apx_ctx* ctx, int32_t key, int64_t value) {
       ctx->one_pass_min_rows = value;
       return APX_OK;
     case APX_OPT_SPARSE_WINDOWS:
-      APX_REQUIRE(value == 0 || value == 1, "APX_OPT_SPARSE_WINDOWS: 0 or 1");
+      APX_REQUIRE(value >= 0 && value <= 3, "APX_OPT_SPARSE_WINDOWS: 0 ... 3");
       ctx->sparse_windows = (int)value;
       return APX_OK;
     case APX_OPT_FAULT_SETUP:
@@ -624,7 +624,9 @@ int32_t apx_matrix_free(apx_matrix* A) {
     if (A->dense_view) apx_matrix_free(A->dense_view);
     if (A->d) (void)hipFree(A->d);
     if (A->dT) (void)hipFree(A->dT);
-    for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval, (void*)A->rwin, (void*)A->twin, (void*)A->rblk, (void*)A->tblk})
+    for (void* q : {(void*)A->rptr, (void*)A->rind, A->rval, (void*)A->tptr, (void*)A->tind, A->tval, (void*)A->rwin, (void*)A->twin, (void*)A->rblk, (void*)A->tblk,
+                    (void*)A->rtile.items, (void*)A->rtile.off, (void*)A->rtile.ind, A->rtile.val, (void*)A->ttile.items, (void*)A->ttile.off,
+                    (void*)A->ttile.ind, A->ttile.val})
       if (q) (void)hipFree(q);
     apx_ctx* ctx = A->ctx;
     delete A;

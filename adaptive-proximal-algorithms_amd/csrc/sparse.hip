@@ -256,6 +256,238 @@ static void launch_side(apx_ctx* ctx, int W, const int64_t* win, const int64_t* 
   }
 }
 
+// LDS TILES (round 5, after tools/gather_probe.hip's last rows: with the operand in LDS and 16 waves on the CU the entries stream at
+// 5.4 - 5.9 TB/s of their 12 bytes, against 2.0 when every gather is an L2 transaction).  The orientation is cut into tiles of
+// kTileRows rows x one 64 KB window of the gathered operand ; a tile's entries lie together, sorted by row, each with its row and index
+// LOCAL to the tile in one 32-bit word, padded to whole chunks of 512.  A workgroup of 1024 lanes owns a row block and a run of its
+// windows (a work item): per window it stages the operand's window in LDS — asked for a tile ahead, held in registers meanwhile — and
+// its 16 waves take the tile's chunks in turn (wave v: chunks v, v + 16, ... — the workgroup reads one contiguous run ; with a run per
+// wave, 4000 streams on the chip, the same kernel was 10 % slower), a lane EIGHT consecutive entries per chunk (six 16-byte loads, the
+// next chunk's in flight).  The rows' sums go to an accumulator in LDS that lives across the windows:
+//  * a row that begins and ends inside one lane's entries is added by that lane ;
+//  * rows that cross lanes are summed by a segmented scan over the wave (data-parallel-primitive moves: four row shifts, two row
+//    broadcasts — no trip through LDS ; the segments from one ballot) ;
+//  * the row a chunk ends in may go on in the next chunk, another wave's: it is left in a table, an entry per chunk, and after the
+//    tile's barrier the first entry of every run of equal rows adds the run in chunk order.
+// Every row's sum has ONE owner and a fixed shape: bit-reproducible (the LDS adds are to addresses no other lane touches between
+// two barriers).  Output: fp64 splits [splits][nrows_pad] like the windows' — the runs of windows of a row block are its splits, the
+// consumers sum them in order.
+// Measured (tools/sparse_kernels.py, 1 M x 100 k, 60 M entries): X w 298 -> 148 us, X' r 343 -> 147 (4.9 TB/s of the entries' bytes) ;
+// Float32 306 -> 118, 328 -> 117.  Along the way: a run of chunks per wave with the crossing rows in registers 160 us ; four entries
+// per lane 144 / 149 but Float32 130 ; the scan through ds_bpermute and read-modify-write adds instead of ds_add_f64: no difference
+// at that stage (the kernel was waiting for its loads).
+constexpr int kTileLanes = 1024, kTileWaves = kTileLanes / 64, kTileE = 8, kTileChunk = 64 * kTileE;
+constexpr int kTileRows = 8192, kTileColBits = 14, kTileWindowBytes = 65536;
+template <typename T>
+struct TileCols { static constexpr int value = kTileWindowBytes / (int)sizeof(T); };
+constexpr int kTileTable = kTileLanes;   // chunks of a tile between two barriers: every chunk leaves its last row in a table, an entry per lane
+constexpr size_t kTileLds = (size_t)kTileWindowBytes + (size_t)kTileRows * 8 + (size_t)kTileTable * 12;
+
+// (an address has one owner between two barriers, and a wave's LDS operations execute in order: the add needs no return and no wait)
+__device__ __forceinline__ void tile_add(double* acc, int row, double v) { unsafeAtomicAdd(acc + row, v); }
+
+// data-parallel-primitive moves (VALU, no trip through the LDS crossbar): lanes without a source keep `old`
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_d(double old, double v) {
+  const long long o = __double_as_longlong(old), q = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)q, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(q >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138,
+              kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+template <typename T>
+__global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restrict__ items, const int32_t* __restrict__ off,
+                                                         const int32_t* __restrict__ ind, const T* __restrict__ val,
+                                                         const T* __restrict__ x, double* __restrict__ part, int64_t ncols_pad,
+                                                         int64_t nrows_pad, int nw, const int* __restrict__ done) {
+  extern __shared__ __align__(16) unsigned char tile_lds[];
+  if (done != nullptr && *done != 0) return;
+  constexpr int kCols = TileCols<T>::value, kPer = 16 / (int)sizeof(T), kVecs = kCols / kPer / kTileLanes;      // 4 vectors per lane
+  typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+  T* xw = (T*)tile_lds;
+  double* acc = (double*)(tile_lds + kTileWindowBytes);
+  double* tsum = acc + kTileRows;
+  int* trow = (int*)(tsum + kTileTable);
+  const int32_t* it = items + (int64_t)blockIdx.x * 6;
+  const int rb = it[0], split = it[1], w1 = it[3], z0 = it[4], z1 = it[5];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* toff = off + (int64_t)rb * nw;
+  auto next_tile = [&](int w) {                        // (uniform: the first tile at or after w that has entries)
+    while (w < w1 && toff[w] == toff[w + 1]) ++w;
+    return w;
+  };
+  // the operand's next window: asked for a tile ahead, kept in registers, stored between the tile's two barriers
+  V xr[kVecs];
+  auto window_load = [&](int w) {
+    const int64_t base = (int64_t)w * kCols;
+#pragma unroll
+    for (int q = 0; q < kVecs; ++q) {
+      const int i = tid + q * kTileLanes;
+      V v = {};
+      if (base + (int64_t)(i + 1) * kPer <= ncols_pad) v = *(const V*)(x + base + (int64_t)i * kPer);
+      xr[q] = v;
+    }
+  };
+  auto window_store = [&]() {
+#pragma unroll
+    for (int q = 0; q < kVecs; ++q) *(V*)(xw + (tid + q * kTileLanes) * kPer) = xr[q];
+  };
+  // a wave's loads of one chunk (a lane: kTileE consecutive entries) — every load instruction 64 lanes x 16 consecutive bytes, the
+  // host stores a chunk so
+  typedef int J4 __attribute__((ext_vector_type(4)));
+  int jn[kTileE] = {};
+  double vn[kTileE] = {};
+  auto load = [&](int64_t c) {
+#pragma unroll
+    for (int q = 0; q < kTileE / 4; ++q) {
+      const J4 t = *((const J4*)(ind + c * kTileChunk) + q * 64 + lane);
+      jn[4 * q] = t.x; jn[4 * q + 1] = t.y; jn[4 * q + 2] = t.z; jn[4 * q + 3] = t.w;
+    }
+    if (sizeof(T) == 8) {
+      typedef double D2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int q = 0; q < kTileE / 2; ++q) {
+        const D2 t = *((const D2*)(val + c * kTileChunk) + q * 64 + lane);
+        vn[2 * q] = t.x; vn[2 * q + 1] = t.y;
+      }
+    } else {
+      typedef float F4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int q = 0; q < kTileE / 4; ++q) {
+        const F4 t = *((const F4*)(val + c * kTileChunk) + q * 64 + lane);
+        vn[4 * q] = t.x; vn[4 * q + 1] = t.y; vn[4 * q + 2] = t.z; vn[4 * q + 3] = t.w;
+      }
+    }
+  };
+  int w = next_tile(it[2]);
+  int64_t cb = 0, c1 = 0;                              // the batch of chunks at hand begins at cb ; the tile ends at c1
+  if (w < w1) {
+    window_load(w);
+    cb = toff[w];
+    c1 = toff[w + 1];
+    if (cb + wave < c1) load(cb + wave);
+  }
+  for (int i = tid; i < kTileRows; i += kTileLanes) acc[i] = 0.0;
+  if (w < w1) window_store();
+  __syncthreads();
+  bool fresh = true;                                   // the tile's first batch: ask for the window after it
+  int wn = w;
+  while (w < w1) {
+    if (fresh) {
+      wn = next_tile(w + 1);
+      if (wn < w1) window_load(wn);
+      fresh = false;
+    }
+    const int64_t ce = std::min<int64_t>(c1, cb + kTileTable);
+    for (int64_t c = cb + wave; c < ce; c += kTileWaves) {
+      int j[kTileE];
+      double p[kTileE];
+#pragma unroll
+      for (int e = 0; e < kTileE; ++e) {
+        j[e] = jn[e];
+        p[e] = vn[e];
+      }
+      if (c + kTileWaves < ce) load(c + kTileWaves);
+      int r[kTileE];
+#pragma unroll
+      for (int e = 0; e < kTileE; ++e) {
+        r[e] = (j[e] >> kTileColBits) & (kTileRows - 1);
+        const double xv = (double)xw[j[e] & ((1 << kTileColBits) - 1)];
+        p[e] = j[e] < 0 ? 0.0 : p[e] * xv;             // (padding: no product, whatever the operand holds)
+      }
+      // the lane's own runs: the first (head) and the last (tail) may go on in the neighbours ; the ones between are whole rows
+      int hr = r[0], cr = r[0], nseg = 0;
+      double hs = 0.0, cs = p[0];
+#pragma unroll
+      for (int e = 1; e < kTileE; ++e) {
+        if (r[e] == cr) cs += p[e];
+        else {
+          if (nseg == 0) hs = cs;
+          else tile_add(acc, cr, cs);
+          ++nseg;
+          cr = r[e];
+          cs = p[e];
+        }
+      }
+      const bool single = nseg == 0;
+      const int tr = cr;
+      const int prev_tr = dpp_i<kDppWaveShr1>(-1, tr);        // (lane 0 keeps -1: the chunk's first row is added as if it began here)
+      const int next_fr = dpp_i<kDppWaveShl1>(-1, r[0]);
+      const bool start = !single || prev_tr != tr;
+      const unsigned long long m = __ballot(start);
+      const int seg = 63 - __clzll(m & (~0ull >> (63 - lane)));      // the lane this lane's last run began in
+      // segmented inclusive scan of the lanes' last runs: within rows of 16 lanes by row shifts, then lane 15 / 47 to the row above, then
+      // lane 31 to the upper half — a fixed tree
+      double S = cs;
+      {
+        double up = dpp_d<kDppRowShr1>(0.0, S);
+        if (lane - 1 >= seg && (lane & 15) >= 1) S = up + S;
+        up = dpp_d<kDppRowShr2>(0.0, S);
+        if (lane - 2 >= seg && (lane & 15) >= 2) S = up + S;
+        up = dpp_d<kDppRowShr4>(0.0, S);
+        if (lane - 4 >= seg && (lane & 15) >= 4) S = up + S;
+        up = dpp_d<kDppRowShr8>(0.0, S);
+        if (lane - 8 >= seg && (lane & 15) >= 8) S = up + S;
+        up = dpp_d<kDppRowBcast15, 0xa>(0.0, S);
+        if ((lane & 16) != 0 && seg < (lane & ~15)) S = up + S;
+        up = dpp_d<kDppRowBcast31, 0xc>(0.0, S);
+        if (lane >= 32 && seg < 32) S = up + S;
+      }
+      const double prevS = dpp_d<kDppWaveShr1>(0.0, S);
+      if (!single) tile_add(acc, hr, prev_tr == hr ? prevS + hs : hs);
+      if (lane < 63) {
+        if (next_fr != tr) tile_add(acc, tr, S);
+      } else {                                         // the chunk's last row may go on in the next chunk — another wave's: to the table
+        trow[c - cb] = tr;
+        tsum[c - cb] = S;
+      }
+    }
+    const int n = (int)(ce - cb);
+    const bool tile_done = ce == c1;
+    // the first chunk of the next batch: in flight across the barriers
+    int64_t nb = ce, n1 = c1;
+    if (tile_done && wn < w1) {
+      nb = toff[wn];
+      n1 = toff[wn + 1];
+    }
+    if ((!tile_done || wn < w1) && nb + wave < n1) load(nb + wave);
+    __syncthreads();                                   // the batch's gathers are done ; its chunks' last rows are in the table
+    if (tile_done && wn < w1) window_store();
+    if (tid < n) {                                     // equal rows are neighbours: the first of a run adds the run in chunk order
+      const int row = trow[tid];
+      if (tid == 0 || trow[tid - 1] != row) {
+        double t = tsum[tid];
+        for (int u = tid + 1; u < n && trow[u] == row; ++u) t += tsum[u];
+        tile_add(acc, row, t);
+      }
+    }
+    __syncthreads();
+    cb = nb;
+    c1 = n1;
+    if (tile_done) {
+      w = wn;
+      fresh = true;
+    }
+  }
+  const int64_t row0 = (int64_t)rb * kTileRows;
+  const int nr = (int)std::min<int64_t>(kTileRows, nrows_pad - row0);
+  for (int i = tid; i < nr; i += kTileLanes) {
+    part[(int64_t)split * nrows_pad + row0 + i] = acc[i];
+    for (int z = z0; z < z1; ++z) part[(int64_t)z * nrows_pad + row0 + i] = 0.0;
+  }
+}
+
+template <typename T>
+static int32_t launch_tiles(apx_ctx* ctx, const apx_matrix::Tiles& t, const void* x, int64_t ncols_pad, int64_t nrows_pad, const int* done) {
+  hipLaunchKernelGGL((spmv_tiles<T>), dim3((unsigned)t.n_items), dim3(kTileLanes), kTileLds, ctx->stream, t.items, t.off, t.ind, (const T*)t.val,
+                     (const T*)x, ctx->part, ncols_pad, nrows_pad, t.nw, done);
+  return APX_OK;
+}
+
 // LONG rows (few rows, thousands of entries each: A' of a tall LIBSVM matrix — covtype is 581 012 x 54 — or A of a
 // wide one): a group of lanes per row leaves the chip idle (54 rows = 54 waves: 390 GB/s), so a row is cut into
 // chunks of kLongChunk entries, one block per (chunk, row), coalesced index / value loads, eight gathers in flight
@@ -334,7 +566,26 @@ static void side_name(apx_ctx* ctx, int kind, const apx_matrix* A, int W, const 
   ctx->kname[kind] = b;
 }
 
+static void tiles_name(apx_ctx* ctx, int kind, const apx_matrix* A, const apx_matrix::Tiles& t) {
+  if (!ctx->profile) return;
+  char b[200];
+  snprintf(b, sizeof b, "spmv_tiles<%s>: %d workgroups of %d lanes, the operand in 64 KB LDS windows (%d), %d split(s)", A->dtype == APX_F32 ? "float" : "double",
+           t.n_items, kTileLanes, t.nw, t.splits);
+  ctx->kname[kind] = b;
+}
+
 int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* splits_out, const int* done) {
+  if (A->rtile.items != nullptr) {                                  // LDS tiles: the runs of windows of a row block are its splits
+    APX_TRY(ensure_part(ctx, (size_t)A->rtile.splits * A->ld * sizeof(double)));
+    tiles_name(ctx, APX_KSTAT_GEMV_N, A, A->rtile);
+    APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_N, spmv_bytes(A)));
+    if (A->dtype == APX_F32) APX_TRY(launch_tiles<float>(ctx, A->rtile, x, A->n_pad, A->ld, done));
+    else APX_TRY(launch_tiles<double>(ctx, A->rtile, x, A->n_pad, A->ld, done));
+    APX_TRY(prof_end(ctx));
+    APX_HIP(hipGetLastError());
+    *splits_out = A->rtile.splits;
+    return APX_OK;
+  }
   int chunks = 1;
   if (long_rows(A->nnz, A->m, A->ld, A->r_maxlen, &chunks)) {      // every chunk is one fp64 split of A x
     APX_TRY(ensure_part(ctx, (size_t)chunks * A->ld * sizeof(double)));
@@ -374,6 +625,16 @@ int32_t launch_spmv_n(apx_ctx* ctx, const apx_matrix* A, const void* x, int* spl
 }
 
 int32_t launch_spmv_t(apx_ctx* ctx, const apx_matrix* A, const void* r, void* out, const int* done) {
+  if (A->ttile.items != nullptr) {
+    APX_TRY(ensure_part(ctx, (size_t)A->ttile.splits * A->n_pad * sizeof(double)));
+    tiles_name(ctx, APX_KSTAT_GEMV_T, A, A->ttile);
+    APX_TRY(prof_begin(ctx, APX_KSTAT_GEMV_T, spmv_bytes(A)));
+    if (A->dtype == APX_F32) APX_TRY(launch_tiles<float>(ctx, A->ttile, r, A->ld, A->n_pad, done));
+    else APX_TRY(launch_tiles<double>(ctx, A->ttile, r, A->ld, A->n_pad, done));
+    APX_TRY(prof_end(ctx));
+    APX_HIP(hipGetLastError());
+    return launch_sum_partials_rows(ctx, A->dtype, A->ttile.splits, A->n_pad, A->n_pad, out, done);
+  }
   int chunks = 1;
   if (long_rows(A->nnz, A->n, A->n_pad, A->t_maxlen, &chunks)) {
     APX_TRY(ensure_part(ctx, (size_t)chunks * A->n_pad * sizeof(double)));
@@ -435,6 +696,123 @@ static void transpose_rows(int64_t nrows, int64_t ncols, const int64_t* ptr, con
       tind[(size_t)dst] = (int32_t)i;
       tval[(size_t)dst] = val[k];
     }
+}
+
+// The LDS-tile form of one orientation (spmv_tiles), built on the host from its compressed rows: the tiles in row-block-major order,
+// each padded to whole chunks ; a chunk stored so that every one of a lane's 16-byte loads is one of 64 consecutive ones (lane L's
+// entries 8L .. 8L+7: its indices at 4L .. 4L+3 and 256+4L .. , its Float64 values at 2L, 2L+1, 128+2L, ...) ; the work items — a row
+// block and a run of its windows each, one per CU, as many per row block as its share of the cost, the largest first — and per row
+// block its number of splits.
+template <typename T>
+struct TilePlan {
+  std::vector<int32_t> items, off, ind;
+  std::vector<T> val;
+  int nw = 0, splits = 0;
+};
+template <typename T>
+static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h, const T* val_h, int64_t nrows, int64_t nrows_pad, int64_t ncols,
+                       int64_t nnz, bool force, TilePlan<T>& tp) {
+  const int64_t wc = TileCols<T>::value;
+  const int64_t RB = (nrows_pad + kTileRows - 1) / kTileRows, NW = std::max<int64_t>(1, (ncols + wc - 1) / wc);
+  if (nnz <= 0 || nrows <= 0 || RB * NW > ((int64_t)1 << 24)) return false;
+  // where they pay: a tile streams its entries and stages 64 KB of the operand — entries worth 1.5 windows per tile on average, and a
+  // matrix large enough for its products to be more than launches
+  if (!force && (nnz < ((int64_t)1 << 22) || nnz / (RB * NW) < 8192)) return false;
+  std::vector<int64_t> cnt((size_t)(RB * NW), 0);
+  for (int64_t i = 0; i < nrows; ++i) {
+    int64_t* c = cnt.data() + (i / kTileRows) * NW;
+    for (int64_t k = ptr_h[i]; k < ptr_h[i + 1]; ++k) c[ind_h[k] / wc]++;
+  }
+  std::vector<int64_t> off((size_t)(RB * NW) + 1, 0);
+  for (int64_t t = 0; t < RB * NW; ++t) off[(size_t)t + 1] = off[(size_t)t] + (cnt[(size_t)t] + kTileChunk - 1) / kTileChunk;
+  const int64_t chunks = off[(size_t)(RB * NW)];
+  if (chunks >= 2147483647LL / 2) return false;
+  tp.off.assign(off.begin(), off.end());
+  tp.ind.assign((size_t)chunks * kTileChunk, 0);
+  tp.val.assign((size_t)chunks * kTileChunk, (T)0);
+  std::vector<int64_t> cur((size_t)NW);
+  std::vector<int32_t> last((size_t)NW);
+  for (int64_t rb = 0; rb < RB; ++rb) {
+    std::fill(cur.begin(), cur.end(), 0);
+    std::fill(last.begin(), last.end(), 0);
+    const int64_t i1 = std::min<int64_t>(nrows, (rb + 1) * kTileRows);
+    for (int64_t i = rb * kTileRows; i < i1; ++i)
+      for (int64_t k = ptr_h[i]; k < ptr_h[i + 1]; ++k) {
+        const int64_t w = ind_h[k] / wc, e = cur[(size_t)w]++;
+        const int64_t base = (off[(size_t)(rb * NW + w)] + e / kTileChunk) * kTileChunk;
+        const int q = (int)(e % kTileChunk), L = q / kTileE, u = q % kTileE;
+        const int32_t rl = (int32_t)(i - rb * kTileRows);
+        const int at4 = (u / 4) * 256 + 4 * L + u % 4, at2 = (u / 2) * 128 + 2 * L + u % 2;      // 16-byte pieces of 4-byte / of 8-byte items
+        tp.ind[(size_t)(base + at4)] = (rl << kTileColBits) | (int32_t)(ind_h[k] - w * wc);
+        tp.val[(size_t)(base + (sizeof(T) == 8 ? at2 : at4))] = val_h[k];
+        last[(size_t)w] = rl;
+      }
+    for (int64_t w = 0; w < NW; ++w) {                 // padding: entries of the tile's last row, flagged
+      const int64_t t = rb * NW + w, n = cnt[(size_t)t], cap = (off[(size_t)t + 1] - off[(size_t)t]) * kTileChunk;
+      for (int64_t e = n; e < cap; ++e) {
+        const int q = (int)(e % kTileChunk), L = q / kTileE, u = q % kTileE;
+        tp.ind[(size_t)((off[(size_t)t] + e / kTileChunk) * kTileChunk + (u / 4) * 256 + 4 * L + u % 4)] =
+            (int32_t)(0x80000000u | (uint32_t)(last[(size_t)w] << kTileColBits));
+      }
+    }
+  }
+  // work items
+  // one item per CU: a workgroup fills a CU (1024 lanes, 140 KB of LDS), so a second round would begin when the first has drained —
+  // measured on 1 M x 100 k, 60 M entries: 256 items 148 / 147 us for X w / X' r, 512 items 146 / 151
+  const int64_t budget = std::max(ctx->num_cu, 1);
+  struct Item { int32_t rb, split, w0, w1, z0, z1; int64_t cost; };
+  std::vector<Item> its;
+  std::vector<int> ngroups((size_t)RB, 1);
+  int splits = 1;
+  // a tile costs its entries and its two barriers (measured: a row block of 1696 rows against one of 8192 — about 3000 entries' time)
+  auto cost = [&](int64_t t) { return cnt[(size_t)t] > 0 ? cnt[(size_t)t] + 3000 : 0; };
+  int64_t all = 0;
+  for (int64_t t = 0; t < RB * NW; ++t) all += cost(t);
+  // the smallest item size with sum over the row blocks of ceil(cost / size) <= budget: one item per CU at most where the row blocks allow
+  std::vector<int64_t> rbcost((size_t)RB, 0);
+  for (int64_t rb = 0; rb < RB; ++rb)
+    for (int64_t w = 0; w < NW; ++w) rbcost[(size_t)rb] += cost(rb * NW + w);
+  const int64_t gmax = std::min<int64_t>(NW, 64);
+  auto groups_of = [&](int64_t c, int64_t size) { return std::max<int64_t>(1, std::min<int64_t>((c + size - 1) / size, gmax)); };
+  int64_t lo = 1, hi = std::max<int64_t>(all, 1);
+  while (lo < hi) {
+    const int64_t size = lo + (hi - lo) / 2;
+    int64_t n = 0;
+    for (int64_t rb = 0; rb < RB; ++rb) n += groups_of(rbcost[(size_t)rb], size);
+    if (n <= std::max<int64_t>(budget, RB)) hi = size;
+    else lo = size + 1;
+  }
+  for (int64_t rb = 0; rb < RB; ++rb) {
+    const int64_t tot = rbcost[(size_t)rb];
+    const int64_t G = groups_of(tot, lo);
+    int g = 0;
+    int64_t cum = 0, w0 = 0, in_group = 0;
+    for (int64_t w = 0; w < NW; ++w) {
+      cum += cost(rb * NW + w);
+      in_group += cost(rb * NW + w);
+      const bool last_w = w + 1 == NW;
+      if (last_w || (g + 1 < G && (double)cum >= (double)tot * (double)(g + 1) / (double)G)) {
+        its.push_back({(int32_t)rb, (int32_t)g, (int32_t)w0, (int32_t)(w + 1), 0, 0, in_group});
+        ++g;
+        w0 = w + 1;
+        in_group = 0;
+      }
+    }
+    ngroups[(size_t)rb] = g;
+    splits = std::max(splits, g);
+  }
+  for (auto& q : its)
+    if (q.split + 1 == ngroups[(size_t)q.rb]) {
+      q.z0 = ngroups[(size_t)q.rb];
+      q.z1 = splits;
+    }
+  std::stable_sort(its.begin(), its.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+  tp.items.reserve(its.size() * 6);
+  for (const auto& q : its)
+    for (int32_t v : {q.rb, q.split, q.w0, q.w1, q.z0, q.z1}) tp.items.push_back(v);
+  tp.nw = (int)NW;
+  tp.splits = splits;
+  return true;
 }
 
 template <typename T>
@@ -528,8 +906,20 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
     if (sd.blk.empty()) sd.blk_off.clear();
   };
   Side sr, st;
-  plan((const int64_t*)p0, (const int32_t*)i0, (const T*)v0, A->m, A->ld, A->n, A->r_maxlen, sr);
-  plan((const int64_t*)p1, (const int32_t*)i1, (const T*)v1, A->n, A->n_pad, A->m, A->t_maxlen, st);
+  // LDS tiles first (APX_OPT_SPARSE_WINDOWS 2: where they pay and the rows are not the long-row form's ; 3: wherever they can be built) ;
+  // a side without them gets the L2 windows / row blocks
+  TilePlan<T> tr, tt;
+  bool has_tr = false, has_tt = false;
+  if (ctx->sparse_windows >= 2) {
+    const bool force = ctx->sparse_windows == 3;
+    int chunks = 0;
+    if (force || !long_rows(nnz, A->m, A->ld, A->r_maxlen, &chunks))
+      has_tr = plan_tiles<T>(ctx, (const int64_t*)p0, (const int32_t*)i0, (const T*)v0, A->m, A->ld, A->n, nnz, force, tr);
+    if (force || !long_rows(nnz, A->n, A->n_pad, A->t_maxlen, &chunks))
+      has_tt = plan_tiles<T>(ctx, (const int64_t*)p1, (const int32_t*)i1, (const T*)v1, A->n, A->n_pad, A->m, nnz, force, tt);
+  }
+  if (!has_tr) plan((const int64_t*)p0, (const int32_t*)i0, (const T*)v0, A->m, A->ld, A->n, A->r_maxlen, sr);
+  if (!has_tt) plan((const int64_t*)p1, (const int32_t*)i1, (const T*)v1, A->n, A->n_pad, A->m, A->t_maxlen, st);
   APX_TRY(up((void**)&A->rptr, p0, (size_t)(A->m + 1) * sizeof(int64_t)));
   APX_TRY(up((void**)&A->rind, sr.W ? (const void*)sr.ind.data() : i0, (size_t)nnz * sizeof(int32_t)));
   APX_TRY(up(&A->rval, sr.W ? (const void*)sr.val.data() : v0, (size_t)nnz * sizeof(T)));
@@ -544,6 +934,20 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
   if (!st.blk.empty()) APX_TRY(up((void**)&A->tblk, st.blk.data(), st.blk.size() * sizeof(int32_t)));
   A->rblk_off = sr.blk_off;
   A->tblk_off = st.blk_off;
+  auto up_tiles = [&](apx_matrix::Tiles& d, const TilePlan<T>& tp) -> int32_t {
+    APX_TRY(up((void**)&d.items, tp.items.data(), tp.items.size() * sizeof(int32_t)));
+    APX_TRY(up((void**)&d.off, tp.off.data(), tp.off.size() * sizeof(int32_t)));
+    APX_TRY(up((void**)&d.ind, tp.ind.data(), tp.ind.size() * sizeof(int32_t)));
+    APX_TRY(up(&d.val, tp.val.data(), tp.val.size() * sizeof(T)));
+    d.n_items = (int32_t)(tp.items.size() / 6);
+    d.nw = tp.nw;
+    d.splits = tp.splits;
+    return APX_OK;
+  };
+  if (has_tr) APX_TRY(up_tiles(A->rtile, tr));
+  if (has_tt) APX_TRY(up_tiles(A->ttile, tt));
+  if (has_tr || has_tt)
+    APX_HIP(hipFuncSetAttribute((const void*)spmv_tiles<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
   APX_HIP(hipStreamSynchronize(ctx->stream));   // the host staging vectors die with this frame
   return APX_OK;
 }

@@ -316,12 +316,16 @@ enum {
                                     allocation had (on ONE rank of a row shard: the ranks must still agree on the two passes —
                                     tests/two_rank_pd_worker.py)                                                              */
   ,
-  APX_OPT_SPARSE_WINDOWS = 18    /* default 1: the round-5 forms of the sparse products, decided when a sparse matrix is uploaded on this
-                                    context — (a) an orientation whose gathered operand (x for A x: n entries ; r for A' r: m entries)
+  APX_OPT_SPARSE_WINDOWS = 18    /* default 2: the round-5 forms of the sparse products, decided when a sparse matrix is uploaded on this
+                                    context.  1: (a) an orientation whose gathered operand (x for A x: n entries ; r for A' r: m entries)
                                     exceeds 3 MB is stored WINDOW-MAJOR and its product runs window by window of the operand (2 MB: half
                                     an XCD's L2 ; tools/gather_probe.hip: 2.0 against 1.1 TB/s of the entries' bytes) ; (b) the
                                     STREAMING form: blocks of rows whose entries are loaded as one run, products through LDS, eight lanes
-                                    per row.  0: round 1's lanes-per-row kernel over whole rows (A/B).                              */
+                                    per row.  2: besides, LDS TILES where they pay (4 M entries or more, 8192 or more per tile of 8192
+                                    rows x 64 KB of operand): the operand's window staged in LDS, every gather an LDS read (the probe:
+                                    5.4 - 5.9 TB/s), the rows' sums in LDS across the windows ; an orientation that has tiles keeps its
+                                    plain rows next to them.  3: TEST hook — tiles on every matrix.  0: round 1's lanes-per-row kernel
+                                    over whole rows (A/B).                                                                          */
   ,
   APX_OPT_ONE_PASS_MIN_ROWS = 19 /* TEST hook, default 4096: the fewest rows a matrix needs for the one-pass kernels (below, a launch's
                                     fixed costs outweigh the second pass) ; 256 ... 4096 — the parity tests of the widest rows run on

@@ -218,14 +218,14 @@ def test_options_one_pass_switch_and_names(lib, ctx):
                          (L.APX_OPT_TEAM_COOPERATIVE, 0), (L.APX_OPT_TEAM_FAULT_GRID, 0), (L.APX_OPT_FUSED_TAIL, 1),
                          (L.APX_OPT_MULTI_WAVES, 0), (L.APX_OPT_TEAM_MEMBERS, 0), (L.APX_OPT_TEAM_SLOTS, 0), (L.APX_OPT_ROW_DEAL, -1),
                          (L.APX_OPT_TEAM_INTERLEAVE, 1), (L.APX_OPT_TEAM_PD_DEFER, 1), (L.APX_OPT_FAULT_SETUP, 0),
-                         (L.APX_OPT_SPARSE_WINDOWS, 1), (L.APX_OPT_ONE_PASS_MIN_ROWS, 4096)):
+                         (L.APX_OPT_SPARSE_WINDOWS, 2), (L.APX_OPT_ONE_PASS_MIN_ROWS, 4096)):
         assert lib.apx_ctx_get_option(ctx, key, C.byref(v)) == L.APX_OK and v.value == default, (key, v.value)
     assert lib.apx_ctx_set_option(ctx, L.APX_OPT_TEAM_WAIT_MS, 250) == L.APX_OK
     assert lib.apx_ctx_get_option(ctx, L.APX_OPT_TEAM_WAIT_MS, C.byref(v)) == L.APX_OK and v.value == 250
     assert lib.apx_ctx_set_option(ctx, L.APX_OPT_TEAM_WAIT_MS, 1000) == L.APX_OK
     for key, bad in ((999, 1), (L.APX_OPT_MULTI_ROWS_MASK, 16), (L.APX_OPT_TEAM_WAIT_MS, 0), (L.APX_OPT_TEAM_MEMBERS, 3),
                      (L.APX_OPT_ROW_DEAL, 3), (L.APX_OPT_MULTI_WAVES, 9), (L.APX_OPT_TEAM_SLOTS, 43), (L.APX_OPT_TEAM_FAULT_GRID, 513),
-                     (L.APX_OPT_TEAM_INTERLEAVE, 3), (L.APX_OPT_TEAM_PD_DEFER, 2), (L.APX_OPT_FAULT_SETUP, 2), (L.APX_OPT_SPARSE_WINDOWS, 2),
+                     (L.APX_OPT_TEAM_INTERLEAVE, 3), (L.APX_OPT_TEAM_PD_DEFER, 2), (L.APX_OPT_FAULT_SETUP, 2), (L.APX_OPT_SPARSE_WINDOWS, 4), (L.APX_OPT_SPARSE_WINDOWS, -1),
                      (L.APX_OPT_ONE_PASS_MIN_ROWS, 255), (L.APX_OPT_ONE_PASS_MIN_ROWS, 4097)):
         assert lib.apx_ctx_set_option(ctx, key, bad) == L.APX_ERR_INVALID and _err(lib), (key, bad)
     assert lib.apx_ctx_get_option(ctx, 999, C.byref(v)) == L.APX_ERR_INVALID

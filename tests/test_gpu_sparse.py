@@ -115,7 +115,8 @@ def test_products_in_l2_windows_of_the_gathered_operand(apx, m, n, per_row, dtyp
 def test_sparse_products_fuzz(apx):
     """Shapes, fills and irregularities drawn at random against scipy: empty rows and columns, a row / a column that holds a large
     share of the entries (a block of its own in the streaming form, or the long-row form), operands on both sides of the 3 MB
-    from which a product runs in L2 windows, CSR and CSC input, both element types ; every product twice (bit-reproducible)."""
+    from which a product runs in L2 windows, CSR and CSC input, both element types, the LDS-tile form forced or not ; every product twice
+    (bit-reproducible)."""
     from hypothesis import HealthCheck, given, settings, strategies as st
 
     big = st.sampled_from([393_215, 393_217, 450_000, 700_001])
@@ -123,8 +124,8 @@ def test_sparse_products_fuzz(apx):
 
     @settings(max_examples=100, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(m=st.one_of(small, big), n=st.one_of(small, big), per_row=st.sampled_from([0.3, 1.0, 3.0, 9.0, 40.0]), heavy=st.sampled_from([0, 1, 2]),
-           fmt=st.sampled_from(["csr", "csc"]), f32=st.booleans(), seed=st.integers(0, 2**31 - 1))
-    def body(m, n, per_row, heavy, fmt, f32, seed):
+           fmt=st.sampled_from(["csr", "csc"]), f32=st.booleans(), seed=st.integers(0, 2**31 - 1), tiles=st.booleans())
+    def body(m, n, per_row, heavy, fmt, f32, seed, tiles):
         if m * per_row > 3_000_000:
             per_row = 3_000_000 / m
         rng = np.random.default_rng(seed)
@@ -145,11 +146,16 @@ def test_sparse_products_fuzz(apx):
         x, r = rng.standard_normal(n).astype(dtype), rng.standard_normal(m).astype(dtype)
         ctx = apx.Context(0)
         ctx.fused_small(False)
+        if tiles:      # the LDS-tile form on whatever is drawn (by itself it takes matrices of millions of entries only)
+            ctx.set_option(importlib.import_module("adaptive-proximal-algorithms_amd._lib").APX_OPT_SPARSE_WINDOWS, 3)
         dA = apx.DeviceMatrix.from_sparse(A, ctx)
         A64 = A.astype(np.float64)
         y_ref, g_ref = A64 @ x.astype(np.float64), A64.T @ r.astype(np.float64)
         tol = 1e-13 if dtype == np.float64 else 3e-6
+        ctx.profile(True)
         y, g = dA @ x, dA.T @ r
+        if A.nnz:
+            assert ("spmv_tiles" in ctx.kernel_name("gemv_n")) == tiles and ("spmv_tiles" in ctx.kernel_name("gemv_t")) == tiles
         scale_y = max(1.0, float(np.max(np.abs(y_ref))) if m else 1.0)
         scale_g = max(1.0, float(np.max(np.abs(g_ref))) if n else 1.0)
         assert np.max(np.abs(y - y_ref)) <= tol * scale_y * max(1.0, np.sqrt(A.nnz / max(m, 1)) / 4), (m, n, per_row, heavy, fmt, f32)
@@ -159,6 +165,94 @@ def test_sparse_products_fuzz(apx):
         dA.free()
 
     body()
+
+
+def _tile_case(rng, m, n, per_row, dtype, heavy):
+    cnt = np.minimum(rng.poisson(per_row, m), n)
+    rows = np.repeat(np.arange(m), cnt)
+    cols = rng.integers(0, n, rows.size)
+    if heavy and m > 40 and n > 40:      # a full row, a full column, ten empty rows
+        rows = np.concatenate([rows, np.full(n, 3), np.arange(m)])
+        cols = np.concatenate([cols, np.arange(n), np.full(m, 7)])
+    A = sp.coo_matrix((rng.uniform(-1, 1, rows.size).astype(dtype), (rows, cols)), shape=(m, n)).tocsr()
+    A.sum_duplicates()
+    if heavy and m > 40 and n > 40:
+        A = A.tolil()
+        A[10:20, :] = 0
+        A = A.tocsr()
+        A.eliminate_zeros()
+    return A
+
+
+@pytest.mark.parametrize("m,n,per_row,heavy", [(5, 5, 3, False), (300, 200, 10, True), (9000, 20_000, 40, True), (20_000, 9000, 40, True),
+                                               (8192, 8192, 10, False), (8193, 16_385, 14, True),      # (a row block / a window of one row / column)
+                                               (1, 50_000, 15_000, False), (50_000, 1, 0.5, False),     # one row ; one column
+                                               (8192, 8192, 90, False),                                # 740 000 entries in ONE tile: two batches of chunks
+                                               (40_000, 17_000, 0.3, True)])                            # fewer entries than rows
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_products_on_lds_tiles(apx, m, n, per_row, heavy, dtype):
+    """Round 5 (csrc/sparse.hip spmv_tiles): the operand's 64 KB windows in LDS, the entries tile by tile with their local row and index
+    in one word, the rows' sums in LDS across the windows — forced on every shape here (APX_OPT_SPARSE_WINDOWS 3 ; by itself only where
+    it pays).  Against scipy to a few units of the last place of sum |a_ij x_j|, against the streaming / window forms, and twice (a
+    row's sum has one owner and a fixed shape: bit-reproducible)."""
+    L = importlib.import_module("adaptive-proximal-algorithms_amd._lib")
+    rng = np.random.default_rng(m * 31 + n)
+    A = _tile_case(rng, m, n, per_row, dtype, heavy)
+    x, r = rng.standard_normal(n).astype(dtype), rng.standard_normal(m).astype(dtype)
+    A64 = A.astype(np.float64)
+    y_ref, g_ref = A64 @ x.astype(np.float64), A64.T @ r.astype(np.float64)
+    sy = abs(A64) @ np.abs(x.astype(np.float64)) + 1e-300
+    sg = abs(A64).T @ np.abs(r.astype(np.float64)) + 1e-300
+    eps = np.finfo(dtype).eps
+    out = {}
+    for mode in (3, 1):
+        ctx = apx.Context(0)
+        ctx.fused_small(False)
+        ctx.set_option(L.APX_OPT_SPARSE_WINDOWS, mode)
+        dA = apx.DeviceMatrix.from_sparse(A if mode == 3 else A.tocsc(), ctx)
+        ctx.profile(True)
+        y, g = dA @ x, dA.T @ r
+        names = (ctx.kernel_name("gemv_n"), ctx.kernel_name("gemv_t"))
+        assert ("spmv_tiles" in names[0]) == (mode == 3) and ("spmv_tiles" in names[1]) == (mode == 3), names
+        assert np.max(np.abs(y - y_ref) / sy) <= 4 * eps and np.max(np.abs(g - g_ref) / sg) <= 4 * eps
+        assert np.array_equal(dA @ x, y) and np.array_equal(dA.T @ r, g)
+        assert dA.norm() == pytest.approx(np.sqrt(A64.multiply(A64).sum()), rel=1e-6 if dtype == np.float32 else 1e-12)
+        out[mode] = (y, g)
+        dA.free()
+    assert np.max(np.abs(out[3][0] - out[1][0]) / sy) <= 4 * eps and np.max(np.abs(out[3][1] - out[1][1]) / sg) <= 4 * eps
+
+
+def test_lds_tiles_by_default_and_through_a_solver(apx):
+    """What a matrix gets BY ITSELF (APX_OPT_SPARSE_WINDOWS 2, the default): 100 000 x 60 000 with 5.5 M entries — 55 000 per tile — runs
+    both products on the LDS tiles ; the same shape with 0.5 M entries keeps the streaming / window forms.  And a sparse logistic
+    regression on the tiles follows the one on the round-5 forms (the fused epilogues take the tiles' splits like the windows')."""
+    L = importlib.import_module("adaptive-proximal-algorithms_amd._lib")
+    rng = np.random.default_rng(5)
+    m, n = 100_000, 60_000
+    for per_row, want in ((55, True), (5, False)):
+        A = _tile_case(rng, m, n, per_row, np.float64, False)
+        ctx = apx.Context(0)
+        assert ctx.get_option(L.APX_OPT_SPARSE_WINDOWS) == 2
+        dA = apx.DeviceMatrix.from_sparse(A, ctx)
+        ctx.profile(True)
+        x, r = rng.standard_normal(n), rng.standard_normal(m)
+        y, g = dA @ x, dA.T @ r
+        names = (ctx.kernel_name("gemv_n"), ctx.kernel_name("gemv_t"))
+        assert all(("spmv_tiles" in k) == want for k in names), names
+        assert np.allclose(y, A @ x, rtol=0, atol=1e-12 * np.max(np.abs(y))) and np.allclose(g, A.T @ r, rtol=0, atol=1e-12 * np.max(np.abs(g)))
+        if want:
+            yy = (rng.uniform(size=m) < 0.5).astype(np.float64)
+            gam = 4.0 * m / (float(A.multiply(A).sum()) + m)
+            run = lambda c, d: apx.adaptive_proxgrad(np.full(n + 1, 0.01), f=apx.LogisticLoss(d, yy, ctx=c), g=apx.NormL1(1e-7),
+                                                     rule=apx.OurRule(gamma=gam), tol=0.0, maxit=12, ctx=c)[0]
+            x_tiles = run(ctx, dA)
+            ctx1 = apx.Context(0)
+            ctx1.set_option(L.APX_OPT_SPARSE_WINDOWS, 1)
+            dA1 = apx.DeviceMatrix.from_sparse(A, ctx1)
+            x_stream = run(ctx1, dA1)
+            assert _rel(x_tiles, x_stream) <= 1e-10 and np.any(x_stream != 0.01)
+            dA1.free()
+        dA.free()
 
 
 @pytest.mark.parametrize("m,n,spmv", [(3000, 112, True), (3000, 112, False), (6414, 123, False), (1500, 400, False),

@@ -20,13 +20,10 @@
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
 
-constexpr int kBlock = 256;
-
-template <int MODE, int U>      // MODE 0 stream, 1 gather from global, 2 gather from LDS tile
+template <int MODE, int U, int kBlock = 256, int kTile = 16384>      // MODE 0 stream, 1 gather from global, 2 gather from LDS tile
 __global__ __launch_bounds__(kBlock) void k_probe(const int32_t* __restrict__ ind, const double* __restrict__ val, const double* __restrict__ x,
                                                   int64_t nnz, int n_x, double* __restrict__ out) {
   extern __shared__ double tile[];
-  constexpr int kTile = 16384;
   if (MODE == 2) {
     for (int i = threadIdx.x; i < kTile; i += kBlock) tile[i] = x[i % n_x];
     __syncthreads();
@@ -56,19 +53,19 @@ __global__ __launch_bounds__(kBlock) void k_probe(const int32_t* __restrict__ in
   if ((threadIdx.x & 63) == 0) out[(int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = s;
 }
 
-template <int MODE, int U>
+template <int MODE, int U, int kBlock = 256, int kTile = 16384>
 static double run(const int32_t* ind, const double* val, const double* x, int64_t nnz, int n_x, double* out, int blocks) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  const size_t lds = MODE == 2 ? 16384 * sizeof(double) : 0;
-  if (MODE == 2) CK(hipFuncSetAttribute((const void*)k_probe<MODE, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_probe<MODE, U>), dim3(blocks), dim3(kBlock), lds, 0, ind, val, x, nnz, n_x, out);
+  const size_t lds = MODE == 2 ? kTile * sizeof(double) : 0;
+  if (MODE == 2) CK(hipFuncSetAttribute((const void*)k_probe<MODE, U, kBlock, kTile>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_probe<MODE, U, kBlock, kTile>), dim3(blocks), dim3(kBlock), lds, 0, ind, val, x, nnz, n_x, out);
   CK(hipDeviceSynchronize());
   float best = 1e30f;
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL((k_probe<MODE, U>), dim3(blocks), dim3(kBlock), lds, 0, ind, val, x, nnz, n_x, out);
+    hipLaunchKernelGGL((k_probe<MODE, U, kBlock, kTile>), dim3(blocks), dim3(kBlock), lds, 0, ind, val, x, nnz, n_x, out);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms;
@@ -101,6 +98,14 @@ int main() {
       printf("  gather, operand %9d  U=4 %7.0f  U=8 %7.0f  U=16 %7.0f GB/s", n_x, run<1, 4>(ind, val, x, nnz, n_x, out, blocks),
              run<1, 8>(ind, val, x, nnz, n_x, out, blocks), run<1, 16>(ind, val, x, nnz, n_x, out, blocks));
       printf("   | LDS tile U=8 %7.0f\n", run<2, 8>(ind, val, x, nnz, n_x, out, blocks));
+      if (blocks == 2048 && n_x == 100'000) {      // the LDS tile with full occupancy: blocks of 1024 lanes, one or two per CU
+        printf("          LDS tile, blocks of 1024: 128 KB x 256 blocks U=4 %7.0f U=8 %7.0f | x 512 U=8 %7.0f | 64 KB x 512 U=4 %7.0f U=8 %7.0f | x 1024 U=8 %7.0f\n",
+               run<2, 4, 1024, 16384>(ind, val, x, nnz, n_x, out, 256), run<2, 8, 1024, 16384>(ind, val, x, nnz, n_x, out, 256),
+               run<2, 8, 1024, 16384>(ind, val, x, nnz, n_x, out, 512), run<2, 4, 1024, 8192>(ind, val, x, nnz, n_x, out, 512),
+               run<2, 8, 1024, 8192>(ind, val, x, nnz, n_x, out, 512), run<2, 8, 1024, 8192>(ind, val, x, nnz, n_x, out, 1024));
+        printf("          global gather, blocks of 1024 x 512 U=8 %7.0f | stream, 1024 x 512 U=8 %7.0f\n",
+               run<1, 8, 1024>(ind, val, x, nnz, n_x, out, 512), run<0, 8, 1024>(ind, val, x, nnz, n_x, out, 512));
+      }
       // indices sorted within every run of 64 consecutive entries (one wave's lanes of one load)
       for (int64_t k = 0; k + 64 <= nnz; k += 64) std::sort(hi.begin() + k, hi.begin() + k + 64);
       CK(hipMemcpy(ind, hi.data(), nnz * 4, hipMemcpyHostToDevice));
