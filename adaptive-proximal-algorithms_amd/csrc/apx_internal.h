@@ -176,7 +176,7 @@ struct apx_matrix {
   struct Tiles {
     int32_t* items = nullptr;   // n_items x 6: row block, split, first / one past the last window, splits to fill with zeros [z0, z1)
     int32_t* off = nullptr;     // [row blocks x windows + 1]: where the tiles begin, in chunks of 256 entries
-    int32_t* ind = nullptr;     // packed entries (pad << 31 | local row << 14 | local index), every tile padded to whole chunks
+    int32_t* ind = nullptr;     // packed entries (local row << 17 | byte offset in the window), every tile padded to whole chunks
     void* val = nullptr;
     int32_t n_items = 0, nw = 0, splits = 0;
   };

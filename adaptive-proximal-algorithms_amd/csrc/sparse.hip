@@ -272,16 +272,21 @@ static void launch_side(apx_ctx* ctx, int W, const int64_t* win, const int64_t* 
 // Every row's sum has ONE owner and a fixed shape: bit-reproducible (the LDS adds are to addresses no other lane touches between
 // two barriers).  Output: fp64 splits [splits][nrows_pad] like the windows' — the runs of windows of a row block are its splits, the
 // consumers sum them in order.
-// Measured (tools/sparse_kernels.py, 1 M x 100 k, 60 M entries): X w 298 -> 148 us, X' r 343 -> 147 (4.9 TB/s of the entries' bytes) ;
-// Float32 306 -> 118, 328 -> 117.  Along the way: a run of chunks per wave with the crossing rows in registers 160 us ; four entries
-// per lane 144 / 149 but Float32 130 ; the scan through ds_bpermute and read-modify-write adds instead of ds_add_f64: no difference
-// at that stage (the kernel was waiting for its loads).
+// Measured (tools/sparse_kernels.py, 1 M x 100 k, 60 M entries): X w 298 -> 142 us, X' r 343 -> 146 (5.0 TB/s of the entries' bytes) ;
+// Float32 306 -> 109, 328 -> 113.  Along the way: a run of chunks per wave with the crossing rows in registers 160 us ; the lane's
+// runs with branches and a guarded product for the padding 148 / 147 (now: selects, and padding that points at a zero) ; four entries
+// per lane 144 / 149 but Float32 130 ; two register sets taken in turn instead of copying the loaded chunk 152 / 154 (128 registers and
+// a spill) ; the scan through ds_bpermute, read-modify-write adds instead of ds_add_f64: no difference.  What is left below the probe's
+// 5.4 - 5.9 TB/s is the tile's barrier: a tile is 74 chunks for 16 waves, the last round of chunks leaves half the waves waiting.
 constexpr int kTileLanes = 1024, kTileWaves = kTileLanes / 64, kTileE = 8, kTileChunk = 64 * kTileE;
-constexpr int kTileRows = 8192, kTileColBits = 14, kTileWindowBytes = 65536;
+constexpr int kTileRows = 8192, kTileWindowBytes = 65536;
+// an entry's word: its local row << 17 | the BYTE offset of its operand entry in the window (0 ... 65536: one slot past the window holds a
+// zero — the padding entries, whose values are zero too, point there: no product to guard, whatever the operand holds)
+constexpr int kTileRowShift = 17, kTileXwBytes = kTileWindowBytes + 16;
 template <typename T>
 struct TileCols { static constexpr int value = kTileWindowBytes / (int)sizeof(T); };
 constexpr int kTileTable = kTileLanes;   // chunks of a tile between two barriers: every chunk leaves its last row in a table, an entry per lane
-constexpr size_t kTileLds = (size_t)kTileWindowBytes + (size_t)kTileRows * 8 + (size_t)kTileTable * 12;
+constexpr size_t kTileLds = (size_t)kTileXwBytes + (size_t)kTileRows * 8 + (size_t)kTileTable * 12;
 
 // (an address has one owner between two barriers, and a wave's LDS operations execute in order: the add needs no return and no wait)
 __device__ __forceinline__ void tile_add(double* acc, int row, double v) { unsafeAtomicAdd(acc + row, v); }
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
   constexpr int kCols = TileCols<T>::value, kPer = 16 / (int)sizeof(T), kVecs = kCols / kPer / kTileLanes;      // 4 vectors per lane
   typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
   T* xw = (T*)tile_lds;
-  double* acc = (double*)(tile_lds + kTileWindowBytes);
+  double* acc = (double*)(tile_lds + kTileXwBytes);
   double* tsum = acc + kTileRows;
   int* trow = (int*)(tsum + kTileTable);
   const int32_t* it = items + (int64_t)blockIdx.x * 6;
@@ -339,9 +344,9 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
   // a wave's loads of one chunk (a lane: kTileE consecutive entries) — every load instruction 64 lanes x 16 consecutive bytes, the
   // host stores a chunk so
   typedef int J4 __attribute__((ext_vector_type(4)));
-  int jn[kTileE] = {};
-  double vn[kTileE] = {};
-  auto load = [&](int64_t c) {
+  int ja[kTileE] = {};
+  double va[kTileE] = {};
+  auto load_into = [&](int (&jn)[kTileE], double (&vn)[kTileE], int64_t c) {
 #pragma unroll
     for (int q = 0; q < kTileE / 4; ++q) {
       const J4 t = *((const J4*)(ind + c * kTileChunk) + q * 64 + lane);
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
       }
     }
   };
+  auto load = [&](int64_t c) { load_into(ja, va, c); };
   int w = next_tile(it[2]);
   int64_t cb = 0, c1 = 0;                              // the batch of chunks at hand begins at cb ; the tile ends at c1
   if (w < w1) {
@@ -372,6 +378,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
     if (cb + wave < c1) load(cb + wave);
   }
   for (int i = tid; i < kTileRows; i += kTileLanes) acc[i] = 0.0;
+  if (tid < 4) ((int*)(tile_lds + kTileWindowBytes))[tid] = 0;      // the zero past the window
   if (w < w1) window_store();
   __syncthreads();
   bool fresh = true;                                   // the tile's first batch: ask for the window after it
@@ -388,33 +395,31 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
       double p[kTileE];
 #pragma unroll
       for (int e = 0; e < kTileE; ++e) {
-        j[e] = jn[e];
-        p[e] = vn[e];
+        j[e] = ja[e];
+        p[e] = va[e];
       }
       if (c + kTileWaves < ce) load(c + kTileWaves);
       int r[kTileE];
 #pragma unroll
       for (int e = 0; e < kTileE; ++e) {
-        r[e] = (j[e] >> kTileColBits) & (kTileRows - 1);
-        const double xv = (double)xw[j[e] & ((1 << kTileColBits) - 1)];
-        p[e] = j[e] < 0 ? 0.0 : p[e] * xv;             // (padding: no product, whatever the operand holds)
+        r[e] = (int)((unsigned)j[e] >> kTileRowShift);
+        p[e] = p[e] * (double)*(const T*)(tile_lds + (j[e] & ((1 << kTileRowShift) - 1)));
       }
-      // the lane's own runs: the first (head) and the last (tail) may go on in the neighbours ; the ones between are whole rows
-      int hr = r[0], cr = r[0], nseg = 0;
-      double hs = 0.0, cs = p[0];
+      // the lane's own runs, without branches: run[e] the sum of the run entry e ends ; the first run (head) and the last (tail) may go on
+      // in the neighbours, the ones between are whole rows — added here where they end
+      double run = p[0], hs = p[0];
+      bool head = true;
 #pragma unroll
       for (int e = 1; e < kTileE; ++e) {
-        if (r[e] == cr) cs += p[e];
-        else {
-          if (nseg == 0) hs = cs;
-          else tile_add(acc, cr, cs);
-          ++nseg;
-          cr = r[e];
-          cs = p[e];
-        }
+        const bool same = r[e] == r[e - 1];
+        if (!same && !head) tile_add(acc, r[e - 1], run);
+        run = same ? run + p[e] : p[e];
+        head = head && same;
+        hs = head ? run : hs;
       }
-      const bool single = nseg == 0;
-      const int tr = cr;
+      const bool single = head;
+      const int hr = r[0], tr = r[kTileE - 1];
+      const double cs = run;
       const int prev_tr = dpp_i<kDppWaveShr1>(-1, tr);        // (lane 0 keeps -1: the chunk's first row is added as if it began here)
       const int next_fr = dpp_i<kDppWaveShl1>(-1, r[0]);
       const bool start = !single || prev_tr != tr;
@@ -743,22 +748,22 @@ static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h,
         const int q = (int)(e % kTileChunk), L = q / kTileE, u = q % kTileE;
         const int32_t rl = (int32_t)(i - rb * kTileRows);
         const int at4 = (u / 4) * 256 + 4 * L + u % 4, at2 = (u / 2) * 128 + 2 * L + u % 2;      // 16-byte pieces of 4-byte / of 8-byte items
-        tp.ind[(size_t)(base + at4)] = (rl << kTileColBits) | (int32_t)(ind_h[k] - w * wc);
+        tp.ind[(size_t)(base + at4)] = (int32_t)(((uint32_t)rl << kTileRowShift) | (uint32_t)((ind_h[k] - w * wc) * (int64_t)sizeof(T)));
         tp.val[(size_t)(base + (sizeof(T) == 8 ? at2 : at4))] = val_h[k];
         last[(size_t)w] = rl;
       }
-    for (int64_t w = 0; w < NW; ++w) {                 // padding: entries of the tile's last row, flagged
+    for (int64_t w = 0; w < NW; ++w) {                 // padding: zero entries of the tile's last row that point at the zero past the window
       const int64_t t = rb * NW + w, n = cnt[(size_t)t], cap = (off[(size_t)t + 1] - off[(size_t)t]) * kTileChunk;
       for (int64_t e = n; e < cap; ++e) {
         const int q = (int)(e % kTileChunk), L = q / kTileE, u = q % kTileE;
         tp.ind[(size_t)((off[(size_t)t] + e / kTileChunk) * kTileChunk + (u / 4) * 256 + 4 * L + u % 4)] =
-            (int32_t)(0x80000000u | (uint32_t)(last[(size_t)w] << kTileColBits));
+            (int32_t)(((uint32_t)last[(size_t)w] << kTileRowShift) | (uint32_t)kTileWindowBytes);
       }
     }
   }
   // work items
   // one item per CU: a workgroup fills a CU (1024 lanes, 140 KB of LDS), so a second round would begin when the first has drained —
-  // measured on 1 M x 100 k, 60 M entries: 256 items 148 / 147 us for X w / X' r, 512 items 146 / 151
+  // measured on 1 M x 100 k, 60 M entries: 256 items 148 / 147 us for X w / X' r, 512 items 146 / 151 (Float32 118 / 117 and 110 / 106)
   const int64_t budget = std::max(ctx->num_cu, 1);
   struct Item { int32_t rb, split, w0, w1, z0, z1; int64_t cost; };
   std::vector<Item> its;
