@@ -169,7 +169,7 @@ struct apx_matrix {
   int32_t* rblk = nullptr;
   int32_t* tblk = nullptr;
   std::vector<int32_t> rblk_off, tblk_off;
-  //  * LDS TILES (spmv_tiles): the orientation cut into tiles of 8192 rows x one 64 KB window of the gathered operand, the entries of a
+  //  * LDS TILES (spmv_tiles): the orientation cut into tiles of (up to) 8192 rows x one 64 KB window of the gathered operand, the entries of a
   //    tile stored together (row-major within it) with their row and index LOCAL to the tile packed into 32 bits — the window of the
   //    operand is staged in LDS and every gather is an LDS read, the rows' sums are kept in LDS across the windows.  A side that has
   //    tiles keeps its plain compressed rows (ptr / ind / val) next to them and has neither windows nor row blocks.
@@ -178,7 +178,7 @@ struct apx_matrix {
     int32_t* off = nullptr;     // [row blocks x windows + 1]: where the tiles begin, in chunks of 256 entries
     int32_t* ind = nullptr;     // packed entries (local row << 17 | byte offset in the window), every tile padded to whole chunks
     void* val = nullptr;
-    int32_t n_items = 0, nw = 0, splits = 0;
+    int32_t n_items = 0, nw = 0, splits = 0, rows = 0;   // rows: of a row block (8192, fewer where the blocks x windows would not fill the chip)
   };
   Tiles rtile, ttile;
   // problems created on this matrix and not yet destroyed: a solver of theirs may hold pointers into the column-major storage (the

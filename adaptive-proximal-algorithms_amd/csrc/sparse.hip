@@ -308,7 +308,7 @@ template <typename T>
 __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restrict__ items, const int32_t* __restrict__ off,
                                                          const int32_t* __restrict__ ind, const T* __restrict__ val,
                                                          const T* __restrict__ x, double* __restrict__ part, int64_t ncols_pad,
-                                                         int64_t nrows_pad, int nw, const int* __restrict__ done) {
+                                                         int64_t nrows_pad, int nw, int rbs, const int* __restrict__ done) {
   extern __shared__ __align__(16) unsigned char tile_lds[];
   if (done != nullptr && *done != 0) return;
   constexpr int kCols = TileCols<T>::value, kPer = 16 / (int)sizeof(T), kVecs = kCols / kPer / kTileLanes;      // 4 vectors per lane
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
       fresh = true;
     }
   }
-  const int64_t row0 = (int64_t)rb * kTileRows;
-  const int nr = (int)std::min<int64_t>(kTileRows, nrows_pad - row0);
+  const int64_t row0 = (int64_t)rb * rbs;
+  const int nr = (int)std::min<int64_t>(rbs, nrows_pad - row0);
   for (int i = tid; i < nr; i += kTileLanes) {
     part[(int64_t)split * nrows_pad + row0 + i] = acc[i];
     for (int z = z0; z < z1; ++z) part[(int64_t)z * nrows_pad + row0 + i] = 0.0;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
 template <typename T>
 static int32_t launch_tiles(apx_ctx* ctx, const apx_matrix::Tiles& t, const void* x, int64_t ncols_pad, int64_t nrows_pad, const int* done) {
   hipLaunchKernelGGL((spmv_tiles<T>), dim3((unsigned)t.n_items), dim3(kTileLanes), kTileLds, ctx->stream, t.items, t.off, t.ind, (const T*)t.val,
-                     (const T*)x, ctx->part, ncols_pad, nrows_pad, t.nw, done);
+                     (const T*)x, ctx->part, ncols_pad, nrows_pad, t.nw, t.rows, done);
   return APX_OK;
 }
 
@@ -574,8 +574,8 @@ static void side_name(apx_ctx* ctx, int kind, const apx_matrix* A, int W, const 
 static void tiles_name(apx_ctx* ctx, int kind, const apx_matrix* A, const apx_matrix::Tiles& t) {
   if (!ctx->profile) return;
   char b[200];
-  snprintf(b, sizeof b, "spmv_tiles<%s>: %d workgroups of %d lanes, the operand in 64 KB LDS windows (%d), %d split(s)", A->dtype == APX_F32 ? "float" : "double",
-           t.n_items, kTileLanes, t.nw, t.splits);
+  snprintf(b, sizeof b, "spmv_tiles<%s>: %d workgroups of %d lanes, the operand in 64 KB LDS windows (%d), row blocks of %d, %d split(s)",
+           A->dtype == APX_F32 ? "float" : "double", t.n_items, kTileLanes, t.nw, t.rows, t.splits);
   ctx->kname[kind] = b;
 }
 
@@ -712,20 +712,31 @@ template <typename T>
 struct TilePlan {
   std::vector<int32_t> items, off, ind;
   std::vector<T> val;
-  int nw = 0, splits = 0;
+  int nw = 0, splits = 0, rows = 0;
 };
 template <typename T>
 static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h, const T* val_h, int64_t nrows, int64_t nrows_pad, int64_t ncols,
                        int64_t nnz, bool force, TilePlan<T>& tp) {
   const int64_t wc = TileCols<T>::value;
-  const int64_t RB = (nrows_pad + kTileRows - 1) / kTileRows, NW = std::max<int64_t>(1, (ncols + wc - 1) / wc);
+  const int64_t NW = std::max<int64_t>(1, (ncols + wc - 1) / wc);
+  // rows of a row block: the accumulator's 8192 — fewer where blocks x windows would not give every CU an item (400 000 x 2000: one
+  // window, 49 blocks of 8192 rows ; with 1568 rows a block there are 256)
+  int64_t rbs = kTileRows;
+  {
+    const int64_t per_block = std::min<int64_t>(NW, 64), cus = std::max(ctx->num_cu, 1);
+    if (((nrows_pad + rbs - 1) / rbs) * per_block < cus) {
+      const int64_t want = (cus + per_block - 1) / per_block;
+      rbs = std::max<int64_t>(32, std::min<int64_t>(kTileRows, round_up((nrows_pad + want - 1) / want, 32)));
+    }
+  }
+  const int64_t RB = (nrows_pad + rbs - 1) / rbs;
   if (nnz <= 0 || nrows <= 0 || RB * NW > ((int64_t)1 << 24)) return false;
   // where they pay: a tile streams its entries and stages 64 KB of the operand — entries worth 1.5 windows per tile on average, and a
   // matrix large enough for its products to be more than launches
   if (!force && (nnz < ((int64_t)1 << 22) || nnz / (RB * NW) < 8192)) return false;
   std::vector<int64_t> cnt((size_t)(RB * NW), 0);
   for (int64_t i = 0; i < nrows; ++i) {
-    int64_t* c = cnt.data() + (i / kTileRows) * NW;
+    int64_t* c = cnt.data() + (i / rbs) * NW;
     for (int64_t k = ptr_h[i]; k < ptr_h[i + 1]; ++k) c[ind_h[k] / wc]++;
   }
   std::vector<int64_t> off((size_t)(RB * NW) + 1, 0);
@@ -740,13 +751,13 @@ static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h,
   for (int64_t rb = 0; rb < RB; ++rb) {
     std::fill(cur.begin(), cur.end(), 0);
     std::fill(last.begin(), last.end(), 0);
-    const int64_t i1 = std::min<int64_t>(nrows, (rb + 1) * kTileRows);
-    for (int64_t i = rb * kTileRows; i < i1; ++i)
+    const int64_t i1 = std::min<int64_t>(nrows, (rb + 1) * rbs);
+    for (int64_t i = rb * rbs; i < i1; ++i)
       for (int64_t k = ptr_h[i]; k < ptr_h[i + 1]; ++k) {
         const int64_t w = ind_h[k] / wc, e = cur[(size_t)w]++;
         const int64_t base = (off[(size_t)(rb * NW + w)] + e / kTileChunk) * kTileChunk;
         const int q = (int)(e % kTileChunk), L = q / kTileE, u = q % kTileE;
-        const int32_t rl = (int32_t)(i - rb * kTileRows);
+        const int32_t rl = (int32_t)(i - rb * rbs);
         const int at4 = (u / 4) * 256 + 4 * L + u % 4, at2 = (u / 2) * 128 + 2 * L + u % 2;      // 16-byte pieces of 4-byte / of 8-byte items
         tp.ind[(size_t)(base + at4)] = (int32_t)(((uint32_t)rl << kTileRowShift) | (uint32_t)((ind_h[k] - w * wc) * (int64_t)sizeof(T)));
         tp.val[(size_t)(base + (sizeof(T) == 8 ? at2 : at4))] = val_h[k];
@@ -817,6 +828,7 @@ static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h,
     for (int32_t v : {q.rb, q.split, q.w0, q.w1, q.z0, q.z1}) tp.items.push_back(v);
   tp.nw = (int)NW;
   tp.splits = splits;
+  tp.rows = (int)rbs;
   return true;
 }
 
@@ -947,6 +959,7 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
     d.n_items = (int32_t)(tp.items.size() / 6);
     d.nw = tp.nw;
     d.splits = tp.splits;
+    d.rows = tp.rows;
     return APX_OK;
   };
   if (has_tr) APX_TRY(up_tiles(A->rtile, tr));

@@ -188,7 +188,8 @@ def _tile_case(rng, m, n, per_row, dtype, heavy):
                                                (8192, 8192, 10, False), (8193, 16_385, 14, True),      # (a row block / a window of one row / column)
                                                (1, 50_000, 15_000, False), (50_000, 1, 0.5, False),     # one row ; one column
                                                (8192, 8192, 90, False),                                # 740 000 entries in ONE tile: two batches of chunks
-                                               (40_000, 17_000, 0.3, True)])                            # fewer entries than rows
+                                               (40_000, 17_000, 0.3, True),                             # fewer entries than rows
+                                               (70_000, 500, 8, False), (500, 70_000, 900, True)])      # one window: row blocks of 288 / 32 rows
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_products_on_lds_tiles(apx, m, n, per_row, heavy, dtype):
     """Round 5 (csrc/sparse.hip spmv_tiles): the operand's 64 KB windows in LDS, the entries tile by tile with their local row and index
@@ -214,6 +215,8 @@ def test_products_on_lds_tiles(apx, m, n, per_row, heavy, dtype):
         y, g = dA @ x, dA.T @ r
         names = (ctx.kernel_name("gemv_n"), ctx.kernel_name("gemv_t"))
         assert ("spmv_tiles" in names[0]) == (mode == 3) and ("spmv_tiles" in names[1]) == (mode == 3), names
+        if mode == 3 and (m, n) == (70_000, 500):      # (blocks x windows must give every CU an item: 70 016 rows / 256)
+            assert "row blocks of 288" in names[0] and "row blocks of 32," in names[1], names
         assert np.max(np.abs(y - y_ref) / sy) <= 4 * eps and np.max(np.abs(g - g_ref) / sg) <= 4 * eps
         assert np.array_equal(dA @ x, y) and np.array_equal(dA.T @ r, g)
         assert dA.norm() == pytest.approx(np.sqrt(A64.multiply(A64).sum()), rel=1e-6 if dtype == np.float32 else 1e-12)

@@ -6,7 +6,10 @@
 //   gather(N)   + one 8-byte gather per entry from an operand of N doubles, uniformly random -> what the L2 / MALL gather costs
 //                 (N = 100 000: 0.8 MB, L2-resident ; N = 1 000 000: 8 MB, beyond an XCD's 4 MB L2)
 //   lds(N)      the same with the operand in LDS tiles of 16 384 doubles (indices taken modulo the tile: the blocked layout's
-//                 best case — every gather a bank-conflicted LDS read instead of an L2 transaction)
+//                 best case — every gather a bank-conflicted LDS read instead of an L2 transaction) ; with blocks of 256 lanes, ONE
+//                 per CU beside 128 KB of LDS, four waves cannot keep the stream going (2.3 TB/s) — the extra rows repeat it with
+//                 blocks of 1024 lanes (16 waves per CU): 5.4 - 5.9 TB/s, the rate of the stream alone.  csrc/sparse.hip's
+//                 spmv_tiles is built on that row.
 //   sorted(N)   gather with indices sorted within each wave's 64-entry stride (neighbouring lanes hit neighbouring lines:
 //                 what a row-local column ordering could buy)
 // Prints GB/s of 12 B / entry.   hipcc -O3 --offload-arch=gfx950 tools/gather_probe.hip -o gather_probe && ./gather_probe

@@ -24,7 +24,7 @@ def short(name):
         return "k_team_rows (primal-dual)" if "k_team_rows<100" in name.replace(" ", "") else "k_team_rows"
     for key in ("k_multi_rows", "k_teampd_rows", "k_slab2_rows", "k_slabpd_rows", "k_slabpd_close", "k_slab_rows", "k_slab_close",
                 "gemv_n_kernel", "gemv_t_kernel", "gemv_t_finish", "k_finish_rows", "k_f_reduce", "k_reduce_n",
-                "k_rule", "k_step", "k_dual", "k_final", "k_fill_uniform", "k_scale_columns", "sum_partials_rows", "spmv_stream", "spmv_rows", "spmv_long", "k_bt_trial"):
+                "k_rule", "k_step", "k_dual", "k_final", "k_fill_uniform", "k_scale_columns", "sum_partials_rows", "spmv_tiles", "spmv_stream", "spmv_rows", "spmv_long", "k_bt_trial"):
         if key in name:
             return key
     return name[:60]
