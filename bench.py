@@ -415,8 +415,9 @@ def other_configs(apx, problems, ctx, barrier) -> dict:
 def sparse_leg(apx, ctx, barrier, m: int = 1_000_000, n: int = 100_000, per_row: int = 60, steps: int = 100) -> dict:
     """The orientation the reference's real datasets use (experiments/sparse_logreg/runme.jl:24,31: `f.X * w`, `f.X' * r` on a
     SparseMatrixCSC, Float64): l1-logistic regression on a SPARSE X, here 1 000 000 x 100 000 with ~60 entries per row (60 M stored
-    entries: 720 MB of values + indices per orientation — beyond the Infinity Cache, so both products stream from HBM and gather
-    their operand through L2).  Not a BASELINE config.  Algorithmic bytes per product: nnz * (sizeof(T) + 4)."""
+    entries: 720 MB of values + indices per orientation — beyond the Infinity Cache, so both products stream from HBM ; their operand
+    is gathered from 64 KB windows staged in LDS, csrc/sparse.hip spmv_tiles).  Not a BASELINE config.  Algorithmic bytes per product:
+    nnz * (sizeof(T) + 4)."""
     import scipy.sparse as sp
     rng = np.random.default_rng(0)
     nnz_row = np.clip(rng.poisson(per_row, m), 1, n)
@@ -445,8 +446,9 @@ def sparse_leg(apx, ctx, barrier, m: int = 1_000_000, n: int = 100_000, per_row:
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": k[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": k[dom]["GBps"] / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_pass,
                          "iteration_frac": 2.0 * per_pass * steps / dt / 1e9 / HBM_PEAK_GBS,
-                         "note": "values + indices per product ; the gathered operand (0.8 MB for X w, 8 MB for X' r) and the row "
-                                 "pointers are excluded.  The ceiling of this access pattern is not the HBM peak: profiles/r05_gather_probe.log"},
+                         "note": "values + indices per product (the entries' 12 bytes ; the tiles' padding, the operand's windows — read "
+                                 "once per tile, from L2 — and the splits written are excluded).  The ceiling of the access pattern "
+                                 "(stream + one gather per entry from LDS) is 5.4 - 5.9 TB/s: profiles/r05_gather_probe.log"},
             "objective": res.objective, "timed_steps_all_real": ok}
 
 
