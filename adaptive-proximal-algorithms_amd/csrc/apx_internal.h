@@ -174,11 +174,11 @@ struct apx_matrix {
   //    operand is staged in LDS and every gather is an LDS read, the rows' sums are kept in LDS across the windows.  A side that has
   //    tiles keeps its plain compressed rows (ptr / ind / val) next to them and has neither windows nor row blocks.
   struct Tiles {
-    int32_t* items = nullptr;   // n_items x 6: row block, split, first / one past the last window, splits to fill with zeros [z0, z1)
+    int32_t* items = nullptr;   // n_items x 8: row block, split, first / one past the last window, splits to fill with zeros [z0, z1), first row, rows
     int32_t* off = nullptr;     // [row blocks x windows + 1]: where the tiles begin, in chunks of 256 entries
     int32_t* ind = nullptr;     // packed entries (local row << 17 | byte offset in the window), every tile padded to whole chunks
     void* val = nullptr;
-    int32_t n_items = 0, nw = 0, splits = 0, rows = 0;   // rows: of a row block (8192, fewer where the blocks x windows would not fill the chip)
+    int32_t n_items = 0, nw = 0, splits = 0, rows = 0;   // rows: of the largest row block (8192 ; fewer where blocks x windows would not fill the chip)
   };
   Tiles rtile, ttile;
   // problems created on this matrix and not yet destroyed: a solver of theirs may hold pointers into the column-major storage (the

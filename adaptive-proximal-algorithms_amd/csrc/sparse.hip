@@ -285,6 +285,7 @@ constexpr int kTileRows = 8192, kTileWindowBytes = 65536;
 constexpr int kTileRowShift = 17, kTileXwBytes = kTileWindowBytes + 16;
 template <typename T>
 struct TileCols { static constexpr int value = kTileWindowBytes / (int)sizeof(T); };
+constexpr int kTileItemInts = 8;         // a work item: row block, split, first / one past the last window, splits to zero [z0, z1), first row, rows
 constexpr int kTileTable = kTileLanes;   // chunks of a tile between two barriers: every chunk leaves its last row in a table, an entry per lane
 constexpr size_t kTileLds = (size_t)kTileXwBytes + (size_t)kTileRows * 8 + (size_t)kTileTable * 12;
 
@@ -308,7 +309,7 @@ template <typename T>
 __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restrict__ items, const int32_t* __restrict__ off,
                                                          const int32_t* __restrict__ ind, const T* __restrict__ val,
                                                          const T* __restrict__ x, double* __restrict__ part, int64_t ncols_pad,
-                                                         int64_t nrows_pad, int nw, int rbs, const int* __restrict__ done) {
+                                                         int64_t nrows_pad, int nw, const int* __restrict__ done) {
   extern __shared__ __align__(16) unsigned char tile_lds[];
   if (done != nullptr && *done != 0) return;
   constexpr int kCols = TileCols<T>::value, kPer = 16 / (int)sizeof(T), kVecs = kCols / kPer / kTileLanes;      // 4 vectors per lane
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
   double* acc = (double*)(tile_lds + kTileXwBytes);
   double* tsum = acc + kTileRows;
   int* trow = (int*)(tsum + kTileTable);
-  const int32_t* it = items + (int64_t)blockIdx.x * 6;
+  const int32_t* it = items + (int64_t)blockIdx.x * kTileItemInts;
   const int rb = it[0], split = it[1], w1 = it[3], z0 = it[4], z1 = it[5];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* toff = off + (int64_t)rb * nw;
@@ -478,8 +479,8 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
       fresh = true;
     }
   }
-  const int64_t row0 = (int64_t)rb * rbs;
-  const int nr = (int)std::min<int64_t>(rbs, nrows_pad - row0);
+  const int64_t row0 = it[6];
+  const int nr = it[7];
   for (int i = tid; i < nr; i += kTileLanes) {
     part[(int64_t)split * nrows_pad + row0 + i] = acc[i];
     for (int z = z0; z < z1; ++z) part[(int64_t)z * nrows_pad + row0 + i] = 0.0;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
 template <typename T>
 static int32_t launch_tiles(apx_ctx* ctx, const apx_matrix::Tiles& t, const void* x, int64_t ncols_pad, int64_t nrows_pad, const int* done) {
   hipLaunchKernelGGL((spmv_tiles<T>), dim3((unsigned)t.n_items), dim3(kTileLanes), kTileLds, ctx->stream, t.items, t.off, t.ind, (const T*)t.val,
-                     (const T*)x, ctx->part, ncols_pad, nrows_pad, t.nw, t.rows, done);
+                     (const T*)x, ctx->part, ncols_pad, nrows_pad, t.nw, done);
   return APX_OK;
 }
 
@@ -574,7 +575,7 @@ static void side_name(apx_ctx* ctx, int kind, const apx_matrix* A, int W, const 
 static void tiles_name(apx_ctx* ctx, int kind, const apx_matrix* A, const apx_matrix::Tiles& t) {
   if (!ctx->profile) return;
   char b[200];
-  snprintf(b, sizeof b, "spmv_tiles<%s>: %d workgroups of %d lanes, the operand in 64 KB LDS windows (%d), row blocks of %d, %d split(s)",
+  snprintf(b, sizeof b, "spmv_tiles<%s>: %d workgroups of %d lanes, the operand in 64 KB LDS windows (%d), row blocks of up to %d, %d split(s)",
            A->dtype == APX_F32 ? "float" : "double", t.n_items, kTileLanes, t.nw, t.rows, t.splits);
   ctx->kname[kind] = b;
 }
@@ -719,25 +720,42 @@ static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h,
                        int64_t nnz, bool force, TilePlan<T>& tp) {
   const int64_t wc = TileCols<T>::value;
   const int64_t NW = std::max<int64_t>(1, (ncols + wc - 1) / wc);
-  // rows of a row block: the accumulator's 8192 — fewer where blocks x windows would not give every CU an item (400 000 x 2000: one
-  // window, 49 blocks of 8192 rows ; with 1568 rows a block there are 256)
+  // row blocks: the accumulator's 8192 rows — fewer where blocks x windows would not give every CU an item (400 000 x 2000: one
+  // window, 49 blocks of 8192 rows ; with 1568 rows a block there are 256), and a block ends early where its entries exceed what its
+  // windows can be divided into (a block makes at most min(windows, 64) items: the head of a power-law X' — a few thousand features
+  // holding half of the entries — becomes several blocks)
+  if (nnz <= 0 || nrows <= 0) return false;
   int64_t rbs = kTileRows;
-  {
-    const int64_t per_block = std::min<int64_t>(NW, 64), cus = std::max(ctx->num_cu, 1);
-    if (((nrows_pad + rbs - 1) / rbs) * per_block < cus) {
-      const int64_t want = (cus + per_block - 1) / per_block;
-      rbs = std::max<int64_t>(32, std::min<int64_t>(kTileRows, round_up((nrows_pad + want - 1) / want, 32)));
-    }
+  const int64_t per_block = std::min<int64_t>(NW, 64), cus = std::max(ctx->num_cu, 1);
+  if (((nrows_pad + rbs - 1) / rbs) * per_block < cus) {
+    const int64_t want = (cus + per_block - 1) / per_block;
+    rbs = std::max<int64_t>(32, std::min<int64_t>(kTileRows, round_up((nrows_pad + want - 1) / want, 32)));
   }
-  const int64_t RB = (nrows_pad + rbs - 1) / rbs;
-  if (nnz <= 0 || nrows <= 0 || RB * NW > ((int64_t)1 << 24)) return false;
+  // (three quarters of what min(windows, 64) items of average size hold ; a block of one window is not divided at all — its rows are)
+  const double cap = per_block >= 2 ? 0.75 * std::max(1.0, (double)nnz * (double)per_block / (double)cus) : 4.0e18;
+  std::vector<int64_t> first(1, 0);
+  {
+    int64_t in_block = 0;
+    for (int64_t i = 0; i < nrows_pad; ++i) {
+      const int64_t len = i < nrows ? ptr_h[i + 1] - ptr_h[i] : 0;
+      if (i > first.back() && (i - first.back() == rbs || (double)(in_block + len) > cap)) {
+        first.push_back(i);
+        in_block = 0;
+      }
+      in_block += len;
+    }
+    first.push_back(nrows_pad);
+  }
+  const int64_t RB = (int64_t)first.size() - 1;
+  if (RB * NW > ((int64_t)1 << 24)) return false;
   // where they pay: a tile streams its entries and stages 64 KB of the operand — entries worth 1.5 windows per tile on average, and a
   // matrix large enough for its products to be more than launches
   if (!force && (nnz < ((int64_t)1 << 22) || nnz / (RB * NW) < 8192)) return false;
   std::vector<int64_t> cnt((size_t)(RB * NW), 0);
-  for (int64_t i = 0; i < nrows; ++i) {
-    int64_t* c = cnt.data() + (i / rbs) * NW;
-    for (int64_t k = ptr_h[i]; k < ptr_h[i + 1]; ++k) c[ind_h[k] / wc]++;
+  for (int64_t rb = 0; rb < RB; ++rb) {
+    int64_t* c = cnt.data() + rb * NW;
+    for (int64_t i = first[(size_t)rb]; i < std::min(nrows, first[(size_t)rb + 1]); ++i)
+      for (int64_t k = ptr_h[i]; k < ptr_h[i + 1]; ++k) c[ind_h[k] / wc]++;
   }
   std::vector<int64_t> off((size_t)(RB * NW) + 1, 0);
   for (int64_t t = 0; t < RB * NW; ++t) off[(size_t)t + 1] = off[(size_t)t] + (cnt[(size_t)t] + kTileChunk - 1) / kTileChunk;
@@ -751,13 +769,13 @@ static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h,
   for (int64_t rb = 0; rb < RB; ++rb) {
     std::fill(cur.begin(), cur.end(), 0);
     std::fill(last.begin(), last.end(), 0);
-    const int64_t i1 = std::min<int64_t>(nrows, (rb + 1) * rbs);
-    for (int64_t i = rb * rbs; i < i1; ++i)
+    const int64_t i1 = std::min<int64_t>(nrows, first[(size_t)rb + 1]);
+    for (int64_t i = first[(size_t)rb]; i < i1; ++i)
       for (int64_t k = ptr_h[i]; k < ptr_h[i + 1]; ++k) {
         const int64_t w = ind_h[k] / wc, e = cur[(size_t)w]++;
         const int64_t base = (off[(size_t)(rb * NW + w)] + e / kTileChunk) * kTileChunk;
         const int q = (int)(e % kTileChunk), L = q / kTileE, u = q % kTileE;
-        const int32_t rl = (int32_t)(i - rb * rbs);
+        const int32_t rl = (int32_t)(i - first[(size_t)rb]);
         const int at4 = (u / 4) * 256 + 4 * L + u % 4, at2 = (u / 2) * 128 + 2 * L + u % 2;      // 16-byte pieces of 4-byte / of 8-byte items
         tp.ind[(size_t)(base + at4)] = (int32_t)(((uint32_t)rl << kTileRowShift) | (uint32_t)((ind_h[k] - w * wc) * (int64_t)sizeof(T)));
         tp.val[(size_t)(base + (sizeof(T) == 8 ? at2 : at4))] = val_h[k];
@@ -823,12 +841,14 @@ static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h,
       q.z1 = splits;
     }
   std::stable_sort(its.begin(), its.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
-  tp.items.reserve(its.size() * 6);
+  tp.items.reserve(its.size() * kTileItemInts);
   for (const auto& q : its)
-    for (int32_t v : {q.rb, q.split, q.w0, q.w1, q.z0, q.z1}) tp.items.push_back(v);
+    for (int32_t v : {q.rb, q.split, q.w0, q.w1, q.z0, q.z1, (int32_t)first[(size_t)q.rb], (int32_t)(first[(size_t)q.rb + 1] - first[(size_t)q.rb])})
+      tp.items.push_back(v);
   tp.nw = (int)NW;
   tp.splits = splits;
-  tp.rows = (int)rbs;
+  tp.rows = 0;
+  for (int64_t rb = 0; rb < RB; ++rb) tp.rows = std::max<int>(tp.rows, (int)(first[(size_t)rb + 1] - first[(size_t)rb]));
   return true;
 }
 
@@ -956,7 +976,7 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
     APX_TRY(up((void**)&d.off, tp.off.data(), tp.off.size() * sizeof(int32_t)));
     APX_TRY(up((void**)&d.ind, tp.ind.data(), tp.ind.size() * sizeof(int32_t)));
     APX_TRY(up(&d.val, tp.val.data(), tp.val.size() * sizeof(T)));
-    d.n_items = (int32_t)(tp.items.size() / 6);
+    d.n_items = (int32_t)(tp.items.size() / kTileItemInts);
     d.nw = tp.nw;
     d.splits = tp.splits;
     d.rows = tp.rows;
