@@ -321,7 +321,7 @@ enum {
                                     exceeds 3 MB is stored WINDOW-MAJOR and its product runs window by window of the operand (2 MB: half
                                     an XCD's L2 ; tools/gather_probe.hip: 2.0 against 1.1 TB/s of the entries' bytes) ; (b) the
                                     STREAMING form: blocks of rows whose entries are loaded as one run, products through LDS, eight lanes
-                                    per row.  2: besides, LDS TILES where they pay (4 M entries or more, 8192 or more per tile of 8192
+                                    per row.  2: besides, LDS TILES where they pay (1 M entries or more, 4096 or more per tile of 8192
                                     rows x 64 KB of operand): the operand's window staged in LDS, every gather an LDS read (the probe:
                                     5.4 - 5.9 TB/s), the rows' sums in LDS across the windows ; an orientation that has tiles keeps its
                                     plain rows next to them.  3: TEST hook — tiles on every matrix.  0: round 1's lanes-per-row kernel

@@ -146,8 +146,8 @@ def test_sparse_products_fuzz(apx):
         x, r = rng.standard_normal(n).astype(dtype), rng.standard_normal(m).astype(dtype)
         ctx = apx.Context(0)
         ctx.fused_small(False)
-        if tiles:      # the LDS-tile form on whatever is drawn (by itself it takes matrices of millions of entries only)
-            ctx.set_option(importlib.import_module("adaptive-proximal-algorithms_amd._lib").APX_OPT_SPARSE_WINDOWS, 3)
+        # the LDS-tile form on whatever is drawn, or never (by itself it takes matrices of a million entries or more)
+        ctx.set_option(importlib.import_module("adaptive-proximal-algorithms_amd._lib").APX_OPT_SPARSE_WINDOWS, 3 if tiles else 1)
         dA = apx.DeviceMatrix.from_sparse(A, ctx)
         A64 = A.astype(np.float64)
         y_ref, g_ref = A64 @ x.astype(np.float64), A64.T @ r.astype(np.float64)
@@ -255,7 +255,7 @@ def test_lds_tiles_on_a_power_law_matrix(apx, dtype):
 
 def test_lds_tiles_by_default_and_through_a_solver(apx):
     """What a matrix gets BY ITSELF (APX_OPT_SPARSE_WINDOWS 2, the default): 100 000 x 60 000 with 5.5 M entries — 55 000 per tile — runs
-    both products on the LDS tiles ; the same shape with 0.5 M entries keeps the streaming / window forms.  And a sparse logistic
+    both products on the LDS tiles ; the same shape with 0.5 M entries (below the million) keeps the streaming / window forms.  And a sparse logistic
     regression on the tiles follows the one on the round-5 forms (the fused epilogues take the tiles' splits like the windows')."""
     L = importlib.import_module("adaptive-proximal-algorithms_amd._lib")
     rng = np.random.default_rng(5)
