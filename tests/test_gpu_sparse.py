@@ -340,6 +340,41 @@ def test_sparse_lad_condat_vu(apx, generic_ctx, m, n, spmv):
     assert _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-10
 
 
+@pytest.mark.parametrize("method", ["condat_vu", "adaptive_primal_dual", "malitsky_pock"])
+def test_sparse_lad_on_lds_tiles_matches_the_oracle(apx, method):
+    """experiments/least_absolute_deviation/runme.jl:41-94 on a sparse A of 2.4 M entries (150 000 x 2500): both products of the
+    primal-dual loops run on the LDS tiles by default ; 60 iterations against the oracle on scipy's products."""
+    rng = np.random.default_rng(6)
+    m, n = 150_000, 2500
+    cnt = np.maximum(rng.poisson(16, m), 1)
+    A = sp.csr_matrix((rng.uniform(-1, 1, cnt.sum()), rng.integers(0, n, cnt.sum()), np.concatenate([[0], np.cumsum(cnt)])), shape=(m, n))
+    A.sum_duplicates()
+    yv = A @ (rng.standard_normal(n) * (rng.uniform(size=n) < 0.1)) + 0.1 * rng.standard_normal(m)
+    nA = float(sp.linalg.svds(A, k=1, return_singular_vectors=False)[0])
+    ctx = apx.Context(0)
+    dA = apx.DeviceMatrix.from_sparse(A, ctx)
+    ctx.profile(True)
+    K = 60
+    if method == "condat_vu":
+        kw = dict(Lf=0.0, norm_A=nA, tol=0.0, maxit=K)
+    elif method == "adaptive_primal_dual":
+        kw = dict(rule=None, tol=0.0, maxit=K)
+    else:
+        kw = dict(sigma=1.0 / nA, tol=0.0, maxit=K)
+    terms = lambda M: dict(f=M.Zero(), g=M.NormL1(0.5), h=M.Translate(M.NormL1(1.0), -yv))
+    if method == "adaptive_primal_dual":
+        kw["rule"] = O.OurRule(t=1.0, norm_A=nA)
+        xo, yo, _ = O.adaptive_primal_dual(np.zeros(n), np.zeros(m), A=A, **terms(O), **kw)
+        kw["rule"] = apx.OurRule(t=1.0, norm_A=nA)
+        x, y, _ = apx.adaptive_primal_dual(np.zeros(n), np.zeros(m), A=dA, ctx=ctx, **terms(apx), **kw)
+    else:
+        xo, yo, _ = getattr(O, method)(np.zeros(n), np.zeros(m), A=A, **terms(O), **kw)
+        x, y, _ = getattr(apx, method)(np.zeros(n), np.zeros(m), A=dA, ctx=ctx, **terms(apx), **kw)
+    assert "spmv_tiles" in ctx.kernel_name("gemv_n") and "spmv_tiles" in ctx.kernel_name("gemv_t")
+    assert _rel(x, xo) <= 1e-10 and _rel(y, yo) <= 1e-10 and np.any(x != 0)
+    dA.free()
+
+
 def test_libsvm_reader(apx, tmp_path):
     lib = importlib.import_module("adaptive-proximal-algorithms_amd.libsvm")
     path = tmp_path / "toy"
