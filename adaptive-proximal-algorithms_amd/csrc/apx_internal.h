@@ -178,6 +178,7 @@ struct apx_matrix {
     int32_t* off = nullptr;     // [row blocks x windows + 1]: where the tiles begin, in chunks of 256 entries
     int32_t* ind = nullptr;     // packed entries (local row << 17 | byte offset in the window), every tile padded to whole chunks
     void* val = nullptr;
+    int32_t wcols = 0;          // entries of the operand per window (<= 64 KB worth: chosen so that a tile is whole rounds of chunks)
     int32_t n_items = 0, nw = 0, splits = 0, rows = 0;   // rows: of the largest row block (8192 ; fewer where blocks x windows would not fill the chip)
   };
   Tiles rtile, ttile;

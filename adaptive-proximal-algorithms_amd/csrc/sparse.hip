@@ -309,7 +309,7 @@ template <typename T>
 __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restrict__ items, const int32_t* __restrict__ off,
                                                          const int32_t* __restrict__ ind, const T* __restrict__ val,
                                                          const T* __restrict__ x, double* __restrict__ part, int64_t ncols_pad,
-                                                         int64_t nrows_pad, int nw, const int* __restrict__ done) {
+                                                         int64_t nrows_pad, int nw, int wcols, const int* __restrict__ done) {
   extern __shared__ __align__(16) unsigned char tile_lds[];
   if (done != nullptr && *done != 0) return;
   constexpr int kCols = TileCols<T>::value, kPer = 16 / (int)sizeof(T), kVecs = kCols / kPer / kTileLanes;      // 4 vectors per lane
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
   // the operand's next window: asked for a tile ahead, kept in registers, stored between the tile's two barriers
   V xr[kVecs];
   auto window_load = [&](int w) {
-    const int64_t base = (int64_t)w * kCols;
+    const int64_t base = (int64_t)w * wcols;
 #pragma unroll
     for (int q = 0; q < kVecs; ++q) {
       const int i = tid + q * kTileLanes;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(kTileLanes) void spmv_tiles(const int32_t* __restri
 template <typename T>
 static int32_t launch_tiles(apx_ctx* ctx, const apx_matrix::Tiles& t, const void* x, int64_t ncols_pad, int64_t nrows_pad, const int* done) {
   hipLaunchKernelGGL((spmv_tiles<T>), dim3((unsigned)t.n_items), dim3(kTileLanes), kTileLds, ctx->stream, t.items, t.off, t.ind, (const T*)t.val,
-                     (const T*)x, ctx->part, ncols_pad, nrows_pad, t.nw, done);
+                     (const T*)x, ctx->part, ncols_pad, nrows_pad, t.nw, t.wcols, done);
   return APX_OK;
 }
 
@@ -575,8 +575,8 @@ static void side_name(apx_ctx* ctx, int kind, const apx_matrix* A, int W, const 
 static void tiles_name(apx_ctx* ctx, int kind, const apx_matrix* A, const apx_matrix::Tiles& t) {
   if (!ctx->profile) return;
   char b[200];
-  snprintf(b, sizeof b, "spmv_tiles<%s>: %d workgroups of %d lanes, the operand in 64 KB LDS windows (%d), row blocks of up to %d, %d split(s)",
-           A->dtype == APX_F32 ? "float" : "double", t.n_items, kTileLanes, t.nw, t.rows, t.splits);
+  snprintf(b, sizeof b, "spmv_tiles<%s>: %d workgroups of %d lanes, the operand in LDS windows (%d of %d), row blocks of up to %d, %d split(s)",
+           A->dtype == APX_F32 ? "float" : "double", t.n_items, kTileLanes, t.nw, t.wcols, t.rows, t.splits);
   ctx->kname[kind] = b;
 }
 
@@ -713,12 +713,19 @@ template <typename T>
 struct TilePlan {
   std::vector<int32_t> items, off, ind;
   std::vector<T> val;
-  int nw = 0, splits = 0, rows = 0;
+  int nw = 0, splits = 0, rows = 0, wcols = 0;
 };
 template <typename T>
 static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h, const T* val_h, int64_t nrows, int64_t nrows_pad, int64_t ncols,
                        int64_t nnz, bool force, TilePlan<T>& tp) {
-  const int64_t wc = TileCols<T>::value;
+  // the window: 64 KB of the operand — or somewhat less, so that the average tile of a full row block is WHOLE rounds of chunks for the
+  // 16 waves (the tile's barrier waits for its last round: 74 chunks = 4.6 rounds leave 7.5 % of the wave slots empty, 63 leave 1.5 %)
+  int64_t wc = TileCols<T>::value;
+  if (ncols > wc && nrows_pad > 0) {
+    const double c = (double)nnz * ((double)std::min<int64_t>(kTileRows, nrows_pad) / (double)nrows_pad) * ((double)wc / (double)ncols) / (double)kTileChunk;
+    const double k = std::floor((c + 1.2) / kTileWaves);
+    if (k >= 1.0 && c > kTileWaves) wc = std::max<int64_t>(wc / 2, (int64_t)((double)wc * (kTileWaves * k - 1.2) / c) / 32 * 32);
+  }
   const int64_t NW = std::max<int64_t>(1, (ncols + wc - 1) / wc);
   // row blocks: the accumulator's 8192 rows — fewer where blocks x windows would not give every CU an item (400 000 x 2000: one
   // window, 49 blocks of 8192 rows ; with 1568 rows a block there are 256), and a block ends early where its entries exceed what its
@@ -852,6 +859,7 @@ static bool plan_tiles(apx_ctx* ctx, const int64_t* ptr_h, const int32_t* ind_h,
     for (int32_t v : {q.rb, q.split, q.w0, q.w1, q.z0, q.z1, (int32_t)first[(size_t)q.rb], (int32_t)(first[(size_t)q.rb + 1] - first[(size_t)q.rb])})
       tp.items.push_back(v);
   tp.nw = (int)NW;
+  tp.wcols = (int)wc;
   tp.splits = splits;
   tp.rows = 0;
   for (int64_t rb = 0; rb < RB; ++rb) tp.rows = std::max<int>(tp.rows, (int)(first[(size_t)rb + 1] - first[(size_t)rb]));
@@ -982,6 +990,7 @@ static int32_t upload_sparse_t(apx_ctx* ctx, apx_matrix* A, int32_t layout, cons
     APX_TRY(up(&d.val, tp.val.data(), tp.val.size() * sizeof(T)));
     d.n_items = (int32_t)(tp.items.size() / kTileItemInts);
     d.nw = tp.nw;
+    d.wcols = tp.wcols;
     d.splits = tp.splits;
     d.rows = tp.rows;
     return APX_OK;
