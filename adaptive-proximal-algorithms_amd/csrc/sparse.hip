@@ -8,10 +8,11 @@
 // fixed order.  No scatter, no atomics => bit-reproducible like the dense path.  Output conventions
 // are those of the dense kernels, so every fused epilogue (residual, logistic link, ...) is
 // shared: spmv_n writes fp64 "splits" into the partial buffer, spmv_t writes T.
-// Three kernels: spmv_stream (round 5, the default wherever rows have a few entries each: a block of rows' entries as
-// one run, products through LDS, eight lanes per row — with the gathered operand taken in L2 WINDOWS where it is large,
-// launch_side), spmv_rows (round 1: G lanes per row ; short rows, unsorted input, the A/B option) and spmv_long (few rows of
-// thousands of entries: chunks).
+// Four kernels: spmv_tiles (round 5, matrices of a million entries or more: the operand's windows staged in LDS, the entries tile by
+// tile, the rows' sums in LDS — 4.7 - 5.1 TB/s of the entries' bytes), spmv_stream (round 5, smaller matrices whose rows have a few
+// entries each: a block of rows' entries as one run, products through LDS, eight lanes per row — with the gathered operand taken
+// in L2 WINDOWS where it is large, launch_side), spmv_rows (round 1: G lanes per row ; short rows, unsorted input, the A/B option)
+// and spmv_long (few rows of thousands of entries: chunks).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -35,7 +36,7 @@ namespace apx {
 // operand runs at
 // 1.1 - 1.7 TB/s of value + index bytes whatever the loads in flight — every random 8-byte gather moves a
 // whole cache line from L2, which is what bounds it; an operand that fits LDS / a row-blocked layout is the
-// next step for that regime, not this kernel's schedule.
+// next step for that regime, not this kernel's schedule (round 5: spmv_tiles below).
 // (p0 / p1: where a row's entries begin and end — the row pointers `ptr` and `ptr + 1`, or two consecutive slabs of a window
 //  table: the entries of the row whose index falls into one L2 window of the operand, see launch_windows)
 template <typename T, typename OUT, int G, int U = 2, int RU = 4>
@@ -258,7 +259,7 @@ static void launch_side(apx_ctx* ctx, int W, const int64_t* win, const int64_t* 
 
 // LDS TILES (round 5, after tools/gather_probe.hip's last rows: with the operand in LDS and 16 waves on the CU the entries stream at
 // 5.4 - 5.9 TB/s of their 12 bytes, against 2.0 when every gather is an L2 transaction).  The orientation is cut into tiles of
-// kTileRows rows x one 64 KB window of the gathered operand ; a tile's entries lie together, sorted by row, each with its row and index
+// (up to) kTileRows rows x one window of the gathered operand (64 KB or somewhat less) ; a tile's entries lie together, sorted by row, each with its row and index
 // LOCAL to the tile in one 32-bit word, padded to whole chunks of 512.  A workgroup of 1024 lanes owns a row block and a run of its
 // windows (a work item): per window it stages the operand's window in LDS — asked for a tile ahead, held in registers meanwhile — and
 // its 16 waves take the tile's chunks in turn (wave v: chunks v, v + 16, ... — the workgroup reads one contiguous run ; with a run per
@@ -272,12 +273,12 @@ static void launch_side(apx_ctx* ctx, int W, const int64_t* win, const int64_t* 
 // Every row's sum has ONE owner and a fixed shape: bit-reproducible (the LDS adds are to addresses no other lane touches between
 // two barriers).  Output: fp64 splits [splits][nrows_pad] like the windows' — the runs of windows of a row block are its splits, the
 // consumers sum them in order.
-// Measured (tools/sparse_kernels.py, 1 M x 100 k, 60 M entries): X w 298 -> 142 us, X' r 343 -> 146 (5.0 TB/s of the entries' bytes) ;
-// Float32 306 -> 109, 328 -> 113.  Along the way: a run of chunks per wave with the crossing rows in registers 160 us ; the lane's
+// Measured (tools/sparse_kernels.py, 1 M x 100 k, 60 M entries): X w 298 -> 137 us, X' r 343 -> 145 (5.0 - 5.2 TB/s of the entries'
+// bytes) ; Float32 306 -> 105, 328 -> 110.  Along the way: a run of chunks per wave with the crossing rows in registers 160 us ; the lane's
 // runs with branches and a guarded product for the padding 148 / 147 (now: selects, and padding that points at a zero) ; four entries
 // per lane 144 / 149 but Float32 130 ; two register sets taken in turn instead of copying the loaded chunk 152 / 154 (128 registers and
 // a spill) ; the scan through ds_bpermute, read-modify-write adds instead of ds_add_f64: no difference.  What is left below the probe's
-// 5.4 - 5.9 TB/s is the tile's barrier: a tile is 74 chunks for 16 waves, the last round of chunks leaves half the waves waiting.
+// 5.4 - 5.9 TB/s is the tile's barrier, which waits for the last round of chunks — hence the window's width (plan_tiles).
 constexpr int kTileLanes = 1024, kTileWaves = kTileLanes / 64, kTileE = 8, kTileChunk = 64 * kTileE;
 constexpr int kTileRows = 8192, kTileWindowBytes = 65536;
 // an entry's word: its local row << 17 | the BYTE offset of its operand entry in the window (0 ... 65536: one slot past the window holds a
