@@ -253,6 +253,39 @@ def test_lds_tiles_on_a_power_law_matrix(apx, dtype):
     dA.free()
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_lds_tiles_take_unsorted_rows_and_duplicates_through_the_c_abi(apx, layout):
+    """apx_matrix_upload_sparse asks for neither sorted indices nor unique ones (the Python wrapper sorts ; a ccall from Julia hands over
+    whatever `SparseMatrixCSC` holds): the tiles bucket the entries by window in the caller's order, duplicates add up like in the rows."""
+    import ctypes as C
+    L = importlib.import_module("adaptive-proximal-algorithms_amd._lib")
+    rng = np.random.default_rng(11)
+    m, n, nnz = 9000, 21_000, 400_000
+    nr, nc = (m, n) if layout == 0 else (n, m)      # layout 0: rows of A (CSR) ; 1: columns of A (CSC)
+    cnt = rng.multinomial(nnz, np.full(nr, 1.0 / nr))
+    ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    idx = rng.integers(0, nc, nnz).astype(np.int32)          # unsorted within a row, with repeats
+    idx[1::7] = idx[0::7][: idx[1::7].size]                  # (many immediate duplicates)
+    val = rng.uniform(-1, 1, nnz)
+    D = np.zeros((m, n))
+    rows = np.repeat(np.arange(nr), cnt)
+    np.add.at(D, (rows, idx) if layout == 0 else (idx, rows), val)
+    ctx = apx.Context(0)
+    ctx.fused_small(False)
+    ctx.set_option(L.APX_OPT_SPARSE_WINDOWS, 3)
+    h = C.c_void_p()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.check(ctx._lib.apx_matrix_upload_sparse(ctx._h, m, n, nnz, layout, p(ptr), p(idx), p(val), L.APX_F64, C.byref(h)))
+    x, r = rng.standard_normal(n), rng.standard_normal(m)
+    y, g = np.empty(m), np.empty(n)
+    ctx.profile(True)
+    L.check(ctx._lib.apx_gemv_n(h, p(x), p(y)))
+    L.check(ctx._lib.apx_gemv_t(h, p(r), p(g)))
+    assert "spmv_tiles" in ctx.kernel_name("gemv_n") and "spmv_tiles" in ctx.kernel_name("gemv_t")
+    assert np.max(np.abs(y - D @ x)) <= 1e-12 * np.max(np.abs(D @ x)) and np.max(np.abs(g - D.T @ r)) <= 1e-12 * np.max(np.abs(D.T @ r))
+    L.check(ctx._lib.apx_matrix_free(h))
+
+
 def test_lds_tiles_by_default_and_through_a_solver(apx):
     """What a matrix gets BY ITSELF (APX_OPT_SPARSE_WINDOWS 2, the default): 100 000 x 60 000 with 5.5 M entries — 55 000 per tile — runs
     both products on the LDS tiles ; the same shape with 0.5 M entries (below the million) keeps the streaming / window forms.  And a sparse logistic
