@@ -441,10 +441,16 @@ def sparse_leg(apx, ctx, barrier, m: int = 1_000_000, n: int = 100_000, per_row:
     s.close()
     dX.free()
     per_pass = float(nnz) * 12.0
+    traffic = None      # (the committed PMC passes of this command, like the main line's: profiles/pmc_traffic.json)
+    try:
+        if (m, n, per_row) == (1_000_000, 100_000, 60) and "spmv_tiles" in names[dom]:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("spmv_tiles", {}).get("hbm_bytes_per_launch")
+    except Exception:      # noqa: BLE001
+        traffic = None
     return {"workload": f"sparse_logreg on a sparse X {m}x{n}, {nnz} stored entries, fp64 values + int32 indices, adaptive_proxgrad (OurRule)",
             "iters_per_s": steps / dt, "ms_per_iter": dt / steps * 1e3, "steps": steps, "kernels": k, "kernel_names": names,
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": k[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": k[dom]["GBps"] / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_pass,
+                         "frac": k[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": per_pass,
                          "iteration_frac": 2.0 * per_pass * steps / dt / 1e9 / HBM_PEAK_GBS,
                          "note": "values + indices per product (the entries' 12 bytes ; the tiles' padding, the operand's windows — read "
                                  "once per tile, from L2 — and the splits written are excluded).  The ceiling of the access pattern "

@@ -120,7 +120,8 @@ def main():
     # so both passes appear as gemv_t_kernel in the trace
     pt = {"gemv_n": traffic.get("gemv_n_kernel") or traffic.get("gemv_t_kernel", {}),
           "gemv_t": traffic.get("gemv_t_kernel", {})}
-    for k in ("k_team_rows", "k_team_rows (primal-dual)", "k_multi_rows", "k_teampd_rows", "k_slab_rows", "k_slab2_rows"):      # the one-pass kernels (A read once per launch)
+    for k in ("k_team_rows", "k_team_rows (primal-dual)", "k_multi_rows", "k_teampd_rows", "k_slab_rows", "k_slab2_rows",      # the one-pass kernels (A read once per launch)
+              "spmv_tiles"):                                                                                                   # the sparse leg's products
         if k in traffic:
             pt[k] = traffic[k]
     if len(sys.argv) > 3:
