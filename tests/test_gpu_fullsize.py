@@ -571,3 +571,59 @@ def test_native_allreduce_hook_world_size_one(apx):
         apx.default_context().fused_small(True)
         if created:
             dist.destroy_process_group()
+
+
+def test_sparse_leg_at_full_size(apx):
+    """The bench's sparse leg at its size (1 000 000 x 100 000, 60 M entries, Float64 ; bench.py sparse_leg — the orientation of
+    experiments/sparse_logreg/runme.jl:24,31) through properties the CPU can afford with scipy: both products to a few units of the
+    last place of sum |a_ij x_j|, run twice bit for bit (LDS tiles: one owner and a fixed shape per row sum), the adjoint identity,
+    and 40 iterations: f and its gradient at the returned point against scipy, the objective down, a second run
+    identical bit for bit."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    m, n, per_row = 1_000_000, 100_000, 60
+    nnz_row = np.clip(rng.poisson(per_row, m), 1, n)
+    indptr = np.concatenate([[0], np.cumsum(nnz_row)]).astype(np.int64)
+    X = sp.csr_matrix((rng.uniform(-1, 1, indptr[-1]), rng.integers(0, n, indptr[-1]).astype(np.int32), indptr), shape=(m, n))
+    X.sum_duplicates()
+    ctx = apx.Context(0)
+    dX = apx.DeviceMatrix.from_sparse(X, ctx)
+    ctx.profile(True)
+    w, r = rng.standard_normal(n), rng.standard_normal(m)
+    z, g = dX @ w, dX.T @ r
+    assert "spmv_tiles" in ctx.kernel_name("gemv_n") and "spmv_tiles" in ctx.kernel_name("gemv_t")
+    eps = np.finfo(np.float64).eps
+    aX = abs(X)
+    assert np.max(np.abs(z - X @ w) / (aX @ np.abs(w) + 1e-300)) <= 4 * eps
+    assert np.max(np.abs(g - X.T @ r) / (aX.T @ np.abs(r) + 1e-300)) <= 4 * eps
+    assert np.array_equal(dX @ w, z) and np.array_equal(dX.T @ r, g)
+    assert float(z @ r) == pytest.approx(float(w @ g), rel=1e-12)
+    y = (1.0 / (1.0 + np.exp(-(X @ np.random.default_rng(3).standard_normal(n)))) > np.random.default_rng(4).uniform(size=m)).astype(np.float64)
+    gam = 4.0 * m / (float(X.multiply(X).sum()) + m)
+    lam = 1e-6
+    recs = []
+    x, it = apx.adaptive_proxgrad(np.zeros(n + 1), f=apx.LogisticLoss(dX, y, ctx=ctx), g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0,
+                                  maxit=40, ctx=ctx, record=recs.append)
+    assert it == 40 and np.all(np.isfinite(x)) and np.any(x[:-1] != 0)
+
+    def f_and_grad(v):      # experiments/sparse_logreg/runme.jl:18-39: mean logistic loss with an intercept, labels in {0, 1}
+        t = X @ v[:-1] + v[-1]
+        p = 1.0 / (1.0 + np.exp(-t))
+        val = float(np.mean(np.logaddexp(0.0, t) - y * t))
+        rr = (p - y) / m
+        return val, np.concatenate([X.T @ rr, [rr.sum()]])
+
+    f = apx.LogisticLoss(dX, y, ctx=ctx)
+    fx_dev, pb = apx.eval_with_pullback(f, x)      # f and its gradient at the returned point: the device against scipy
+    grad_dev = pb()
+    fx, grad = f_and_grad(x)
+    assert fx_dev == pytest.approx(fx, rel=1e-12)
+    assert np.max(np.abs(grad_dev - grad)) <= 1e-12 * np.max(np.abs(grad))
+    assert recs[-1]["objective"] < recs[0]["objective"] - 0.01      # (log 2 at x = 0 ; the residual is not monotone while the step size grows)
+    recs2 = []
+    x2, _ = apx.adaptive_proxgrad(np.zeros(n + 1), f=f, g=apx.NormL1(lam), rule=apx.OurRule(gamma=gam), tol=0.0, maxit=40, ctx=ctx,
+                                  record=recs2.append)
+    assert np.array_equal(x, x2)                    # two runs: the same iterates and records, bit for bit
+    for a, b in zip(recs, recs2):
+        assert a["objective"] == b["objective"] and a["gamma"] == b["gamma"]
+    dX.free()
